@@ -1,0 +1,203 @@
+// BEiT self-attention with additive relative-position bias, flash-style on MFMA (head_dim 64).
+//   HF modeling_beit.py:268-341 (eager_attention_forward) + :179-265 (relative position bias)
+//
+// Layouts (written by the QKV projection's BS_OUT_QKV epilogue): Q [B,nh,Sp,64] pre-scaled by
+// 1/sqrt(64), K [B,nh,Sp,64], V^T [B,nh,64,Sp]; rows / columns >= S are zero.  bias fp32
+// [nh,Sp,Sp] with -1e30 in key columns >= S (no in-kernel masking).
+//
+// One wave owns 32 queries; the scores are computed TRANSPOSED, S^T = K Q^T, with
+// v_mfma_f32_32x32x16: the query sits on the lane (column), the 32 keys of a sub-tile sit in the 16
+// accumulator registers of the two lane halves.  Row statistics are then lane-local (one
+// cross-half exchange per sub-tile for the max), and the exponentiated accumulator registers ARE
+// the B operand of the second product O^T += V^T P^T -- no LDS round trip for P.  The MFMA row ->
+// key assignment is permuted (bits 2 and 3 of the row swapped) so that each lane's 8 P values of a
+// k-step are 8 CONSECUTIVE keys, i.e. one 16-byte read of the V^T image.
+// K and V^T tiles (64 keys) are staged by global_load_lds into double-buffered, XOR-swizzled LDS
+// images shared by the QW waves of a block.
+#include "common.h"
+
+namespace bs {
+
+template <typename T, int QW>
+__global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ Vt,
+                                                             const float* __restrict__ bias, T* __restrict__ out, int B, int nh, int S,
+                                                             int Sp, int nqt, int nqb) {
+    typedef typename T16<T>::v8 v8;
+    constexpr int STAGE = 16 * 1024;  // K tile 8 KiB + V^T tile 8 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // work id -> (head, q-block, image): all images of one (head, q-block) are consecutive ids and the
+    // chunked XCD remap keeps them on one XCD, so its L2 serves the shared bias rows
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + loc;
+    const int b = wg % B;
+    const int qblk = (wg / B) % nqb;
+    const int head = wg / (B * nqb);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h2 = lane >> 5;
+    int qt = qblk * QW + wave;
+    const bool active = qt < nqt;
+    qt = active ? qt : nqt - 1;
+    const int q0 = qt * 32;
+    const int64_t bh = (int64_t)b * nh + head;
+
+    const T* Qg = Q + bh * Sp * 64;
+    const T* Kg = K + bh * Sp * 64;
+    const T* Vg = Vt + bh * 64 * Sp;
+
+    v8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const v8*>(Qg + (int64_t)(q0 + r) * 64 + ks * 16 + h2 * 8);
+
+    const int srow = lane >> 3;                       // row inside one 1-KiB DMA piece
+    const int cs8 = ((lane & 7) ^ srow) * 8;          // swizzled source chunk (elements)
+    auto stage = [&](int kt, int buf) {
+        char* sb = smem + buf * STAGE;
+        for (int i = wave; i < 16; i += QW) {
+            const T* src;
+            if (i < 8) {
+                src = Kg + (int64_t)(kt * 64 + i * 8 + srow) * 64 + cs8;
+            } else {
+                src = Vg + (int64_t)((i - 8) * 8 + srow) * Sp + kt * 64 + cs8;
+            }
+            glds16(src, sb + i * 1024);
+        }
+    };
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        oacc[0][i] = 0.f;
+        oacc[1][i] = 0.f;
+    }
+    float m_run = -1.0e30f, l_run = 0.f;
+
+    // MFMA row rho -> key kappa(rho): swap bits 2 and 3
+    const int kap = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+    const float* bias_row = bias + ((int64_t)head * Sp + q0 + r) * Sp + 8 * h2;
+
+    const int nkt = (S + 63) >> 6;
+    stage(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
+        const char* sk = smem + (kt & 1) * STAGE;
+        const char* sv = sk + 8 * 1024;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int key0 = kt * 64 + sub * 32;
+            if (key0 >= S) break;
+            // ---- S^T = K Q^T
+            f32x16 sacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+            const int krow = sub * 32 + kap;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int chunk = 2 * ks + h2;
+                const v8 kf = *reinterpret_cast<const v8*>(sk + krow * 128 + ((chunk ^ (krow & 7)) << 4));
+                sacc = T16<T>::mfma32(kf, qf[ks], sacc);
+            }
+            // ---- + bias; registers 8s..8s+7 of lane half h2 are keys key0 + 16s + 8*h2 + 0..7
+            float sc[16];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_row + key0 + 16 * s);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias_row + key0 + 16 * s + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sc[8 * s + e] = sacc[8 * s + e] + b0[e];
+                    sc[8 * s + 4 + e] = sacc[8 * s + 4 + e] + b1[e];
+                }
+            }
+            float mloc = sc[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) mloc = fmaxf(mloc, sc[i]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run, mloc);
+            const float alpha = __expf(m_run - m_new);
+            float psum = 0.f;
+            float p[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                p[i] = __expf(sc[i] - m_new);
+                psum += p[i];
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                oacc[0][i] *= alpha;
+                oacc[1][i] *= alpha;
+            }
+            // ---- O^T += V^T P^T
+            v8 pf[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[s][e] = T16<T>::from_f32(p[8 * s + e]);
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh) {
+                const int drow = dh * 32 + r;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int chunk = sub * 4 + 2 * s + h2;
+                    const v8 vf = *reinterpret_cast<const v8*>(sv + drow * 128 + ((chunk ^ (drow & 7)) << 4));
+                    oacc[dh] = T16<T>::mfma32(vf, pf[s], oacc[dh]);
+                }
+            }
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + r;
+    if (active && q < S) {
+        T* orow = out + ((int64_t)b * S + q) * (nh * 64) + head * 64;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                typename T16<T>::v4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(oacc[dh][gg * 4 + e] * inv);
+                *reinterpret_cast<typename T16<T>::v4*>(orow + dh * 32 + 8 * gg + 4 * h2) = o;
+            }
+    }
+}
+
+template <typename T, int QW>
+static int launch_attn(const void* q, const void* k, const void* vt, const float* bias, void* out, int B, int nh, int S, int Sp,
+                       hipStream_t st) {
+    const int nqt = cdiv(S, 32), nqb = cdiv(nqt, QW);
+    hipLaunchKernelGGL((attention_kernel<T, QW>), dim3(B * nh * nqb), dim3(QW * 64), 32 * 1024, st, (const T*)q, (const T*)k,
+                       (const T*)vt, bias, (T*)out, B, nh, S, Sp, nqt, nqb);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+template <typename T>
+static int dispatch_attn(const void* q, const void* k, const void* vt, const float* bias, void* out, int B, int nh, int S, int Sp,
+                         hipStream_t st) {
+    const int nqt = cdiv(S, 32);
+    if (nqt % 5 == 0) return launch_attn<T, 5>(q, k, vt, bias, out, B, nh, S, Sp, st);
+    if (nqt % 3 == 0) return launch_attn<T, 3>(q, k, vt, bias, out, B, nh, S, Sp, st);
+    return launch_attn<T, 4>(q, k, vt, bias, out, B, nh, S, Sp, st);
+}
+
+}  // namespace bs
+
+extern "C" int bs_attention(const void* q, const void* k, const void* vt, const float* bias, void* out, int32_t B, int32_t nh, int32_t S,
+                            int32_t Sp, int32_t dtype, void* stream) {
+    using namespace bs;
+    if (!initialized()) { set_error("bs_attention: call bs_init first"); return BS_ERR_NOT_INIT; }
+    BS_REQUIRE(q && k && vt && bias && out && B >= 0 && nh > 0 && S > 0, "bs_attention: bad argument");
+    BS_REQUIRE(Sp % 64 == 0 && Sp >= S, "bs_attention: Sp=%d must be a multiple of 64 and >= S=%d", Sp, S);
+    BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_attention: dtype");
+    if (B == 0) return BS_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return dtype == BS_F16 ? dispatch_attn<f16>(q, k, vt, bias, out, B, nh, S, Sp, st)
+                           : dispatch_attn<bf16>(q, k, vt, bias, out, B, nh, S, Sp, st);
+}

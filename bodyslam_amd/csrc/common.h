@@ -1,0 +1,92 @@
+// Internal helpers shared by the HIP translation units of libbodyslam_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/bodyslam_hip.h"
+
+namespace bs {
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+void set_error(const char* fmt, ...);
+const void* zero_page();          // 4 KiB of device zeros (allocated by bs_init)
+bool initialized();
+
+#define BS_CHECK_HIP(expr)                                                             \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) {                                                        \
+            bs::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return BS_ERR_HIP;                                                         \
+        }                                                                              \
+    } while (0)
+
+#define BS_REQUIRE(cond, ...)                  \
+    do {                                       \
+        if (!(cond)) {                         \
+            bs::set_error(__VA_ARGS__);        \
+            return BS_ERR_INVALID;             \
+        }                                      \
+    } while (0)
+
+#define BS_CHECK_LAUNCH() BS_CHECK_HIP(hipGetLastError())
+
+// 16-bit storage traits -----------------------------------------------------------------------
+template <typename T> struct T16;
+template <> struct T16<f16> {
+    typedef f16x8 v8;
+    typedef f16x4 v4;
+    static __device__ __forceinline__ float to_f32(f16 x) { return (float)x; }
+    static __device__ __forceinline__ f16 from_f32(float x) { return (f16)x; }
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct T16<bf16> {
+    typedef bf16x8 v8;
+    typedef bf16x4 v4;
+    static __device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
+    static __device__ __forceinline__ bf16 from_f32(float x) { return (bf16)x; }
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// torch.nn.Softplus(beta=1, threshold=20)
+__device__ __forceinline__ float softplus20(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+__device__ __forceinline__ float apply_act(float y, int act) {
+    if (act == BS_ACT_RELU) return fmaxf(y, 0.0f);
+    if (act == BS_ACT_GELU) return gelu_erf(y);
+    if (act == BS_ACT_SOFTPLUS) return softplus20(y);
+    return y;
+}
+
+// async global -> LDS, 16 bytes per lane; LDS destination = wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace bs

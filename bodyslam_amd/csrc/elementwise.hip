@@ -1,0 +1,410 @@
+// HBM-bound helper kernels of the MDEM path: LayerNorm, casts, uint8 -> patch-matrix
+// pre-processing (reflect pad + bilinear resize + normalise fused with the 16x16 patch gather),
+// NHWC bilinear resampling, the final bicubic/flip-average/uint16 post-processing.
+//   HF image_processing_pil_zoedepth.py:181-232,234-341; HF modeling_beit.py:63-176,418,432;
+//   HF modeling_zoedepth.py:259,319,360
+#include "common.h"
+
+namespace bs {
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row; the row is cached in registers when cols <= 1024
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* gamma, const float* beta, T* out16, float* out32,
+                                                         int rows, int cols, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (int64_t)row * cols;
+    constexpr int VPT = 4;
+    f32x4 v[VPT];
+    const int nvec = cols >> 2;
+    const bool cached = nvec <= 64 * VPT;
+    float s = 0.f;
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int vi = lane + i * 64;
+            v[i] = vi < nvec ? *reinterpret_cast<const f32x4*>(xr + vi * 4) : f32x4{0, 0, 0, 0};
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    } else {
+        for (int vi = lane; vi < nvec; vi += 64) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(xr + vi * 4);
+            s += t[0] + t[1] + t[2] + t[3];
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)cols;
+    float q = 0.f;
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            if (lane + i * 64 < nvec) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = v[i][e] - mean;
+                    q += d * d;
+                }
+            }
+        }
+    } else {
+        for (int vi = lane; vi < nvec; vi += 64) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(xr + vi * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = t[e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)cols + eps);
+    for (int i = 0, vi = lane; vi < nvec; vi += 64, ++i) {
+        f32x4 t;
+        if (cached) {
+            // static indexing only (runtime-indexed vector arrays go to scratch)
+            t = i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3]));
+        } else {
+            t = *reinterpret_cast<const f32x4*>(xr + vi * 4);
+        }
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + vi * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + vi * 4);
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (t[e] - mean) * rstd * g[e] + b[e];
+        if (out16) {
+            typename T16<T>::v4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(y[e]);
+            *reinterpret_cast<typename T16<T>::v4*>(out16 + (int64_t)row * cols + vi * 4) = o;
+        }
+        if (out32) *reinterpret_cast<f32x4*>(out32 + (int64_t)row * cols + vi * 4) = f32x4{y[0], y[1], y[2], y[3]};
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_kernel(const float* x, T* out, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(x + i * 4);
+        typename T16<T>::v4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(t[e]);
+        *reinterpret_cast<typename T16<T>::v4*>(out + i * 4) = o;
+    }
+}
+
+__global__ void fill_rows_kernel(float* x, const float* v, int rows_per_image, int cols) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < cols; i += blockDim.x) x[(int64_t)b * rows_per_image * cols + i] = v[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// pre-processing
+// ---------------------------------------------------------------------------------------------
+struct PreGeom {
+    int H, W, ph, pw, nh, nw;
+    float sy, sx;  // align_corners=True scales: (Hp-1)/(nh-1), (Wp-1)/(nw-1)
+};
+
+__device__ __forceinline__ float pre_sample(const uint8_t* frame, const PreGeom& g, int c, int y, int x) {
+    // value of the normalised network input at (c, y, x) of the UNFLIPPED image
+    const float fy = g.sy * (float)y, fx = g.sx * (float)x;
+    const int Hp = g.H + 2 * g.ph, Wp = g.W + 2 * g.pw;
+    int y0 = (int)fy, x0 = (int)fx;
+    y0 = y0 > Hp - 1 ? Hp - 1 : y0;
+    x0 = x0 > Wp - 1 ? Wp - 1 : x0;
+    const int y1 = y0 + (y0 < Hp - 1 ? 1 : 0), x1 = x0 + (x0 < Wp - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float hy = 1.0f - ly, hx = 1.0f - lx;
+    auto refl = [](int i, int pad, int n) {
+        int s = i - pad;
+        s = s < 0 ? -s : s;
+        return s >= n ? 2 * (n - 1) - s : s;
+    };
+    const int sy0 = refl(y0, g.ph, g.H), sy1 = refl(y1, g.ph, g.H);
+    const int sx0 = refl(x0, g.pw, g.W), sx1 = refl(x1, g.pw, g.W);
+    const float k = 1.0f / 255.0f;
+    const float p00 = (float)frame[((int64_t)sy0 * g.W + sx0) * 3 + c] * k;
+    const float p01 = (float)frame[((int64_t)sy0 * g.W + sx1) * 3 + c] * k;
+    const float p10 = (float)frame[((int64_t)sy1 * g.W + sx0) * 3 + c] * k;
+    const float p11 = (float)frame[((int64_t)sy1 * g.W + sx1) * 3 + c] * k;
+    const float v = hy * (hx * p00 + lx * p01) + ly * (hx * p10 + lx * p11);
+    return (v - 0.5f) / 0.5f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pre_patches_kernel(const uint8_t* frames, T* out, int B, int nimg, PreGeom g) {
+    const int hp = g.nh / 16, wp = g.nw / 16;
+    const int64_t total = (int64_t)nimg * hp * wp * 768;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int k = (int)(gid % 768);
+    const int64_t r = gid / 768;
+    const int px = (int)(r % wp), py = (int)((r / wp) % hp), img = (int)(r / ((int64_t)wp * hp));
+    const int c = k >> 8, ky = (k >> 4) & 15, kx = k & 15;
+    const int y = py * 16 + ky;
+    int x = px * 16 + kx;
+    const int b = img >= B ? img - B : img;
+    if (img >= B) x = g.nw - 1 - x;  // torch.flip(x, dims=[3]) of the network input
+    out[gid] = T16<T>::from_f32(pre_sample(frames + (int64_t)b * g.H * g.W * 3, g, c, y, x));
+}
+
+__global__ __launch_bounds__(256) void pre_image_kernel(const uint8_t* frames, float* out, int B, int nimg, PreGeom g) {
+    const int64_t total = (int64_t)nimg * 3 * g.nh * g.nw;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    int x = (int)(gid % g.nw);
+    const int y = (int)((gid / g.nw) % g.nh), c = (int)((gid / ((int64_t)g.nw * g.nh)) % 3), img = (int)(gid / ((int64_t)3 * g.nw * g.nh));
+    const int b = img >= B ? img - B : img;
+    if (img >= B) x = g.nw - 1 - x;
+    out[gid] = pre_sample(frames + (int64_t)b * g.H * g.W * 3, g, c, y, x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// NHWC bilinear resize (+ optional add): thread = one 8-channel group of one output pixel
+// ---------------------------------------------------------------------------------------------
+template <typename T, bool ADD>
+__global__ __launch_bounds__(256) void resize_nhwc_kernel(const T* x, const T* addend, T* out, int B, int Hin, int Win, int C, int Hout,
+                                                           int Wout, float sy, float sx, int align) {
+    const int c8n = C >> 3;
+    const int64_t total = (int64_t)B * Hout * Wout * c8n;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int c8 = (int)(gid % c8n);
+    const int64_t pix = gid / c8n;
+    const int ox = (int)(pix % Wout), oy = (int)((pix / Wout) % Hout), b = (int)(pix / ((int64_t)Wout * Hout));
+    float fy, fx;
+    if (align) {
+        fy = sy * (float)oy;
+        fx = sx * (float)ox;
+    } else {
+        fy = fmaxf(sy * ((float)oy + 0.5f) - 0.5f, 0.0f);
+        fx = fmaxf(sx * ((float)ox + 0.5f) - 0.5f, 0.0f);
+    }
+    int y0 = (int)fy, x0 = (int)fx;
+    y0 = y0 > Hin - 1 ? Hin - 1 : y0;
+    x0 = x0 > Win - 1 ? Win - 1 : x0;
+    const int y1 = y0 + (y0 < Hin - 1 ? 1 : 0), x1 = x0 + (x0 < Win - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+    typedef typename T16<T>::v8 v8;
+    const T* xb = x + (int64_t)b * Hin * Win * C + c8 * 8;
+    const v8 p00 = *reinterpret_cast<const v8*>(xb + ((int64_t)y0 * Win + x0) * C);
+    const v8 p01 = *reinterpret_cast<const v8*>(xb + ((int64_t)y0 * Win + x1) * C);
+    const v8 p10 = *reinterpret_cast<const v8*>(xb + ((int64_t)y1 * Win + x0) * C);
+    const v8 p11 = *reinterpret_cast<const v8*>(xb + ((int64_t)y1 * Win + x1) * C);
+    v8 a;
+    if (ADD) a = *reinterpret_cast<const v8*>(addend + pix * C + c8 * 8);
+    v8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = hy * (hx * (float)p00[e] + lx * (float)p01[e]) + ly * (hx * (float)p10[e] + lx * (float)p11[e]);
+        if (ADD) v += (float)a[e];
+        o[e] = T16<T>::from_f32(v);
+    }
+    *reinterpret_cast<v8*>(out + pix * C + c8 * 8) = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// post-processing: flip-average + bicubic (A = -0.75, align_corners=False) + crop + x256 -> u16
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cubic_coeffs(float t, float (&c)[4]) {
+    const float A = -0.75f;
+    auto c1 = [&](float x) { return ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f; };
+    auto c2 = [&](float x) { return ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A; };
+    c[0] = c2(t + 1.0f);
+    c[1] = c1(t);
+    c[2] = c1(1.0f - t);
+    c[3] = c2(2.0f - t);
+}
+
+__global__ __launch_bounds__(256) void postprocess_kernel(const float* dnet, float* depth_m, uint16_t* depth_u16, int B, int H, int W,
+                                                           int nh, int nw, int ph, int pw, float sy, float sx, int flip) {
+    const int64_t total = (int64_t)B * H * W;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int x = (int)(gid % W), y = (int)((gid / W) % H), b = (int)(gid / ((int64_t)W * H));
+    const int yp = y + ph, xp = x + pw;  // position in the padded (resize target) frame
+    const float fy = sy * ((float)yp + 0.5f) - 0.5f, fx = sx * ((float)xp + 0.5f) - 0.5f;
+    const float fly = floorf(fy), flx = floorf(fx);
+    const int iy = (int)fly, ix = (int)flx;
+    float cy[4], cx[4];
+    cubic_coeffs(fy - fly, cy);
+    cubic_coeffs(fx - flx, cx);
+    const float* d0 = dnet + (int64_t)b * nh * nw;
+    const float* d1 = dnet + (int64_t)(B + b) * nh * nw;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int yy = iy - 1 + i;
+        yy = yy < 0 ? 0 : (yy > nh - 1 ? nh - 1 : yy);
+        float row = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int xx = ix - 1 + j;
+            xx = xx < 0 ? 0 : (xx > nw - 1 ? nw - 1 : xx);
+            float v = d0[(int64_t)yy * nw + xx];
+            if (flip) v = (v + d1[(int64_t)yy * nw + (nw - 1 - xx)]) / 2.0f;
+            row += v * cx[j];
+        }
+        acc += row * cy[i];
+    }
+    depth_m[gid] = acc;
+    if (depth_u16) {
+        float s = acc * 256.0f;  // numpy float32 -> uint16 cast: truncation toward zero
+        s = s < 0.f ? 0.f : (s > 65535.f ? 65535.f : s);
+        depth_u16[gid] = (uint16_t)s;
+    }
+}
+
+static PreGeom make_geom(int H, int W, int nh, int nw) {
+    PreGeom g;
+    g.H = H; g.W = W; g.nh = nh; g.nw = nw;
+    g.ph = (int)(sqrt((double)H / 2.0) * 3.0);
+    g.pw = (int)(sqrt((double)W / 2.0) * 3.0);
+    g.sy = nh > 1 ? (float)(H + 2 * g.ph - 1) / (float)(nh - 1) : 0.f;
+    g.sx = nw > 1 ? (float)(W + 2 * g.pw - 1) / (float)(nw - 1) : 0.f;
+    return g;
+}
+
+}  // namespace bs
+
+using namespace bs;
+#define BS_ENTRY(name) \
+    if (!initialized()) { set_error(name ": call bs_init first"); return BS_ERR_NOT_INIT; }
+
+extern "C" int bs_layernorm(const float* x, const float* gamma, const float* beta, void* out16, float* out32, int32_t rows,
+                            int32_t cols, float eps, int32_t dtype, void* stream) {
+    BS_ENTRY("bs_layernorm");
+    BS_REQUIRE(x && gamma && beta && (out16 || out32) && rows >= 0 && cols > 0 && cols % 4 == 0, "bs_layernorm: bad argument");
+    BS_REQUIRE(!out16 || dtype == BS_F16 || dtype == BS_BF16, "bs_layernorm: dtype");
+    if (rows == 0) return BS_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid(cdiv(rows, 4));
+    if (dtype == BS_BF16)
+        hipLaunchKernelGGL(layernorm_kernel<bf16>, grid, dim3(256), 0, st, x, gamma, beta, (bf16*)out16, out32, rows, cols, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<f16>, grid, dim3(256), 0, st, x, gamma, beta, (f16*)out16, out32, rows, cols, eps);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+extern "C" int bs_cast(const float* x, void* out, int64_t n, int32_t out_dtype, void* stream) {
+    BS_ENTRY("bs_cast");
+    BS_REQUIRE(x && out && n >= 0 && n % 4 == 0, "bs_cast: n must be a multiple of 4");
+    BS_REQUIRE(out_dtype == BS_F16 || out_dtype == BS_BF16, "bs_cast: dtype");
+    if (n == 0) return BS_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t n4 = n / 4;
+    const unsigned blocks = (unsigned)(cdiv64(n4, 256) < 8192 ? cdiv64(n4, 256) : 8192);
+    if (out_dtype == BS_F16)
+        hipLaunchKernelGGL(cast_kernel<f16>, dim3(blocks), dim3(256), 0, st, x, (f16*)out, n4);
+    else
+        hipLaunchKernelGGL(cast_kernel<bf16>, dim3(blocks), dim3(256), 0, st, x, (bf16*)out, n4);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+extern "C" int bs_fill_rows(float* x, const float* v, int32_t B, int32_t rows_per_image, int32_t cols, void* stream) {
+    BS_ENTRY("bs_fill_rows");
+    BS_REQUIRE(x && v && B >= 0 && rows_per_image > 0 && cols > 0, "bs_fill_rows: bad argument");
+    if (B == 0) return BS_OK;
+    hipLaunchKernelGGL(fill_rows_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, v, rows_per_image, cols);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+extern "C" int bs_preprocess_patches(const uint8_t* frames, void* out, int32_t B, int32_t H, int32_t W, int32_t nh, int32_t nw,
+                                     int32_t flip, int32_t out_dtype, void* stream) {
+    BS_ENTRY("bs_preprocess_patches");
+    BS_REQUIRE(frames && out && B >= 0 && H > 1 && W > 1 && nh % 16 == 0 && nw % 16 == 0 && nh > 0 && nw > 0,
+               "bs_preprocess_patches: bad geometry");
+    BS_REQUIRE(out_dtype == BS_F16 || out_dtype == BS_BF16, "bs_preprocess_patches: dtype");
+    if (B == 0) return BS_OK;
+    const PreGeom g = make_geom(H, W, nh, nw);
+    BS_REQUIRE(g.ph < H && g.pw < W, "bs_preprocess_patches: reflect pad exceeds the frame");
+    const int nimg = flip ? 2 * B : B;
+    const int64_t total = (int64_t)nimg * (nh / 16) * (nw / 16) * 768;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (out_dtype == BS_F16)
+        hipLaunchKernelGGL(pre_patches_kernel<f16>, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, frames, (f16*)out, B, nimg, g);
+    else
+        hipLaunchKernelGGL(pre_patches_kernel<bf16>, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, frames, (bf16*)out, B, nimg, g);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+extern "C" int bs_preprocess_image(const uint8_t* frames, float* out, int32_t B, int32_t H, int32_t W, int32_t nh, int32_t nw,
+                                   int32_t flip, void* stream) {
+    BS_ENTRY("bs_preprocess_image");
+    BS_REQUIRE(frames && out && B >= 0 && H > 1 && W > 1 && nh > 0 && nw > 0, "bs_preprocess_image: bad geometry");
+    if (B == 0) return BS_OK;
+    const PreGeom g = make_geom(H, W, nh, nw);
+    BS_REQUIRE(g.ph < H && g.pw < W, "bs_preprocess_image: reflect pad exceeds the frame");
+    const int nimg = flip ? 2 * B : B;
+    const int64_t total = (int64_t)nimg * 3 * nh * nw;
+    hipLaunchKernelGGL(pre_image_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), frames,
+                       out, B, nimg, g);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+template <typename T>
+static int launch_resize(const void* x, const void* addend, void* out, int B, int Hin, int Win, int C, int Hout, int Wout, int align,
+                         hipStream_t st) {
+    float sy, sx;
+    if (align) {
+        sy = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f;
+        sx = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
+    } else {
+        sy = (float)Hin / (float)Hout;
+        sx = (float)Win / (float)Wout;
+    }
+    const int64_t total = (int64_t)B * Hout * Wout * (C / 8);
+    const unsigned blocks = (unsigned)cdiv64(total, 256);
+    if (addend)
+        hipLaunchKernelGGL((resize_nhwc_kernel<T, true>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)addend, (T*)out, B, Hin,
+                           Win, C, Hout, Wout, sy, sx, align);
+    else
+        hipLaunchKernelGGL((resize_nhwc_kernel<T, false>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)nullptr, (T*)out, B,
+                           Hin, Win, C, Hout, Wout, sy, sx, align);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+extern "C" int bs_resize_bilinear_nhwc(const void* x, void* out, int32_t B, int32_t Hin, int32_t Win, int32_t C, int32_t Hout,
+                                       int32_t Wout, int32_t align_corners, int32_t dtype, void* stream) {
+    BS_ENTRY("bs_resize_bilinear_nhwc");
+    BS_REQUIRE(x && out && B >= 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && C > 0 && C % 8 == 0, "bs_resize_bilinear_nhwc: bad argument");
+    BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_resize_bilinear_nhwc: dtype");
+    if (B == 0) return BS_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return dtype == BS_F16 ? launch_resize<f16>(x, nullptr, out, B, Hin, Win, C, Hout, Wout, align_corners, st)
+                           : launch_resize<bf16>(x, nullptr, out, B, Hin, Win, C, Hout, Wout, align_corners, st);
+}
+
+extern "C" int bs_add_resized(const void* x, const void* prev, void* out, int32_t B, int32_t Hp, int32_t Wp, int32_t H, int32_t W,
+                              int32_t C, int32_t dtype, void* stream) {
+    BS_ENTRY("bs_add_resized");
+    BS_REQUIRE(x && prev && out && B >= 0 && Hp > 0 && Wp > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "bs_add_resized: bad argument");
+    BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_add_resized: dtype");
+    if (B == 0) return BS_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return dtype == BS_F16 ? launch_resize<f16>(prev, x, out, B, Hp, Wp, C, H, W, 1, st)
+                           : launch_resize<bf16>(prev, x, out, B, Hp, Wp, C, H, W, 1, st);
+}
+
+extern "C" int bs_postprocess_depth(const float* depth_net, float* depth_m, uint16_t* depth_u16, int32_t B, int32_t H, int32_t W,
+                                    int32_t nh, int32_t nw, int32_t flip, void* stream) {
+    BS_ENTRY("bs_postprocess_depth");
+    BS_REQUIRE(depth_net && depth_m && B >= 0 && H > 1 && W > 1 && nh > 0 && nw > 0, "bs_postprocess_depth: bad argument");
+    if (B == 0) return BS_OK;
+    const PreGeom g = make_geom(H, W, nh, nw);
+    const int Hp = H + 2 * g.ph, Wp = W + 2 * g.pw;
+    const float sy = (float)nh / (float)Hp, sx = (float)nw / (float)Wp;
+    const int64_t total = (int64_t)B * H * W;
+    hipLaunchKernelGGL(postprocess_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       depth_net, depth_m, depth_u16, B, H, W, nh, nw, g.ph, g.pw, sy, sx, flip);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}

@@ -1,0 +1,408 @@
+// Implicit-GEMM on MFMA for gfx950: out[m, n] = epilogue(sum_k A(m, k) * W[n, k]).
+//
+// One kernel family serves every Linear / Conv2d / ConvTranspose2d(k == stride) on the hot path
+// (include/bodyslam_hip.h: bs_gemm lists the reference call sites).  Design:
+//   * NHWC activations, weights [N][KH][KW][Cin]: a BK = 64 slice of K is ONE filter tap and 64
+//     contiguous channels, i.e. one 128-byte line per output pixel.  The A tile is therefore a row
+//     gather: each lane of a `global_load_lds_dwordx4` supplies the address of 16 bytes of its pixel
+//     (or of a zero page when the tap falls into the padding) and the data lands in LDS without
+//     touching VGPRs.  No im2col buffer exists anywhere.
+//   * LDS image per operand: [rows][64] 16-bit, 128-byte rows, 16-byte chunk c of row r stored at
+//     chunk position c ^ (r & 7).  The DMA destination is lane-linear, so the XOR is applied to the
+//     SOURCE chunk each lane fetches and again on the ds_read_b128 address (conflict-free for the
+//     16x16x32 operand pattern: 16 distinct rows x one chunk per lane group).
+//   * v_mfma_f32_16x16x32_{f16,bf16}; operands swapped (W fragment as "A", activation fragment as
+//     "B") so a lane ends with 4 consecutive n for one m: 8/16-byte epilogue stores.
+//   * double-buffered LDS, one barrier per K tile: the DMA of tile t+1 is in flight while tile t
+//     is multiplied.
+//   * 1-D grid with the bijective XCD remap: the N-tiles of one M-tile (which share the gathered
+//     activations) are consecutive work ids and land on one XCD's L2.
+// Epilogue fuses bias (optionally per row group), ReLU/GELU/softplus, per-channel scale
+// (BEiT layer-scale), residual add (fp32 or 16-bit), and three store layouts (plain with row
+// regrouping, ConvTranspose pixel shuffle, Q/K/V^T head scatter).
+#include "common.h"
+
+namespace bs {
+
+struct IgemmParams {
+    const void* A;
+    const void* W;
+    const void* zero;
+    int M, N, K, lda;
+    int Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_h, pad_w;
+    int tiles_per_tap;
+    int relu_a;
+    const float* bias;
+    int bias_group_rows;
+    int act;
+    const float* scale;
+    const void* res;
+    int res_dtype, ldr;
+    void* out;
+    void* out2;
+    void* out3;
+    int out_dtype, ldo, out_mode;
+    int out_group_rows, out_group_stride, out_row_offset;
+    int shuffle_s, shuffle_cout;
+    int qkv_hidden, qkv_tokens, qkv_sp;
+    float q_scale;
+    int ntm, ntn;
+};
+
+template <typename T>
+__device__ __forceinline__ typename T16<T>::v8 relu8(typename T16<T>::v8 x) {
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 b = __builtin_bit_cast(s16x8, x);
+    s16x8 neg = b >> 15;  // 0xFFFF where the sign bit is set
+    b = b & ~neg;
+    return __builtin_bit_cast(typename T16<T>::v8, b);
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(void* base, int64_t off, int out_dtype, const float (&y)[4]) {
+    if (out_dtype == BS_F32) {
+        f32x4 v = {y[0], y[1], y[2], y[3]};
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off) = v;
+    } else {
+        typename T16<T>::v4 v;
+        v[0] = T16<T>::from_f32(y[0]);
+        v[1] = T16<T>::from_f32(y[1]);
+        v[2] = T16<T>::from_f32(y[2]);
+        v[3] = T16<T>::from_f32(y[3]);
+        *reinterpret_cast<typename T16<T>::v4*>(reinterpret_cast<T*>(base) + off) = v;
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool CONV>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int RPR = NT / 8;  // rows staged per DMA round (8 lanes x 16 B = one 128-B row)
+    constexpr int RA = BM / RPR, RB = BN / RPR;
+    static_assert(BM % RPR == 0 && BN % RPR == 0, "tile rows must be a multiple of the DMA round");
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int FM = TM / 16, FN = TN / 16;
+    static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be a multiple of 16");
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    typedef typename T16<T>::v8 v8;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // ---- work id -> tile, XCD-aware (blocks b and b+8 share an XCD; give each XCD a contiguous
+    // run of work ids so that the N-tiles of one M-tile hit the same L2)
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + loc;
+    const int tm = wg / p.ntn, tn = wg - tm * p.ntn;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int srow = tid >> 3;
+    const int cs8 = ((tid & 7) ^ (srow & 7)) * 8;  // element offset of the source chunk this lane fetches
+
+    const T* Ag = reinterpret_cast<const T*>(p.A);
+    const T* Wg = reinterpret_cast<const T*>(p.W);
+    const T* zp = reinterpret_cast<const T*>(p.zero) + cs8;
+
+    // ---- per-lane row bookkeeping for the DMA rounds
+    const T* a_ptr[RA];
+    int a_iy0[RA], a_ix0[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        int m = tm * BM + j * RPR + srow;
+        m = m < p.M ? m : p.M - 1;
+        if (CONV) {
+            const int hw = p.Hout * p.Wout;
+            const int b = m / hw, rem = m - b * hw;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            a_iy0[j] = oy * p.stride - p.pad_h;
+            a_ix0[j] = ox * p.stride - p.pad_w;
+            a_ptr[j] = Ag + ((int64_t)(b * p.Hin + a_iy0[j]) * p.Win + a_ix0[j]) * p.lda + cs8;
+        } else {
+            a_iy0[j] = a_ix0[j] = 0;
+            a_ptr[j] = Ag + (int64_t)m * p.lda + cs8;
+        }
+    }
+    const T* w_ptr[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        int n = tn * BN + j * RPR + srow;
+        n = n < p.N ? n : p.N - 1;
+        w_ptr[j] = Wg + (int64_t)n * p.K + cs8;
+    }
+
+    // running tap state of the NEXT tile to stage (conv): ky, kx, channel offset
+    int s_ky = 0, s_kx = 0, s_c0 = 0, s_t = 0;
+
+    auto stage = [&](int buf) {
+        char* sa = smem + buf * STAGE;
+        char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const T* src;
+            if (CONV) {
+                const bool ok = (unsigned)(a_iy0[j] + s_ky) < (unsigned)p.Hin && (unsigned)(a_ix0[j] + s_kx) < (unsigned)p.Win;
+                src = ok ? a_ptr[j] + (int64_t)(s_ky * p.Win + s_kx) * p.lda + s_c0 : zp;
+            } else {
+                src = a_ptr[j] + s_t * 64;
+            }
+            glds16(src, sa + (j * RPR + wave * 8) * 128);
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) glds16(w_ptr[j] + s_t * 64, sb + (j * RPR + wave * 8) * 128);
+        // advance
+        ++s_t;
+        if (CONV) {
+            s_c0 += 64;
+            if (s_c0 >= p.Cin) {
+                s_c0 = 0;
+                if (++s_kx >= p.KW) {
+                    s_kx = 0;
+                    ++s_ky;
+                }
+            }
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets: row = tile row of the 16-row fragment + (lane & 15); (row & 7) == (lane & 7)
+    const int frow = lane & 15, fq = lane >> 4, sw = lane & 7;
+    const int koff0 = ((0 + fq) ^ sw) << 4, koff1 = ((4 + fq) ^ sw) << 4;
+    const int a_base = (wm * TM + frow) * 128, b_base = (wn * TN + frow) * 128;
+
+    const int nt = p.K >> 6;
+    stage(0);
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();  // tile t has landed (vmcnt(0) precedes the barrier) and buffer (t+1)&1 is free
+        if (t + 1 < nt) stage((t + 1) & 1);
+        const char* sa = smem + (t & 1) * STAGE;
+        const char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ko = kk ? koff1 : koff0;
+            v8 af[FM], bf[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                af[i] = *reinterpret_cast<const v8*>(sa + a_base + i * 16 * 128 + ko);
+                if (p.relu_a) af[i] = relu8<T>(af[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const v8*>(sb + b_base + j * 16 * 128 + ko);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = T16<T>::mfma16(bf[j], af[i], acc[i][j]);
+        }
+    }
+
+    // ---- epilogue, staged through LDS so that global stores are row-contiguous and the fused
+    // epilogue code exists once (a runtime loop) instead of once per accumulator fragment.
+    // lane holds acc[m = ..+(lane&15)][n = ..+(lane>>4)*4 + 0..3]
+    constexpr int LDC = BN + 4;                                  // fp32 row stride (pad: conflict-free b128 writes)
+    constexpr int PASS_ROWS = (2 * STAGE) / (LDC * 4) >= BM ? BM : BM / 2;
+    static_assert(PASS_ROWS * LDC * 4 <= 2 * STAGE, "epilogue staging does not fit the main-loop LDS");
+    static_assert(PASS_ROWS % TM == 0, "a pass must cover whole wave tiles");
+    constexpr int PASSES = BM / PASS_ROWS;
+    float* sc = reinterpret_cast<float*>(smem);
+    const bool v_tile = (p.out_mode == BS_OUT_QKV) && (tn * BN >= 2 * p.qkv_hidden);
+    for (int ps = 0; ps < PASSES; ++ps) {
+        __syncthreads();  // main loop (or previous pass) is done with the LDS
+        if ((wm * TM) / PASS_ROWS == ps) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int r = wm * TM - ps * PASS_ROWS + i * 16 + frow;
+                    *reinterpret_cast<f32x4*>(sc + r * LDC + wn * TN + j * 16 + fq * 4) = acc[i][j];
+                }
+        }
+        __syncthreads();
+        const int m_base = tm * BM + ps * PASS_ROWS;
+        if (!v_tile) {
+            constexpr int C4 = BN / 4;
+            for (int idx = tid; idx < PASS_ROWS * C4; idx += NT) {
+                const int r = idx / C4, c4 = idx - r * C4;
+                const int m = m_base + r, n0 = tn * BN + c4 * 4;
+                if (m >= p.M || n0 >= p.N) continue;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(sc + r * LDC + c4 * 4);
+                float y[4] = {a[0], a[1], a[2], a[3]};
+                if (p.bias) {
+                    const float* bias_row = p.bias + (p.bias_group_rows ? (int64_t)(m / p.bias_group_rows) * p.N : 0);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(bias_row + n0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] += b[e];
+                }
+                if (p.act != BS_ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = apply_act(y[e], p.act);
+                }
+                if (p.scale) {
+                    const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.scale + n0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] *= s4[e];
+                }
+                if (p.res) {
+                    const int64_t ro = (int64_t)m * p.ldr + n0;
+                    if (p.res_dtype == BS_F32) {
+                        const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + ro);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] += rr[e];
+                    } else {
+                        const typename T16<T>::v4 rr = *reinterpret_cast<const typename T16<T>::v4*>(reinterpret_cast<const T*>(p.res) + ro);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] += T16<T>::to_f32(rr[e]);
+                    }
+                }
+                if (p.out_mode == BS_OUT_PLAIN) {
+                    int64_t orow = m;
+                    if (p.out_group_rows) {
+                        const int g = m / p.out_group_rows;
+                        orow = (int64_t)g * p.out_group_stride + (m - g * p.out_group_rows) + p.out_row_offset;
+                    }
+                    store4<T>(p.out, orow * p.ldo + n0, p.out_dtype, y);
+                } else if (p.out_mode == BS_OUT_SHUFFLE) {
+                    const int hw = p.Hout * p.Wout;
+                    const int ob = m / hw, rem = m - ob * hw;
+                    const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+                    const int s = p.shuffle_s;
+                    const int tap = n0 / p.shuffle_cout, co = n0 - tap * p.shuffle_cout;
+                    const int ky = tap / s, kx = tap - ky * s;
+                    const int64_t pix = ((int64_t)(ob * p.Hout + oy) * s + ky) * (p.Wout * s) + ox * s + kx;
+                    store4<T>(p.out, pix * p.ldo + co, p.out_dtype, y);
+                } else {  // Q or K part of the fused QKV projection
+                    const int ob = m / p.qkv_tokens, otok = m - ob * p.qkv_tokens;
+                    const int which = n0 / p.qkv_hidden, rem = n0 - which * p.qkv_hidden;
+                    const int hh = rem >> 6, d = rem & 63, nh = p.qkv_hidden >> 6;
+                    const int64_t off = (((int64_t)ob * nh + hh) * p.qkv_sp + otok) * 64 + d;
+                    if (which == 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] *= p.q_scale;
+                        store4<T>(p.out, off, p.out_dtype, y);
+                    } else {
+                        store4<T>(p.out2, off, p.out_dtype, y);
+                    }
+                }
+            }
+        } else {
+            // V part: written transposed (V^T [B,nh,64,Sp]); consecutive lanes take consecutive tokens
+            T* vt = reinterpret_cast<T*>(p.out3);
+            const int nh = p.qkv_hidden >> 6;
+            for (int idx = tid; idx < PASS_ROWS * BN; idx += NT) {
+                const int c = idx / PASS_ROWS, r = idx - c * PASS_ROWS;
+                const int m = m_base + r, n = tn * BN + c;
+                if (m >= p.M || n >= p.N) continue;
+                float y = sc[r * LDC + c];
+                if (p.bias) y += p.bias[n];
+                const int ob = m / p.qkv_tokens, otok = m - ob * p.qkv_tokens;
+                const int rem = n - 2 * p.qkv_hidden;
+                const int hh = rem >> 6, d = rem & 63;
+                vt[(((int64_t)ob * nh + hh) * 64 + d) * p.qkv_sp + otok] = T16<T>::from_f32(y);
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_variant(const IgemmParams& p, bool conv, hipStream_t st) {
+    constexpr int smem = 2 * (BM + BN) * 128;
+    dim3 grid(p.ntm * p.ntn), block(WM * WN * 64);
+    if (conv) {
+        auto k = igemm_kernel<T, BM, BN, WM, WN, true>;
+        static bool attr = false;
+        if (!attr) {
+            BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr = true;
+        }
+        hipLaunchKernelGGL(k, grid, block, smem, st, p);
+    } else {
+        auto k = igemm_kernel<T, BM, BN, WM, WN, false>;
+        static bool attr = false;
+        if (!attr) {
+            BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr = true;
+        }
+        hipLaunchKernelGGL(k, grid, block, smem, st, p);
+    }
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+template <typename T>
+static int dispatch(IgemmParams& p, bool conv, int tile, hipStream_t st) {
+    if (tile == 0) {
+        if (p.N <= 32) tile = 3;
+        else if (p.N <= 64) tile = 2;
+        else if (p.M >= 16384 && p.N % 128 == 0) tile = 4;
+        else tile = 1;
+    }
+    int BM, BN;
+    switch (tile) {
+        case 1: BM = 128; BN = 128; break;
+        case 2: BM = 128; BN = 64; break;
+        case 3: BM = 128; BN = 32; break;
+        case 4: BM = 256; BN = 128; break;
+        default: set_error("bs_gemm: unknown tile %d", tile); return BS_ERR_INVALID;
+    }
+    p.ntm = cdiv(p.M, BM);
+    p.ntn = cdiv(p.N, BN);
+    switch (tile) {
+        case 1: return launch_variant<T, 128, 128, 2, 2>(p, conv, st);
+        case 2: return launch_variant<T, 128, 64, 2, 2>(p, conv, st);
+        case 3: return launch_variant<T, 128, 32, 4, 1>(p, conv, st);
+        default: return launch_variant<T, 256, 128, 4, 2>(p, conv, st);
+    }
+}
+
+}  // namespace bs
+
+extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
+    using namespace bs;
+    if (!initialized()) { set_error("bs_gemm: call bs_init first"); return BS_ERR_NOT_INIT; }
+    BS_REQUIRE(d && d->A && d->W && d->out, "bs_gemm: null operand");
+    BS_REQUIRE(d->dtype == BS_F16 || d->dtype == BS_BF16, "bs_gemm: dtype must be f16 or bf16");
+    BS_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "bs_gemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
+    BS_REQUIRE(d->N % 4 == 0, "bs_gemm: N=%d must be a multiple of 4", d->N);
+    BS_REQUIRE(d->K % 64 == 0, "bs_gemm: K=%d must be a multiple of 64", d->K);
+    BS_REQUIRE(d->lda % 8 == 0, "bs_gemm: lda=%d must be a multiple of 8 (16-byte rows)", d->lda);
+    BS_REQUIRE(d->out_dtype == BS_F32 || d->out_dtype == d->dtype, "bs_gemm: out_dtype must be f32 or the operand dtype");
+    BS_REQUIRE(!d->res || d->res_dtype == BS_F32 || d->res_dtype == d->dtype, "bs_gemm: res_dtype must be f32 or the operand dtype");
+    IgemmParams p{};
+    p.A = d->A; p.W = d->W; p.zero = zero_page();
+    p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda;
+    p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin; p.Hout = d->Hout; p.Wout = d->Wout;
+    p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
+    if (d->conv) {
+        BS_REQUIRE(d->Cin > 0 && d->Cin % 64 == 0, "bs_gemm: conv Cin=%d must be a multiple of 64", d->Cin);
+        BS_REQUIRE(d->K == d->KH * d->KW * d->Cin, "bs_gemm: conv K=%d != KH*KW*Cin", d->K);
+        BS_REQUIRE(d->Hout > 0 && d->Wout > 0 && d->M % (d->Hout * d->Wout) == 0, "bs_gemm: conv M=%d not a multiple of Hout*Wout", d->M);
+        BS_REQUIRE(d->stride > 0 && d->lda >= d->Cin, "bs_gemm: bad conv stride/lda");
+        p.tiles_per_tap = d->Cin / 64;
+    }
+    p.relu_a = d->relu_a;
+    p.bias = d->bias; p.bias_group_rows = d->bias_group_rows; p.act = d->act; p.scale = d->scale;
+    p.res = d->res; p.res_dtype = d->res_dtype; p.ldr = d->ldr;
+    p.out = d->out; p.out2 = d->out2; p.out3 = d->out3; p.out_dtype = d->out_dtype; p.ldo = d->ldo; p.out_mode = d->out_mode;
+    p.out_group_rows = d->out_group_rows; p.out_group_stride = d->out_group_stride; p.out_row_offset = d->out_row_offset;
+    p.shuffle_s = d->shuffle_s; p.shuffle_cout = d->shuffle_cout;
+    p.qkv_hidden = d->qkv_hidden; p.qkv_tokens = d->qkv_tokens; p.qkv_sp = d->qkv_sp; p.q_scale = d->q_scale;
+    if (d->out_mode == BS_OUT_SHUFFLE) {
+        BS_REQUIRE(!d->conv && d->shuffle_s > 0 && d->shuffle_cout % 4 == 0 && d->N == d->shuffle_s * d->shuffle_s * d->shuffle_cout,
+                   "bs_gemm: bad shuffle geometry");
+        BS_REQUIRE(d->Hout > 0 && d->Wout > 0 && d->M % (d->Hout * d->Wout) == 0, "bs_gemm: shuffle needs the input grid in Hout/Wout");
+    } else if (d->out_mode == BS_OUT_QKV) {
+        BS_REQUIRE(d->out2 && d->out3 && d->qkv_hidden % 64 == 0 && d->N == 3 * d->qkv_hidden && d->qkv_tokens > 0 &&
+                       d->M % d->qkv_tokens == 0 && d->qkv_sp >= d->qkv_tokens && d->out_dtype == d->dtype,
+                   "bs_gemm: bad qkv geometry");
+    } else {
+        BS_REQUIRE(d->out_mode == BS_OUT_PLAIN && d->ldo >= d->N, "bs_gemm: bad out_mode/ldo");
+        BS_REQUIRE(d->ldo % 4 == 0, "bs_gemm: ldo must be a multiple of 4");
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == BS_F16) return dispatch<f16>(p, d->conv != 0, d->tile, st);
+    return dispatch<bf16>(p, d->conv != 0, d->tile, st);
+}

@@ -1,0 +1,296 @@
+// Metric-bins head (ZoeD_NK) per-pixel kernels and the domain router's small pieces.
+// The [B,64,384,512] bin/probability tensors of the reference are never materialised: the final
+// kernel interpolates bin centres, evaluates the per-pixel MLP tail, the log-binomial softmax and
+// the expectation in registers.
+//   HF modeling_zoedepth.py:376-491 (log-binomial), :665-746 (attractor, unnormed), :885-962 (router),
+//   :965-1103 (multi-head forward)
+#include "common.h"
+
+namespace bs {
+
+// bilinear, align_corners=True source coordinates
+struct Lerp2 {
+    int y0, y1, x0, x1;
+    float ly, lx, hy, hx;
+};
+__device__ __forceinline__ Lerp2 lerp_ac(int oy, int ox, int Hin, int Win, float sy, float sx) {
+    Lerp2 l;
+    const float fy = sy * (float)oy, fx = sx * (float)ox;
+    l.y0 = (int)fy;
+    l.x0 = (int)fx;
+    l.y0 = l.y0 > Hin - 1 ? Hin - 1 : l.y0;
+    l.x0 = l.x0 > Win - 1 ? Win - 1 : l.x0;
+    l.y1 = l.y0 + (l.y0 < Hin - 1 ? 1 : 0);
+    l.x1 = l.x0 + (l.x0 < Win - 1 ? 1 : 0);
+    l.ly = fy - (float)l.y0;
+    l.lx = fx - (float)l.x0;
+    l.hy = 1.0f - l.ly;
+    l.hx = 1.0f - l.lx;
+    return l;
+}
+
+// ---------------------------------------------------------------------------------------------
+// attractor step.  bins are NHWC fp32 with G groups (heads) of nb bins; A has G groups of na
+// attractors.  thread = (pixel, group, 4 consecutive bins).  With `route`, only the group that an
+// image is routed to is computed (the other group's output is left untouched).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attractor_kernel(const float* A, const float* bins_prev, float* bins_out, const int32_t* route,
+                                                         int B, int Hp, int Wp, int H, int W, int G, int nb, int na, float sy, float sx) {
+    const int q4 = nb >> 2;
+    const int64_t total = (int64_t)B * H * W * G * q4;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int q = (int)(gid % q4);
+    const int g = (int)((gid / q4) % G);
+    const int64_t pix = gid / ((int64_t)q4 * G);
+    const int ox = (int)(pix % W), oy = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+    if (route && route[b] != g) return;
+    const Lerp2 l = lerp_ac(oy, ox, Hp, Wp, sy, sx);
+    const int CB = G * nb, CA = G * na;
+    const float* pb = bins_prev + (int64_t)b * Hp * Wp * CB + g * nb + q * 4;
+    const f32x4 p00 = *reinterpret_cast<const f32x4*>(pb + ((int64_t)l.y0 * Wp + l.x0) * CB);
+    const f32x4 p01 = *reinterpret_cast<const f32x4*>(pb + ((int64_t)l.y0 * Wp + l.x1) * CB);
+    const f32x4 p10 = *reinterpret_cast<const f32x4*>(pb + ((int64_t)l.y1 * Wp + l.x0) * CB);
+    const f32x4 p11 = *reinterpret_cast<const f32x4*>(pb + ((int64_t)l.y1 * Wp + l.x1) * CB);
+    float c[4], dsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c[e] = l.hy * (l.hx * p00[e] + l.lx * p01[e]) + l.ly * (l.hx * p10[e] + l.lx * p11[e]);
+    const float* pa = A + pix * CA + g * na;
+    for (int a = 0; a < na; ++a) {
+        const float av = pa[a];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float dx = av - c[e];
+            dsum[e] += dx / (1.0f + 300.0f * (dx * dx));  // inv_attractor defaults alpha=300, gamma=2
+        }
+    }
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = c[e] + dsum[e] / (float)na;
+    *reinterpret_cast<f32x4*>(bins_out + pix * CB + g * nb + q * 4) = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// conditional log-binomial + expectation.  thread = one output pixel.
+//   hidden = gelu( interp(Eh)[40] + W0_last[40x32] . last[32] )     (Eh already holds W0_emb.emb + b0)
+//   pt = softplus(W2[4x40] . hidden + b2); p = (pt0+eps)/(pt0+pt1+2eps); T = (max-min)*t + min
+//   y_k = logC(n-1,k) + k log p + (n-1-k) log(1-p); depth = sum_k softmax(y/T)_k * interp(bins)_k
+// ---------------------------------------------------------------------------------------------
+constexpr int LB_HID = 40, LB_IN = 32, LB_BINS = 64;
+
+template <typename T>
+__global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const float* Eh, const float* bins, const float* w0_last,
+                                                        const float* w2, const float* b2, const int32_t* route, float* depth, int B, int H,
+                                                        int W, int He, int We, float sy, float sx, float min_temp, float max_temp) {
+    __shared__ float s_w0[2][LB_HID][LB_IN + 1];
+    __shared__ float s_w2[2][4][LB_HID];
+    __shared__ float s_b2[2][4];
+    __shared__ float s_lb[LB_BINS];
+    for (int i = threadIdx.x; i < 2 * LB_HID * LB_IN; i += blockDim.x) {
+        const int g = i / (LB_HID * LB_IN), r = (i / LB_IN) % LB_HID, c = i % LB_IN;
+        s_w0[g][r][c] = w0_last[i];
+    }
+    for (int i = threadIdx.x; i < 2 * 4 * LB_HID; i += blockDim.x) s_w2[i / (4 * LB_HID)][(i / LB_HID) % 4][i % LB_HID] = w2[i];
+    if (threadIdx.x < 8) s_b2[threadIdx.x / 4][threadIdx.x % 4] = b2[threadIdx.x];
+    if (threadIdx.x < LB_BINS) {
+        // log_binom(n = 63, k) with the reference's eps placement (modeling_zoedepth.py:376-381)
+        const float e = 1e-7f;
+        const float n = (float)(LB_BINS - 1) + e, k = (float)threadIdx.x + e;
+        s_lb[threadIdx.x] = n * logf(n) - k * logf(k) - (n - k) * logf(n - k + e);
+    }
+    __syncthreads();
+    const int64_t total = (int64_t)B * H * W;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int ox = (int)(gid % W), oy = (int)((gid / W) % H), b = (int)(gid / ((int64_t)W * H));
+    const int g = route[b];
+    const Lerp2 l = lerp_ac(oy, ox, He, We, sy, sx);
+    const float w00 = l.hy * l.hx, w01 = l.hy * l.lx, w10 = l.ly * l.hx, w11 = l.ly * l.lx;
+    const int64_t e00 = ((int64_t)b * He + l.y0) * We + l.x0, e01 = ((int64_t)b * He + l.y0) * We + l.x1;
+    const int64_t e10 = ((int64_t)b * He + l.y1) * We + l.x0, e11 = ((int64_t)b * He + l.y1) * We + l.x1;
+
+    // the 32 `last` features of this pixel
+    float xin[LB_IN];
+    {
+        typedef typename T16<T>::v8 v8;
+        const T* lp = last + gid * LB_IN;
+#pragma unroll
+        for (int v = 0; v < LB_IN / 8; ++v) {
+            const v8 t = *reinterpret_cast<const v8*>(lp + v * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xin[v * 8 + e] = (float)t[e];
+        }
+    }
+    float pt[4] = {s_b2[g][0], s_b2[g][1], s_b2[g][2], s_b2[g][3]};
+    const int EC = 2 * LB_HID;
+    for (int h = 0; h < LB_HID; ++h) {
+        const int ch = g * LB_HID + h;
+        // same bilinear operation order as torch: hy*(hx*p00 + lx*p01) + ly*(hx*p10 + lx*p11)
+        float a = l.hy * (l.hx * Eh[e00 * EC + ch] + l.lx * Eh[e01 * EC + ch]) + l.ly * (l.hx * Eh[e10 * EC + ch] + l.lx * Eh[e11 * EC + ch]);
+#pragma unroll
+        for (int c = 0; c < LB_IN; ++c) a += s_w0[g][h][c] * xin[c];
+        a = gelu_erf(a);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) pt[o] += s_w2[g][o][h] * a;
+    }
+    (void)w00; (void)w01; (void)w10; (void)w11;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) pt[o] = softplus20(pt[o]);
+    const float eps = 1e-4f;
+    float p = (pt[0] + eps) / ((pt[0] + eps) + (pt[1] + eps));
+    float t = (pt[2] + eps) / ((pt[2] + eps) + (pt[3] + eps));
+    t = (max_temp - min_temp) * t + min_temp;
+    float omp = 1.0f - p;
+    omp = fminf(fmaxf(omp, eps), 1.0f);
+    p = fminf(fmaxf(p, eps), 1.0f);
+    const float lp_ = logf(p), lomp = logf(omp);
+    // pass 1: max of y/T
+    float mx = -3.0e38f;
+    for (int k = 0; k < LB_BINS; ++k) {
+        const float y = (s_lb[k] + (float)k * lp_ + (float)(LB_BINS - 1 - k) * lomp) / t;
+        mx = fmaxf(mx, y);
+    }
+    const int CB = 2 * LB_BINS;
+    const float* bb = bins + g * LB_BINS;
+    float den = 0.f, num = 0.f;
+    for (int k4 = 0; k4 < LB_BINS / 4; ++k4) {
+        const f32x4 c00 = *reinterpret_cast<const f32x4*>(bb + e00 * CB + k4 * 4);
+        const f32x4 c01 = *reinterpret_cast<const f32x4*>(bb + e01 * CB + k4 * 4);
+        const f32x4 c10 = *reinterpret_cast<const f32x4*>(bb + e10 * CB + k4 * 4);
+        const f32x4 c11 = *reinterpret_cast<const f32x4*>(bb + e11 * CB + k4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k4 * 4 + e;
+            const float y = (s_lb[k] + (float)k * lp_ + (float)(LB_BINS - 1 - k) * lomp) / t;
+            const float w = expf(y - mx);
+            const float c = l.hy * (l.hx * c00[e] + l.lx * c01[e]) + l.ly * (l.hx * c10[e] + l.lx * c11[e]);
+            den += w;
+            num += w * c;
+        }
+    }
+    depth[gid] = num / den;
+}
+
+// ---------------------------------------------------------------------------------------------
+// router pieces: small multi-head attention (S <= 256, head_dim 32, no mask), argmax
+// qkv fp32 [B*S, 3*D] (q | k | v), out 16-bit [B*S, D]
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void small_attention_kernel(const float* qkv, T* out, int S, int nheads, float scale) {
+    constexpr int HD = 32;
+    const int b = blockIdx.x / nheads, h = blockIdx.x % nheads;
+    const int D = nheads * HD;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* ks = reinterpret_cast<float*>(smem_raw);  // [S][HD+1]
+    float* vs = ks + S * (HD + 1);
+    for (int i = threadIdx.x; i < S * HD; i += blockDim.x) {
+        const int t = i / HD, d = i % HD;
+        const float* row = qkv + ((int64_t)b * S + t) * 3 * D + h * HD + d;
+        ks[t * (HD + 1) + d] = row[D];
+        vs[t * (HD + 1) + d] = row[2 * D];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < S; t += blockDim.x) {
+        float q[HD], o[HD];
+        const float* qr = qkv + ((int64_t)b * S + t) * 3 * D + h * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            q[d] = qr[d];
+            o[d] = 0.f;
+        }
+        float mx = -3.0e38f;
+        for (int j = 0; j < S; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) s += q[d] * ks[j * (HD + 1) + d];
+            mx = fmaxf(mx, s * scale);
+        }
+        float den = 0.f;
+        for (int j = 0; j < S; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) s += q[d] * ks[j * (HD + 1) + d];
+            const float w = expf(s * scale - mx);
+            den += w;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) o[d] += w * vs[j * (HD + 1) + d];
+        }
+        T* orow = out + ((int64_t)b * S + t) * D + h * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) orow[d] = T16<T>::from_f32(o[d] / den);
+    }
+}
+
+__global__ void route_argmax_kernel(const float* logits, int ld, int32_t* route, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    // torch.argmax returns the first maximal index
+    route[b] = logits[(int64_t)b * ld + 1] > logits[(int64_t)b * ld] ? 1 : 0;
+}
+
+}  // namespace bs
+
+using namespace bs;
+#define BS_ENTRY(name) \
+    if (!initialized()) { set_error(name ": call bs_init first"); return BS_ERR_NOT_INIT; }
+
+extern "C" int bs_attractor_step(const float* A, const float* bins_prev, float* bins_out, const int32_t* route, int32_t B, int32_t Hp,
+                                 int32_t Wp, int32_t H, int32_t W, int32_t groups, int32_t n_bins, int32_t n_attr, void* stream) {
+    BS_ENTRY("bs_attractor_step");
+    BS_REQUIRE(A && bins_prev && bins_out && B >= 0 && Hp > 0 && Wp > 0 && H > 0 && W > 0 && groups > 0 && n_bins % 4 == 0 && n_attr > 0,
+               "bs_attractor_step: bad argument");
+    if (B == 0) return BS_OK;
+    const float sy = H > 1 ? (float)(Hp - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(Wp - 1) / (float)(W - 1) : 0.f;
+    const int64_t total = (int64_t)B * H * W * groups * (n_bins / 4);
+    hipLaunchKernelGGL(attractor_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A,
+                       bins_prev, bins_out, route, B, Hp, Wp, H, W, groups, n_bins, n_attr, sy, sx);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+extern "C" int bs_logbinom_depth(const void* last, const float* Eh, const float* bins, const float* w0_last, const float* w2,
+                                 const float* b2, const int32_t* route, float* depth, int32_t B, int32_t H, int32_t W, int32_t He,
+                                 int32_t We, float min_temp, float max_temp, int32_t dtype, void* stream) {
+    BS_ENTRY("bs_logbinom_depth");
+    BS_REQUIRE(last && Eh && bins && w0_last && w2 && b2 && route && depth && B >= 0 && H > 0 && W > 0 && He > 0 && We > 0,
+               "bs_logbinom_depth: bad argument");
+    BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_logbinom_depth: dtype");
+    if (B == 0) return BS_OK;
+    const float sy = H > 1 ? (float)(He - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(We - 1) / (float)(W - 1) : 0.f;
+    const int64_t total = (int64_t)B * H * W;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == BS_F16)
+        hipLaunchKernelGGL(logbinom_kernel<f16>, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, (const f16*)last, Eh, bins, w0_last,
+                           w2, b2, route, depth, B, H, W, He, We, sy, sx, min_temp, max_temp);
+    else
+        hipLaunchKernelGGL(logbinom_kernel<bf16>, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, (const bf16*)last, Eh, bins,
+                           w0_last, w2, b2, route, depth, B, H, W, He, We, sy, sx, min_temp, max_temp);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+extern "C" int bs_small_attention(const float* qkv, void* out, int32_t B, int32_t S, int32_t nheads, int32_t dtype, void* stream) {
+    BS_ENTRY("bs_small_attention");
+    BS_REQUIRE(qkv && out && B >= 0 && S > 0 && S <= 512 && nheads > 0, "bs_small_attention: bad argument");
+    BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_small_attention: dtype");
+    if (B == 0) return BS_OK;
+    const size_t smem = (size_t)2 * S * 33 * sizeof(float);
+    BS_REQUIRE(smem <= 64 * 1024, "bs_small_attention: S too large for LDS");
+    const float scale = 1.0f / sqrtf(32.0f);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == BS_F16)
+        hipLaunchKernelGGL(small_attention_kernel<f16>, dim3(B * nheads), dim3(256), smem, st, qkv, (f16*)out, S, nheads, scale);
+    else
+        hipLaunchKernelGGL(small_attention_kernel<bf16>, dim3(B * nheads), dim3(256), smem, st, qkv, (bf16*)out, S, nheads, scale);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+extern "C" int bs_route_argmax(const float* logits, int32_t ld, int32_t* route, int32_t B, void* stream) {
+    BS_ENTRY("bs_route_argmax");
+    BS_REQUIRE(logits && route && B >= 0 && ld >= 2, "bs_route_argmax: bad argument");
+    if (B == 0) return BS_OK;
+    hipLaunchKernelGGL(route_argmax_kernel, dim3(cdiv(B, 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), logits, ld, route, B);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}

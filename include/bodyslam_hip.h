@@ -1,0 +1,198 @@
+/* bodyslam_hip.h -- C ABI of libbodyslam_hip.so (gfx950 / MI355X only).
+ *
+ * The reference (GuidoManni/BodySLAM) is pure Python with no FFI of its own: every op on its hot
+ * path is a PyTorch-CUDA dispatch.  Each entry point below names the reference call it replaces
+ * (paths relative to the reference repo; "HF" = transformers 5.15.0, the installed restatement of
+ * the un-vendored isl-org/ZoeDepth network the reference pulls through torch.hub at
+ * BodySLAM_Refactored/src/depth_estimation/interface.py:46).
+ *
+ * Conventions: plain pointers are DEVICE pointers unless marked host; `stream` is a hipStream_t
+ * passed as void*; every function returns 0 or a negative bs_status and never throws; the library
+ * allocates nothing per call (callers own every buffer; bs_init allocates one 4 KiB zero page).
+ * INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ */
+#ifndef BODYSLAM_HIP_H
+#define BODYSLAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    BS_OK = 0,
+    BS_ERR_INVALID = -1,   /* bad argument / unsupported shape */
+    BS_ERR_HIP = -2,       /* a HIP runtime call failed; see bs_last_error() */
+    BS_ERR_NOT_INIT = -3
+} bs_status;
+
+enum { BS_F32 = 0, BS_F16 = 1, BS_BF16 = 2 };
+enum { BS_ACT_NONE = 0, BS_ACT_RELU = 1, BS_ACT_GELU = 2, BS_ACT_SOFTPLUS = 3 };
+enum { BS_OUT_PLAIN = 0, BS_OUT_SHUFFLE = 1, BS_OUT_QKV = 2 };
+
+/* library ------------------------------------------------------------------------------------ */
+int bs_init(int device);                 /* replaces .to("cuda") at interface.py:49-51, mpem_interface.py:34,60 */
+const char* bs_last_error(void);
+int bs_version(void);
+
+/* implicit GEMM on MFMA ---------------------------------------------------------------------- *
+ * out[m, n] = epilogue( sum_k A(m, k) * W[n, k] ),  A/W fp16 or bf16, fp32 accumulate.
+ * Replaces every nn.Linear / nn.Conv2d / nn.ConvTranspose2d(k == stride) on the path:
+ *   BEiT q/k/v/o_proj, fc1, fc2           HF modeling_beit.py:296-357
+ *   patch embedding Conv16x16 s16         HF modeling_beit.py:63-90
+ *   DPT readout / 1x1 / ConvT / 3x3 convs HF modeling_zoedepth.py:55-149,153-329,332-373
+ *   metric-head 1x1 convs                 HF modeling_zoedepth.py:494-547,665-772
+ *   CyclePose Conv7x7 / Conv3x3 s2        MPEM/architecture_v3.py:120-147
+ * conv == 0: A is [M, K] with row stride lda.   conv == 1: A is an NHWC batch [B, Hin, Win, lda>=Cin],
+ * K = KH*KW*Cin ordered (ky, kx, ci), M = B*Hout*Wout, zero padding pad_h/pad_w (may be negative:
+ * a crop), W is [N][KH][KW][Cin].  Cin (conv) / K (plain) must be a multiple of 64.
+ * epilogue: y = acc + bias[(m / bias_group_rows) * N + n]  (bias_group_rows == 0: bias[n]);
+ *           y = act(y); y *= scale[n]; y += res[m * ldr + n]; store as out_dtype.
+ * out_mode BS_OUT_PLAIN  : out[orow * ldo + n], orow = (m / out_group_rows) * out_group_stride
+ *                          + m % out_group_rows + out_row_offset (out_group_rows == 0: orow = m)
+ *          BS_OUT_SHUFFLE: ConvTranspose2d(kernel == stride == shuffle_s): n = (ky*s + kx)*Cout + co,
+ *                          out is NHWC [B, Hout*s, Wout*s, shuffle_cout]
+ *          BS_OUT_QKV    : n = which*hidden + head*64 + d; tokens_per_image rows per image;
+ *                          out -> Q [B,nh,Sp,64] (scaled by q_scale), out2 -> K [B,nh,Sp,64],
+ *                          out3 -> V^T [B,nh,64,Sp]
+ */
+typedef struct bs_gemm_desc {
+    const void* A;
+    const void* W;
+    int32_t dtype;                 /* BS_F16 | BS_BF16 */
+    int32_t M, N, K;
+    int32_t lda;
+    int32_t conv;
+    int32_t Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_h, pad_w;
+    int32_t relu_a;                /* ReLU on A while loading (pre-activation residual unit) */
+    const float* bias;
+    int32_t bias_group_rows;
+    int32_t act;
+    const float* scale;
+    const void* res;
+    int32_t res_dtype;             /* BS_F32 | BS_F16 | BS_BF16 */
+    int32_t ldr;
+    void* out;
+    void* out2;
+    void* out3;
+    int32_t out_dtype;
+    int32_t ldo;
+    int32_t out_mode;
+    int32_t out_group_rows, out_group_stride, out_row_offset;
+    int32_t shuffle_s, shuffle_cout;
+    int32_t qkv_hidden, qkv_tokens, qkv_sp;
+    float q_scale;
+    int32_t tile;                  /* 0 = auto; else forces a tile variant (tests / tuning) */
+} bs_gemm_desc;
+int bs_gemm(const bs_gemm_desc* d, void* stream);
+
+/* BEiT attention: softmax(Q K^T + relpos_bias) V -------------------------------------------- *
+ * HF modeling_beit.py:268-341 (eager_attention_forward with the additive relative-position bias
+ * of :179-265).  q [B,nh,Sp,64] (pre-scaled by 1/8), k [B,nh,Sp,64], vt [B,nh,64,Sp], Sp % 64 == 0,
+ * rows/cols >= S zero; bias fp32 [nh,Sp,Sp] with -inf (<= -1e30) in key columns >= S.
+ * out [B*S, nh*64] token-major (the o_proj GEMM's A operand). */
+int bs_attention(const void* q, const void* k, const void* vt, const float* bias, void* out,
+                 int32_t B, int32_t nh, int32_t S, int32_t Sp, int32_t dtype, void* stream);
+
+/* LayerNorm over the last dim, fp32 in; out16 (fp16/bf16, nullable) and out32 (fp32, nullable, may
+ * alias x) -- HF modeling_beit.py:418,432; post-norm of the router HF modeling_zoedepth.py:876-881 */
+int bs_layernorm(const float* x, const float* gamma, const float* beta, void* out16, float* out32, int32_t rows,
+                 int32_t cols, float eps, int32_t dtype, void* stream);
+
+/* fp32 -> fp16/bf16 cast (tap copies of the residual stream) */
+int bs_cast(const float* x, void* out, int64_t n, int32_t out_dtype, void* stream);
+
+/* MDEM pre-processing: uint8 frames -> im2col'ed patch matrix --------------------------------- *
+ * HF image_processing_pil_zoedepth.py:181-232 (upstream depth_model.py#L57): /255, reflect pad,
+ * bilinear align_corners=True resize to (nh, nw), (x-0.5)/0.5; fused with the 16x16 patch gather
+ * of HF modeling_beit.py:83-90.  frames [B,H,W,3] u8; out [2B or B][(nh/16)*(nw/16)][3*16*16]
+ * (k = c*256 + ky*16 + kx); images B..2B-1 are the W-flipped copies when flip != 0. */
+int bs_preprocess_patches(const uint8_t* frames, void* out, int32_t B, int32_t H, int32_t W, int32_t nh,
+                          int32_t nw, int32_t flip, int32_t out_dtype, void* stream);
+/* the same pre-processing to a plain NCHW fp32 image (tests) */
+int bs_preprocess_image(const uint8_t* frames, float* out, int32_t B, int32_t H, int32_t W, int32_t nh,
+                        int32_t nw, int32_t flip, void* stream);
+
+/* rows[b*rows_per_image + 0, :] = v  (cls token, HF modeling_beit.py:166-167) */
+int bs_fill_rows(float* x, const float* v, int32_t B, int32_t rows_per_image, int32_t cols, void* stream);
+
+/* bilinear resize of an NHWC fp16/bf16 map (align_corners as given) -- F.interpolate calls at HF
+ * modeling_zoedepth.py:259,319,360 */
+int bs_resize_bilinear_nhwc(const void* x, void* out, int32_t B, int32_t Hin, int32_t Win, int32_t C,
+                            int32_t Hout, int32_t Wout, int32_t align_corners, int32_t dtype, void* stream);
+
+/* metric-bins head ---------------------------------------------------------------------------- *
+ * Both heads (nyu | kitti) are carried side by side as channel groups; `route` int32 [B] (from
+ * bs_route_argmax) says which group an image uses -- per image, because the reference always runs
+ * the network with batch 1 (interface.py:61), never HF's batch-summed vote (modeling_zoedepth.py:1063-1067).
+ *
+ * attractor step, HF modeling_zoedepth.py:665-746 (unnormed, memory_efficient, kind "mean",
+ * inv_attractor defaults alpha=300 gamma=2): bins_out[b,y,x,g,:] = c + mean_a dx/(1+300 dx^2),
+ * c = bilinear(align_corners=True) resample of bins_prev to (H, W), dx = A[b,y,x,g,a] - c.
+ * A fp32 [B,H,W,groups*n_attr] (softplus already applied), bins fp32 NHWC [.,groups*n_bins];
+ * route nullable (null: every group is computed). */
+int bs_attractor_step(const float* A, const float* bins_prev, float* bins_out, const int32_t* route, int32_t B,
+                      int32_t Hp, int32_t Wp, int32_t H, int32_t W, int32_t groups, int32_t n_bins, int32_t n_attr,
+                      void* stream);
+/* out[b,y,x,:] = x[b,y,x,:] + bilinear_align_corners(prev)[b,y,x,:] (fp16/bf16 NHWC); HF :726-730 */
+int bs_add_resized(const void* x, const void* prev, void* out, int32_t B, int32_t Hp, int32_t Wp, int32_t H,
+                   int32_t W, int32_t C, int32_t dtype, void* stream);
+/* conditional log-binomial + expectation, HF modeling_zoedepth.py:376-491,1086-1101, per output pixel:
+ *   h = gelu(bilinear(Eh)[g] + W0_last[g] . last)     Eh fp32 [B,He,We,2*40] = W0_emb . emb + b0 (a bs_gemm; the
+ *                                                      1x1 conv commutes with the bilinear resample)
+ *   pt = softplus(W2[g] h + b2[g]); p, T; y_k = logC(63,k) + k log p + (63-k) log(1-p)
+ *   depth = sum_k softmax(y/T)_k * bilinear(bins)[g,k]
+ * last 16-bit [B,H,W,32]; bins fp32 [B,He,We,2*64]; w0_last [2,40,32], w2 [2,4,40], b2 [2,4] fp32. */
+int bs_logbinom_depth(const void* last, const float* Eh, const float* bins, const float* w0_last, const float* w2,
+                      const float* b2, const int32_t* route, float* depth, int32_t B, int32_t H, int32_t W,
+                      int32_t He, int32_t We, float min_temp, float max_temp, int32_t dtype, void* stream);
+/* domain router pieces, HF modeling_zoedepth.py:775-962: multi-head attention of the 4-layer patch
+ * transformer (head_dim 32, S = 1 + h*w tokens, no mask) on fused fp32 qkv [B*S, 3*D] -> out 16-bit
+ * [B*S, D]; the linear layers run on bs_gemm and the post-norms on bs_layernorm. */
+int bs_small_attention(const float* qkv, void* out, int32_t B, int32_t S, int32_t nheads, int32_t dtype, void* stream);
+/* route[b] = argmax(logits[b, 0:2]) (first maximal index, as torch.argmax), HF :1066-1067 */
+int bs_route_argmax(const float* logits, int32_t ld, int32_t* route, int32_t B, void* stream);
+
+/* MDEM post-processing: HF image_processing_pil_zoedepth.py:234-341 + upstream infer_pil:
+ * average d[b] with the un-flipped d[B+b], bicubic (A=-0.75, align_corners=False) resize of the
+ * (nh, nw) map to the padded size, crop, write metres fp32 [B,H,W] and (nullable) uint16 = trunc(m*256). */
+int bs_postprocess_depth(const float* depth_net, float* depth_m, uint16_t* depth_u16, int32_t B, int32_t H,
+                         int32_t W, int32_t nh, int32_t nw, int32_t flip, void* stream);
+
+/* MPEM (CyclePose pose branch) ---------------------------------------------------------------- */
+/* mpem_interface.py:40-44,85-94 + architecture_v3.py:120-122: center-crop 128, /255, (x-.5)/.5, pair
+ * concat, ReflectionPad(3) and 7x7 im2col: out [P*128*128, 320] (k = (ky*7+kx)*6 + c, zero padded 294..319) */
+int bs_cyclepose_im2col(const uint8_t* frames, const int32_t* pairs, void* out, int32_t P, int32_t H, int32_t W,
+                        int32_t dtype, void* stream);
+/* InstanceNorm2d(eps, no affine) + ReLU on an NHWC map, fp32 in -> fp16/bf16 out (+ optional fp32 copy)
+ * architecture_v3.py:123-124,134-137 */
+int bs_instnorm_relu_nhwc(const float* x, void* out, float* out_f32, int32_t P, int32_t HW, int32_t C, float eps,
+                          int32_t dtype, void* stream);
+/* AdaptiveAvgPool2d(1) of an NHWC fp32 map -> [P, C] fp32 (architecture_v3.py:146) */
+int bs_avgpool_nhwc(const float* x, float* out, int32_t P, int32_t HW, int32_t C, void* stream);
+/* pose head: skip_linear(cat[pooled, flatten_NCHW(x2)]) + pose_dense(pooled) -> quaternion normalise
+ * -> 4x4 (architecture_v3.py:205-226, geometry_utils.py:230-265).  x2 is NHWC fp32 [P,32,32,256]; w_skip_x2 is
+ * the skip weight re-laid to [7][HW][C]; outputs pose7 [P,7] and T [P,16] fp32.  The 262 144-long dot
+ * products are split-K partial sums combined in a fixed order (bitwise reproducible). */
+int bs_cyclepose_head(const float* pooled, const float* x2, const float* w_skip_pool, const float* w_skip_x2,
+                      const float* b_skip, const float* w1, const float* b1, const float* w2, const float* b2,
+                      float* pose7, float* T, float* scratch /* >= P*ceil(HW*C/4096)*8 floats */, int32_t P,
+                      int32_t HW, int32_t C, void* stream);
+
+/* 3DM ----------------------------------------------------------------------------------------- */
+/* 3DM/scaling_system.py:72-77 pixel_to_3d + RGBD constants of 3DM/slam_utils.py:173,212-220,232.
+ * depth u16 [B,H,W]; K = fx,fy,cx,cy (host); poses fp64 [B,16] device, nullable; xyz fp32 [B,H*W,3],
+ * idx int32 [B,H*W] (row-major order of the valid pixels), count int32 [B]; scratch int32 >= B*(H*W/256+2). */
+int bs_backproject(const uint16_t* depth, int32_t B, int32_t H, int32_t W, const double* K_host, double depth_scale,
+                   double depth_trunc, const double* poses, float* xyz, int32_t* idx, int32_t* count,
+                   int32_t* scratch, void* stream);
+/* 3DM/slam_utils.py:110-122 compute_curr_estimate_global_pose chained over N relatives (fp32 [N,16]) from
+ * g0 (fp64 [16], host, nullable = identity) -> g_abs fp64 [N+1,16]; per-step SO(3) projection
+ * (slam_utils.py:93-108).  Sequential by construction: one wavefront. */
+int bs_pose_chain(const float* t_rel, int32_t N, const double* g0_host, double* g_abs, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BODYSLAM_HIP_H */

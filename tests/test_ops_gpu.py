@@ -1,0 +1,447 @@
+"""Per-kernel parity of the HIP library (through the C ABI) against plain torch fp32 of the same op.
+Every test here needs a real MI355X: run with `pytest -m gpu`."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = os.path.join(ROOT, "gpurun_out", "ops_report.txt")
+
+
+def report(line):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(line + "\n")
+    print(line)
+
+
+@pytest.fixture(scope="module")
+def L():
+    from bodyslam_amd import _lib
+    _lib.init(0)
+    return _lib
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev())
+
+
+DT = [torch.float16, torch.bfloat16]
+
+
+def tol(dtype, k):
+    # 16-bit inputs are exact in the fp32 reference; only the fp32-accumulate order and the output rounding differ
+    return (2e-3 if dtype == torch.float16 else 1.6e-2)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K,tile", [(128, 128, 64, 1), (300, 256, 192, 1), (257, 64, 128, 2), (1000, 32, 256, 3),
+                                        (513, 384, 1024, 4), (64, 8, 64, 0), (2049, 1024, 512, 0), (40000, 256, 256, 0)])
+def test_gemm_plain(L, dtype, M, N, K, tile):
+    A = rnd(M, K, seed=1, dtype=dtype)
+    W = rnd(N, K, seed=2, scale=1 / math.sqrt(K), dtype=dtype)
+    bias = rnd(N, seed=3)
+    out = torch.empty(M, N, device=dev(), dtype=torch.float32)
+    L.gemm(A, W, out, M=M, N=N, K=K, lda=K, bias=bias, tile=tile)
+    ref = A.float() @ W.float().t() + bias
+    err = (out - ref).abs().max().item()
+    report(f"gemm_plain {dtype} M{M} N{N} K{K} tile{tile}: max|err|={err:.3e}")
+    assert err < 2e-3 * max(1.0, ref.abs().max().item())
+    # 16-bit output + relu
+    out16 = torch.empty(M, N, device=dev(), dtype=dtype)
+    L.gemm(A, W, out16, M=M, N=N, K=K, lda=K, bias=bias, act=L.ACT_RELU, tile=tile)
+    assert (out16.float() - F.relu(ref)).abs().max().item() < tol(dtype, K) * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_epilogue_gelu_scale_residual_groups(L, dtype):
+    M, N, K = 2 * 768, 256, 128
+    A = rnd(M, K, seed=1, dtype=dtype)
+    W = rnd(N, K, seed=2, scale=1 / math.sqrt(K), dtype=dtype)
+    bias_g = rnd(2, N, seed=3)
+    scale = rnd(N, seed=4)
+    # output rows regrouped 768 -> 769 with offset 1 (the patch-embed / readout pattern), fp32 residual in the output geometry
+    res = rnd(2 * 769, N, seed=5)
+    out = res.clone()
+    L.gemm(A, W, out, M=M, N=N, K=K, lda=K, bias=bias_g, bias_group_rows=768, act=L.ACT_GELU, scale=scale, res=out, ldr=N,
+           out_group=(768, 769, 1))
+    y = F.gelu(A.float() @ W.float().t() + bias_g.repeat_interleave(768, 0)) * scale
+    ref = res.clone()
+    ref.view(2, 769, N)[:, 1:, :] += y.view(2, 768, N)
+    err = (out - ref).abs().max().item()
+    report(f"gemm_epilogue {dtype}: max|err|={err:.3e}")
+    assert err < 3e-3
+    assert torch.equal(out.view(2, 769, N)[:, 0], res.view(2, 769, N)[:, 0])  # untouched cls rows
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,relu_a", [(2, 12, 16, 64, 64, 1, False), (1, 24, 32, 256, 256, 1, True),
+                                                           (3, 17, 19, 128, 32, 1, False), (2, 32, 32, 64, 128, 2, False),
+                                                           (1, 48, 64, 512, 256, 1, False), (1, 24, 32, 1024, 1024, 2, False)])
+def test_conv3x3(L, dtype, B, H, W, Cin, Cout, stride, relu_a):
+    x = rnd(B, H, W, Cin, seed=1, dtype=dtype)                       # NHWC
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=1 / math.sqrt(9 * Cin), dtype=dtype)
+    bias = rnd(Cout, seed=3)
+    wk = w.permute(0, 2, 3, 1).contiguous()                          # [O][kh][kw][I]
+    g = L.conv_geom(H, W, Cin, 3, 3, stride, 1)
+    Ho, Wo = g[3], g[4]
+    res = rnd(B, Ho, Wo, Cout, seed=4, dtype=dtype)
+    out = torch.empty(B, Ho, Wo, Cout, device=dev(), dtype=dtype)
+    L.gemm(x, wk, out, M=B * Ho * Wo, N=Cout, K=9 * Cin, lda=Cin, conv=g, relu_a=relu_a, bias=bias, res=res, ldr=Cout)
+    xin = x.float().permute(0, 3, 1, 2)
+    if relu_a:
+        xin = F.relu(xin)
+    ref = F.conv2d(xin, w.float(), bias, stride=stride, padding=1).permute(0, 2, 3, 1) + res.float()
+    err = (out.float() - ref).abs().max().item()
+    report(f"conv3x3 {dtype} B{B} {H}x{W} {Cin}->{Cout} s{stride} relu_a={relu_a}: max|err|={err:.3e}")
+    assert err < tol(dtype, 9 * Cin) * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("s,C", [(2, 64), (4, 128)])
+def test_conv_transpose_shuffle(L, dtype, s, C):
+    B, H, W = 2, 6, 8
+    x = rnd(B, H, W, C, seed=1, dtype=dtype)
+    w = rnd(C, C, s, s, seed=2, scale=1 / math.sqrt(C), dtype=dtype)   # ConvTranspose2d weight [Cin, Cout, k, k]
+    bias = rnd(C, seed=3)
+    wk = w.permute(2, 3, 1, 0).reshape(s * s * C, C).contiguous()      # [(ky,kx,co)][ci]
+    bias_k = bias.repeat(s * s).contiguous()
+    out = torch.empty(B, H * s, W * s, C, device=dev(), dtype=dtype)
+    L.gemm(x, wk, out, M=B * H * W, N=s * s * C, K=C, lda=C, bias=bias_k, ldo=C, shuffle=(s, C, H, W))
+    ref = F.conv_transpose2d(x.float().permute(0, 3, 1, 2), w.float(), bias, stride=s).permute(0, 2, 3, 1)
+    err = (out.float() - ref).abs().max().item()
+    report(f"convT {dtype} s{s}: max|err|={err:.3e}")
+    assert err < tol(dtype, C) * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_readout_crop_rows(L, dtype):
+    """A rows = tokens 1..768 of every image (skip the cls row): conv mode with Hin=1, pad_w=-1."""
+    B, T, C, N = 2, 769, 128, 64
+    x = rnd(B, T, C, seed=1, dtype=dtype)
+    w = rnd(N, C, seed=2, scale=1 / math.sqrt(C), dtype=dtype)
+    out = torch.empty(B * (T - 1), N, device=dev(), dtype=torch.float32)
+    L.gemm(x, w, out, M=B * (T - 1), N=N, K=C, lda=C, conv=(1, T, C, 1, T - 1, 1, 1, 1, 0, -1))
+    ref = (x[:, 1:, :].float() @ w.float().t()).reshape(B * (T - 1), N)
+    assert (out - ref).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,S,nh", [(2, 769, 16), (1, 833, 4), (3, 50, 2)])
+def test_qkv_scatter_and_attention(L, dtype, B, S, nh):
+    hidden = nh * 64
+    Sp = (S + 63) // 64 * 64
+    x = rnd(B * S, hidden, seed=1, dtype=dtype)
+    wqkv = rnd(3 * hidden, hidden, seed=2, scale=1 / math.sqrt(hidden), dtype=dtype)
+    bqkv = rnd(3 * hidden, seed=3, scale=0.1)
+    q = torch.zeros(B, nh, Sp, 64, device=dev(), dtype=dtype)
+    k = torch.zeros(B, nh, Sp, 64, device=dev(), dtype=dtype)
+    vt = torch.zeros(B, nh, 64, Sp, device=dev(), dtype=dtype)
+    L.gemm(x, wqkv, q, M=B * S, N=3 * hidden, K=hidden, lda=hidden, bias=bqkv, qkv=(hidden, S, Sp, 0.125, k, vt))
+    y = (x.float() @ wqkv.float().t() + bqkv).view(B, S, 3, nh, 64)
+    qr, kr, vr = y[:, :, 0].permute(0, 2, 1, 3), y[:, :, 1].permute(0, 2, 1, 3), y[:, :, 2].permute(0, 2, 1, 3)
+    t = tol(dtype, hidden) * 4
+    assert (q[:, :, :S].float() - qr * 0.125).abs().max().item() < t
+    assert (k[:, :, :S].float() - kr).abs().max().item() < t
+    assert (vt[:, :, :, :S].float() - vr.transpose(2, 3)).abs().max().item() < t
+    assert q[:, :, S:].abs().max().item() == 0 and vt[:, :, :, S:].abs().max().item() == 0
+    # attention on exactly the 16-bit q/k/v the kernel sees
+    bias = torch.full((nh, Sp, Sp), -1.0e30, device=dev())
+    bias[:, :S, :S] = rnd(nh, S, S, seed=4)
+    bias[:, S:, :S] = 0
+    out = torch.empty(B * S, hidden, device=dev(), dtype=dtype)
+    L.attention(q, k, vt, bias, out, B, nh, S, Sp)
+    qf, kf, vf = q[:, :, :S].float(), k[:, :, :S].float(), vt[:, :, :, :S].float().transpose(2, 3)
+    a = torch.softmax(qf @ kf.transpose(2, 3) + bias[None, :, :S, :S], dim=-1)
+    ref = (a @ vf).permute(0, 2, 1, 3).reshape(B * S, hidden)
+    err = (out.float() - ref).abs().max().item()
+    report(f"attention {dtype} B{B} S{S} nh{nh}: max|err|={err:.3e} (ref max {ref.abs().max().item():.2f})")
+    assert err < (4e-3 if dtype == torch.float16 else 3e-2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,cols", [(769 * 2, 1024), (193, 128), (7, 2048)])
+def test_layernorm_and_cast(L, dtype, rows, cols):
+    x = rnd(rows, cols, seed=1, scale=3.0) + 0.5
+    g, b = rnd(cols, seed=2), rnd(cols, seed=3)
+    o16 = torch.empty(rows, cols, device=dev(), dtype=dtype)
+    o32 = torch.empty(rows, cols, device=dev())
+    L.layernorm(x, g, b, o16, o32, rows, cols, 1e-12)
+    ref = F.layer_norm(x, (cols,), g, b, 1e-12)
+    assert (o32 - ref).abs().max().item() < 2e-5
+    assert torch.equal(o16, o32.to(dtype))
+    c = torch.empty(rows, cols, device=dev(), dtype=dtype)
+    L.cast(x, c)
+    assert torch.equal(c, x.to(dtype))
+
+
+def test_preprocess_matches_oracle(L):
+    from oracle import zoedepth_ref as Z
+    g = torch.Generator().manual_seed(0)
+    for (H, W, nh, nw) in [(480, 640, 384, 512), (480, 600, 416, 512)]:
+        f = torch.randint(0, 256, (2, H, W, 3), dtype=torch.uint8, generator=g)
+        ref = Z.preprocess(f)
+        assert ref.shape[-2:] == (nh, nw)
+        fd = f.to(dev())
+        out = torch.empty(4, 3, nh, nw, device=dev())
+        L.preprocess_image(fd, out, 2, H, W, nh, nw, True)
+        e0 = (out[:2].cpu() - ref).abs().max().item()
+        e1 = (out[2:].cpu() - torch.flip(ref, dims=[3])).abs().max().item()
+        report(f"preprocess {W}x{H}: max|err|={e0:.3e} flipped {e1:.3e}")
+        assert e0 < 2e-5 and e1 < 2e-5
+        pat = torch.empty(4, (nh // 16) * (nw // 16), 768, device=dev(), dtype=torch.float16)
+        L.preprocess_patches(fd, pat, 2, H, W, nh, nw, True)
+        refp = F.unfold(out, kernel_size=16, stride=16).transpose(1, 2)   # [4, L, 768] with k = c*256 + ky*16 + kx
+        assert torch.equal(pat, refp.to(torch.float16))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_resize_and_add(L, dtype):
+    B, H, W, C = 2, 12, 16, 64
+    x = rnd(B, H, W, C, seed=1, dtype=dtype)
+    out = torch.empty(B, 2 * H, 2 * W, C, device=dev(), dtype=dtype)
+    L.resize_bilinear_nhwc(x, out, B, H, W, C, 2 * H, 2 * W, True)
+    ref = F.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    assert (out.float() - ref).abs().max().item() < tol(dtype, 1) * 4
+    y = rnd(B, 2 * H, 2 * W, C, seed=2, dtype=dtype)
+    o2 = torch.empty_like(y)
+    L.add_resized(y, x, o2, B, H, W, 2 * H, 2 * W, C)
+    assert (o2.float() - (ref + y.float())).abs().max().item() < tol(dtype, 1) * 8
+    o3 = torch.empty(B, 17, 23, C, device=dev(), dtype=dtype)
+    L.resize_bilinear_nhwc(x, o3, B, H, W, C, 17, 23, False)
+    ref3 = F.interpolate(x.float().permute(0, 3, 1, 2), size=(17, 23), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    assert (o3.float() - ref3).abs().max().item() < tol(dtype, 1) * 4
+
+
+def test_attractor_step(L):
+    B, Hp, Wp, H, W = 2, 6, 8, 12, 16
+    A = F.softplus(rnd(B, H, W, 32, seed=1, scale=2.0))
+    prev = F.softplus(rnd(B, Hp, Wp, 128, seed=2, scale=2.0))
+    route = torch.tensor([1, 0], dtype=torch.int32, device=dev())
+    out = torch.full((B, H, W, 128), -7.0, device=dev())
+    L.attractor_step(A, prev, out, route, B, Hp, Wp, H, W, 2, 64, 16)
+    c = F.interpolate(prev.permute(0, 3, 1, 2), (H, W), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    for b in range(B):
+        g = int(route[b])
+        cg, Ag = c[b, :, :, g * 64:(g + 1) * 64], A[b, :, :, g * 16:(g + 1) * 16]
+        dx = Ag.unsqueeze(-1) - cg.unsqueeze(-2)
+        ref = cg + (dx / (1 + 300 * dx * dx)).sum(-2) / 16
+        assert (out[b, :, :, g * 64:(g + 1) * 64] - ref).abs().max().item() < 1e-5
+        assert (out[b, :, :, (1 - g) * 64:(2 - g) * 64] == -7.0).all()
+    out2 = torch.empty_like(out)
+    L.attractor_step(A, prev, out2, None, B, Hp, Wp, H, W, 2, 64, 16)
+    assert torch.isfinite(out2).all()
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_logbinom_depth(L, dtype):
+    B, He, We, H, W = 2, 6, 8, 12, 16
+    last = rnd(B, H, W, 32, seed=1, dtype=dtype)
+    Eh = rnd(B, He, We, 80, seed=2)
+    bins = F.softplus(rnd(B, He, We, 128, seed=3, scale=2.0))
+    w0 = rnd(2, 40, 32, seed=4, scale=0.3)
+    w2 = rnd(2, 4, 40, seed=5, scale=1.0)
+    b2 = rnd(2, 4, seed=6)
+    route = torch.tensor([0, 1], dtype=torch.int32, device=dev())
+    depth = torch.empty(B, H, W, device=dev())
+    L.logbinom_depth(last, Eh, bins, w0, w2, b2, route, depth, B, H, W, He, We, 0.0212, 50.0)
+    up = lambda t: F.interpolate(t.permute(0, 3, 1, 2), (H, W), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    Ehu, bu = up(Eh), up(bins)
+    for b in range(B):
+        g = int(route[b])
+        h = F.gelu(Ehu[b, :, :, g * 40:(g + 1) * 40] + last[b].float() @ w0[g].t())
+        pt = F.softplus(h @ w2[g].t() + b2[g])
+        p = (pt[..., 0] + 1e-4) / (pt[..., 0] + pt[..., 1] + 2e-4)
+        t = (pt[..., 2] + 1e-4) / (pt[..., 2] + pt[..., 3] + 2e-4)
+        t = (50.0 - 0.0212) * t + 0.0212
+        omp = (1 - p).clamp(1e-4, 1.0)
+        p = p.clamp(1e-4, 1.0)
+        k = torch.arange(64, device=dev(), dtype=torch.float32)
+        n = torch.tensor(63.0, device=dev()) + 1e-7
+        kk = k + 1e-7
+        lb = n * torch.log(n) - kk * torch.log(kk) - (n - kk) * torch.log(n - kk + 1e-7)
+        y = lb + k * torch.log(p)[..., None] + (63 - k) * torch.log(omp)[..., None]
+        px = torch.softmax(y / t[..., None], dim=-1)
+        ref = (px * bu[b, :, :, g * 64:(g + 1) * 64]).sum(-1)
+        err = (depth[b] - ref).abs().max().item()
+        report(f"logbinom {dtype} b{b}: max|err|={err:.3e}")
+        assert err < 2e-4
+
+
+def test_postprocess_matches_oracle(L):
+    from oracle import zoedepth_ref as Z
+    B, H, W, nh, nw = 2, 480, 640, 384, 512
+    d = torch.rand(2 * B, nh, nw, generator=torch.Generator().manual_seed(0)) * 3 + 0.2
+    ref = Z.postprocess(d[:B], d[B:], H, W)
+    dd = d.to(dev())
+    m = torch.empty(B, H, W, device=dev())
+    u = torch.empty(B, H, W, device=dev(), dtype=torch.int16)
+    L.postprocess_depth(dd, m, u, B, H, W, nh, nw, True)
+    err = (m.cpu() - ref).abs().max().item()
+    report(f"postprocess: max|err|={err:.3e}")
+    assert err < 5e-6
+    u16 = u.cpu().numpy().view(np.uint16)
+    assert np.array_equal(u16, (m.cpu().numpy() * 256.0).astype(np.uint16))
+    assert np.abs(u16.astype(np.int32) - Z.to_uint16(ref).astype(np.int32)).max() <= 1
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_small_attention(L, dtype):
+    B, S, nh, D = 3, 193, 4, 128
+    qkv = rnd(B * S, 3 * D, seed=1)
+    out = torch.empty(B * S, D, device=dev(), dtype=dtype)
+    L.small_attention(qkv, out, B, S, nh)
+    y = qkv.view(B, S, 3, nh, 32)
+    q, k, v = y[:, :, 0].transpose(1, 2), y[:, :, 1].transpose(1, 2), y[:, :, 2].transpose(1, 2)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(32), -1) @ v).transpose(1, 2).reshape(B * S, D)
+    assert (out.float() - ref).abs().max().item() < tol(dtype, 1) * 4
+    lg = torch.tensor([[0.1, 0.2, 0, 0], [0.3, 0.3, 0, 0], [0.5, -1.0, 0, 0]], device=dev())
+    r = torch.empty(3, dtype=torch.int32, device=dev())
+    L.route_argmax(lg, 4, r, 3)
+    assert r.tolist() == [1, 0, 0]
+
+
+# ------------------------------------------------------------------------------------------------
+# MPEM pieces
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DT)
+def test_cyclepose_im2col(L, dtype):
+    from oracle import cyclepose_ref as CP
+    H, W = 480, 640
+    f = torch.randint(0, 256, (3, H, W, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(0))
+    pairs = torch.tensor([[0, 1], [1, 2]], dtype=torch.int32)
+    x = CP.center_crop_pair(f, pairs.long())                                   # [P,6,128,128]
+    cols = F.unfold(F.pad(x, (3, 3, 3, 3), mode="reflect"), kernel_size=7)     # [P, 6*49, 16384], k = c*49 + ky*7 + kx
+    ref = cols.view(2, 6, 49, 128 * 128).permute(0, 3, 2, 1).reshape(2 * 128 * 128, 294)   # k = (ky*7+kx)*6 + c
+    out = torch.full((2 * 128 * 128, 320), 9.0, device=dev(), dtype=dtype)
+    L.cyclepose_im2col(f.to(dev()), pairs.to(dev()), out, 2, H, W)
+    assert torch.equal(out[:, :294].cpu(), ref.to(dtype))
+    assert out[:, 294:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_instnorm_avgpool(L, dtype):
+    P, HW, C = 3, 64 * 64, 128
+    x = rnd(P, HW, C, seed=1, scale=2.0) + 0.7
+    o = torch.empty(P, HW, C, device=dev(), dtype=dtype)
+    o32 = torch.empty(P, HW, C, device=dev())
+    L.instnorm_relu_nhwc(x, o, o32, P, HW, C)
+    ref = F.relu(F.instance_norm(x.permute(0, 2, 1).reshape(P, C, 64, 64), eps=1e-5)).reshape(P, C, HW).permute(0, 2, 1)
+    assert (o32 - ref).abs().max().item() < 2e-5
+    assert torch.equal(o, o32.to(dtype))
+    pooled = torch.empty(P, C, device=dev())
+    L.avgpool_nhwc(x, pooled, P, HW, C)
+    assert (pooled - x.mean(1)).abs().max().item() < 1e-5
+
+
+def test_cyclepose_head(L):
+    from oracle import cyclepose_ref as CP
+    P, HW, C = 3, 1024, 256
+    w = {k: v.to(dev()) for k, v in CP.synth_weights(3).items()}
+    pooled = rnd(P, 512, seed=1).abs()
+    x2 = rnd(P, HW, C, seed=2).abs()                                            # NHWC
+    ws = w["skip_linear.weight"]
+    w_pool = ws[:, :512].contiguous()
+    w_x2 = ws[:, 512:].view(7, C, HW).permute(0, 2, 1).contiguous()             # [7][HW][C]
+    pose7 = torch.empty(P, 7, device=dev())
+    T = torch.empty(P, 16, device=dev())
+    scratch = torch.empty(P * 64 * 8, device=dev())
+    L.cyclepose_head(pooled, x2, w_pool, w_x2, w["skip_linear.bias"], w["pose_dense.1.weight"], w["pose_dense.1.bias"],
+                     w["pose_dense.3.weight"], w["pose_dense.3.bias"], pose7, T, scratch, P, HW, C)
+    cat = torch.cat([pooled, x2.permute(0, 2, 1).reshape(P, -1)], dim=1)        # NCHW flatten order
+    ref7 = F.linear(cat.double(), ws.double(), w["skip_linear.bias"].double()) + \
+        F.linear(F.relu(F.linear(pooled.double(), w["pose_dense.1.weight"].double(), w["pose_dense.1.bias"].double())),
+                 w["pose_dense.3.weight"].double(), w["pose_dense.3.bias"].double())
+    err = (pose7.double() - ref7).abs().max().item()
+    report(f"cyclepose_head: max|err pose7|={err:.3e}")
+    assert err < 2e-4
+    refT = CP.pose_matrix(pose7.cpu())
+    assert (T.view(P, 4, 4).cpu() - refT).abs().max().item() < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# 3DM
+# ------------------------------------------------------------------------------------------------
+def _bp(L, depth, K, poses=None):
+    B, H, W = depth.shape
+    d = torch.from_numpy(depth.view(np.int16)).to(dev())
+    xyz = torch.zeros(B, H * W, 3, device=dev())
+    idx = torch.full((B, H * W), -1, dtype=torch.int32, device=dev())
+    cnt = torch.zeros(B, dtype=torch.int32, device=dev())
+    scratch = torch.zeros(B * (H * W // 256 + 2), dtype=torch.int32, device=dev())
+    pz = None if poses is None else torch.from_numpy(poses.reshape(B, 16)).to(dev())
+    L.backproject(d, K, 1000.0, 3.0, pz, xyz, idx, cnt, scratch, B, H, W)
+    torch.cuda.synchronize()
+    return xyz.cpu().numpy(), idx.cpu().numpy(), cnt.cpu().numpy()
+
+
+def test_backproject_golden_and_random(L, golden_dir):
+    from oracle import geom3d_ref as G
+    g = np.load(os.path.join(golden_dir, "geom3d_backproject.npz"))
+    xyz, idx, cnt = _bp(L, g["depth"][None], tuple(g["K"]))
+    m = int(cnt[0])
+    assert m == len(g["idx"])
+    assert np.array_equal(idx[0, :m], g["idx"])                       # bit-exact indices
+    assert np.array_equal(xyz[0, :m], g["xyz"].astype(np.float32))    # and, without a pose, bit-exact points
+    # full-size frames, ragged validity, with poses
+    rng = np.random.default_rng(1)
+    depth = rng.integers(0, 4000, size=(3, 480, 640)).astype(np.uint16)
+    depth[1] = 0                                                      # empty frame
+    depth[2, :, :] = 1500                                             # fully valid frame
+    chain = np.load(os.path.join(golden_dir, "geom3d_chain.npz"))["g_abs"]
+    poses = chain[[10, 20, 30]]
+    xyz, idx, cnt = _bp(L, depth, G.REF_INTRINSICS, poses)
+    for b in range(3):
+        rx, ri = G.backproject(depth[b], pose=poses[b])
+        assert int(cnt[b]) == len(ri)
+        assert np.array_equal(idx[b, :len(ri)], ri)
+        assert np.allclose(xyz[b, :len(ri)], rx, rtol=0, atol=1e-6)
+    assert cnt[1] == 0 and cnt[2] == 480 * 640
+    report(f"backproject: counts {cnt.tolist()} indices exact")
+
+
+def test_backproject_odd_sizes(L):
+    from oracle import geom3d_ref as G
+    rng = np.random.default_rng(2)
+    for (H, W) in [(1, 1), (3, 5), (37, 61), (1, 2049)]:
+        depth = rng.integers(0, 3500, size=(2, H, W)).astype(np.uint16)
+        xyz, idx, cnt = _bp(L, depth, G.REF_INTRINSICS)
+        for b in range(2):
+            rx, ri = G.backproject(depth[b])
+            assert int(cnt[b]) == len(ri) and np.array_equal(idx[b, :len(ri)], ri)
+            assert np.array_equal(xyz[b, :len(ri)], rx)
+
+
+def test_pose_chain(L, golden_dir):
+    g = np.load(os.path.join(golden_dir, "geom3d_chain.npz"))
+    t_rel = torch.from_numpy(g["t_rel"]).to(dev())
+    N = t_rel.shape[0]
+    out = torch.empty(N + 1, 16, dtype=torch.float64, device=dev())
+    L.pose_chain(t_rel.view(N, 16), N, None, out)
+    got = out.cpu().numpy().reshape(N + 1, 4, 4)
+    err = np.abs(got - g["g_abs"]).max()
+    report(f"pose_chain N={N}: max|err| vs reference = {err:.3e}")
+    assert err < 1e-9          # fp64 Jacobi SVD vs LAPACK gesdd, accumulated over 1000 steps
+    g0 = g["g_abs"][500]
+    out2 = torch.empty(11, 16, dtype=torch.float64, device=dev())
+    L.pose_chain(t_rel[500:510].reshape(10, 16).contiguous(), 10, g0.reshape(16), out2)
+    assert np.abs(out2.cpu().numpy().reshape(11, 4, 4) - g["g_abs"][500:511]).max() < 1e-12
+    # reflection input: the det correction must act on the smallest singular direction
+    from oracle import geom3d_ref as G
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = np.diag([1.0, 0.9, -0.8]).astype(np.float32)
+    out3 = torch.empty(2, 16, dtype=torch.float64, device=dev())
+    L.pose_chain(torch.from_numpy(T.reshape(1, 16)).to(dev()), 1, None, out3)
+    assert np.abs(out3.cpu().numpy()[1].reshape(4, 4) - G.pose_chain(T[None])[1]).max() < 1e-12
