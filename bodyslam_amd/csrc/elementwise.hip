@@ -179,8 +179,8 @@ __global__ __launch_bounds__(256) void resize_nhwc_kernel(const T* x, const T* a
         fy = sy * (float)oy;
         fx = sx * (float)ox;
     } else {
-        fy = fmaxf(sy * ((float)oy + 0.5f) - 0.5f, 0.0f);
-        fx = fmaxf(sx * ((float)ox + 0.5f) - 0.5f, 0.0f);
+        fy = fmaxf(__fmaf_rn(sy, (float)oy + 0.5f, -0.5f), 0.0f);
+        fx = fmaxf(__fmaf_rn(sx, (float)ox + 0.5f, -0.5f), 0.0f);
     }
     int y0 = (int)fy, x0 = (int)fx;
     y0 = y0 > Hin - 1 ? Hin - 1 : y0;
@@ -225,7 +225,9 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* dnet, flo
     if (gid >= total) return;
     const int x = (int)(gid % W), y = (int)((gid / W) % H), b = (int)(gid / ((int64_t)W * H));
     const int yp = y + ph, xp = x + pw;  // position in the padded (resize target) frame
-    const float fy = sy * ((float)yp + 0.5f) - 0.5f, fx = sx * ((float)xp + 0.5f) - 0.5f;
+    // torch evaluates the source index with one rounding (FMA contraction, CPU and CUDA builds alike); near
+    // index 384 a float ulp is 3e-5, so two roundings would move the cubic weights visibly
+    const float fy = __fmaf_rn(sy, (float)yp + 0.5f, -0.5f), fx = __fmaf_rn(sx, (float)xp + 0.5f, -0.5f);
     const float fly = floorf(fy), flx = floorf(fx);
     const int iy = (int)fly, ix = (int)flx;
     float cy[4], cx[4];

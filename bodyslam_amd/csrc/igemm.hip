@@ -246,8 +246,13 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) y[e] *= s4[e];
                 }
+                int64_t orow = m;
+                if (p.out_mode == BS_OUT_PLAIN && p.out_group_rows) {
+                    const int g = m / p.out_group_rows;
+                    orow = (int64_t)g * p.out_group_stride + (m - g * p.out_group_rows) + p.out_row_offset;
+                }
                 if (p.res) {
-                    const int64_t ro = (int64_t)m * p.ldr + n0;
+                    const int64_t ro = orow * p.ldr + n0;  // the residual lives in the OUTPUT row geometry
                     if (p.res_dtype == BS_F32) {
                         const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + ro);
 #pragma unroll
@@ -259,11 +264,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                     }
                 }
                 if (p.out_mode == BS_OUT_PLAIN) {
-                    int64_t orow = m;
-                    if (p.out_group_rows) {
-                        const int g = m / p.out_group_rows;
-                        orow = (int64_t)g * p.out_group_stride + (m - g * p.out_group_rows) + p.out_row_offset;
-                    }
                     store4<T>(p.out, orow * p.ldo + n0, p.out_dtype, y);
                 } else if (p.out_mode == BS_OUT_SHUFFLE) {
                     const int hw = p.Hout * p.Wout;

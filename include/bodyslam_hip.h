@@ -48,7 +48,7 @@ int bs_version(void);
  * K = KH*KW*Cin ordered (ky, kx, ci), M = B*Hout*Wout, zero padding pad_h/pad_w (may be negative:
  * a crop), W is [N][KH][KW][Cin].  Cin (conv) / K (plain) must be a multiple of 64.
  * epilogue: y = acc + bias[(m / bias_group_rows) * N + n]  (bias_group_rows == 0: bias[n]);
- *           y = act(y); y *= scale[n]; y += res[m * ldr + n]; store as out_dtype.
+ *           y = act(y); y *= scale[n]; y += res[orow * ldr + n] (orow = m unless regrouped, below); store.
  * out_mode BS_OUT_PLAIN  : out[orow * ldo + n], orow = (m / out_group_rows) * out_group_stride
  *                          + m % out_group_rows + out_row_offset (out_group_rows == 0: orow = m)
  *          BS_OUT_SHUFFLE: ConvTranspose2d(kernel == stride == shuffle_s): n = (ky*s + kx)*Cout + co,
