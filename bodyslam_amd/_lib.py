@@ -36,7 +36,7 @@ class GemmDesc(C.Structure):
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad_h", C.c_int32), ("pad_w", C.c_int32),
         ("relu_a", C.c_int32),
         ("bias", C.c_void_p), ("bias_group_rows", C.c_int32), ("act", C.c_int32),
-        ("scale", C.c_void_p), ("res", C.c_void_p), ("res_dtype", C.c_int32), ("ldr", C.c_int32),
+        ("scale", C.c_void_p), ("res", C.c_void_p), ("res_dtype", C.c_int32), ("ldr", C.c_int32), ("res2", C.c_void_p),
         ("out", C.c_void_p), ("out2", C.c_void_p), ("out3", C.c_void_p),
         ("out_dtype", C.c_int32), ("ldo", C.c_int32), ("out_mode", C.c_int32),
         ("out_group_rows", C.c_int32), ("out_group_stride", C.c_int32), ("out_row_offset", C.c_int32),
@@ -55,6 +55,7 @@ _SIGS = {
     "bs_attention": [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p],
     "bs_layernorm": [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p],
     "bs_cast": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p],
+    "bs_copy_f32": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "bs_preprocess_patches": [C.c_void_p, C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p],
     "bs_preprocess_image": [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p],
     "bs_fill_rows": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
@@ -132,17 +133,16 @@ def p(t: Optional[torch.Tensor]) -> Optional[int]:
 # thin typed wrappers (argument checking that needs tensor metadata lives here; numeric argument
 # validation lives in the C library)
 # ---------------------------------------------------------------------------------------------
-def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int, lda: int,
-         conv=None, relu_a: bool = False, bias: Optional[torch.Tensor] = None, bias_group_rows: int = 0,
-         act: int = ACT_NONE, scale: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, ldr: int = 0,
-         ldo: Optional[int] = None, out_group=None, shuffle=None, qkv=None, a_offset: int = 0, tile: int = 0) -> None:
-    """conv = (Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_h, pad_w) or None.
+def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int, lda: int,
+                   conv=None, relu_a: bool = False, bias: Optional[torch.Tensor] = None, bias_group_rows: int = 0,
+                   act: int = ACT_NONE, scale: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+                   res2: Optional[torch.Tensor] = None, ldr: int = 0, ldo: Optional[int] = None, out_group=None,
+                   shuffle=None, qkv=None, a_offset: int = 0, tile: int = 0) -> GemmDesc:
+    """Fill a bs_gemm_desc.  conv = (Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_h, pad_w) or None;
     out_group = (rows, stride, offset); shuffle = (s, Cout, Hgrid, Wgrid);
-    qkv = (hidden, tokens, Sp, q_scale, out_k, out_vt)."""
-    lib = load_library()
+    qkv = (hidden, tokens, Sp, q_scale, out_k, out_vt); a_offset in elements."""
     d = GemmDesc()
-    es = A.element_size()
-    d.A = A.data_ptr() + a_offset * es
+    d.A = A.data_ptr() + a_offset * A.element_size()
     d.W = W.data_ptr()
     assert A.dtype == W.dtype and A.dtype in (torch.float16, torch.bfloat16), (A.dtype, W.dtype)
     d.dtype = dt(A)
@@ -163,6 +163,9 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
         d.res = res.data_ptr()
         d.res_dtype = dt(res)
         d.ldr = ldr if ldr else N
+    if res2 is not None:
+        assert res is not None and res2.dtype == A.dtype
+        d.res2 = res2.data_ptr()
     d.out = out.data_ptr()
     d.out_dtype = dt(out)
     d.ldo = N if ldo is None else ldo
@@ -178,7 +181,59 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
         d.out2 = out_k.data_ptr()
         d.out3 = out_vt.data_ptr()
     d.tile = tile
-    check(lib.bs_gemm(C.byref(d), stream_ptr()), "bs_gemm")
+    return d
+
+
+def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, **kw) -> None:
+    d = make_gemm_desc(A, W, out, **kw)
+    check(load_library().bs_gemm(C.byref(d), stream_ptr()), "bs_gemm")
+
+
+class Plan:
+    """A prebuilt sequence of C-ABI calls over static buffers: descriptors and pointer arguments are
+    marshalled once, so replaying a forward costs one ctypes call per kernel (and the whole sequence
+    can be captured into a HIP graph).  `mark(name, tensor)` records a named intermediate for tests."""
+
+    def __init__(self):
+        self.calls = []      # (cfunc, args) ; args exclude the trailing stream
+        self.names = []
+        self.keep = []       # keeps descriptors / tensors alive
+        self.marks = {}      # call index -> [(name, tensor)]
+
+    def gemm(self, name, A, W, out, **kw):
+        d = make_gemm_desc(A, W, out, **kw)
+        self.keep.append((d, A, W, out, kw))
+        self.calls.append((load_library().bs_gemm, (C.byref(d),)))
+        self.names.append(name)
+
+    def add(self, name, fn_name, *args):
+        cargs = []
+        for a in args:
+            if isinstance(a, torch.Tensor):
+                self.keep.append(a)
+                cargs.append(a.data_ptr())
+            else:
+                cargs.append(a)
+        self.calls.append((getattr(load_library(), fn_name), tuple(cargs)))
+        self.names.append(name)
+
+    def mark(self, name, tensor, meta=None):
+        self.marks.setdefault(len(self.calls), []).append((name, tensor, meta))
+
+    def run(self, taps: Optional[dict] = None):
+        st = stream_ptr()
+        if taps is None:
+            for i, (fn, args) in enumerate(self.calls):
+                rc = fn(*args, st)
+                if rc:
+                    check(rc, self.names[i])
+            return
+        for i in range(len(self.calls) + 1):
+            for (name, t, meta) in self.marks.get(i, []):
+                taps[name] = (t.clone(), meta)
+            if i < len(self.calls):
+                fn, args = self.calls[i]
+                check(fn(*args, st), self.names[i])
 
 
 def conv_geom(Hin, Win, Cin, KH, KW, stride, pad):

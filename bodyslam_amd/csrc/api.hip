@@ -42,3 +42,12 @@ extern "C" int bs_init(int device) {
 
 extern "C" const char* bs_last_error(void) { return bs::g_err; }
 extern "C" int bs_version(void) { return 1; }
+
+extern "C" int bs_copy_f32(const float* src, float* dst, int64_t n, void* stream) {
+    using namespace bs;
+    if (!initialized()) { set_error("bs_copy_f32: call bs_init first"); return BS_ERR_NOT_INIT; }
+    BS_REQUIRE(src && dst && n >= 0, "bs_copy_f32: bad argument");
+    if (n == 0) return BS_OK;
+    BS_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream)));
+    return BS_OK;
+}

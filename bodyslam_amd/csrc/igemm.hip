@@ -37,6 +37,7 @@ struct IgemmParams {
     int act;
     const float* scale;
     const void* res;
+    const void* res2;
     int res_dtype, ldr;
     void* out;
     void* out2;
@@ -263,6 +264,11 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                         for (int e = 0; e < 4; ++e) y[e] += T16<T>::to_f32(rr[e]);
                     }
                 }
+                if (p.res2) {  // second residual, 16-bit, same row geometry (fusion: fused + residual_unit(skip))
+                    const typename T16<T>::v4 rr = *reinterpret_cast<const typename T16<T>::v4*>(reinterpret_cast<const T*>(p.res2) + orow * p.ldr + n0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] += T16<T>::to_f32(rr[e]);
+                }
                 if (p.out_mode == BS_OUT_PLAIN) {
                     store4<T>(p.out, orow * p.ldo + n0, p.out_dtype, y);
                 } else if (p.out_mode == BS_OUT_SHUFFLE) {
@@ -385,7 +391,8 @@ extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
     }
     p.relu_a = d->relu_a;
     p.bias = d->bias; p.bias_group_rows = d->bias_group_rows; p.act = d->act; p.scale = d->scale;
-    p.res = d->res; p.res_dtype = d->res_dtype; p.ldr = d->ldr;
+    p.res = d->res; p.res2 = d->res2; p.res_dtype = d->res_dtype; p.ldr = d->ldr;
+    BS_REQUIRE(!d->res2 || d->res, "bs_gemm: res2 needs res (they share ldr)");
     p.out = d->out; p.out2 = d->out2; p.out3 = d->out3; p.out_dtype = d->out_dtype; p.ldo = d->ldo; p.out_mode = d->out_mode;
     p.out_group_rows = d->out_group_rows; p.out_group_stride = d->out_group_stride; p.out_row_offset = d->out_row_offset;
     p.shuffle_s = d->shuffle_s; p.shuffle_cout = d->shuffle_cout;

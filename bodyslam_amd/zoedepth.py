@@ -1,0 +1,477 @@
+"""MDEM on MI355X: ZoeDepth (ZoeD_NK: BEiT-L/16 backbone, DPT neck, relative head, metric-bins head)
+as a prebuilt plan of HIP kernel launches through the C ABI (bodyslam_amd/_lib.py).
+
+What the reference does for this path: ``torch.hub.load("isl-org/ZoeDepth", "ZoeD_NK")`` then
+``model.infer_pil(image, output_type="pil")`` per frame (BodySLAM_Refactored/src/depth_estimation/
+interface.py:46,61; BodySLAM_not_refactored/MDEM/mdem_interface.py:37-44,68).  The network itself is
+un-vendored; layer-by-layer citations below are to the installed weight-compatible restatement
+("HF" = transformers 5.15.0 models/zoedepth/modeling_zoedepth.py, models/beit/modeling_beit.py,
+models/zoedepth/image_processing_pil_zoedepth.py).  Parameter names are HF state-dict names.
+
+Data layout in HBM (B frames, flip-aug doubles the image batch: NB = 2B):
+  residual stream      fp32 [NB*S, hidden]            S = 1 + hp*wp tokens (cls first)
+  GEMM operands        fp16/bf16, K-major weights [N, K]; conv weights [O][kh][kw][I]
+  Q, K / V^T           [NB, heads, Sp, 64] / [NB, heads, 64, Sp], Sp = S rounded up to 64, zero padded
+  rel-pos bias         fp32 [layers][heads, Sp, Sp], -1e30 in padded key columns (built once per window)
+  conv activations     NHWC 16-bit
+  bins / attractors    fp32 NHWC, both heads side by side ([nyu 64 | kitti 64], [16 | 16])
+PyTorch is used for allocation, views and one-off weight re-layout only.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+
+
+@dataclass
+class ZoeConfig:
+    """The part of HF ZoeDepthConfig/BeitConfig the forward depends on (defaults: ZoeD_NK)."""
+    hidden: int = 1024
+    layers: int = 24
+    heads: int = 16
+    intermediate: int = 4096
+    taps: Tuple[int, ...] = (6, 12, 18, 24)
+    image_size: int = 384
+    patch: int = 16
+    ln_eps: float = 1e-12
+    neck_hidden: Tuple[int, ...] = (256, 512, 1024, 1024)
+    fusion: int = 256
+    rel_features: int = 32
+    bottleneck: int = 256
+    bin_dim: int = 128
+    n_attractors: int = 16
+    n_bins: int = 64
+    min_temp: float = 0.0212
+    max_temp: float = 50.0
+    pt_layers: int = 4
+    pt_hidden: int = 128
+    pt_inter: int = 1024
+    pt_heads: int = 4
+    head_names: Tuple[str, ...] = ("nyu", "kitti")
+
+
+def pad_sizes(h: int, w: int) -> Tuple[int, int]:
+    """HF image_processing_pil_zoedepth.py:181-201."""
+    return int(np.sqrt(h / 2) * 3), int(np.sqrt(w / 2) * 3)
+
+
+def net_size(h: int, w: int, out_hw=(384, 512), multiple: int = 32) -> Tuple[int, int]:
+    """Network input size for an (h, w) frame: pad, keep_aspect_ratio resize, multiple of 32
+    (HF image_processing_pil_zoedepth.py:72-108; upstream PrepForMidas ensure_multiple_of=32)."""
+    ph, pw = pad_sizes(h, w)
+    hp, wp = h + 2 * ph, w + 2 * pw
+    sh, sw = out_hw[0] / hp, out_hw[1] / wp
+    if abs(1 - sw) < abs(1 - sh):
+        sh = sw
+    else:
+        sw = sh
+    return int(np.round(sh * hp / multiple) * multiple), int(np.round(sw * wp / multiple) * multiple)
+
+
+def _relative_position_index(wh: int, ww: int) -> torch.Tensor:
+    """HF modeling_beit.py:194-218."""
+    nrd = (2 * wh - 1) * (2 * ww - 1) + 3
+    coords = torch.stack(torch.meshgrid(torch.arange(wh), torch.arange(ww), indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += wh - 1
+    rel[:, :, 1] += ww - 1
+    rel[:, :, 0] *= 2 * ww - 1
+    idx = torch.zeros((wh * ww + 1,) * 2, dtype=rel.dtype)
+    idx[1:, 1:] = rel.sum(-1)
+    idx[0, 0:] = nrd - 3
+    idx[0:, 0] = nrd - 2
+    idx[0, 0] = nrd - 1
+    return idx
+
+
+class ZoeDepthEngine:
+    """Weights resident on the GPU + per-shape launch plans.
+
+    ``weights``: HF-named fp32 CPU/GPU tensors (an ``Intel/zoedepth-nyu-kitti`` state dict, or the
+    synthetic set used by the tests / bench).  ``dtype``: GEMM operand type (fp16 or bf16); all
+    accumulation, LayerNorm, softmax, residual stream and the bins head are fp32.
+    """
+
+    def __init__(self, weights: Dict[str, torch.Tensor], cfg: Optional[ZoeConfig] = None, dtype=torch.float16,
+                 device: int = 0, target_hw: Tuple[int, int] = (384, 512)):
+        L.init(device)
+        self.target_hw = target_hw       # the processor's resize target (384x512 for every released checkpoint)
+        self.cfg = cfg or ZoeConfig()
+        assert dtype in (torch.float16, torch.bfloat16)
+        self.dtype = dtype
+        self.dev = torch.device("cuda", device)
+        self.w: Dict[str, torch.Tensor] = {}
+        self._bias_cache: Dict[Tuple[int, int], list] = {}
+        self._plans: Dict[Tuple, "_ZoePlan"] = {}
+        self._raw_tables = []
+        with torch.no_grad():
+            self._ingest(weights)
+
+    # ------------------------------------------------------------------------------------------
+    # weight ingestion (one-off re-layout; names on the left are this engine's, on the right HF's)
+    # ------------------------------------------------------------------------------------------
+    def _h(self, t: torch.Tensor) -> torch.Tensor:
+        return t.to(self.dev, dtype=self.dtype).contiguous()
+
+    def _f(self, t: torch.Tensor) -> torch.Tensor:
+        return t.to(self.dev, dtype=torch.float32).contiguous()
+
+    def _conv_w(self, t: torch.Tensor) -> torch.Tensor:
+        """[O, I, kh, kw] -> [O][kh][kw][I] (K-major over (ky, kx, ci))."""
+        return self._h(t.permute(0, 2, 3, 1).reshape(t.shape[0], -1))
+
+    def _ingest(self, sd: Dict[str, torch.Tensor]):
+        c, w = self.cfg, self.w
+        g = lambda k: sd[k].detach().float()
+        pe = "backbone.beit.embeddings."
+        w["pe.w"] = self._h(g(pe + "patch_embeddings.projection.weight").reshape(c.hidden, -1))
+        w["pe.b"] = self._f(g(pe + "patch_embeddings.projection.bias"))
+        w["cls"] = self._f(g(pe + "cls_token").reshape(-1))
+        for l in range(c.layers):
+            p = f"backbone.beit.layers.{l}."
+            w[f"l{l}.ln1.g"], w[f"l{l}.ln1.b"] = self._f(g(p + "layernorm_before.weight")), self._f(g(p + "layernorm_before.bias"))
+            w[f"l{l}.ln2.g"], w[f"l{l}.ln2.b"] = self._f(g(p + "layernorm_after.weight")), self._f(g(p + "layernorm_after.bias"))
+            w[f"l{l}.qkv.w"] = self._h(torch.cat([g(p + "attention.q_proj.weight"), g(p + "attention.k_proj.weight"),
+                                                  g(p + "attention.v_proj.weight")], 0))
+            # k_proj has no bias (HF modeling_beit.py:305-307)
+            w[f"l{l}.qkv.b"] = self._f(torch.cat([g(p + "attention.q_proj.bias"), torch.zeros(c.hidden),
+                                                  g(p + "attention.v_proj.bias")], 0))
+            w[f"l{l}.o.w"], w[f"l{l}.o.b"] = self._h(g(p + "attention.o_proj.weight")), self._f(g(p + "attention.o_proj.bias"))
+            w[f"l{l}.fc1.w"], w[f"l{l}.fc1.b"] = self._h(g(p + "mlp.fc1.weight")), self._f(g(p + "mlp.fc1.bias"))
+            w[f"l{l}.fc2.w"], w[f"l{l}.fc2.b"] = self._h(g(p + "mlp.fc2.weight")), self._f(g(p + "mlp.fc2.bias"))
+            w[f"l{l}.lam1"], w[f"l{l}.lam2"] = self._f(g(p + "lambda_1")), self._f(g(p + "lambda_2"))
+            self._raw_tables.append(g(p + "relative_position_bias.relative_position_bias_table"))
+        factors = (4, 2, 1, 0.5)
+        for i, (ch, f) in enumerate(zip(c.neck_hidden, factors)):
+            ro = g(f"neck.reassemble_stage.readout_projects.{i}.0.weight")
+            w[f"ro{i}.w_tok"] = self._h(ro[:, :c.hidden])          # concat(token, cls) @ W^T = token @ W1^T + cls @ W2^T
+            w[f"ro{i}.w_cls"] = self._h(ro[:, c.hidden:])
+            w[f"ro{i}.b"] = self._f(g(f"neck.reassemble_stage.readout_projects.{i}.0.bias"))
+            p = f"neck.reassemble_stage.layers.{i}."
+            w[f"ra{i}.proj.w"] = self._h(g(p + "projection.weight").reshape(ch, c.hidden))
+            w[f"ra{i}.proj.b"] = self._f(g(p + "projection.bias"))
+            if f > 1:
+                s = int(f)
+                wt = g(p + "resize.weight")                         # ConvTranspose2d [Cin, Cout, s, s]
+                w[f"ra{i}.up.w"] = self._h(wt.permute(2, 3, 1, 0).reshape(s * s * ch, ch))   # n = (ky*s+kx)*Cout + co
+                w[f"ra{i}.up.b"] = self._f(g(p + "resize.bias").repeat(s * s))
+            elif f < 1:
+                w[f"ra{i}.down.w"] = self._conv_w(g(p + "resize.weight"))
+                w[f"ra{i}.down.b"] = self._f(g(p + "resize.bias"))
+            w[f"nc{i}.w"] = self._conv_w(g(f"neck.convs.{i}.weight"))
+        for i in range(4):
+            p = f"neck.fusion_stage.layers.{i}."
+            w[f"fu{i}.proj.w"] = self._h(g(p + "projection.weight").reshape(c.fusion, c.fusion))
+            w[f"fu{i}.proj.b"] = self._f(g(p + "projection.bias"))
+            for r in (1, 2):
+                for cv in (1, 2):
+                    w[f"fu{i}.r{r}.c{cv}.w"] = self._conv_w(g(p + f"residual_layer{r}.convolution{cv}.weight"))
+                    w[f"fu{i}.r{r}.c{cv}.b"] = self._f(g(p + f"residual_layer{r}.convolution{cv}.bias"))
+        for n in ("projection", "conv1", "conv2"):
+            w[f"rh.{n}.w"] = self._conv_w(g(f"relative_head.{n}.weight"))
+            w[f"rh.{n}.b"] = self._f(g(f"relative_head.{n}.bias"))
+        # ---- metric head
+        mh = "metric_head."
+        B_, E = c.bottleneck, c.bin_dim
+        w["mh.conv2.w"] = self._h(g(mh + "conv2.weight").reshape(B_, B_))
+        w["mh.conv2.b"] = self._f(g(mh + "conv2.bias"))
+        n0, n1 = c.head_names
+        sq = lambda k: g(k).reshape(g(k).shape[0], -1)
+        w["seed.c1.w"] = self._h(torch.cat([sq(mh + f"seed_bin_regressors.{n0}.conv1.weight"), sq(mh + f"seed_bin_regressors.{n1}.conv1.weight"),
+                                            sq(mh + "seed_projector.conv1.weight")], 0))                      # [192, 256]
+        w["seed.c1.b"] = self._f(torch.cat([g(mh + f"seed_bin_regressors.{n0}.conv1.bias"), g(mh + f"seed_bin_regressors.{n1}.conv1.bias"),
+                                            g(mh + "seed_projector.conv1.bias")], 0))
+        w["seed.c2.w"] = self._h(torch.block_diag(sq(mh + f"seed_bin_regressors.{n0}.conv2.weight"),
+                                                  sq(mh + f"seed_bin_regressors.{n1}.conv2.weight")))        # [128, 128]
+        w["seed.c2.b"] = self._f(torch.cat([g(mh + f"seed_bin_regressors.{n0}.conv2.bias"), g(mh + f"seed_bin_regressors.{n1}.conv2.bias")]))
+        w["seedproj.c2.w"] = self._h(sq(mh + "seed_projector.conv2.weight"))                                 # [128, 64]
+        w["seedproj.c2.b"] = self._f(g(mh + "seed_projector.conv2.bias"))
+        for i in range(4):
+            p = mh + f"projectors.{i}."
+            w[f"pj{i}.c1.w"], w[f"pj{i}.c1.b"] = self._h(sq(p + "conv1.weight")), self._f(g(p + "conv1.bias"))
+            w[f"pj{i}.c2.w"], w[f"pj{i}.c2.b"] = self._h(sq(p + "conv2.weight")), self._f(g(p + "conv2.bias"))
+            a0, a1 = mh + f"attractors.{n0}.{i}.", mh + f"attractors.{n1}.{i}."
+            w[f"at{i}.c1.w"] = self._h(torch.cat([sq(a0 + "conv1.weight"), sq(a1 + "conv1.weight")], 0))      # [256, 128]
+            w[f"at{i}.c1.b"] = self._f(torch.cat([g(a0 + "conv1.bias"), g(a1 + "conv1.bias")]))
+            w[f"at{i}.c2.w"] = self._h(torch.block_diag(sq(a0 + "conv2.weight"), sq(a1 + "conv2.weight")))    # [32, 256]
+            w[f"at{i}.c2.b"] = self._f(torch.cat([g(a0 + "conv2.bias"), g(a1 + "conv2.bias")]))
+        clb = [mh + f"conditional_log_binomial.{n}.mlp." for n in (n0, n1)]
+        R = c.rel_features
+        w0 = [sq(p + "0.weight") for p in clb]                                                                # [40, 160] = [last 32 | emb 128]
+        w["clb.emb.w"] = self._h(torch.cat([w0[0][:, R:], w0[1][:, R:]], 0))                                   # [80, 128]
+        w["clb.emb.b"] = self._f(torch.cat([g(clb[0] + "0.bias"), g(clb[1] + "0.bias")]))
+        w["clb.w0_last"] = self._f(torch.stack([w0[0][:, :R], w0[1][:, :R]]))                                  # [2, 40, 32]
+        w["clb.w2"] = self._f(torch.stack([sq(p + "2.weight") for p in clb]))                                  # [2, 4, 40]
+        w["clb.b2"] = self._f(torch.stack([g(p + "2.bias") for p in clb]))                                     # [2, 4]
+        # ---- router (HF modeling_zoedepth.py:775-962)
+        pt = mh + "patch_transformer."
+        w["rt.emb.w"] = self._h(sq(pt + "embedding_convPxP.weight"))
+        w["rt.emb.b"] = self._f(g(pt + "embedding_convPxP.bias"))
+        for l in range(c.pt_layers):
+            p = pt + f"transformer_encoder.{l}."
+            w[f"rt{l}.qkv.w"] = self._h(torch.cat([g(p + "self_attn.query.weight"), g(p + "self_attn.key.weight"), g(p + "self_attn.value.weight")], 0))
+            w[f"rt{l}.qkv.b"] = self._f(torch.cat([g(p + "self_attn.query.bias"), g(p + "self_attn.key.bias"), g(p + "self_attn.value.bias")]))
+            w[f"rt{l}.o.w"], w[f"rt{l}.o.b"] = self._h(g(p + "self_attn.out_proj.weight")), self._f(g(p + "self_attn.out_proj.bias"))
+            w[f"rt{l}.l1.w"], w[f"rt{l}.l1.b"] = self._h(g(p + "linear1.weight")), self._f(g(p + "linear1.bias"))
+            w[f"rt{l}.l2.w"], w[f"rt{l}.l2.b"] = self._h(g(p + "linear2.weight")), self._f(g(p + "linear2.bias"))
+            for n in (1, 2):
+                w[f"rt{l}.n{n}.g"], w[f"rt{l}.n{n}.b"] = self._f(g(p + f"norm{n}.weight")), self._f(g(p + f"norm{n}.bias"))
+        w["cl.l1.w"], w["cl.l1.b"] = self._h(g(mh + "mlp_classifier.linear1.weight")), self._f(g(mh + "mlp_classifier.linear1.bias"))
+        l2w, l2b = g(mh + "mlp_classifier.linear2.weight"), g(mh + "mlp_classifier.linear2.bias")
+        w["cl.l2.w"] = self._h(torch.cat([l2w, torch.zeros(2, l2w.shape[1])], 0))                              # N padded 2 -> 4
+        w["cl.l2.b"] = self._f(torch.cat([l2b, torch.zeros(2)]))
+
+    # ------------------------------------------------------------------------------------------
+    def _rel_bias(self, hp: int, wp: int, Sp: int):
+        """[layers] x fp32 [heads, Sp, Sp]: the table re-interpolated for an (hp, wp) window and
+        gathered (HF modeling_beit.py:220-265); -1e30 in the padded key columns."""
+        key = (hp, wp)
+        if key in self._bias_cache:
+            return self._bias_cache[key]
+        c = self.cfg
+        old = 2 * (c.image_size // c.patch) - 1
+        nh_, nw_ = 2 * hp - 1, 2 * wp - 1
+        idx = _relative_position_index(hp, wp).view(-1)
+        S = hp * wp + 1
+        out = []
+        for tab in self._raw_tables:
+            sub = tab[: old * old].reshape(1, old, old, -1).permute(0, 3, 1, 2)
+            new = F.interpolate(sub, size=(nh_, nw_), mode="bilinear").permute(0, 2, 3, 1).reshape(nh_ * nw_, -1)
+            full = torch.cat([new, tab[old * old:]])
+            b = full[idx].view(S, S, -1).permute(2, 0, 1)
+            pad = torch.full((c.heads, Sp, Sp), -1.0e30)
+            pad[:, :S, :S] = b
+            pad[:, S:, :S] = 0.0
+            out.append(pad.to(self.dev))
+        self._bias_cache[key] = out
+        return out
+
+    def plan_for(self, B: int, H: int, W: int, flip: bool = True) -> "_ZoePlan":
+        key = (B, H, W, flip)
+        if key not in self._plans:
+            self._plans[key] = _ZoePlan(self, B, H, W, flip)
+        return self._plans[key]
+
+    def infer(self, frames_u8: torch.Tensor, flip_aug: bool = True, taps: Optional[dict] = None, want_u16: bool = True):
+        """uint8 [B,H,W,3] on the GPU -> (depth metres fp32 [B,H,W], uint16 metres*256 [B,H,W] as int16 storage).
+
+        Outputs are the plan's static buffers (valid until the next call with the same shape)."""
+        assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and frames_u8.dim() == 4 and frames_u8.shape[-1] == 3
+        B, H, W, _ = frames_u8.shape
+        plan = self.plan_for(B, H, W, flip_aug)
+        plan.frames.copy_(frames_u8)
+        plan.run(taps)
+        return plan.depth_m, plan.depth_u16
+
+
+class _ZoePlan:
+    """All buffers + the launch sequence for one (frames, H, W, flip) configuration."""
+
+    def __init__(self, eng: ZoeDepthEngine, B: int, H: int, W: int, flip: bool):
+        self.eng = eng
+        c, w, dt_, dev = eng.cfg, eng.w, eng.dtype, eng.dev
+        NB = 2 * B if flip else B
+        nh_, nw_ = net_size(H, W, eng.target_hw)
+        hp, wp = nh_ // c.patch, nw_ // c.patch
+        T0 = hp * wp
+        S = T0 + 1
+        Sp = (S + 63) // 64 * 64
+        Hd = c.hidden
+        self.geom = dict(B=B, NB=NB, H=H, W=W, nh=nh_, nw=nw_, hp=hp, wp=wp, S=S, Sp=Sp)
+        P = L.Plan()
+        self.plan = P
+        e16 = lambda *s: torch.empty(*s, device=dev, dtype=dt_)
+        z16 = lambda *s: torch.zeros(*s, device=dev, dtype=dt_)
+        e32 = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        bias = eng._rel_bias(hp, wp, Sp)
+
+        self.frames = torch.empty(B, H, W, 3, device=dev, dtype=torch.uint8)
+        patches = e16(NB * T0, 3 * c.patch * c.patch)
+        x = e32(NB * S, Hd)
+        xn = e16(NB * S, Hd)
+        q, k, vt = z16(NB, c.heads, Sp, 64), z16(NB, c.heads, Sp, 64), z16(NB, c.heads, 64, Sp)
+        ao = e16(NB * S, Hd)
+        hid = e16(NB * S, c.intermediate)
+        taps16 = [e16(NB * S, Hd) for _ in c.taps]
+
+        # ---- Z1 + Z2: pre-processing fused with the patch gather, patch embedding, cls token
+        P.add("preprocess", "bs_preprocess_patches", self.frames, patches, B, H, W, nh_, nw_, int(flip), L.dt(patches))
+        P.add("cls", "bs_fill_rows", x, w["cls"], NB, S, Hd)
+        P.gemm("patch_embed", patches, w["pe.w"], x, M=NB * T0, N=Hd, K=patches.shape[1], lda=patches.shape[1], bias=w["pe.b"],
+               out_group=(T0, S, 1))
+        P.mark("embed", x, ("tokens", NB, S, Hd))
+        # ---- Z3: BEiT layers
+        ti = 0
+        for l in range(c.layers):
+            P.add(f"l{l}.ln1", "bs_layernorm", x, w[f"l{l}.ln1.g"], w[f"l{l}.ln1.b"], xn, None, NB * S, Hd, c.ln_eps, L.dt(xn))
+            P.gemm(f"l{l}.qkv", xn, w[f"l{l}.qkv.w"], q, M=NB * S, N=3 * Hd, K=Hd, lda=Hd, bias=w[f"l{l}.qkv.b"],
+                   qkv=(Hd, S, Sp, 1.0 / math.sqrt(64.0), k, vt))
+            P.add(f"l{l}.attn", "bs_attention", q, k, vt, bias[l], ao, NB, c.heads, S, Sp, L.dt(q))
+            P.gemm(f"l{l}.o", ao, w[f"l{l}.o.w"], x, M=NB * S, N=Hd, K=Hd, lda=Hd, bias=w[f"l{l}.o.b"], scale=w[f"l{l}.lam1"], res=x, ldr=Hd)
+            P.add(f"l{l}.ln2", "bs_layernorm", x, w[f"l{l}.ln2.g"], w[f"l{l}.ln2.b"], xn, None, NB * S, Hd, c.ln_eps, L.dt(xn))
+            P.gemm(f"l{l}.fc1", xn, w[f"l{l}.fc1.w"], hid, M=NB * S, N=c.intermediate, K=Hd, lda=Hd, bias=w[f"l{l}.fc1.b"], act=L.ACT_GELU)
+            P.gemm(f"l{l}.fc2", hid, w[f"l{l}.fc2.w"], x, M=NB * S, N=Hd, K=c.intermediate, lda=c.intermediate, bias=w[f"l{l}.fc2.b"],
+                   scale=w[f"l{l}.lam2"], res=x, ldr=Hd)
+            P.mark(f"layer{l + 1}", x, ("tokens", NB, S, Hd))
+            if (l + 1) in c.taps:
+                P.add(f"tap{ti}", "bs_cast", x, taps16[ti], x.numel(), L.dt(xn))
+                ti += 1
+        # ---- Z4: reassemble (readout project, 1x1 projection, resize) + neck 3x3 convs
+        feats, fshape = [], []
+        cb = e32(NB, Hd)
+        r16 = e16(NB * T0, Hd)
+        for i, ch in enumerate(c.neck_hidden):
+            t16 = taps16[i]
+            # cls half of the readout: per-image bias vector  c_b = cls_b @ W_cls^T + b
+            P.gemm(f"ro{i}.cls", t16, w[f"ro{i}.w_cls"], cb, M=NB, N=Hd, K=Hd, lda=S * Hd, bias=w[f"ro{i}.b"])
+            # token half: rows 1..S-1 of every image (a 1-row "conv" with a -1 column crop), + c_b, GELU
+            P.gemm(f"ro{i}.tok", t16, w[f"ro{i}.w_tok"], r16, M=NB * T0, N=Hd, K=Hd, lda=Hd, conv=(1, S, Hd, 1, T0, 1, 1, 1, 0, -1),
+                   bias=cb, bias_group_rows=T0, act=L.ACT_GELU)
+            pr = e16(NB * T0, ch)
+            P.gemm(f"ra{i}.proj", r16, w[f"ra{i}.proj.w"], pr, M=NB * T0, N=ch, K=Hd, lda=Hd, bias=w[f"ra{i}.proj.b"])
+            if i == 0 or i == 1:
+                s = 4 if i == 0 else 2
+                up = e16(NB, hp * s, wp * s, ch)
+                P.gemm(f"ra{i}.up", pr, w[f"ra{i}.up.w"], up, M=NB * T0, N=s * s * ch, K=ch, lda=ch, bias=w[f"ra{i}.up.b"], ldo=ch,
+                       shuffle=(s, ch, hp, wp))
+                fh, fw, src = hp * s, wp * s, up
+            elif i == 2:
+                fh, fw, src = hp, wp, pr
+            else:
+                g_ = L.conv_geom(hp, wp, ch, 3, 3, 2, 1)
+                fh, fw = g_[3], g_[4]
+                src = e16(NB, fh, fw, ch)
+                P.gemm(f"ra{i}.down", pr, w[f"ra{i}.down.w"], src, M=NB * fh * fw, N=ch, K=9 * ch, lda=ch, conv=g_, bias=w[f"ra{i}.down.b"])
+            P.mark(f"reassemble{i}", src, ("nhwc", NB, fh, fw, ch))
+            f16_ = e16(NB, fh, fw, c.fusion)
+            P.gemm(f"nc{i}", src, w[f"nc{i}.w"], f16_, M=NB * fh * fw, N=c.fusion, K=9 * ch, lda=ch, conv=L.conv_geom(fh, fw, ch, 3, 3, 1, 1))
+            P.mark(f"neckconv{i}", f16_, ("nhwc", NB, fh, fw, c.fusion))
+            feats.append(f16_)
+            fshape.append((fh, fw))
+        # ---- Z5: fusion stage (pre-activation residual units, x2 bilinear, 1x1 projection)
+        Fc = c.fusion
+
+        def res_unit(name, xin, hh, ww, other=None):
+            """y = conv2(relu(conv1(relu(x)))) + x (+ other)."""
+            g_ = L.conv_geom(hh, ww, Fc, 3, 3, 1, 1)
+            t = e16(NB, hh, ww, Fc)
+            y = e16(NB, hh, ww, Fc)
+            M_ = NB * hh * ww
+            P.gemm(name + ".c1", xin, w[name + ".c1.w"], t, M=M_, N=Fc, K=9 * Fc, lda=Fc, conv=g_, relu_a=True, bias=w[name + ".c1.b"], act=L.ACT_RELU)
+            P.gemm(name + ".c2", t, w[name + ".c2.w"], y, M=M_, N=Fc, K=9 * Fc, lda=Fc, conv=g_, bias=w[name + ".c2.b"], res=xin, res2=other, ldr=Fc)
+            return y
+
+        fused_list = []
+        fused = None
+        for li in range(4):
+            feat = feats[3 - li]
+            fh, fw = fshape[3 - li]
+            if fused is None:
+                cur = feat
+            else:
+                cur = res_unit(f"fu{li}.r1", feat, fh, fw, other=fused)     # fused + residual_layer1(feat)
+            cur = res_unit(f"fu{li}.r2", cur, fh, fw)
+            up = e16(NB, 2 * fh, 2 * fw, Fc)
+            P.add(f"fu{li}.up", "bs_resize_bilinear_nhwc", cur, up, NB, fh, fw, Fc, 2 * fh, 2 * fw, 1, L.dt(up))
+            fused = e16(NB, 2 * fh, 2 * fw, Fc)
+            P.gemm(f"fu{li}.proj", up, w[f"fu{li}.proj.w"], fused, M=NB * 4 * fh * fw, N=Fc, K=Fc, lda=Fc, bias=w[f"fu{li}.proj.b"])
+            P.mark(f"fused{li}", fused, ("nhwc", NB, 2 * fh, 2 * fw, Fc))
+            fused_list.append((fused, 2 * fh, 2 * fw))
+        bott, (bh_, bw_) = feats[3], fshape[3]
+        # ---- Z6: relative head (conv3 + ReLU -> relative depth is dead code for the NK output and not launched)
+        f3, h3, w3 = fused_list[3]
+        g_ = L.conv_geom(h3, w3, Fc, 3, 3, 1, 1)
+        rp = e16(NB, h3, w3, Fc)
+        P.gemm("rh.projection", f3, w["rh.projection.w"], rp, M=NB * h3 * w3, N=Fc, K=9 * Fc, lda=Fc, conv=g_, bias=w["rh.projection.b"], act=L.ACT_RELU)
+        r1 = e16(NB, h3, w3, Fc // 2)
+        P.gemm("rh.conv1", rp, w["rh.conv1.w"], r1, M=NB * h3 * w3, N=Fc // 2, K=9 * Fc, lda=Fc, conv=g_, bias=w["rh.conv1.b"])
+        r1u = e16(NB, 2 * h3, 2 * w3, Fc // 2)
+        P.add("rh.up", "bs_resize_bilinear_nhwc", r1, r1u, NB, h3, w3, Fc // 2, 2 * h3, 2 * w3, 1, L.dt(r1))
+        last = e16(NB, 2 * h3, 2 * w3, c.rel_features)
+        P.gemm("rh.conv2", r1u, w["rh.conv2.w"], last, M=NB * 4 * h3 * w3, N=c.rel_features, K=9 * (Fc // 2), lda=Fc // 2,
+               conv=L.conv_geom(2 * h3, 2 * w3, Fc // 2, 3, 3, 1, 1), bias=w["rh.conv2.b"], act=L.ACT_RELU)
+        P.mark("rel_features", last, ("nhwc", NB, 2 * h3, 2 * w3, c.rel_features))
+        # ---- Z7: metric-bins head
+        Mb = NB * bh_ * bw_
+        xb = e16(Mb, c.bottleneck)
+        P.gemm("mh.conv2", bott, w["mh.conv2.w"], xb, M=Mb, N=c.bottleneck, K=c.bottleneck, lda=c.bottleneck, bias=w["mh.conv2.b"])
+        # router: 4-layer post-norm transformer over (1 + bh*bw) tokens, classifier on token 0
+        D, St = c.pt_hidden, bh_ * bw_ + 1
+        pos = torch.arange(0, St, dtype=torch.float32).unsqueeze(1)
+        div = torch.exp(torch.arange(0, D, 2, dtype=torch.float32).unsqueeze(0) * (-torch.log(torch.full((), 10000.0)) / D))
+        pe_tab = torch.cat([torch.sin(pos * div), torch.cos(pos * div)], dim=1).to(dev)          # [St, D]
+        self._pe_src = pe_tab.unsqueeze(0).expand(NB, St, D).contiguous().view(NB * St, D)
+        e32b = e32(NB * St, D)
+        e16b = e16(NB * St, D)
+        self._router_init = (e32b, self._pe_src)
+        # e = pos_enc (token 0 is the zero "cls" pad) ; tokens 1.. += embedding conv
+        P.add("rt.init", "bs_copy_f32", self._pe_src, e32b, e32b.numel())
+        P.gemm("rt.emb", xb, w["rt.emb.w"], e32b, M=Mb, N=D, K=c.bottleneck, lda=c.bottleneck, bias=w["rt.emb.b"], res=e32b, ldr=D,
+               out_group=(bh_ * bw_, St, 1))
+        P.add("rt.cast", "bs_cast", e32b, e16b, e32b.numel(), L.dt(e16b))
+        qkv32 = e32(NB * St, 3 * D)
+        at16 = e16(NB * St, D)
+        tmp32 = e32(NB * St, D)
+        h16 = e16(NB * St, c.pt_inter)
+        for l in range(c.pt_layers):
+            P.gemm(f"rt{l}.qkv", e16b, w[f"rt{l}.qkv.w"], qkv32, M=NB * St, N=3 * D, K=D, lda=D, bias=w[f"rt{l}.qkv.b"])
+            P.add(f"rt{l}.attn", "bs_small_attention", qkv32, at16, NB, St, c.pt_heads, L.dt(at16))
+            P.gemm(f"rt{l}.o", at16, w[f"rt{l}.o.w"], tmp32, M=NB * St, N=D, K=D, lda=D, bias=w[f"rt{l}.o.b"], res=e32b, ldr=D)
+            P.add(f"rt{l}.n1", "bs_layernorm", tmp32, w[f"rt{l}.n1.g"], w[f"rt{l}.n1.b"], e16b, e32b, NB * St, D, 1e-5, L.dt(e16b))
+            P.gemm(f"rt{l}.l1", e16b, w[f"rt{l}.l1.w"], h16, M=NB * St, N=c.pt_inter, K=D, lda=D, bias=w[f"rt{l}.l1.b"], act=L.ACT_RELU)
+            P.gemm(f"rt{l}.l2", h16, w[f"rt{l}.l2.w"], tmp32, M=NB * St, N=D, K=c.pt_inter, lda=c.pt_inter, bias=w[f"rt{l}.l2.b"], res=e32b, ldr=D)
+            P.add(f"rt{l}.n2", "bs_layernorm", tmp32, w[f"rt{l}.n2.g"], w[f"rt{l}.n2.b"], e16b, e32b, NB * St, D, 1e-5, L.dt(e16b))
+        c1 = e16(NB, D)
+        self.logits = e32(NB, 4)
+        self.route = torch.zeros(NB, dtype=torch.int32, device=dev)
+        P.gemm("cl.l1", e16b, w["cl.l1.w"], c1, M=NB, N=D, K=D, lda=St * D, bias=w["cl.l1.b"], act=L.ACT_RELU)
+        P.gemm("cl.l2", c1, w["cl.l2.w"], self.logits, M=NB, N=4, K=D, lda=D, bias=w["cl.l2.b"])
+        P.add("route", "bs_route_argmax", self.logits, 4, self.route, NB)
+        P.mark("logits", self.logits, ("raw",))
+        # seeds + seed projector
+        E, nb, na = c.bin_dim, c.n_bins, c.n_attractors
+        sh = e16(Mb, 3 * (E // 2))
+        P.gemm("seed.c1", xb, w["seed.c1.w"], sh, M=Mb, N=3 * (E // 2), K=c.bottleneck, lda=c.bottleneck, bias=w["seed.c1.b"], act=L.ACT_RELU)
+        bins_prev = e32(NB, bh_, bw_, 2 * nb)
+        P.gemm("seed.c2", sh, w["seed.c2.w"], bins_prev, M=Mb, N=2 * nb, K=E, lda=3 * (E // 2), bias=w["seed.c2.b"], act=L.ACT_SOFTPLUS)
+        emb_prev = e16(Mb, E)
+        P.gemm("seedproj.c2", sh, w["seedproj.c2.w"], emb_prev, M=Mb, N=E, K=E // 2, lda=3 * (E // 2), a_offset=E, bias=w["seedproj.c2.b"])
+        ph_, pw_ = bh_, bw_
+        for i in range(4):
+            feat, fh, fw = fused_list[i]
+            Mi = NB * fh * fw
+            e1 = e16(Mi, E // 2)
+            P.gemm(f"pj{i}.c1", feat, w[f"pj{i}.c1.w"], e1, M=Mi, N=E // 2, K=Fc, lda=Fc, bias=w[f"pj{i}.c1.b"], act=L.ACT_RELU)
+            emb = e16(Mi, E)
+            P.gemm(f"pj{i}.c2", e1, w[f"pj{i}.c2.w"], emb, M=Mi, N=E, K=E // 2, lda=E // 2, bias=w[f"pj{i}.c2.b"])
+            y = e16(Mi, E)
+            P.add(f"at{i}.add", "bs_add_resized", emb, emb_prev, y, NB, ph_, pw_, fh, fw, E, L.dt(y))
+            a1 = e16(Mi, 2 * E)
+            P.gemm(f"at{i}.c1", y, w[f"at{i}.c1.w"], a1, M=Mi, N=2 * E, K=E, lda=E, bias=w[f"at{i}.c1.b"], act=L.ACT_RELU)
+            A = e32(Mi, 2 * na)
+            P.gemm(f"at{i}.c2", a1, w[f"at{i}.c2.w"], A, M=Mi, N=2 * na, K=2 * E, lda=2 * E, bias=w[f"at{i}.c2.b"], act=L.ACT_SOFTPLUS)
+            bins = e32(NB, fh, fw, 2 * nb)
+            P.add(f"at{i}.step", "bs_attractor_step", A, bins_prev, bins, self.route, NB, ph_, pw_, fh, fw, 2, nb, na)
+            P.mark(f"bins{i}", bins, ("nhwc_route", NB, fh, fw, 2 * nb))
+            bins_prev, emb_prev, ph_, pw_ = bins, emb, fh, fw
+        Eh = e32(NB * ph_ * pw_, 2 * 40)
+        P.gemm("clb.emb", emb_prev, w["clb.emb.w"], Eh, M=NB * ph_ * pw_, N=80, K=E, lda=E, bias=w["clb.emb.b"])
+        self.depth_net = e32(NB, nh_, nw_)
+        assert (nh_, nw_) == (2 * h3, 2 * w3)
+        P.add("logbinom", "bs_logbinom_depth", last, Eh, bins_prev, w["clb.w0_last"], w["clb.w2"], w["clb.b2"], self.route, self.depth_net,
+              NB, nh_, nw_, ph_, pw_, c.min_temp, c.max_temp, L.dt(last))
+        P.mark("depth_net", self.depth_net, ("raw",))
+        # ---- Z8: flip average + bicubic + crop + x256 -> uint16
+        self.depth_m = e32(B, H, W)
+        self.depth_u16 = torch.empty(B, H, W, device=dev, dtype=torch.int16)   # uint16 payload
+        P.add("postprocess", "bs_postprocess_depth", self.depth_net, self.depth_m, self.depth_u16, B, H, W, nh_, nw_, int(flip))
+
+    def run(self, taps: Optional[dict] = None):
+        self.plan.run(taps)

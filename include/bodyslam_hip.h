@@ -73,6 +73,7 @@ typedef struct bs_gemm_desc {
     const void* res;
     int32_t res_dtype;             /* BS_F32 | BS_F16 | BS_BF16 */
     int32_t ldr;
+    const void* res2;              /* optional second residual, operand dtype, same ldr */
     void* out;
     void* out2;
     void* out3;
@@ -99,6 +100,9 @@ int bs_attention(const void* q, const void* k, const void* vt, const float* bias
  * alias x) -- HF modeling_beit.py:418,432; post-norm of the router HF modeling_zoedepth.py:876-881 */
 int bs_layernorm(const float* x, const float* gamma, const float* beta, void* out16, float* out32, int32_t rows,
                  int32_t cols, float eps, int32_t dtype, void* stream);
+
+/* device-to-device copy on the stream (re-arming the router's positional-encoding buffer) */
+int bs_copy_f32(const float* src, float* dst, int64_t n, void* stream);
 
 /* fp32 -> fp16/bf16 cast (tap copies of the residual stream) */
 int bs_cast(const float* x, void* out, int64_t n, int32_t out_dtype, void* stream);

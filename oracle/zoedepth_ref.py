@@ -270,14 +270,15 @@ def net_size(h_padded: int, w_padded: int, out_hw=(384, 512), multiple: int = 32
     return con(sh * h_padded), con(sw * w_padded)
 
 
-def preprocess(frames_u8: torch.Tensor) -> torch.Tensor:
+def preprocess(frames_u8: torch.Tensor, out_hw=(384, 512)) -> torch.Tensor:
     """uint8 [B,H,W,3] -> float32 [B,3,h,w] network input (rescale, reflect pad, bilinear
-    align_corners=True resize, normalise mean=std=0.5)."""
+    align_corners=True resize, normalise mean=std=0.5).  out_hw is the processor's target size
+    (384x512 for every released checkpoint; tests use smaller targets to run quickly)."""
     x = frames_u8.permute(0, 3, 1, 2).to(torch.float32) * (1.0 / 255.0)
     H, W = x.shape[-2:]
     ph, pw = pad_sizes(H, W)
     x = F.pad(x, (pw, pw, ph, ph), mode="reflect")
-    nh, nw = net_size(H + 2 * ph, W + 2 * pw)
+    nh, nw = net_size(H + 2 * ph, W + 2 * pw, out_hw)
     x = F.interpolate(x, (nh, nw), mode="bilinear", align_corners=True)
     return (x - 0.5) / 0.5
 
@@ -566,14 +567,14 @@ def zoedepth_forward(w: Dict[str, torch.Tensor], cfg: ZoeConfig, x: torch.Tensor
 
 
 def infer_depth(w: Dict[str, torch.Tensor], cfg: ZoeConfig, frames_u8: torch.Tensor, flip_aug: bool = True,
-                chunk: int = 2) -> torch.Tensor:
+                chunk: int = 2, out_hw=(384, 512)) -> torch.Tensor:
     """The whole MDEM path on uint8 frames [B,H,W,3] -> float32 metres [B,H,W] (before the
     x256 -> uint16 quantisation of infer_pil)."""
     B, H, W, _ = frames_u8.shape
     outs = []
     with torch.no_grad():
         for s in range(0, B, chunk):
-            x = preprocess(frames_u8[s:s + chunk])
+            x = preprocess(frames_u8[s:s + chunk], out_hw)
             d, _ = zoedepth_forward(w, cfg, x)
             df = None
             if flip_aug:
