@@ -72,6 +72,7 @@ _SIGS = {
     "bs_cyclepose_head": [C.c_void_p] * 12 + [C.c_int32] * 3 + [C.c_void_p],
     "bs_backproject": [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_double, C.c_double] + [C.c_void_p] * 6,
     "bs_pose_chain": [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+    "bs_pixel_to_3d": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p],
 }
 EXPORTS = sorted(list(_SIGS) + ["bs_last_error"])
 
@@ -329,3 +330,8 @@ def pose_chain(t_rel, N, g0, g_abs):
     if g0 is not None:
         g0arr = C.cast((C.c_double * 16)(*[float(v) for v in g0]), C.c_void_p)
     check(load_library().bs_pose_chain(p(t_rel), N, g0arr, p(g_abs), stream_ptr()), "bs_pose_chain")
+
+
+def pixel_to_3d(uvd, K4, out, n):
+    Karr = (C.c_double * 4)(*[float(v) for v in K4])
+    check(load_library().bs_pixel_to_3d(p(uvd), n, C.cast(Karr, C.c_void_p), p(out), stream_ptr()), "bs_pixel_to_3d")

@@ -234,7 +234,27 @@ __global__ void pose_chain_kernel(const float* t_rel, int N, const double* g0, d
     }
 }
 
+__global__ void pixel_to_3d_kernel(const double* uvd, int64_t n, double fx, double fy, double cx, double cy, double* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double u = uvd[3 * i], v = uvd[3 * i + 1], d = uvd[3 * i + 2];
+    out[3 * i] = (u - cx) * d / fx;
+    out[3 * i + 1] = (v - cy) * d / fy;
+    out[3 * i + 2] = d;
+}
+
 }  // namespace bs
+
+extern "C" int bs_pixel_to_3d(const double* uvd, int64_t n, const double* K, double* out, void* stream) {
+    using namespace bs;
+    if (!initialized()) { set_error("bs_pixel_to_3d: call bs_init first"); return BS_ERR_NOT_INIT; }
+    BS_REQUIRE(uvd && K && out && n >= 0, "bs_pixel_to_3d: bad argument");
+    if (n == 0) return BS_OK;
+    hipLaunchKernelGGL(pixel_to_3d_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), uvd, n, K[0],
+                       K[1], K[2], K[3], out);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
 
 extern "C" int bs_backproject(const uint16_t* depth, int32_t B, int32_t H, int32_t W, const double* K, double depth_scale,
                               double depth_trunc, const double* poses, float* xyz, int32_t* idx, int32_t* count,

@@ -1,0 +1,112 @@
+"""MPEM on MI355X: the CyclePose generator's pose branch as a plan of HIP launches.
+
+Reference: ConditionalGenerator.forward(mode="pose") BodySLAM_not_refactored/MPEM/architecture_v3.py:195-226
+(initial_model :120-125, downsampling :129-139, pose_conv :143-147, pose_dense :150-155, skip_linear
+:208-211) with the input transform of MPEMInterface.infer_relative_pose_between
+(MPEM/mpem_interface.py:40-44,85-94).  Parameter names are the reference's state-dict names.
+
+Quirk Q1: the reference creates ``skip_linear`` lazily inside forward, AFTER
+load_state_dict(strict=False) ran, so a fresh MPEMInterface uses randomly initialised skip weights.
+Here ``skip_linear.weight/bias`` are explicit weights (taken from the checkpoint when present).
+
+Layout: 7x7 conv as a GEMM over a reflect-padded patch matrix [P*128*128, 320] (K = 294 padded);
+the three stride-2 3x3 convs as implicit GEMM over NHWC; conv outputs fp32 (InstanceNorm statistics
+are taken in fp32), normalised activations 16-bit; the 262 656-long skip dot products in fp32.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib as L
+
+CROP = 128
+K0 = 320
+SKIP_FEATURES = 512 + 256 * 32 * 32
+
+
+class CyclePoseEngine:
+    def __init__(self, weights: Dict[str, torch.Tensor], dtype=torch.float16, device: int = 0):
+        L.init(device)
+        assert dtype in (torch.float16, torch.bfloat16)
+        self.dtype = dtype
+        self.dev = torch.device("cuda", device)
+        self._plans = {}
+        g = lambda k: weights[k].detach().float()
+        h = lambda t: t.to(self.dev, dtype=dtype).contiguous()
+        f = lambda t: t.to(self.dev, dtype=torch.float32).contiguous()
+        cw = lambda t: t.permute(0, 2, 3, 1).reshape(t.shape[0], -1)          # [O,I,kh,kw] -> [O][(ky,kx,ci)]
+        w = self.w = {}
+        w0 = cw(g("initial_model.1.weight"))                                   # [64, 294]
+        w["c0.w"] = h(torch.cat([w0, torch.zeros(w0.shape[0], K0 - w0.shape[1])], 1))
+        w["c0.b"] = f(g("initial_model.1.bias"))
+        for name, key in (("c1", "downsampling.0"), ("c2", "downsampling.3"), ("c3", "pose_conv.0")):
+            w[name + ".w"] = h(cw(g(key + ".weight")))
+            w[name + ".b"] = f(g(key + ".bias"))
+        if "skip_linear.weight" not in weights:
+            raise KeyError("skip_linear.weight missing: the reference would silently use a random layer here "
+                           "(architecture_v3.py:208-209); pass it explicitly")
+        ws = g("skip_linear.weight")
+        assert ws.shape == (7, SKIP_FEATURES), ws.shape
+        w["skip.pool"] = f(ws[:, :512])
+        w["skip.x2"] = f(ws[:, 512:].view(7, 256, 1024).permute(0, 2, 1))      # NCHW flatten -> [7][HW][C]
+        w["skip.b"] = f(g("skip_linear.bias"))
+        w["d1.w"], w["d1.b"] = f(g("pose_dense.1.weight")), f(g("pose_dense.1.bias"))
+        w["d2.w"], w["d2.b"] = f(g("pose_dense.3.weight")), f(g("pose_dense.3.bias"))
+
+    def plan_for(self, N: int, P: int, H: int, W: int) -> "_PosePlan":
+        key = (N, P, H, W)
+        if key not in self._plans:
+            self._plans[key] = _PosePlan(self, N, P, H, W)
+        return self._plans[key]
+
+    def infer_pairs(self, frames_u8: torch.Tensor, pairs: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+        """frames uint8 [N,H,W,3] (GPU), pairs int32 [P,2] (indices into frames: prev, curr)
+        -> relative poses fp32 [P,4,4] (the plan's static buffer)."""
+        assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and pairs.dtype == torch.int32
+        N, H, W, _ = frames_u8.shape
+        P = pairs.shape[0]
+        plan = self.plan_for(N, P, H, W)
+        plan.frames.copy_(frames_u8)
+        plan.pairs.copy_(pairs)
+        plan.plan.run(taps)
+        return plan.T.view(P, 4, 4)
+
+
+class _PosePlan:
+    def __init__(self, eng: CyclePoseEngine, N: int, P: int, H: int, W: int):
+        w, dt_, dev = eng.w, eng.dtype, eng.dev
+        e16 = lambda *s: torch.empty(*s, device=dev, dtype=dt_)
+        e32 = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        self.frames = torch.empty(N, H, W, 3, device=dev, dtype=torch.uint8)
+        self.pairs = torch.zeros(P, 2, device=dev, dtype=torch.int32)
+        Pl = self.plan = L.Plan()
+        cols = e16(P * CROP * CROP, K0)
+        Pl.add("im2col", "bs_cyclepose_im2col", self.frames, self.pairs, cols, P, H, W, L.dt(cols))
+        c0 = e32(P, CROP, CROP, 64)
+        Pl.gemm("c0", cols, w["c0.w"], c0, M=P * CROP * CROP, N=64, K=K0, lda=K0, bias=w["c0.b"])
+        a0 = e16(P, CROP, CROP, 64)
+        Pl.add("in0", "bs_instnorm_relu_nhwc", c0, a0, None, P, CROP * CROP, 64, 1e-5, L.dt(a0))
+        Pl.mark("c0", a0, ("nhwc", P, CROP, CROP, 64))
+        c1 = e32(P, 64, 64, 128)
+        Pl.gemm("c1", a0, w["c1.w"], c1, M=P * 64 * 64, N=128, K=9 * 64, lda=64, conv=L.conv_geom(128, 128, 64, 3, 3, 2, 1), bias=w["c1.b"])
+        a1 = e16(P, 64, 64, 128)
+        Pl.add("in1", "bs_instnorm_relu_nhwc", c1, a1, None, P, 64 * 64, 128, 1e-5, L.dt(a1))
+        c2 = e32(P, 32, 32, 256)
+        Pl.gemm("c2", a1, w["c2.w"], c2, M=P * 32 * 32, N=256, K=9 * 128, lda=128, conv=L.conv_geom(64, 64, 128, 3, 3, 2, 1), bias=w["c2.b"])
+        a2 = e16(P, 32, 32, 256)
+        x2 = e32(P, 32, 32, 256)
+        Pl.add("in2", "bs_instnorm_relu_nhwc", c2, a2, x2, P, 32 * 32, 256, 1e-5, L.dt(a2))
+        Pl.mark("c2", x2, ("nhwc", P, 32, 32, 256))
+        c3 = e32(P, 16, 16, 512)
+        Pl.gemm("c3", a2, w["c3.w"], c3, M=P * 16 * 16, N=512, K=9 * 256, lda=256, conv=L.conv_geom(32, 32, 256, 3, 3, 2, 1), bias=w["c3.b"],
+                act=L.ACT_RELU)
+        pooled = e32(P, 512)
+        Pl.add("pool", "bs_avgpool_nhwc", c3, pooled, P, 16 * 16, 512)
+        Pl.mark("pooled", pooled, ("raw",))
+        self.pose7 = e32(P, 7)
+        self.T = e32(P, 16)
+        scratch = e32(P * 64 * 8)
+        Pl.add("head", "bs_cyclepose_head", pooled, x2, w["skip.pool"], w["skip.x2"], w["skip.b"], w["d1.w"], w["d1.b"], w["d2.w"], w["d2.b"],
+               self.pose7, self.T, scratch, P, 32 * 32, 256)

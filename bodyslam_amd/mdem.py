@@ -1,0 +1,44 @@
+"""Drop-in for BodySLAM_not_refactored/MDEM/mdem_interface.py (MDEMInterface, :17-83): legacy names of the
+same MDEM API.  ``save_depth_map`` APPENDS the extension (FrameIO.save_p_img, UTILS/io_utils.py:49-74)."""
+import warnings
+
+import numpy as np
+import torch
+from PIL import Image
+
+from .weights import load_zoedepth_weights
+from .zoedepth import ZoeDepthEngine
+
+
+class MDEMInterface:
+    def __init__(self, model_type: str = "ZoeD_NK", weights=None, dtype=torch.float16):
+        self.zoe = self._initialize_ZOE(model_type, weights, dtype)
+
+    def _initialize_ZOE(self, model_type: str, weights=None, dtype=torch.float16):
+        if model_type not in ("ZoeD_N", "ZoeD_K", "ZoeD_NK"):
+            # mdem_interface.py:42-44 warns (and then still asks the hub for the bad name); here: warn + default
+            warnings.warn(f"The model type selected [{model_type}], does not exist! Using default model [ZoeD_NK]")
+            model_type = "ZoeD_NK"
+        if model_type != "ZoeD_NK":
+            raise NotImplementedError("only ZoeD_NK is built so far")
+        sd = weights if isinstance(weights, dict) else load_zoedepth_weights(weights)
+        print("[INFO] model loaded on cuda (MI355X, HIP)")
+        return ZoeDepthEngine(sd, dtype=dtype)
+
+    def infer_monocular_depth_map(self, path_to_frame: str) -> Image.Image:
+        image = Image.open(path_to_frame).convert("RGB")
+        frame = torch.from_numpy(np.asarray(image, dtype=np.uint8).copy()).unsqueeze(0).cuda()
+        _, u16 = self.zoe.infer(frame, flip_aug=True)
+        return Image.fromarray(u16[0].cpu().numpy().view(np.uint16), mode="I;16")
+
+    @staticmethod
+    def save_depth_map(image: Image.Image, saving_path: str, extension: str = None):
+        try:
+            if extension is None:
+                warnings.warn("No extension has been provided")
+                image.save(saving_path)
+                return True
+            image.save(saving_path + extension)
+            return True
+        except ValueError as e:
+            print(f"Error while saving: {e}")

@@ -1,0 +1,166 @@
+"""The per-frame depth + pose + back-projection loop over a frame sequence, one process per GPU.
+
+What it reproduces (per-stage; the reference runs MDEM offline and the rest in SLAM._sequential_loop):
+  depth per frame                 compute_dp / DepthEstimator.infer_depth_map      MDEM/compute_dp.py:8-18
+  relative pose per pair (i-1,i)  MPEMInterface.infer_relative_pose_between        EVALUATION/MPEM_eval.py:216-223
+  absolute poses                  compute_curr_estimate_global_pose chain          3DM/slam.py:148-153
+  points per frame                pixel_to_3d + RGBD constants                     3DM/scaling_system.py:72-77
+N frames -> N depth maps, N-1 relatives, N absolute poses (the first is the identity), N point sets.
+
+Multi-GPU: the sequence is cut into contiguous blocks, one per rank.  Rank r
+runs MDEM on its frames and MPEM on the pairs (i-1, i) for i in its block (it reads frame start-1 as a
+one-frame halo).  ONE RCCL all-gather (torch.distributed backend "nccl" on ROCm) of the per-rank
+relative poses [N_r, 16] fp32 stitches the chain; every rank then evaluates the identical fp64 chain
+and back-projects its own frames with their absolute poses.  No other collective is on the path.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import geom3d
+from .cyclepose import CyclePoseEngine
+from .zoedepth import ZoeConfig, ZoeDepthEngine
+
+
+def shard_bounds(n_frames: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block [start, end) of rank `rank`; blocks differ by at most one frame."""
+    base, rem = divmod(n_frames, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def local_pairs(start: int, end: int) -> np.ndarray:
+    """Global (prev, curr) index pairs owned by a block: (i-1, i) for i in [max(start,1), end)."""
+    i = np.arange(max(start, 1), end, dtype=np.int32)
+    return np.stack([i - 1, i], axis=1) if i.size else np.zeros((0, 2), np.int32)
+
+
+def gather_relative_poses(t_local: torch.Tensor, counts: Sequence[int], group=None) -> torch.Tensor:
+    """All-gather the per-rank relative poses [P_r,16] into the full [sum P_r,16] in rank order.
+    Ranks own different pair counts (rank 0 has one fewer), so blocks are padded to the maximum."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return t_local
+    pmax = max(counts)
+    buf = torch.zeros(pmax, 16, dtype=torch.float32, device=t_local.device)
+    buf[: t_local.shape[0]] = t_local
+    out = torch.empty(world * pmax, 16, dtype=torch.float32, device=t_local.device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    return torch.cat([out[r * pmax: r * pmax + counts[r]] for r in range(world)], dim=0)
+
+
+@dataclass
+class SequenceResult:
+    start: int
+    end: int
+    depth_u16: torch.Tensor            # int16 storage of uint16 metres*256, [n_local, H, W]
+    t_rel: torch.Tensor                # fp32 [N-1, 4, 4]  (full sequence, identical on every rank)
+    g_abs: torch.Tensor                # fp64 [N, 4, 4]    (full sequence, identical on every rank)
+    point_counts: torch.Tensor         # int32 [n_local]
+    points: Optional[list] = None      # optional [(xyz [M,3] fp32, idx [M] int32)] per local frame
+    depth_m: Optional[torch.Tensor] = None
+
+
+class BodySlamPipeline:
+    def __init__(self, zoe_weights: Dict[str, torch.Tensor], pose_weights: Dict[str, torch.Tensor],
+                 zoe_cfg: Optional[ZoeConfig] = None, dtype=torch.float16, device: int = 0, batch: int = 8,
+                 K: Sequence[float] = geom3d.REF_INTRINSICS, depth_scale: float = geom3d.REF_DEPTH_SCALE,
+                 depth_trunc: float = geom3d.REF_DEPTH_TRUNC, flip_aug: bool = True,
+                 target_hw: Tuple[int, int] = (384, 512)):
+        L.init(device)
+        self.dev = torch.device("cuda", device)
+        self.batch = batch
+        self.K, self.depth_scale, self.depth_trunc, self.flip = tuple(K), depth_scale, depth_trunc, flip_aug
+        self.zoe = ZoeDepthEngine(zoe_weights, zoe_cfg, dtype=dtype, device=device, target_hw=target_hw)
+        self.pose = CyclePoseEngine(pose_weights, dtype=dtype, device=device)
+
+    # -- stage 1+2 for one block of frames ----------------------------------------------------------
+    def depth_and_pose_block(self, frames: torch.Tensor, start: int, end: int, keep_depth_m: bool = False):
+        """frames: the FULL sequence as a uint8 tensor [N,H,W,3] (CPU pinned or GPU); processes [start,end)."""
+        N, H, W, _ = frames.shape
+        n_local = end - start
+        depth = torch.empty(n_local, H, W, dtype=torch.int16, device=self.dev)
+        depth_m = torch.empty(n_local, H, W, dtype=torch.float32, device=self.dev) if keep_depth_m else None
+        pairs_g = local_pairs(start, end)
+        t_rel = torch.empty(pairs_g.shape[0], 16, dtype=torch.float32, device=self.dev)
+        pi = 0
+        for b0 in range(start, end, self.batch):
+            b1 = min(b0 + self.batch, end)
+            h0 = max(b0 - 1, 0)                                     # one-frame halo for the first pair of the batch
+            chunk = frames[h0:b1].to(self.dev, non_blocking=True)
+            dm, du = self.zoe.infer(chunk[b0 - h0:], flip_aug=self.flip)
+            depth[b0 - start: b1 - start].copy_(du)
+            if keep_depth_m:
+                depth_m[b0 - start: b1 - start].copy_(dm)
+            i = np.arange(max(b0, 1), b1, dtype=np.int32)
+            if i.size:
+                pl = torch.from_numpy(np.stack([i - 1 - h0, i - h0], axis=1).astype(np.int32)).to(self.dev)
+                T = self.pose.infer_pairs(chunk, pl)
+                t_rel[pi: pi + i.size].copy_(T.reshape(-1, 16))
+                pi += i.size
+        return depth, depth_m, t_rel
+
+    def run_sequence(self, frames, rank: int = 0, world: int = 1, group=None, keep_points: bool = False,
+                     keep_depth_m: bool = False, on_points: Optional[Callable] = None) -> SequenceResult:
+        frames = torch.as_tensor(frames)
+        assert frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[-1] == 3
+        N = frames.shape[0]
+        start, end = shard_bounds(N, world, rank)
+        depth, depth_m, t_local = self.depth_and_pose_block(frames, start, end, keep_depth_m)
+        counts = [local_pairs(*shard_bounds(N, world, r)).shape[0] for r in range(world)]
+        t_all = gather_relative_poses(t_local, counts, group) if world > 1 else t_local
+        g_abs = geom3d.pose_chain(t_all, device=self.dev.index or 0)          # [N,4,4] fp64, replicated
+        n_local = end - start
+        cnt_all = torch.empty(n_local, dtype=torch.int32, device=self.dev)
+        points = [] if keep_points else None
+        for b0 in range(0, n_local, self.batch):
+            b1 = min(b0 + self.batch, n_local)
+            xyz, idx, cnt = geom3d.backproject(depth[b0:b1], self.K, self.depth_scale, self.depth_trunc,
+                                               poses=g_abs[start + b0: start + b1])
+            cnt_all[b0:b1].copy_(cnt)
+            if on_points is not None:
+                on_points(start + b0, xyz, idx, cnt)
+            if keep_points:
+                c = cnt.cpu().tolist()
+                for j in range(b1 - b0):
+                    points.append((xyz[j, :c[j]].clone(), idx[j, :c[j]].clone()))
+        return SequenceResult(start, end, depth, t_all.view(-1, 4, 4), g_abs, cnt_all, points, depth_m)
+
+
+def smoke() -> None:
+    """One tiny end-to-end invocation checked against the oracle (called by __graft_entry__.smoke())."""
+    import dataclasses
+    from oracle import cyclepose_ref as CP
+    from oracle import geom3d_ref as G
+    from oracle import zoedepth_ref as Z
+    from .synthetic import make_sequence
+    cfg_o = Z.ZoeConfig(hidden=128, layers=4, heads=2, intermediate=256, taps=(1, 2, 3, 4), image_size=64)
+    names = {f.name for f in dataclasses.fields(ZoeConfig)}
+    cfg_p = ZoeConfig(**{k: v for k, v in dataclasses.asdict(cfg_o).items() if k in names})
+    wz, wp = Z.synth_weights(cfg_o, seed=2), CP.synth_weights(seed=2)
+    frames = make_sequence(3, 160, 192, seed=5)
+    pipe = BodySlamPipeline(wz, wp, cfg_p, batch=2, target_hw=(64, 96))
+    res = pipe.run_sequence(frames, keep_points=True, keep_depth_m=True)
+    ft = torch.from_numpy(frames)
+    ref_d = Z.infer_depth(wz, cfg_o, ft, out_hw=(64, 96))
+    l1 = (res.depth_m.cpu() - ref_d).abs().mean().item()
+    assert l1 < 2e-3, f"depth L1 vs oracle {l1}"
+    pairs = torch.tensor([[0, 1], [1, 2]])
+    ref_T = CP.forward_pose(wp, CP.center_crop_pair(ft, pairs)).numpy()
+    et = np.abs(res.t_rel.cpu().numpy() - ref_T).max()
+    assert et < 5e-3, f"relative pose error vs oracle {et}"
+    ref_g = G.pose_chain(res.t_rel.cpu().numpy())
+    assert np.abs(res.g_abs.cpu().numpy() - ref_g).max() < 1e-10
+    du = res.depth_u16.cpu().numpy().view(np.uint16)
+    for j in range(3):
+        rx, ri = G.backproject(du[j], pose=ref_g[j])
+        xyz, idx = res.points[j]
+        assert np.array_equal(idx.cpu().numpy(), ri), "point indices differ from the oracle"
+        assert np.allclose(xyz.cpu().numpy(), rx, atol=1e-5)
+    print(f"pipeline smoke ok: depth L1 {l1:.2e} m, pose max err {et:.2e}")

@@ -191,6 +191,8 @@ int bs_cyclepose_head(const float* pooled, const float* x2, const float* w_skip_
 int bs_backproject(const uint16_t* depth, int32_t B, int32_t H, int32_t W, const double* K_host, double depth_scale,
                    double depth_trunc, const double* poses, float* xyz, int32_t* idx, int32_t* count,
                    int32_t* scratch, void* stream);
+/* 3DM/scaling_system.py:72-77 pixel_to_3d verbatim on n (u, v, depth) fp64 triples -> (x, y, z) fp64 */
+int bs_pixel_to_3d(const double* uvd, int64_t n, const double* K_host, double* out, void* stream);
 /* 3DM/slam_utils.py:110-122 compute_curr_estimate_global_pose chained over N relatives (fp32 [N,16]) from
  * g0 (fp64 [16], host, nullable = identity) -> g_abs fp64 [N+1,16]; per-step SO(3) projection
  * (slam_utils.py:93-108).  Sequential by construction: one wavefront. */
