@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Benchmark of the BodySLAM hot path on MI355X: frames/s of depth (ZoeD_NK, flip-aug) + relative pose
+(CyclePose) + pose chain + back-projection on synthetic 640x480 sequences.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype f16|bf16]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the full loop over one batch of B consecutive frames per rank:
+  MDEM  B frames -> 2B network forwards (flip-aug) -> B depth maps (fp32 metres + uint16)
+  MPEM  the B frame pairs (i-1, i) of the batch (one halo frame) -> B relative poses
+  RCCL  all-gather of the per-rank [B,16] relatives (N > 1), fp64 pose chain over the gathered block
+  3DM   back-projection + compaction of the rank's B depth maps with their absolute poses
+Inputs are resident in HBM before the timed region.  K steps are timed between barrier +
+torch.cuda.synchronize() pairs; the value is (ranks x K x B frames) / max-over-ranks time.
+Weights are random-init (no checkpoint is reachable offline); data is synthetic.
+
+roofline: per-kernel HIP-event timing of every bs_gemm launch inside the timed steps, aggregated per
+kernel instantiation (tile variant x conv/plain); the dominant one by time is reported against the dense
+fp16/bf16 MFMA peak (2.5 PFLOP/s), next to the conv-stack aggregate the north star names.
+cpu_baseline: the CPU oracle (torch fp32, all host cores) on ONE frame of the same workload, rank 0 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+TILE_NAMES = {1: "128x128", 2: "128x64", 3: "128x32", 4: "256x128"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="frames per step per GPU")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (pure throughput run)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+        args.gpus = world
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from bodyslam_amd import _lib as L
+    from bodyslam_amd import geom3d
+    from bodyslam_amd.pipeline import BodySlamPipeline, gather_relative_poses
+    from bodyslam_amd.synthetic import make_sequence, random_cyclepose_weights, random_zoedepth_weights
+    from bodyslam_amd.zoedepth import ZoeConfig
+
+    dtype = torch.float16 if args.dtype == "f16" else torch.bfloat16
+    B, K, Wm = args.batch, args.steps, args.warmup
+    H, W = args.height, args.width
+    dev = torch.device("cuda", local_rank)
+    cfg = ZoeConfig()
+    wz = random_zoedepth_weights(cfg, seed=0)
+    wp = random_cyclepose_weights(seed=0)
+    pipe = BodySlamPipeline(wz, wp, cfg, dtype=dtype, device=local_rank, batch=B)
+    n_frames = (K + Wm) * B + 1
+    frames = torch.from_numpy(make_sequence(n_frames, H, W, seed=rank)).to(dev)     # resident in HBM
+    pairs = torch.tensor([[i, i + 1] for i in range(B)], dtype=torch.int32, device=dev)
+    zplan = pipe.zoe.plan_for(B, H, W, True)
+    pplan = pipe.pose.plan_for(B + 1, B, H, W)
+    counts = [B] * world
+    events = []
+
+    def step(k, timed_kernels):
+        chunk = frames[k * B: (k + 1) * B + 1]                                       # halo frame + B frames
+        zplan.frames.copy_(chunk[1:])
+        if timed_kernels:
+            zplan.plan.run_timed(events)
+        else:
+            zplan.plan.run()
+        pplan.frames.copy_(chunk)
+        pplan.pairs.copy_(pairs)
+        pplan.plan.run()
+        t_all = gather_relative_poses(pplan.T, counts) if world > 1 else pplan.T
+        g_abs = geom3d.pose_chain(t_all, device=local_rank)
+        xyz, idx, cnt = geom3d.backproject(zplan.depth_u16, pipe.K, pipe.depth_scale, pipe.depth_trunc,
+                                           poses=g_abs[rank * B + 1: (rank + 1) * B + 1])
+        return cnt
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(Wm):
+        step(k, False)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(Wm, Wm + K):
+        cnt = step(k, not args.no_kernel_timing)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = te.item()
+    total_frames = world * K * B
+    fps = total_frames / elapsed
+
+    # ---- per-kernel roofline from the HIP events of the timed steps (rank 0's view)
+    roof, roof_conv, kern_table = None, None, {}
+    if events:
+        agg = {}
+        for (ci, e0, e1) in events:
+            gi = zplan.plan.gemm_info[ci]
+            key = ("conv" if gi["conv"] else "gemm", gi["tile"])
+            a = agg.setdefault(key, dict(ms=0.0, flops=0.0, n=0))
+            a["ms"] += e0.elapsed_time(e1)
+            a["flops"] += gi["flops"]
+            a["n"] += 1
+        for (kind, tile), a in agg.items():
+            kern_table[f"igemm_{kind}_{TILE_NAMES[tile]}"] = dict(
+                launches=a["n"], avg_us=1e3 * a["ms"] / a["n"], tflops=a["flops"] / (a["ms"] * 1e-3) / 1e12,
+                gflop_per_launch=a["flops"] / a["n"] / 1e9, share_of_step=a["ms"] / (elapsed * 1e3))
+        dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        (kind, tile), a = dom
+        ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        roof = dict(bound="mfma", kernel=f"igemm_kernel<{args.dtype},{TILE_NAMES[tile]},{kind}>", achieved=round(ach, 1),
+                    peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=None,
+                    avg_launch_us=round(1e3 * a["ms"] / a["n"], 2), gflop_per_launch=round(a["flops"] / a["n"] / 1e9, 3))
+        cms = sum(a["ms"] for (kd, _), a in agg.items() if kd == "conv")
+        cfl = sum(a["flops"] for (kd, _), a in agg.items() if kd == "conv")
+        if cms > 0:
+            roof_conv = dict(bound="mfma", what="ZoeDepth conv stack (all conv-mode igemm launches)", achieved=round(cfl / (cms * 1e-3) / 1e12, 1),
+                             peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(cfl / (cms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4))
+
+    # ---- CPU baseline (rank 0): the oracle on one frame of the same sequence, all host cores
+    cpu = None
+    l1 = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import cyclepose_ref as CP
+        from oracle import geom3d_ref as G
+        from oracle import zoedepth_ref as Z
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        f2 = frames[:2].cpu()
+        gd, _ = pipe.zoe.infer(frames[1:2])
+        gd = gd.cpu().clone()
+        tc = time.perf_counter()
+        with torch.no_grad():
+            d_ref = Z.infer_depth(wz, Z.ZOED_NK, f2[1:2], flip_aug=True)
+            T = CP.forward_pose(wp, CP.center_crop_pair(f2, torch.tensor([[0, 1]])))
+        g_ref = G.pose_chain(T.numpy())
+        G.backproject(Z.to_uint16(d_ref)[0], pose=g_ref[1])
+        tcpu = time.perf_counter() - tc
+        l1 = float((gd - d_ref).abs().mean())
+        cpu = dict(value=round(1.0 / tcpu, 4), unit="frames/s", cores=ncores, kind="port",
+                   sample="1 frame 640x480: ZoeD_NK x2 (flip-aug) + 1 CyclePose pair + chain + back-projection, torch fp32 oracle")
+
+    if rank == 0:
+        out = {
+            "metric": "frames/sec depth+pose+back-proj, 640x480 seq", "value": round(fps, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic frames, random-init weights",
+            "config": {"workload": f"full MDEM(ZoeD_NK, flip-aug)+MPEM(CyclePose)+3DM loop, {K * B} synthetic {W}x{H} frames per GPU, "
+                                   f"batch {B} frames/step", "frames_per_step_per_gpu": B, "net_input": list(zplan.geom[k] for k in ("nh", "nw")),
+                       "sharding": "contiguous frame blocks per rank, one RCCL all-gather of relative poses per step" if world > 1 else "single GPU"},
+            "roofline": roof, "roofline_conv_stack": roof_conv, "cpu_baseline": cpu,
+            "depth_l1_vs_oracle_m": l1, "kernels": kern_table,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

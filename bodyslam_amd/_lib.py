@@ -52,6 +52,7 @@ _SIGS = {
     "bs_init": [C.c_int],
     "bs_version": [],
     "bs_gemm": [C.POINTER(GemmDesc), C.c_void_p],
+    "bs_gemm_tile": [C.POINTER(GemmDesc)],
     "bs_attention": [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p],
     "bs_layernorm": [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p],
     "bs_cast": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p],
@@ -200,12 +201,17 @@ class Plan:
         self.names = []
         self.keep = []       # keeps descriptors / tensors alive
         self.marks = {}      # call index -> [(name, tensor)]
+        self.gemm_info = {}  # call index -> dict(tile, conv, flops, bytes)
 
     def gemm(self, name, A, W, out, **kw):
         d = make_gemm_desc(A, W, out, **kw)
         self.keep.append((d, A, W, out, kw))
         self.calls.append((load_library().bs_gemm, (C.byref(d),)))
         self.names.append(name)
+        # bookkeeping for the roofline: which kernel instantiation and how many algorithmic FLOPs
+        self.gemm_info[len(self.calls) - 1] = dict(
+            name=name, tile=load_library().bs_gemm_tile(C.byref(d)), conv=bool(d.conv), flops=2.0 * d.M * d.N * d.K,
+            bytes=float(d.M) * (d.Cin if d.conv else d.K) * 2 + float(d.N) * d.K * 2 + float(d.M) * d.N * (4 if d.out_dtype == F32 else 2))
 
     def add(self, name, fn_name, *args):
         cargs = []
@@ -220,6 +226,22 @@ class Plan:
 
     def mark(self, name, tensor, meta=None):
         self.marks.setdefault(len(self.calls), []).append((name, tensor, meta))
+
+    def run_timed(self, events: list):
+        """Like run(), with a HIP event pair (recorded on the launch stream) around every bs_gemm launch;
+        appends (call_index, start_event, end_event) to `events`."""
+        st = stream_ptr()
+        for i, (fn, args) in enumerate(self.calls):
+            if i in self.gemm_info:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = fn(*args, st)
+                e1.record()
+                events.append((i, e0, e1))
+            else:
+                rc = fn(*args, st)
+            if rc:
+                check(rc, self.names[i])
 
     def run(self, taps: Optional[dict] = None):
         st = stream_ptr()

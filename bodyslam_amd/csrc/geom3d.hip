@@ -187,9 +187,10 @@ __device__ void svd3_project_so3(double (&M)[3][3]) {
         for (int i = 0; i < 3; ++i) U[i][j] = A[i][j] * inv;
     }
     // the reflection correction acts on the SMALLEST singular direction (LAPACK orders them descending)
+    // (ties -> the last index, which is where a descending LAPACK ordering leaves the flipped direction)
     int kmin = 0;
-    if (s[1] < s[kmin]) kmin = 1;
-    if (s[2] < s[kmin]) kmin = 2;
+    if (s[1] <= s[kmin]) kmin = 1;
+    if (s[2] <= s[kmin]) kmin = 2;
     auto det3 = [](const double (&X)[3][3]) {
         return X[0][0] * (X[1][1] * X[2][2] - X[1][2] * X[2][1]) - X[0][1] * (X[1][0] * X[2][2] - X[1][2] * X[2][0]) +
                X[0][2] * (X[1][0] * X[2][1] - X[1][1] * X[2][0]);

@@ -338,14 +338,17 @@ static int launch_variant(const IgemmParams& p, bool conv, hipStream_t st) {
     return BS_OK;
 }
 
+static int auto_tile(int M, int N, int tile) {
+    if (tile != 0) return tile;
+    if (N <= 32) return 3;
+    if (N <= 64) return 2;
+    if (M >= 16384 && N % 128 == 0) return 4;
+    return 1;
+}
+
 template <typename T>
 static int dispatch(IgemmParams& p, bool conv, int tile, hipStream_t st) {
-    if (tile == 0) {
-        if (p.N <= 32) tile = 3;
-        else if (p.N <= 64) tile = 2;
-        else if (p.M >= 16384 && p.N % 128 == 0) tile = 4;
-        else tile = 1;
-    }
+    tile = auto_tile(p.M, p.N, tile);
     int BM, BN;
     switch (tile) {
         case 1: BM = 128; BN = 128; break;
@@ -365,6 +368,8 @@ static int dispatch(IgemmParams& p, bool conv, int tile, hipStream_t st) {
 }
 
 }  // namespace bs
+
+extern "C" int bs_gemm_tile(const bs_gemm_desc* d) { return d ? bs::auto_tile(d->M, d->N, d->tile) : BS_ERR_INVALID; }
 
 extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
     using namespace bs;

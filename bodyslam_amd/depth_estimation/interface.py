@@ -42,7 +42,7 @@ class DepthEstimator:
         frame = torch.from_numpy(np.asarray(image, dtype=np.uint8).copy()).unsqueeze(0).cuda()
         _, u16 = self.model.infer(frame, flip_aug=True)
         arr = u16[0].cpu().numpy().view(np.uint16)
-        return Image.fromarray(arr, mode="I;16") if hasattr(Image, "fromarray") else arr
+        return Image.fromarray(arr)          # uint16 array -> mode "I;16"
 
     @staticmethod
     def load_image(path: str) -> Image.Image:

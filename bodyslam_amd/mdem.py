@@ -29,7 +29,7 @@ class MDEMInterface:
         image = Image.open(path_to_frame).convert("RGB")
         frame = torch.from_numpy(np.asarray(image, dtype=np.uint8).copy()).unsqueeze(0).cuda()
         _, u16 = self.zoe.infer(frame, flip_aug=True)
-        return Image.fromarray(u16[0].cpu().numpy().view(np.uint16), mode="I;16")
+        return Image.fromarray(u16[0].cpu().numpy().view(np.uint16))   # mode "I;16"
 
     @staticmethod
     def save_depth_map(image: Image.Image, saving_path: str, extension: str = None):

@@ -87,6 +87,8 @@ typedef struct bs_gemm_desc {
     int32_t tile;                  /* 0 = auto; else forces a tile variant (tests / tuning) */
 } bs_gemm_desc;
 int bs_gemm(const bs_gemm_desc* d, void* stream);
+/* the tile variant bs_gemm will pick for this descriptor (1: 128x128, 2: 128x64, 3: 128x32, 4: 256x128) */
+int bs_gemm_tile(const bs_gemm_desc* d);
 
 /* BEiT attention: softmax(Q K^T + relpos_bias) V -------------------------------------------- *
  * HF modeling_beit.py:268-341 (eager_attention_forward with the additive relative-position bias
