@@ -154,7 +154,8 @@ def main():
         from oracle import cyclepose_ref as CP
         from oracle import geom3d_ref as G
         from oracle import zoedepth_ref as Z
-        ncores = os.cpu_count() or 1
+        # torch CPU ops stop scaling (and then collapse) far below a 256-thread host: use at most 32 threads
+        ncores = min(os.cpu_count() or 1, 32)
         torch.set_num_threads(ncores)
         f2 = frames[:2].cpu()
         gd, _ = pipe.zoe.infer(frames[1:2])

@@ -68,7 +68,7 @@ _SIGS = {
     "bs_route_argmax": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p],
     "bs_postprocess_depth": [C.c_void_p] * 3 + [C.c_int32] * 6 + [C.c_void_p],
     "bs_cyclepose_im2col": [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p],
-    "bs_instnorm_relu_nhwc": [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_float, C.c_int32, C.c_void_p],
+    "bs_instnorm_relu_nhwc": [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_float, C.c_int32, C.c_void_p],
     "bs_avgpool_nhwc": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
     "bs_cyclepose_head": [C.c_void_p] * 12 + [C.c_int32] * 3 + [C.c_void_p],
     "bs_backproject": [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_double, C.c_double] + [C.c_void_p] * 6,
@@ -327,8 +327,8 @@ def cyclepose_im2col(frames, pairs, out, P, H, W):
     check(load_library().bs_cyclepose_im2col(p(frames), p(pairs), p(out), P, H, W, dt(out), stream_ptr()), "bs_cyclepose_im2col")
 
 
-def instnorm_relu_nhwc(x, out, out_f32, P, HW, Cch, eps=1e-5):
-    check(load_library().bs_instnorm_relu_nhwc(p(x), p(out), p(out_f32), P, HW, Cch, eps, dt(out), stream_ptr()),
+def instnorm_relu_nhwc(x, out, out_f32, scratch, P, HW, Cch, eps=1e-5):
+    check(load_library().bs_instnorm_relu_nhwc(p(x), p(out), p(out_f32), p(scratch), P, HW, Cch, eps, dt(out), stream_ptr()),
           "bs_instnorm_relu_nhwc")
 
 

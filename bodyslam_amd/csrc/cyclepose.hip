@@ -48,46 +48,91 @@ __global__ __launch_bounds__(256) void cp_im2col_kernel(const uint8_t* frames, c
     }
 }
 
-// InstanceNorm2d (biased variance, eps, no affine) + ReLU over an NHWC fp32 map.
-// grid (C/64, P); block 256 = 4 row-groups x 64 channels: coalesced 256-B reads along C.
+// InstanceNorm2d (biased variance, eps, no affine) + ReLU over an NHWC fp32 map, in two fully parallel passes:
+//   (1) per (image, 256-row chunk): chunk mean and M2 (sum of squared deviations about the chunk mean) per channel;
+//   (2) per chunk: combine the partials (Chan et al.: equal-weight chunks, numerically as good as two-pass over
+//       the whole map), normalise + ReLU, write 16-bit (and optionally fp32).
+// thread = 4 consecutive channels (16-byte loads); a 256-thread block covers 1024/C rows per sweep.
+constexpr int IN_CHUNK = 256;   // rows (pixels) per block
+
+__global__ __launch_bounds__(256) void instnorm_stats_kernel(const float* x, float* part, int HW, int C, int nchunk) {
+    const int p = blockIdx.y, ch = blockIdx.x;
+    const int tpr = C >> 2, rps = 256 / tpr;            // threads per row, rows per sweep
+    const int c4 = (threadIdx.x % tpr) * 4, rg = threadIdx.x / tpr;
+    const int r0 = ch * IN_CHUNK, r1 = min(HW, r0 + IN_CHUNK);
+    const float* xp = x + ((int64_t)p * HW) * C + c4;
+    __shared__ float red[256 * 4];
+    __shared__ float mean_s[256];
+    f32x4 s = {0, 0, 0, 0};
+    for (int r = r0 + rg; r < r1; r += rps) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xp + (int64_t)r * C);
+        s += v;
+    }
+    *reinterpret_cast<f32x4*>(red + threadIdx.x * 4) = s;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        const int c = threadIdx.x;
+        float a = 0.f;
+        for (int g = 0; g < rps; ++g) a += red[(g * tpr + (c >> 2)) * 4 + (c & 3)];
+        mean_s[c] = a / (float)(r1 - r0);
+    }
+    __syncthreads();
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean_s + c4);
+    f32x4 q = {0, 0, 0, 0};
+    for (int r = r0 + rg; r < r1; r += rps) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xp + (int64_t)r * C) - mu;
+        q += v * v;
+    }
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(red + threadIdx.x * 4) = q;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        const int c = threadIdx.x;
+        float a = 0.f;
+        for (int g = 0; g < rps; ++g) a += red[(g * tpr + (c >> 2)) * 4 + (c & 3)];
+        float* o = part + (((int64_t)p * nchunk + ch) * 2) * C;
+        o[c] = mean_s[c];
+        o[C + c] = a;
+    }
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void instnorm_relu_kernel(const float* x, T* out, float* out_f32, int HW, int C, float eps) {
-    const int p = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
-    const float* xp = x + (int64_t)p * HW * C + c;
-    __shared__ float red[4][64];
-    __shared__ float stat[2][64];
-    // pass 1: mean
-    float s = 0.f;
-    for (int i = g; i < HW; i += 4) s += xp[(int64_t)i * C];
-    red[g][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (g == 0) {
-        const int l = threadIdx.x;
-        stat[0][l] = (red[0][l] + red[1][l] + red[2][l] + red[3][l]) / (float)HW;
+__global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* x, const float* part, T* out, float* out_f32, int HW, int C,
+                                                              int nchunk, float eps) {
+    const int p = blockIdx.y, ch = blockIdx.x;
+    const int tpr = C >> 2, rps = 256 / tpr;
+    const int c4 = (threadIdx.x % tpr) * 4, rg = threadIdx.x / tpr;
+    const int r0 = ch * IN_CHUNK, r1 = min(HW, r0 + IN_CHUNK);
+    __shared__ float mean_s[256], rstd_s[256];
+    if (threadIdx.x < C) {
+        const int c = threadIdx.x;
+        const float* pp = part + ((int64_t)p * nchunk * 2) * C + c;
+        // all chunks but possibly the last hold IN_CHUNK rows; weight by the true counts
+        float msum = 0.f;
+        for (int k = 0; k < nchunk; ++k) msum += pp[(int64_t)k * 2 * C] * (float)(min(HW, (k + 1) * IN_CHUNK) - k * IN_CHUNK);
+        const float mean = msum / (float)HW;
+        float m2 = 0.f;
+        for (int k = 0; k < nchunk; ++k) {
+            const float d = pp[(int64_t)k * 2 * C] - mean;
+            m2 += pp[(int64_t)k * 2 * C + C] + d * d * (float)(min(HW, (k + 1) * IN_CHUNK) - k * IN_CHUNK);
+        }
+        mean_s[c] = mean;
+        rstd_s[c] = 1.0f / sqrtf(m2 / (float)HW + eps);
     }
     __syncthreads();
-    const float mean = stat[0][threadIdx.x & 63];
-    // pass 2: variance about the mean (matches torch's two-pass numerics far better than E[x^2]-E[x]^2)
-    float v = 0.f;
-    for (int i = g; i < HW; i += 4) {
-        const float d = xp[(int64_t)i * C] - mean;
-        v += d * d;
-    }
-    __syncthreads();
-    red[g][threadIdx.x & 63] = v;
-    __syncthreads();
-    if (g == 0) {
-        const int l = threadIdx.x;
-        stat[1][l] = 1.0f / sqrtf((red[0][l] + red[1][l] + red[2][l] + red[3][l]) / (float)HW + eps);
-    }
-    __syncthreads();
-    const float rstd = stat[1][threadIdx.x & 63];
-    T* op = out + (int64_t)p * HW * C + c;
-    float* of = out_f32 ? out_f32 + (int64_t)p * HW * C + c : nullptr;
-    for (int i = g; i < HW; i += 4) {
-        const float y = fmaxf((xp[(int64_t)i * C] - mean) * rstd, 0.0f);
-        op[(int64_t)i * C] = T16<T>::from_f32(y);
-        if (of) of[(int64_t)i * C] = y;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean_s + c4), rs = *reinterpret_cast<const f32x4*>(rstd_s + c4);
+    const int64_t base = ((int64_t)p * HW) * C + c4;
+    for (int r = r0 + rg; r < r1; r += rps) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + base + (int64_t)r * C);
+        f32x4 y;
+        typename T16<T>::v4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y[e] = fmaxf((v[e] - mu[e]) * rs[e], 0.0f);
+            o[e] = T16<T>::from_f32(y[e]);
+        }
+        *reinterpret_cast<typename T16<T>::v4*>(out + base + (int64_t)r * C) = o;
+        if (out_f32) *reinterpret_cast<f32x4*>(out_f32 + base + (int64_t)r * C) = y;
     }
 }
 
@@ -202,19 +247,23 @@ extern "C" int bs_cyclepose_im2col(const uint8_t* frames, const int32_t* pairs, 
     return BS_OK;
 }
 
-extern "C" int bs_instnorm_relu_nhwc(const float* x, void* out, float* out_f32, int32_t P, int32_t HW, int32_t C, float eps,
-                                     int32_t dtype, void* stream) {
+extern "C" int bs_instnorm_relu_nhwc(const float* x, void* out, float* out_f32, float* scratch, int32_t P, int32_t HW, int32_t C,
+                                     float eps, int32_t dtype, void* stream) {
     using namespace bs;
     if (!initialized()) { set_error("bs_instnorm_relu_nhwc: call bs_init first"); return BS_ERR_NOT_INIT; }
-    BS_REQUIRE(x && out && P >= 0 && HW > 0 && C % 64 == 0, "bs_instnorm_relu_nhwc: bad argument (C must be a multiple of 64)");
+    BS_REQUIRE(x && out && scratch && P >= 0 && HW > 0 && C % 4 == 0 && C >= 4 && C <= 256 && 256 % (C / 4) == 0,
+               "bs_instnorm_relu_nhwc: bad argument (C must be 4..256 with C/4 dividing 256)");
     BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_instnorm_relu_nhwc: dtype");
     if (P == 0) return BS_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    dim3 grid(C / 64, P);
+    const int nchunk = cdiv(HW, IN_CHUNK);
+    dim3 grid(nchunk, P);
+    hipLaunchKernelGGL(instnorm_stats_kernel, grid, dim3(256), 0, st, x, scratch, HW, C, nchunk);
+    BS_CHECK_LAUNCH();
     if (dtype == BS_F16)
-        hipLaunchKernelGGL(instnorm_relu_kernel<f16>, grid, dim3(256), 0, st, x, (f16*)out, out_f32, HW, C, eps);
+        hipLaunchKernelGGL(instnorm_apply_kernel<f16>, grid, dim3(256), 0, st, x, (const float*)scratch, (f16*)out, out_f32, HW, C, nchunk, eps);
     else
-        hipLaunchKernelGGL(instnorm_relu_kernel<bf16>, grid, dim3(256), 0, st, x, (bf16*)out, out_f32, HW, C, eps);
+        hipLaunchKernelGGL(instnorm_apply_kernel<bf16>, grid, dim3(256), 0, st, x, (const float*)scratch, (bf16*)out, out_f32, HW, C, nchunk, eps);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }

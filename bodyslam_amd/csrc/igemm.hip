@@ -28,6 +28,7 @@ struct IgemmParams {
     const void* A;
     const void* W;
     const void* zero;
+    long long a_bytes;   // extent of A in bytes (bounds of the buffer descriptor)
     int M, N, K, lda;
     int Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_h, pad_w;
     int tiles_per_tap;
@@ -74,16 +75,35 @@ __device__ __forceinline__ void store4(void* base, int64_t off, int out_dtype, c
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Tile variants.  BK is the K slice per stage (one 64- or 128-byte LDS row per tile row), STAGES the depth
+// of the LDS ring: STAGES-1 tiles are in flight (global_load_lds) while one is multiplied.
+// MODE: 0 plain GEMM rows, 1 implicit conv, 2 implicit conv with ReLU applied to A on load
+template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int MODE>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins exist in the device pass only; the host pass needs just the stub
+    constexpr bool CONV = MODE != 0;
+    constexpr bool RELU_A = MODE == 2;
     constexpr int NT = WM * WN * 64;
-    constexpr int RPR = NT / 8;  // rows staged per DMA round (8 lanes x 16 B = one 128-B row)
+    constexpr int ROWB = BK * 2;        // bytes per LDS row
+    constexpr int LPR = ROWB / 16;      // lanes (16-byte chunks) per row: 8 (BK 64) or 4 (BK 32)
+    constexpr int RPR = NT / LPR;       // rows staged per DMA round
+    constexpr int RPW = 64 / LPR;       // rows per wave-instruction (1 KiB)
     constexpr int RA = BM / RPR, RB = BN / RPR;
+    static_assert(BK == 64 || BK == 32, "BK");
     static_assert(BM % RPR == 0 && BN % RPR == 0, "tile rows must be a multiple of the DMA round");
+    constexpr int GL = RA + RB;         // LDS-DMA instructions per wave per stage
+    static_assert(GL * (STAGES - 1) <= 63, "vmcnt range");
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 16, FN = TN / 16;
     static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be a multiple of 16");
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int LDS_BYTES = STAGES * STAGE;
+    constexpr unsigned OOB = 0x80000000u;   // voffset sentinel: beyond every descriptor (num_records < 2^31) -> the DMA writes zeros
     typedef typename T16<T>::v8 v8;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -98,68 +118,97 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave - wm * WN;
-    const int srow = tid >> 3;
-    const int cs8 = ((tid & 7) ^ (srow & 7)) * 8;  // element offset of the source chunk this lane fetches
+    const int srow = tid / LPR;
+    // LDS image: 16-byte chunk c of row r sits at chunk position c ^ swz(r); swz(r) = r & 7 (128-byte rows) or
+    // (-(r >> 2)) & 3 (64-byte rows): conflict-free ds_read_b128 for the 16x16x32 operand pattern in both cases
+    // (the b128 lane groups pair rows {0-3,12-15} at chunk c with rows {4-11} at chunk c^1).
+    const int sswz = (BK == 64) ? (srow & 7) : ((0 - (srow >> 2)) & 3);
+    const int cs16 = ((tid & (LPR - 1)) ^ sswz) * 16;  // byte offset of the SOURCE chunk this lane fetches
 
-    const T* Ag = reinterpret_cast<const T*>(p.A);
-    const T* Wg = reinterpret_cast<const T*>(p.W);
-    const T* zp = reinterpret_cast<const T*>(p.zero) + cs8;
+    // ---- buffer descriptors (wave-uniform): A window starting at this tile's first image / row, W whole.
+    // Out-of-range lanes of a `buffer_load ... lds` write ZEROS to LDS (probed: tools/probes/lds_dma_oob.hip):
+    // that is the convolution's zero padding -- no zero page, no per-lane pointer select, 32-bit offsets only.
+    const int m0 = tm * BM;
+    long long a_base_el;
+    int img0 = 0;
+    if (CONV) {
+        img0 = m0 / (p.Hout * p.Wout);
+        a_base_el = (long long)img0 * p.Hin * p.Win * p.lda;
+    } else {
+        a_base_el = (long long)m0 * p.lda;
+    }
+    long long a_left = p.a_bytes - a_base_el * 2;
+    a_left = a_left > 0x7FFFFFF0ll ? 0x7FFFFFF0ll : a_left;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(reinterpret_cast<const T*>(p.A)) + a_base_el, 0, (int)a_left, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.W), 0, (int)((long long)p.N * p.K * 2), 0x00020000);
 
-    // ---- per-lane row bookkeeping for the DMA rounds
-    const T* a_ptr[RA];
-    int a_iy0[RA], a_ix0[RA];
+    // ---- per-lane row bookkeeping for the DMA rounds: a 32-bit byte offset and (conv) a tap-validity bitmask
+    unsigned a_off[RA];
+    unsigned a_mask[RA];
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
-        int m = tm * BM + j * RPR + srow;
+        int m = m0 + j * RPR + srow;
         m = m < p.M ? m : p.M - 1;
         if (CONV) {
             const int hw = p.Hout * p.Wout;
             const int b = m / hw, rem = m - b * hw;
             const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-            a_iy0[j] = oy * p.stride - p.pad_h;
-            a_ix0[j] = ox * p.stride - p.pad_w;
-            a_ptr[j] = Ag + ((int64_t)(b * p.Hin + a_iy0[j]) * p.Win + a_ix0[j]) * p.lda + cs8;
+            const int iy0 = oy * p.stride - p.pad_h, ix0 = ox * p.stride - p.pad_w;
+            // offset of tap (0,0); may be "negative" (wraps): it is only used where the tap is valid, where the sum is in range
+            a_off[j] = (unsigned)((((b - img0) * p.Hin + iy0) * p.Win + ix0) * p.lda * 2 + cs16);
+            unsigned mk = 0;
+            for (int ky = 0; ky < p.KH; ++ky)
+                for (int kx = 0; kx < p.KW; ++kx) {
+                    const bool ok = (unsigned)(iy0 + ky) < (unsigned)p.Hin && (unsigned)(ix0 + kx) < (unsigned)p.Win;
+                    mk |= (ok ? 1u : 0u) << (ky * p.KW + kx);
+                }
+            a_mask[j] = mk;
         } else {
-            a_iy0[j] = a_ix0[j] = 0;
-            a_ptr[j] = Ag + (int64_t)m * p.lda + cs8;
+            a_off[j] = (unsigned)((m - m0) * p.lda * 2 + cs16);
+            a_mask[j] = 1u;
         }
     }
-    const T* w_ptr[RB];
+    unsigned w_off[RB];
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
         int n = tn * BN + j * RPR + srow;
         n = n < p.N ? n : p.N - 1;
-        w_ptr[j] = Wg + (int64_t)n * p.K + cs8;
+        w_off[j] = (unsigned)(n * p.K * 2 + cs16);
     }
 
-    // running tap state of the NEXT tile to stage (conv): ky, kx, channel offset
-    int s_ky = 0, s_kx = 0, s_c0 = 0, s_t = 0;
+    // running state of the NEXT tile to stage: tap index / tap byte offset / channel byte offset (conv), k byte offset
+    int s_tap = 0, s_kx = 0, s_tapoff = 0, s_c0 = 0, s_k = 0;
 
     auto stage = [&](int buf) {
         char* sa = smem + buf * STAGE;
         char* sb = sa + A_BYTES;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
-            const T* src;
+            unsigned vo;
             if (CONV) {
-                const bool ok = (unsigned)(a_iy0[j] + s_ky) < (unsigned)p.Hin && (unsigned)(a_ix0[j] + s_kx) < (unsigned)p.Win;
-                src = ok ? a_ptr[j] + (int64_t)(s_ky * p.Win + s_kx) * p.lda + s_c0 : zp;
+                vo = ((a_mask[j] >> s_tap) & 1u) ? a_off[j] + (unsigned)s_tapoff : OOB;
             } else {
-                src = a_ptr[j] + s_t * 64;
+                vo = a_off[j];
             }
-            glds16(src, sa + (j * RPR + wave * 8) * 128);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(sa + (j * RPR + wave * RPW) * ROWB), 16, vo,
+                                                     CONV ? s_c0 : s_k, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < RB; ++j) glds16(w_ptr[j] + s_t * 64, sb + (j * RPR + wave * 8) * 128);
-        // advance
-        ++s_t;
+        for (int j = 0; j < RB; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(sb + (j * RPR + wave * RPW) * ROWB), 16, w_off[j],
+                                                     s_k, 0, 0);
+        s_k += BK * 2;
         if (CONV) {
-            s_c0 += 64;
-            if (s_c0 >= p.Cin) {
+            s_c0 += BK * 2;
+            if (s_c0 >= p.Cin * 2) {
                 s_c0 = 0;
+                ++s_tap;
+                s_tapoff += p.lda * 2;
                 if (++s_kx >= p.KW) {
                     s_kx = 0;
-                    ++s_ky;
+                    s_tapoff += (p.Win - p.KW) * p.lda * 2;
                 }
             }
         }
@@ -171,56 +220,68 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // fragment read offsets: row = tile row of the 16-row fragment + (lane & 15); (row & 7) == (lane & 7)
-    const int frow = lane & 15, fq = lane >> 4, sw = lane & 7;
-    const int koff0 = ((0 + fq) ^ sw) << 4, koff1 = ((4 + fq) ^ sw) << 4;
-    const int a_base = (wm * TM + frow) * 128, b_base = (wn * TN + frow) * 128;
+    // fragment read offsets: row = 16-row fragment base + (lane & 15)
+    const int frow = lane & 15, fq = lane >> 4;
+    const int fswz = (BK == 64) ? (lane & 7) : ((0 - ((lane & 15) >> 2)) & 3);
+    const int koff0 = ((0 + fq) ^ fswz) << 4, koff1 = (BK == 64) ? (((4 + fq) ^ fswz) << 4) : 0;
+    const int a_base = (wm * TM + frow) * ROWB, b_base = (wn * TN + frow) * ROWB;
 
-    const int nt = p.K >> 6;
-    stage(0);
+    const int nt = p.K / BK;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nt) stage(s);
+    int cbuf = 0, sbuf = STAGES - 1;   // buffer multiplied this iteration / buffer staged this iteration
     for (int t = 0; t < nt; ++t) {
-        __syncthreads();  // tile t has landed (vmcnt(0) precedes the barrier) and buffer (t+1)&1 is free
-        if (t + 1 < nt) stage((t + 1) & 1);
-        const char* sa = smem + (t & 1) * STAGE;
+        // my own DMA for tile t has landed once at most (tiles issued after t) x GL operations are outstanding
+        const int younger = nt - 1 - t;
+        if (STAGES >= 4 && younger >= 2) wait_vmcnt<(STAGES >= 4 ? 2 : 0) * GL>();
+        else if (STAGES >= 3 && younger >= 1) wait_vmcnt<(STAGES >= 3 ? 1 : 0) * GL>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();   // everyone's tile t has landed; everyone is done reading buffer sbuf (tile t-1)
+        asm volatile("" ::: "memory");
+        if (t + STAGES - 1 < nt) stage(sbuf);
+        const char* sa = smem + cbuf * STAGE;
         const char* sb = sa + A_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BK / 32; ++kk) {
             const int ko = kk ? koff1 : koff0;
             v8 af[FM], bf[FN];
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                af[i] = *reinterpret_cast<const v8*>(sa + a_base + i * 16 * 128 + ko);
-                if (p.relu_a) af[i] = relu8<T>(af[i]);
+                af[i] = *reinterpret_cast<const v8*>(sa + a_base + i * 16 * ROWB + ko);
+                if (RELU_A) af[i] = relu8<T>(af[i]);
             }
 #pragma unroll
-            for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const v8*>(sb + b_base + j * 16 * 128 + ko);
+            for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const v8*>(sb + b_base + j * 16 * ROWB + ko);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) acc[i][j] = T16<T>::mfma16(bf[j], af[i], acc[i][j]);
         }
+        cbuf = cbuf + 1 == STAGES ? 0 : cbuf + 1;
+        sbuf = sbuf + 1 == STAGES ? 0 : sbuf + 1;
     }
 
     // ---- epilogue, staged through LDS so that global stores are row-contiguous and the fused
     // epilogue code exists once (a runtime loop) instead of once per accumulator fragment.
     // lane holds acc[m = ..+(lane&15)][n = ..+(lane>>4)*4 + 0..3]
     constexpr int LDC = BN + 4;                                  // fp32 row stride (pad: conflict-free b128 writes)
-    constexpr int PASS_ROWS = (2 * STAGE) / (LDC * 4) >= BM ? BM : BM / 2;
-    static_assert(PASS_ROWS * LDC * 4 <= 2 * STAGE, "epilogue staging does not fit the main-loop LDS");
-    static_assert(PASS_ROWS % TM == 0, "a pass must cover whole wave tiles");
+    constexpr int MAXR = LDS_BYTES / (LDC * 4);
+    constexpr int PASS_ROWS = MAXR >= BM ? BM : (MAXR >= BM / 2 ? BM / 2 : (MAXR >= BM / 4 ? BM / 4 : BM / 8));
+    static_assert(PASS_ROWS % 16 == 0 && PASS_ROWS * LDC * 4 <= LDS_BYTES, "epilogue staging does not fit the main-loop LDS");
     constexpr int PASSES = BM / PASS_ROWS;
     float* sc = reinterpret_cast<float*>(smem);
     const bool v_tile = (p.out_mode == BS_OUT_QKV) && (tn * BN >= 2 * p.qkv_hidden);
     for (int ps = 0; ps < PASSES; ++ps) {
         __syncthreads();  // main loop (or previous pass) is done with the LDS
-        if ((wm * TM) / PASS_ROWS == ps) {
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+        for (int i = 0; i < FM; ++i) {
+            const int r0 = wm * TM + i * 16;                     // first tile row of this fragment
+            if (r0 / PASS_ROWS == ps) {
 #pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    const int r = wm * TM - ps * PASS_ROWS + i * 16 + frow;
-                    *reinterpret_cast<f32x4*>(sc + r * LDC + wn * TN + j * 16 + fq * 4) = acc[i][j];
-                }
+                for (int j = 0; j < FN; ++j)
+                    *reinterpret_cast<f32x4*>(sc + (r0 - ps * PASS_ROWS + frow) * LDC + wn * TN + j * 16 + fq * 4) = acc[i][j];
+            }
         }
         __syncthreads();
         const int m_base = tm * BM + ps * PASS_ROWS;
@@ -311,59 +372,69 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
             }
         }
     }
+#endif
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
-static int launch_variant(const IgemmParams& p, bool conv, hipStream_t st) {
-    constexpr int smem = 2 * (BM + BN) * 128;
+template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int MODE>
+static int launch_mode(const IgemmParams& p, hipStream_t st) {
+    constexpr int smem = STAGES * (BM + BN) * BK * 2;
     dim3 grid(p.ntm * p.ntn), block(WM * WN * 64);
-    if (conv) {
-        auto k = igemm_kernel<T, BM, BN, WM, WN, true>;
-        static bool attr = false;
-        if (!attr) {
-            BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            attr = true;
-        }
-        hipLaunchKernelGGL(k, grid, block, smem, st, p);
-    } else {
-        auto k = igemm_kernel<T, BM, BN, WM, WN, false>;
-        static bool attr = false;
-        if (!attr) {
-            BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            attr = true;
-        }
-        hipLaunchKernelGGL(k, grid, block, smem, st, p);
+    auto k = igemm_kernel<T, BM, BN, WM, WN, BK, STAGES, MODE>;
+    static bool attr = false;
+    if (!attr) {
+        BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr = true;
     }
+    hipLaunchKernelGGL(k, grid, block, smem, st, p);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }
 
+template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES>
+static int launch_variant(const IgemmParams& p, bool conv, hipStream_t st) {
+    if (!conv) return launch_mode<T, BM, BN, WM, WN, BK, STAGES, 0>(p, st);
+    if (p.relu_a) return launch_mode<T, BM, BN, WM, WN, BK, STAGES, 2>(p, st);
+    return launch_mode<T, BM, BN, WM, WN, BK, STAGES, 1>(p, st);
+}
+
+// tile ids: 1 128x128x64 2-stage (2 blocks/CU) | 2 128x64 | 3 128x32 | 4 256x128x64 2-stage
+//           5 256x128x64 3-stage (144 KiB) | 6 256x256x32 4-stage (128 KiB) | 7 128x128x64 3-stage | 8 256x128x32 4-stage
 static int auto_tile(int M, int N, int tile) {
     if (tile != 0) return tile;
     if (N <= 32) return 3;
     if (N <= 64) return 2;
-    if (M >= 16384 && N % 128 == 0) return 4;
+    // the 256x256 4-stage tile needs >= 2 full rounds of blocks over the 256 CUs to pay (measured, tools/bench_kernels.py)
+    if (N % 256 == 0 && (long long)cdiv(M, 256) * (N / 256) >= 512) return 6;
     return 1;
+}
+
+static void tile_dims(int tile, int& BM, int& BN) {
+    switch (tile) {
+        case 2: BM = 128; BN = 64; break;
+        case 3: BM = 128; BN = 32; break;
+        case 4: case 5: case 8: BM = 256; BN = 128; break;
+        case 6: BM = 256; BN = 256; break;
+        default: BM = 128; BN = 128; break;
+    }
 }
 
 template <typename T>
 static int dispatch(IgemmParams& p, bool conv, int tile, hipStream_t st) {
     tile = auto_tile(p.M, p.N, tile);
+    if (tile < 1 || tile > 8) { set_error("bs_gemm: unknown tile %d", tile); return BS_ERR_INVALID; }
     int BM, BN;
-    switch (tile) {
-        case 1: BM = 128; BN = 128; break;
-        case 2: BM = 128; BN = 64; break;
-        case 3: BM = 128; BN = 32; break;
-        case 4: BM = 256; BN = 128; break;
-        default: set_error("bs_gemm: unknown tile %d", tile); return BS_ERR_INVALID;
-    }
+    tile_dims(tile, BM, BN);
     p.ntm = cdiv(p.M, BM);
     p.ntn = cdiv(p.N, BN);
     switch (tile) {
-        case 1: return launch_variant<T, 128, 128, 2, 2>(p, conv, st);
-        case 2: return launch_variant<T, 128, 64, 2, 2>(p, conv, st);
-        case 3: return launch_variant<T, 128, 32, 4, 1>(p, conv, st);
-        default: return launch_variant<T, 256, 128, 4, 2>(p, conv, st);
+        case 1: return launch_variant<T, 128, 128, 2, 2, 64, 2>(p, conv, st);
+        case 2: return launch_variant<T, 128, 64, 2, 2, 64, 2>(p, conv, st);
+        case 3: return launch_variant<T, 128, 32, 4, 1, 64, 2>(p, conv, st);
+        case 4: return launch_variant<T, 256, 128, 4, 2, 64, 2>(p, conv, st);
+        case 5: return launch_variant<T, 256, 128, 4, 2, 64, 3>(p, conv, st);
+        case 6: return launch_variant<T, 256, 256, 2, 4, 32, 4>(p, conv, st);
+        case 7: return launch_variant<T, 128, 128, 2, 2, 64, 3>(p, conv, st);
+        default: return launch_variant<T, 256, 128, 4, 2, 32, 4>(p, conv, st);
     }
 }
 
@@ -384,6 +455,9 @@ extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
     BS_REQUIRE(!d->res || d->res_dtype == BS_F32 || d->res_dtype == d->dtype, "bs_gemm: res_dtype must be f32 or the operand dtype");
     IgemmParams p{};
     p.A = d->A; p.W = d->W; p.zero = zero_page();
+    p.a_bytes = d->conv ? (long long)(d->M / (d->Hout > 0 && d->Wout > 0 ? d->Hout * d->Wout : 1)) * d->Hin * d->Win * d->lda * 2
+                        : ((long long)(d->M - 1) * d->lda + d->K) * 2;
+    BS_REQUIRE((long long)d->N * d->K * 2 < 0x7FFFFFF0ll, "bs_gemm: weight matrix too large for one descriptor");
     p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda;
     p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin; p.Hout = d->Hout; p.Wout = d->Wout;
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
@@ -392,9 +466,12 @@ extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
         BS_REQUIRE(d->K == d->KH * d->KW * d->Cin, "bs_gemm: conv K=%d != KH*KW*Cin", d->K);
         BS_REQUIRE(d->Hout > 0 && d->Wout > 0 && d->M % (d->Hout * d->Wout) == 0, "bs_gemm: conv M=%d not a multiple of Hout*Wout", d->M);
         BS_REQUIRE(d->stride > 0 && d->lda >= d->Cin, "bs_gemm: bad conv stride/lda");
+        BS_REQUIRE(d->KH > 0 && d->KW > 0 && d->KH * d->KW <= 32, "bs_gemm: conv window %dx%d: at most 32 taps", d->KH, d->KW);
+        BS_REQUIRE((long long)d->Hin * d->Win * d->lda * 2 * 4 < 0x7FFFFFF0ll, "bs_gemm: image too large for the 2 GiB tile window");
         p.tiles_per_tap = d->Cin / 64;
     }
     p.relu_a = d->relu_a;
+    BS_REQUIRE(!d->relu_a || d->conv, "bs_gemm: relu_a is only built for conv mode");
     p.bias = d->bias; p.bias_group_rows = d->bias_group_rows; p.act = d->act; p.scale = d->scale;
     p.res = d->res; p.res2 = d->res2; p.res_dtype = d->res_dtype; p.ldr = d->ldr;
     BS_REQUIRE(!d->res2 || d->res, "bs_gemm: res2 needs res (they share ldr)");

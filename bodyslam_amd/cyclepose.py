@@ -82,22 +82,23 @@ class _PosePlan:
         self.frames = torch.empty(N, H, W, 3, device=dev, dtype=torch.uint8)
         self.pairs = torch.zeros(P, 2, device=dev, dtype=torch.int32)
         Pl = self.plan = L.Plan()
+        in_scratch = e32(P * (CROP * CROP // 256) * 2 * 256)
         cols = e16(P * CROP * CROP, K0)
         Pl.add("im2col", "bs_cyclepose_im2col", self.frames, self.pairs, cols, P, H, W, L.dt(cols))
         c0 = e32(P, CROP, CROP, 64)
         Pl.gemm("c0", cols, w["c0.w"], c0, M=P * CROP * CROP, N=64, K=K0, lda=K0, bias=w["c0.b"])
         a0 = e16(P, CROP, CROP, 64)
-        Pl.add("in0", "bs_instnorm_relu_nhwc", c0, a0, None, P, CROP * CROP, 64, 1e-5, L.dt(a0))
+        Pl.add("in0", "bs_instnorm_relu_nhwc", c0, a0, None, in_scratch, P, CROP * CROP, 64, 1e-5, L.dt(a0))
         Pl.mark("c0", a0, ("nhwc", P, CROP, CROP, 64))
         c1 = e32(P, 64, 64, 128)
         Pl.gemm("c1", a0, w["c1.w"], c1, M=P * 64 * 64, N=128, K=9 * 64, lda=64, conv=L.conv_geom(128, 128, 64, 3, 3, 2, 1), bias=w["c1.b"])
         a1 = e16(P, 64, 64, 128)
-        Pl.add("in1", "bs_instnorm_relu_nhwc", c1, a1, None, P, 64 * 64, 128, 1e-5, L.dt(a1))
+        Pl.add("in1", "bs_instnorm_relu_nhwc", c1, a1, None, in_scratch, P, 64 * 64, 128, 1e-5, L.dt(a1))
         c2 = e32(P, 32, 32, 256)
         Pl.gemm("c2", a1, w["c2.w"], c2, M=P * 32 * 32, N=256, K=9 * 128, lda=128, conv=L.conv_geom(64, 64, 128, 3, 3, 2, 1), bias=w["c2.b"])
         a2 = e16(P, 32, 32, 256)
         x2 = e32(P, 32, 32, 256)
-        Pl.add("in2", "bs_instnorm_relu_nhwc", c2, a2, x2, P, 32 * 32, 256, 1e-5, L.dt(a2))
+        Pl.add("in2", "bs_instnorm_relu_nhwc", c2, a2, x2, in_scratch, P, 32 * 32, 256, 1e-5, L.dt(a2))
         Pl.mark("c2", x2, ("nhwc", P, 32, 32, 256))
         c3 = e32(P, 16, 16, 512)
         Pl.gemm("c3", a2, w["c3.w"], c3, M=P * 16 * 16, N=512, K=9 * 256, lda=256, conv=L.conv_geom(32, 32, 256, 3, 3, 2, 1), bias=w["c3.b"],

@@ -172,9 +172,9 @@ int bs_postprocess_depth(const float* depth_net, float* depth_m, uint16_t* depth
 int bs_cyclepose_im2col(const uint8_t* frames, const int32_t* pairs, void* out, int32_t P, int32_t H, int32_t W,
                         int32_t dtype, void* stream);
 /* InstanceNorm2d(eps, no affine) + ReLU on an NHWC map, fp32 in -> fp16/bf16 out (+ optional fp32 copy)
- * architecture_v3.py:123-124,134-137 */
-int bs_instnorm_relu_nhwc(const float* x, void* out, float* out_f32, int32_t P, int32_t HW, int32_t C, float eps,
-                          int32_t dtype, void* stream);
+ * architecture_v3.py:123-124,134-137.  scratch: >= P * ceil(HW/256) * 2 * C floats (per-chunk mean / M2). */
+int bs_instnorm_relu_nhwc(const float* x, void* out, float* out_f32, float* scratch, int32_t P, int32_t HW, int32_t C,
+                          float eps, int32_t dtype, void* stream);
 /* AdaptiveAvgPool2d(1) of an NHWC fp32 map -> [P, C] fp32 (architecture_v3.py:146) */
 int bs_avgpool_nhwc(const float* x, float* out, int32_t P, int32_t HW, int32_t C, void* stream);
 /* pose head: skip_linear(cat[pooled, flatten_NCHW(x2)]) + pose_dense(pooled) -> quaternion normalise

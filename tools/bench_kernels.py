@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the implicit-GEMM kernel on the shapes the ZoeD_NK forward launches
+(NB = 32 images = 16 frames with flip-aug).  Interleaved rounds in ONE process; prints TFLOP/s per
+(shape, tile variant).  Usage on the GPU box:  python tools/bench_kernels.py [--nb 32] [--reps 20]"""
+import argparse
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bodyslam_amd import _lib as L  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nb", type=int, default=32)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--tiles", default="1,4,5,6,7,8")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    L.init(0)
+    dev = torch.device("cuda:0")
+    NB = a.nb
+    S = 769
+    dt = torch.float16
+    shapes = []
+    M = NB * S
+    shapes += [("qkv   K1024 N3072", dict(M=M, N=3072, K=1024), None), ("oproj K1024 N1024 f32res", dict(M=M, N=1024, K=1024), "res"),
+               ("fc1   K1024 N4096 gelu", dict(M=M, N=4096, K=1024), "gelu"), ("fc2   K4096 N1024 f32res", dict(M=M, N=1024, K=4096), "res")]
+    convs = [("conv 256->256 @96x128", 96, 128, 256, 256), ("conv 256->256 @192x256", 192, 256, 256, 256), ("conv 256->128 @192x256", 192, 256, 256, 128),
+             ("conv 256->256 @48x64", 48, 64, 256, 256), ("conv 1024->256 @24x32", 24, 32, 1024, 256), ("conv 128->32 @384x512", 384, 512, 128, 32)]
+    tiles = [int(t) for t in a.tiles.split(",")]
+    results = []
+    for name, g, epi in shapes:
+        if a.only and a.only not in name:
+            continue
+        A = torch.randn(g["M"], g["K"], device=dev).to(dt)
+        Wt = (torch.randn(g["N"], g["K"], device=dev) / math.sqrt(g["K"])).to(dt)
+        bias = torch.randn(g["N"], device=dev)
+        if epi == "res":
+            out = torch.randn(g["M"], g["N"], device=dev)
+            kw = dict(bias=bias, scale=bias, res=out, ldr=g["N"])
+        elif epi == "gelu":
+            out = torch.empty(g["M"], g["N"], device=dev, dtype=dt)
+            kw = dict(bias=bias, act=L.ACT_GELU)
+        else:
+            out = torch.empty(g["M"], g["N"], device=dev, dtype=dt)
+            kw = dict(bias=bias)
+        for t in tiles:
+            pl = L.Plan()
+            pl.gemm(name, A, Wt, out, M=g["M"], N=g["N"], K=g["K"], lda=g["K"], tile=t, **kw)
+            results.append((name, t, 2.0 * g["M"] * g["N"] * g["K"], pl.run))
+    for name, H, W_, Ci, Co in convs:
+        if a.only and a.only not in name:
+            continue
+        x = torch.randn(NB, H, W_, Ci, device=dev).to(dt)
+        w = (torch.randn(Co, 9 * Ci, device=dev) / math.sqrt(9 * Ci)).to(dt)
+        bias = torch.randn(Co, device=dev)
+        out = torch.empty(NB, H, W_, Co, device=dev, dtype=dt)
+        geom = L.conv_geom(H, W_, Ci, 3, 3, 1, 1)
+        for t in ([x_ for x_ in tiles if not (x_ == 6 and Co < 256)] if Co >= 128 else [0]):
+            pl = L.Plan()
+            pl.gemm(name, x, w, out, M=NB * H * W_, N=Co, K=9 * Ci, lda=Ci, conv=geom, bias=bias, act=L.ACT_RELU, tile=t)
+            results.append((name, t, 2.0 * NB * H * W_ * Co * 9 * Ci, pl.run))
+    # warm up, then interleaved rounds
+    for _, _, _, fn in results:
+        fn()
+    torch.cuda.synchronize()
+    times = [0.0] * len(results)
+    for r in range(a.reps):
+        for i, (_, _, _, fn) in enumerate(results):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            times[i] += e0.elapsed_time(e1)
+    for i, (name, t, fl, _) in enumerate(results):
+        ms = times[i] / a.reps
+        print(f"{name:28s} tile{t}: {ms * 1e3:9.1f} us  {fl / ms / 1e9:8.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
