@@ -2,8 +2,8 @@
 //   HF modeling_beit.py:268-341 (eager_attention_forward) + :179-265 (relative position bias)
 //
 // Layouts (written by the QKV projection's BS_OUT_QKV epilogue): Q [B,nh,Sp,64] pre-scaled by
-// 1/sqrt(64), K [B,nh,Sp,64], V^T [B,nh,64,Sp]; rows / columns >= S are zero.  bias fp32
-// [nh,Sp,Sp] with -1e30 in key columns >= S (no in-kernel masking).
+// log2(e)/sqrt(64), K [B,nh,Sp,64], V^T [B,nh,64,Sp]; rows / columns >= S are zero.  bias fp32
+// [nh,Sp,Sp], pre-multiplied by log2(e), with -1e30 in key columns >= S (no in-kernel masking).
 //
 // One wave owns 32 queries; the scores are computed TRANSPOSED, S^T = K Q^T, with
 // v_mfma_f32_32x32x16: the query sits on the lane (column), the 32 keys of a sub-tile sit in the 16
@@ -80,6 +80,18 @@ __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict_
     const float* bias_row = bias + ((int64_t)head * Sp + q0 + r) * Sp + 8 * h2;
 
     const int nkt = (S + 63) >> 6;
+    // scores live in the log2 domain (Q and the bias carry a factor log2(e)), so the exponential is one v_exp_f32.
+    // The bias rows of the NEXT 32-key sub-tile are fetched while the current one is processed: their L2 latency
+    // (each lane reads 64 bytes of its own query row per sub-tile) would otherwise sit in front of every softmax.
+    f32x4 bnext[4];
+    auto load_bias = [&](int key0) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bnext[2 * s] = *reinterpret_cast<const f32x4*>(bias_row + key0 + 16 * s);
+            bnext[2 * s + 1] = *reinterpret_cast<const f32x4*>(bias_row + key0 + 16 * s + 4);
+        }
+    };
+    load_bias(0);
     stage(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();
@@ -90,6 +102,10 @@ __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict_
         for (int sub = 0; sub < 2; ++sub) {
             const int key0 = kt * 64 + sub * 32;
             if (key0 >= S) break;
+            f32x4 bcur[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bcur[i] = bnext[i];
+            if (key0 + 32 < Sp) load_bias(key0 + 32);
             // ---- S^T = K Q^T
             f32x16 sacc;
 #pragma unroll
@@ -104,35 +120,35 @@ __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict_
             // ---- + bias; registers 8s..8s+7 of lane half h2 are keys key0 + 16s + 8*h2 + 0..7
             float sc[16];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_row + key0 + 16 * s);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias_row + key0 + 16 * s + 4);
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    sc[8 * s + e] = sacc[8 * s + e] + b0[e];
-                    sc[8 * s + 4 + e] = sacc[8 * s + 4 + e] + b1[e];
+                    sc[8 * s + e] = sacc[8 * s + e] + bcur[2 * s][e];
+                    sc[8 * s + 4 + e] = sacc[8 * s + 4 + e] + bcur[2 * s + 1][e];
                 }
-            }
             float mloc = sc[0];
 #pragma unroll
             for (int i = 1; i < 16; ++i) mloc = fmaxf(mloc, sc[i]);
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
             const float m_new = fmaxf(m_run, mloc);
-            const float alpha = __expf(m_run - m_new);
             float psum = 0.f;
             float p[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                p[i] = __expf(sc[i] - m_new);
+                p[i] = __builtin_amdgcn_exp2f(sc[i] - m_new);
                 psum += p[i];
             }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
+            if (!__all(m_new == m_run)) {   // wave-uniform: rescale only when some query's running max moved
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run *= alpha;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                oacc[0][i] *= alpha;
-                oacc[1][i] *= alpha;
+                for (int i = 0; i < 16; ++i) {
+                    oacc[0][i] *= alpha;
+                    oacc[1][i] *= alpha;
+                }
+                m_run = m_new;
             }
+            l_run += psum;
             // ---- O^T += V^T P^T
             v8 pf[2];
 #pragma unroll

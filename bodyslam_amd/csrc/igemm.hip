@@ -253,45 +253,52 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
             }
 #pragma unroll
             for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const v8*>(sb + b_base + j * 16 * ROWB + ko);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) acc[i][j] = T16<T>::mfma16(bf[j], af[i], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
         }
         cbuf = cbuf + 1 == STAGES ? 0 : cbuf + 1;
         sbuf = sbuf + 1 == STAGES ? 0 : sbuf + 1;
     }
 
-    // ---- epilogue, staged through LDS so that global stores are row-contiguous and the fused
-    // epilogue code exists once (a runtime loop) instead of once per accumulator fragment.
+    // ---- epilogue.  Each wave stages ITS OWN accumulator sub-tile through a private LDS region (XOR-swizzled
+    // float4 slots, no padding) and streams it out row by row: one block barrier in total (the main loop must be
+    // done with the LDS), no barrier between passes, the fused epilogue code exists once (a runtime loop), and a
+    // wave-instruction stores whole rows (TN*2 or TN*4 contiguous bytes per row).
     // lane holds acc[m = ..+(lane&15)][n = ..+(lane>>4)*4 + 0..3]
-    constexpr int LDC = BN + 4;                                  // fp32 row stride (pad: conflict-free b128 writes)
-    constexpr int MAXR = LDS_BYTES / (LDC * 4);
-    constexpr int PASS_ROWS = MAXR >= BM ? BM : (MAXR >= BM / 2 ? BM / 2 : (MAXR >= BM / 4 ? BM / 4 : BM / 8));
-    static_assert(PASS_ROWS % 16 == 0 && PASS_ROWS * LDC * 4 <= LDS_BYTES, "epilogue staging does not fit the main-loop LDS");
-    constexpr int PASSES = BM / PASS_ROWS;
-    float* sc = reinterpret_cast<float*>(smem);
+    constexpr int NW = WM * WN;
+    constexpr int S4 = TN / 4;                                     // float4 slots per staged row
+    constexpr int MAXR = LDS_BYTES / (NW * TN * 4);
+    constexpr int PASS_R = MAXR >= TM ? TM : (MAXR >= TM / 2 ? TM / 2 : (MAXR >= TM / 4 ? TM / 4 : TM / 8));
+    static_assert(PASS_R >= 16 && PASS_R % 16 == 0 && NW * PASS_R * TN * 4 <= LDS_BYTES, "epilogue staging does not fit the main-loop LDS");
+    static_assert(64 % S4 == 0, "rows per sweep");
+    constexpr int PASSES = TM / PASS_R;
+    constexpr int RPS = 64 / S4;                                   // rows per 64-lane sweep
+    float* sc = reinterpret_cast<float*>(smem) + wave * (PASS_R * TN);
+    const int n_wave = tn * BN + wn * TN;
     const bool v_tile = (p.out_mode == BS_OUT_QKV) && (tn * BN >= 2 * p.qkv_hidden);
+    __syncthreads();  // every wave is done reading the main-loop LDS
     for (int ps = 0; ps < PASSES; ++ps) {
-        __syncthreads();  // main loop (or previous pass) is done with the LDS
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            const int r0 = wm * TM + i * 16;                     // first tile row of this fragment
-            if (r0 / PASS_ROWS == ps) {
+            if ((i * 16) / PASS_R == ps) {
+                const int r = i * 16 - ps * PASS_R + frow;
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    *reinterpret_cast<f32x4*>(sc + (r0 - ps * PASS_ROWS + frow) * LDC + wn * TN + j * 16 + fq * 4) = acc[i][j];
+                for (int j = 0; j < FN; ++j) *reinterpret_cast<f32x4*>(sc + r * TN + (((j * 4 + fq) ^ (r & (S4 - 1))) << 2)) = acc[i][j];
             }
         }
-        __syncthreads();
-        const int m_base = tm * BM + ps * PASS_ROWS;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int m_base = tm * BM + wm * TM + ps * PASS_R;
         if (!v_tile) {
-            constexpr int C4 = BN / 4;
-            for (int idx = tid; idx < PASS_ROWS * C4; idx += NT) {
-                const int r = idx / C4, c4 = idx - r * C4;
-                const int m = m_base + r, n0 = tn * BN + c4 * 4;
+            for (int it = 0; it < PASS_R / RPS; ++it) {
+                const int r = it * RPS + lane / S4, c4 = lane % S4;
+                const int m = m_base + r, n0 = n_wave + c4 * 4;
                 if (m >= p.M || n0 >= p.N) continue;
-                const f32x4 a = *reinterpret_cast<const f32x4*>(sc + r * LDC + c4 * 4);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(sc + r * TN + ((c4 ^ (r & (S4 - 1))) << 2));
                 float y[4] = {a[0], a[1], a[2], a[3]};
                 if (p.bias) {
                     const float* bias_row = p.bias + (p.bias_group_rows ? (int64_t)(m / p.bias_group_rows) * p.N : 0);
@@ -359,11 +366,11 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
             // V part: written transposed (V^T [B,nh,64,Sp]); consecutive lanes take consecutive tokens
             T* vt = reinterpret_cast<T*>(p.out3);
             const int nh = p.qkv_hidden >> 6;
-            for (int idx = tid; idx < PASS_ROWS * BN; idx += NT) {
-                const int c = idx / PASS_ROWS, r = idx - c * PASS_ROWS;
-                const int m = m_base + r, n = tn * BN + c;
+            for (int idx = lane; idx < PASS_R * TN; idx += 64) {
+                const int c = idx / PASS_R, r = idx - c * PASS_R;
+                const int m = m_base + r, n = n_wave + c;
                 if (m >= p.M || n >= p.N) continue;
-                float y = sc[r * LDC + c];
+                float y = sc[r * TN + ((((c >> 2) ^ (r & (S4 - 1))) << 2) | (c & 3))];
                 if (p.bias) y += p.bias[n];
                 const int ob = m / p.qkv_tokens, otok = m - ob * p.qkv_tokens;
                 const int rem = n - 2 * p.qkv_hidden;
@@ -371,6 +378,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                 vt[(((int64_t)ob * nh + hh) * 64 + d) * p.qkv_sp + otok] = T16<T>::from_f32(y);
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // the next pass overwrites this wave's region
     }
 #endif
 }
@@ -399,12 +408,15 @@ static int launch_variant(const IgemmParams& p, bool conv, hipStream_t st) {
 
 // tile ids: 1 128x128x64 2-stage (2 blocks/CU) | 2 128x64 | 3 128x32 | 4 256x128x64 2-stage
 //           5 256x128x64 3-stage (144 KiB) | 6 256x256x32 4-stage (128 KiB) | 7 128x128x64 3-stage | 8 256x128x32 4-stage
-static int auto_tile(int M, int N, int tile) {
+//           9 256x256x64 2-stage (128 KiB)
+static int auto_tile(int M, int N, int tile, bool conv) {
     if (tile != 0) return tile;
     if (N <= 32) return 3;
     if (N <= 64) return 2;
-    // the 256x256 4-stage tile needs >= 2 full rounds of blocks over the 256 CUs to pay (measured, tools/bench_kernels.py)
-    if (N % 256 == 0 && (long long)cdiv(M, 256) * (N / 256) >= 512) return 6;
+    // the 256x256x64 tile (1 block/CU, 128 KiB LDS) wins once the grid covers the 256 CUs often enough to amortise its
+    // coarse tail; measured with tools/bench_kernels.py (plain K=1024..4096 GEMMs: from ~1.5 rounds; 3x3 convs: from 2)
+    const long long blocks = (long long)cdiv(M, 256) * (N / 256);
+    if (N % 256 == 0 && blocks >= (conv ? 512 : 384)) return 9;
     return 1;
 }
 
@@ -413,15 +425,15 @@ static void tile_dims(int tile, int& BM, int& BN) {
         case 2: BM = 128; BN = 64; break;
         case 3: BM = 128; BN = 32; break;
         case 4: case 5: case 8: BM = 256; BN = 128; break;
-        case 6: BM = 256; BN = 256; break;
+        case 6: case 9: BM = 256; BN = 256; break;
         default: BM = 128; BN = 128; break;
     }
 }
 
 template <typename T>
 static int dispatch(IgemmParams& p, bool conv, int tile, hipStream_t st) {
-    tile = auto_tile(p.M, p.N, tile);
-    if (tile < 1 || tile > 8) { set_error("bs_gemm: unknown tile %d", tile); return BS_ERR_INVALID; }
+    tile = auto_tile(p.M, p.N, tile, conv);
+    if (tile < 1 || tile > 9) { set_error("bs_gemm: unknown tile %d", tile); return BS_ERR_INVALID; }
     int BM, BN;
     tile_dims(tile, BM, BN);
     p.ntm = cdiv(p.M, BM);
@@ -434,13 +446,14 @@ static int dispatch(IgemmParams& p, bool conv, int tile, hipStream_t st) {
         case 5: return launch_variant<T, 256, 128, 4, 2, 64, 3>(p, conv, st);
         case 6: return launch_variant<T, 256, 256, 2, 4, 32, 4>(p, conv, st);
         case 7: return launch_variant<T, 128, 128, 2, 2, 64, 3>(p, conv, st);
-        default: return launch_variant<T, 256, 128, 4, 2, 32, 4>(p, conv, st);
+        case 8: return launch_variant<T, 256, 128, 4, 2, 32, 4>(p, conv, st);
+        default: return launch_variant<T, 256, 256, 2, 4, 64, 2>(p, conv, st);
     }
 }
 
 }  // namespace bs
 
-extern "C" int bs_gemm_tile(const bs_gemm_desc* d) { return d ? bs::auto_tile(d->M, d->N, d->tile) : BS_ERR_INVALID; }
+extern "C" int bs_gemm_tile(const bs_gemm_desc* d) { return d ? bs::auto_tile(d->M, d->N, d->tile, d->conv != 0) : BS_ERR_INVALID; }
 
 extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
     using namespace bs;

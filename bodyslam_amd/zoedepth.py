@@ -29,6 +29,8 @@ import torch.nn.functional as F
 
 from . import _lib as L
 
+LOG2E = 1.4426950408889634
+
 
 @dataclass
 class ZoeConfig:
@@ -247,7 +249,7 @@ class ZoeDepthEngine:
             full = torch.cat([new, tab[old * old:]])
             b = full[idx].view(S, S, -1).permute(2, 0, 1)
             pad = torch.full((c.heads, Sp, Sp), -1.0e30)
-            pad[:, :S, :S] = b
+            pad[:, :S, :S] = b * LOG2E          # bs_attention works in the log2 domain
             pad[:, S:, :S] = 0.0
             out.append(pad.to(self.dev))
         self._bias_cache[key] = out
@@ -312,7 +314,7 @@ class _ZoePlan:
         for l in range(c.layers):
             P.add(f"l{l}.ln1", "bs_layernorm", x, w[f"l{l}.ln1.g"], w[f"l{l}.ln1.b"], xn, None, NB * S, Hd, c.ln_eps, L.dt(xn))
             P.gemm(f"l{l}.qkv", xn, w[f"l{l}.qkv.w"], q, M=NB * S, N=3 * Hd, K=Hd, lda=Hd, bias=w[f"l{l}.qkv.b"],
-                   qkv=(Hd, S, Sp, 1.0 / math.sqrt(64.0), k, vt))
+                   qkv=(Hd, S, Sp, LOG2E / math.sqrt(64.0), k, vt))
             P.add(f"l{l}.attn", "bs_attention", q, k, vt, bias[l], ao, NB, c.heads, S, Sp, L.dt(q))
             P.gemm(f"l{l}.o", ao, w[f"l{l}.o.w"], x, M=NB * S, N=Hd, K=Hd, lda=Hd, bias=w[f"l{l}.o.b"], scale=w[f"l{l}.lam1"], res=x, ldr=Hd)
             P.add(f"l{l}.ln2", "bs_layernorm", x, w[f"l{l}.ln2.g"], w[f"l{l}.ln2.b"], xn, None, NB * S, Hd, c.ln_eps, L.dt(xn))

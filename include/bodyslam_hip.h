@@ -92,8 +92,9 @@ int bs_gemm_tile(const bs_gemm_desc* d);
 
 /* BEiT attention: softmax(Q K^T + relpos_bias) V -------------------------------------------- *
  * HF modeling_beit.py:268-341 (eager_attention_forward with the additive relative-position bias
- * of :179-265).  q [B,nh,Sp,64] (pre-scaled by 1/8), k [B,nh,Sp,64], vt [B,nh,64,Sp], Sp % 64 == 0,
- * rows/cols >= S zero; bias fp32 [nh,Sp,Sp] with -inf (<= -1e30) in key columns >= S.
+ * of :179-265).  The softmax is evaluated in the log2 domain: q [B,nh,Sp,64] must be pre-scaled by
+ * log2(e)/sqrt(64) and bias pre-multiplied by log2(e).  k [B,nh,Sp,64], vt [B,nh,64,Sp], Sp % 64 == 0,
+ * rows/cols >= S zero; bias fp32 [nh,Sp,Sp] with <= -1e30 in key columns >= S.
  * out [B*S, nh*64] token-major (the o_proj GEMM's A operand). */
 int bs_attention(const void* q, const void* k, const void* vt, const float* bias, void* out,
                  int32_t B, int32_t nh, int32_t S, int32_t Sp, int32_t dtype, void* stream);

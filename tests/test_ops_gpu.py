@@ -50,7 +50,7 @@ def tol(dtype, k):
 @pytest.mark.parametrize("M,N,K,tile", [(128, 128, 64, 1), (300, 256, 192, 1), (257, 64, 128, 2), (1000, 32, 256, 3),
                                         (513, 384, 1024, 4), (64, 8, 64, 0), (2049, 1024, 512, 0), (40000, 256, 256, 0),
                                         (1000, 384, 1024, 5), (1000, 640, 448, 6), (777, 256, 64, 6), (1000, 384, 320, 7),
-                                        (1000, 384, 1056 - 32, 8), (300, 128, 64, 8)])
+                                        (1000, 384, 1056 - 32, 8), (300, 128, 64, 8), (1000, 640, 448, 9), (5000, 256, 128, 9)])
 def test_gemm_plain(L, dtype, M, N, K, tile):
     A = rnd(M, K, seed=1, dtype=dtype)
     W = rnd(N, K, seed=2, scale=1 / math.sqrt(K), dtype=dtype)
@@ -94,7 +94,8 @@ def test_gemm_epilogue_gelu_scale_residual_groups(L, dtype):
                                                                 (1, 48, 64, 512, 256, 1, False, 0), (1, 24, 32, 1024, 1024, 2, False, 0),
                                                                 (2, 24, 32, 256, 256, 1, True, 5), (2, 24, 32, 256, 256, 1, True, 6),
                                                                 (3, 17, 19, 128, 256, 1, False, 6), (2, 24, 32, 64, 256, 1, False, 7),
-                                                                (2, 24, 32, 128, 128, 1, True, 8), (2, 31, 33, 64, 128, 2, False, 6)])
+                                                                (2, 24, 32, 128, 128, 1, True, 8), (2, 31, 33, 64, 128, 2, False, 6),
+                                                                (2, 24, 32, 256, 256, 1, True, 9), (3, 17, 19, 128, 256, 1, False, 9)])
 def test_conv3x3(L, dtype, B, H, W, Cin, Cout, stride, relu_a, tile):
     x = rnd(B, H, W, Cin, seed=1, dtype=dtype)                       # NHWC
     w = rnd(Cout, Cin, 3, 3, seed=2, scale=1 / math.sqrt(9 * Cin), dtype=dtype)
@@ -154,6 +155,7 @@ def test_qkv_scatter_and_attention(L, dtype, B, S, nh):
     q = torch.zeros(B, nh, Sp, 64, device=dev(), dtype=dtype)
     k = torch.zeros(B, nh, Sp, 64, device=dev(), dtype=dtype)
     vt = torch.zeros(B, nh, 64, Sp, device=dev(), dtype=dtype)
+    LOG2E = 1.4426950408889634
     L.gemm(x, wqkv, q, M=B * S, N=3 * hidden, K=hidden, lda=hidden, bias=bqkv, qkv=(hidden, S, Sp, 0.125, k, vt))
     y = (x.float() @ wqkv.float().t() + bqkv).view(B, S, 3, nh, 64)
     qr, kr, vr = y[:, :, 0].permute(0, 2, 1, 3), y[:, :, 1].permute(0, 2, 1, 3), y[:, :, 2].permute(0, 2, 1, 3)
@@ -167,8 +169,12 @@ def test_qkv_scatter_and_attention(L, dtype, B, S, nh):
     bias[:, :S, :S] = rnd(nh, S, S, seed=4)
     bias[:, S:, :S] = 0
     out = torch.empty(B * S, hidden, device=dev(), dtype=dtype)
-    L.attention(q, k, vt, bias, out, B, nh, S, Sp)
-    qf, kf, vf = q[:, :, :S].float(), k[:, :, :S].float(), vt[:, :, :, :S].float().transpose(2, 3)
+    # the kernel's contract: scores arrive in the log2 domain (q and bias carry log2(e))
+    ql = (q.float() * LOG2E).to(dtype)
+    bl = bias.clone()
+    bl[:, :S, :S] *= LOG2E
+    L.attention(ql, k, vt, bl, out, B, nh, S, Sp)
+    qf, kf, vf = ql[:, :, :S].float() / LOG2E, k[:, :, :S].float(), vt[:, :, :, :S].float().transpose(2, 3)
     a = torch.softmax(qf @ kf.transpose(2, 3) + bias[None, :, :S, :S], dim=-1)
     ref = (a @ vf).permute(0, 2, 1, 3).reshape(B * S, hidden)
     err = (out.float() - ref).abs().max().item()
@@ -298,13 +304,15 @@ def test_postprocess_matches_oracle(L):
     report(f"postprocess: max|err|={err:.3e}")
     assert err < 1e-5
     u16 = u.cpu().numpy().view(np.uint16)
-    exp = (m.cpu().numpy() * 256.0).astype(np.uint16)
-    bad = np.argwhere(u16 != exp)
+    mm = m.cpu().numpy()
+    exp = (np.maximum(mm, 0) * 256.0).astype(np.uint16)   # negative metres (bicubic overshoot of this noise input) clamp to 0;
+    bad = np.argwhere(u16 != exp)                          # numpy's own cast of a negative float is undefined behaviour
     if len(bad):
         b0 = tuple(bad[0])
         report(f"postprocess u16 mismatches {len(bad)}: at {b0} got {u16[b0]} expected {exp[b0]} metres {m.cpu().numpy()[b0]!r}")
     assert len(bad) == 0
-    assert np.abs(u16.astype(np.int32) - Z.to_uint16(ref).astype(np.int32)).max() <= 1
+    ok = ref.numpy() > 0.01
+    assert np.abs(u16.astype(np.int32) - Z.to_uint16(ref).astype(np.int32))[ok].max() <= 1
 
 
 @pytest.mark.parametrize("dtype", DT)
