@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 TILE_NAMES = {1: "128x128x64s2", 2: "128x64x64s2", 3: "128x32x64s2", 4: "256x128x64s2", 5: "256x128x64s3", 6: "256x256x32s4",
-              7: "128x128x64s3", 8: "256x128x32s4", 9: "256x256x64s2"}
+              7: "128x128x64s3", 8: "256x128x32s4", 9: "256x256x64s2", 10: "256x256x32s4pp", 11: "256x128x32s3"}
 
 
 def main():

@@ -52,16 +52,20 @@ __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict_
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const v8*>(Qg + (int64_t)(q0 + r) * 64 + ks * 16 + h2 * 8);
 
-    const int srow = lane >> 3;                       // row inside one 1-KiB DMA piece
-    const int cs8 = ((lane & 7) ^ srow) * 8;          // swizzled source chunk (elements)
+    // LDS images: [64 rows][64 x 16-bit], 16-byte chunk c of row r at chunk position c ^ ((r >> 1) & 7).  The 32x32x16
+    // operand read has every ds_read_b128 lane group on 16 rows {0-3,12-15,20-27} / {4-11,16-19,28-31} at ONE chunk: with
+    // the pair (row parity, (r >> 1) & 7) those 16 rows land on 16 different 16-byte slots (r & 7 alone collides 2-way).
+    const int srow = lane >> 3;                       // row inside one 1-KiB DMA piece (8 rows x 128 bytes)
     auto stage = [&](int kt, int buf) {
         char* sb = smem + buf * STAGE;
         for (int i = wave; i < 16; i += QW) {
+            const int row = (i & 7) * 8 + srow;       // row of the K (i < 8) or V^T (i >= 8) image
+            const int cs8 = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
             const T* src;
             if (i < 8) {
-                src = Kg + (int64_t)(kt * 64 + i * 8 + srow) * 64 + cs8;
+                src = Kg + (int64_t)(kt * 64 + row) * 64 + cs8;
             } else {
-                src = Vg + (int64_t)((i - 8) * 8 + srow) * Sp + kt * 64 + cs8;
+                src = Vg + (int64_t)row * Sp + kt * 64 + cs8;
             }
             glds16(src, sb + i * 1024);
         }
@@ -80,9 +84,12 @@ __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict_
     const float* bias_row = bias + ((int64_t)head * Sp + q0 + r) * Sp + 8 * h2;
 
     const int nkt = (S + 63) >> 6;
-    // scores live in the log2 domain (Q and the bias carry a factor log2(e)), so the exponential is one v_exp_f32.
-    // The bias rows of the NEXT 32-key sub-tile are fetched while the current one is processed: their L2 latency
-    // (each lane reads 64 bytes of its own query row per sub-tile) would otherwise sit in front of every softmax.
+    // Scores live in the log2 domain (Q and the bias carry log2(e)): the exponential is one v_exp_f32.
+    // VALU diet (the loop is VALU-bound, not MFMA-bound): the accumulator of S^T = K Q^T is INITIALISED with
+    // (bias - m_run), so the MFMA chain delivers s + bias - m_run and p = exp2(acc) needs no add and no subtract; the
+    // running max is only moved when a sub-tile exceeds it by more than 2^THR (deferred max: p <= 2^THR stays exact in
+    // fp32 and well inside fp16 for the P operand).  The bias rows of the NEXT sub-tile are fetched one sub-tile ahead.
+    constexpr float THR = 6.0f;
     f32x4 bnext[4];
     auto load_bias = [&](int key0) {
 #pragma unroll
@@ -91,6 +98,8 @@ __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict_
             bnext[2 * s + 1] = *reinterpret_cast<const f32x4*>(bias_row + key0 + 16 * s + 4);
         }
     };
+    m_run = 0.f;
+    bool first = true;
     load_bias(0);
     stage(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
@@ -102,51 +111,47 @@ __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict_
         for (int sub = 0; sub < 2; ++sub) {
             const int key0 = kt * 64 + sub * 32;
             if (key0 >= S) break;
-            f32x4 bcur[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bcur[i] = bnext[i];
-            if (key0 + 32 < Sp) load_bias(key0 + 32);
-            // ---- S^T = K Q^T
+            // registers 8s..8s+7 of lane half h2 are keys key0 + 16s + 8*h2 + 0..7
             f32x16 sacc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
-            const int krow = sub * 32 + kap;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int chunk = 2 * ks + h2;
-                const v8 kf = *reinterpret_cast<const v8*>(sk + krow * 128 + ((chunk ^ (krow & 7)) << 4));
-                sacc = T16<T>::mfma32(kf, qf[ks], sacc);
-            }
-            // ---- + bias; registers 8s..8s+7 of lane half h2 are keys key0 + 16s + 8*h2 + 0..7
-            float sc[16];
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    sc[8 * s + e] = sacc[8 * s + e] + bcur[2 * s][e];
-                    sc[8 * s + 4 + e] = sacc[8 * s + 4 + e] + bcur[2 * s + 1][e];
+                    sacc[8 * s + e] = bnext[2 * s][e] - m_run;
+                    sacc[8 * s + 4 + e] = bnext[2 * s + 1][e] - m_run;
                 }
-            float mloc = sc[0];
+            if (key0 + 32 < Sp) load_bias(key0 + 32);
+            // ---- S^T = K Q^T (+ bias - m_run)
+            const int krow = sub * 32 + kap;
 #pragma unroll
-            for (int i = 1; i < 16; ++i) mloc = fmaxf(mloc, sc[i]);
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            const float m_new = fmaxf(m_run, mloc);
-            float psum = 0.f;
-            float p[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                p[i] = __builtin_amdgcn_exp2f(sc[i] - m_new);
-                psum += p[i];
+            for (int ks = 0; ks < 4; ++ks) {
+                const int chunk = 2 * ks + h2;
+                const v8 kf = *reinterpret_cast<const v8*>(sk + krow * 128 + ((chunk ^ ((krow >> 1) & 7)) << 4));
+                sacc = T16<T>::mfma32(kf, qf[ks], sacc);
             }
-            if (!__all(m_new == m_run)) {   // wave-uniform: rescale only when some query's running max moved
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            float mloc = fmaxf(fmaxf(sacc[0], sacc[1]), sacc[2]);
+#pragma unroll
+            for (int i = 3; i < 15; i += 2) mloc = fmaxf(fmaxf(mloc, sacc[i]), sacc[i + 1]);
+            mloc = fmaxf(mloc, sacc[15]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            if (first || __any(mloc > THR)) {   // wave-uniform: move the running max (always on the first sub-tile)
+                const float alpha = __builtin_amdgcn_exp2f(-mloc);
                 l_run *= alpha;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     oacc[0][i] *= alpha;
                     oacc[1][i] *= alpha;
+                    sacc[i] -= mloc;
                 }
-                m_run = m_new;
+                m_run += mloc;
+                first = false;
+            }
+            float p[16];
+            float psum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                p[i] = __builtin_amdgcn_exp2f(sacc[i]);
+                psum += p[i];
             }
             l_run += psum;
             // ---- O^T += V^T P^T
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict_
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const int chunk = sub * 4 + 2 * s + h2;
-                    const v8 vf = *reinterpret_cast<const v8*>(sv + drow * 128 + ((chunk ^ (drow & 7)) << 4));
+                    const v8 vf = *reinterpret_cast<const v8*>(sv + drow * 128 + ((chunk ^ ((drow >> 1) & 7)) << 4));
                     oacc[dh] = T16<T>::mfma32(vf, pf[s], oacc[dh]);
                 }
             }

@@ -167,13 +167,13 @@ __global__ __launch_bounds__(256) void pre_image_kernel(const uint8_t* frames, f
 template <typename T, bool ADD>
 __global__ __launch_bounds__(256) void resize_nhwc_kernel(const T* x, const T* addend, T* out, int B, int Hin, int Win, int C, int Hout,
                                                            int Wout, float sy, float sx, int align) {
+    // grid.y = (image, output row); grid.x covers (column, 8-channel group) of that row
     const int c8n = C >> 3;
-    const int64_t total = (int64_t)B * Hout * Wout * c8n;
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    const int c8 = (int)(gid % c8n);
-    const int64_t pix = gid / c8n;
-    const int ox = (int)(pix % Wout), oy = (int)((pix / Wout) % Hout), b = (int)(pix / ((int64_t)Wout * Hout));
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (unsigned)Wout * c8n) return;
+    const int c8 = idx % c8n, ox = idx / c8n;
+    const int b = blockIdx.y / Hout, oy = blockIdx.y - b * Hout;
+    const int64_t pix = ((int64_t)b * Hout + oy) * Wout + ox;
     float fy, fx;
     if (align) {
         fy = sy * (float)oy;
@@ -362,13 +362,12 @@ static int launch_resize(const void* x, const void* addend, void* out, int B, in
         sy = (float)Hin / (float)Hout;
         sx = (float)Win / (float)Wout;
     }
-    const int64_t total = (int64_t)B * Hout * Wout * (C / 8);
-    const unsigned blocks = (unsigned)cdiv64(total, 256);
+    const dim3 blocks(cdiv(Wout * (C / 8), 256), B * Hout);
     if (addend)
-        hipLaunchKernelGGL((resize_nhwc_kernel<T, true>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)addend, (T*)out, B, Hin,
+        hipLaunchKernelGGL((resize_nhwc_kernel<T, true>), blocks, dim3(256), 0, st, (const T*)x, (const T*)addend, (T*)out, B, Hin,
                            Win, C, Hout, Wout, sy, sx, align);
     else
-        hipLaunchKernelGGL((resize_nhwc_kernel<T, false>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)nullptr, (T*)out, B,
+        hipLaunchKernelGGL((resize_nhwc_kernel<T, false>), blocks, dim3(256), 0, st, (const T*)x, (const T*)nullptr, (T*)out, B,
                            Hin, Win, C, Hout, Wout, sy, sx, align);
     BS_CHECK_LAUNCH();
     return BS_OK;

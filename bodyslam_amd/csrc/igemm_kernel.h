@@ -1,0 +1,531 @@
+// Implicit-GEMM on MFMA for gfx950: out[m, n] = epilogue(sum_k A(m, k) * W[n, k]).
+//
+// One kernel family serves every Linear / Conv2d / ConvTranspose2d(k == stride) on the hot path
+// (include/bodyslam_hip.h: bs_gemm lists the reference call sites).  Design:
+//   * NHWC activations, weights [N][KH][KW][Cin]: a BK = 64 slice of K is ONE filter tap and 64
+//     contiguous channels, i.e. one 128-byte line per output pixel.  The A tile is therefore a row
+//     gather: each lane of a `global_load_lds_dwordx4` supplies the address of 16 bytes of its pixel
+//     (or of a zero page when the tap falls into the padding) and the data lands in LDS without
+//     touching VGPRs.  No im2col buffer exists anywhere.
+//   * LDS image per operand: [rows][64] 16-bit, 128-byte rows, 16-byte chunk c of row r stored at
+//     chunk position c ^ (r & 7).  The DMA destination is lane-linear, so the XOR is applied to the
+//     SOURCE chunk each lane fetches and again on the ds_read_b128 address (conflict-free for the
+//     16x16x32 operand pattern: 16 distinct rows x one chunk per lane group).
+//   * v_mfma_f32_16x16x32_{f16,bf16}; operands swapped (W fragment as "A", activation fragment as
+//     "B") so a lane ends with 4 consecutive n for one m: 8/16-byte epilogue stores.
+//   * double-buffered LDS, one barrier per K tile: the DMA of tile t+1 is in flight while tile t
+//     is multiplied.
+//   * 1-D grid with the bijective XCD remap: the N-tiles of one M-tile (which share the gathered
+//     activations) are consecutive work ids and land on one XCD's L2.
+// Epilogue fuses bias (optionally per row group), ReLU/GELU/softplus, per-channel scale
+// (BEiT layer-scale), residual add (fp32 or 16-bit), and three store layouts (plain with row
+// regrouping, ConvTranspose pixel shuffle, Q/K/V^T head scatter).
+#pragma once
+#include <type_traits>
+
+#include "common.h"
+
+namespace bs {
+
+struct IgemmParams {
+    const void* A;
+    const void* W;
+    const void* zero;
+    long long a_bytes;   // extent of A in bytes (bounds of the buffer descriptor)
+    int M, N, K, lda;
+    int Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_h, pad_w;
+    int tiles_per_tap;
+    int relu_a;
+    const float* bias;
+    int bias_group_rows;
+    int act;
+    const float* scale;
+    const void* res;
+    const void* res2;
+    int res_dtype, ldr;
+    void* out;
+    void* out2;
+    void* out3;
+    int out_dtype, ldo, out_mode;
+    int out_group_rows, out_group_stride, out_row_offset;
+    int shuffle_s, shuffle_cout;
+    int qkv_hidden, qkv_tokens, qkv_sp;
+    float q_scale;
+    int ntm, ntn;
+    int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue
+};
+
+template <typename T>
+__device__ __forceinline__ typename T16<T>::v8 relu8(typename T16<T>::v8 x) {
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 b = __builtin_bit_cast(s16x8, x);
+    s16x8 neg = b >> 15;  // 0xFFFF where the sign bit is set
+    b = b & ~neg;
+    return __builtin_bit_cast(typename T16<T>::v8, b);
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(void* base, int64_t off, int out_dtype, const float (&y)[4]) {
+    if (out_dtype == BS_F32) {
+        f32x4 v = {y[0], y[1], y[2], y[3]};
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off) = v;
+    } else {
+        typename T16<T>::v4 v;
+        v[0] = T16<T>::from_f32(y[0]);
+        v[1] = T16<T>::from_f32(y[1]);
+        v[2] = T16<T>::from_f32(y[2]);
+        v[3] = T16<T>::from_f32(y[3]);
+        *reinterpret_cast<typename T16<T>::v4*>(reinterpret_cast<T*>(base) + off) = v;
+    }
+}
+
+constexpr int NW_CHECK(int a, int b) { return a * b; }
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Tile variants.  BK is the K slice per stage (one 64- or 128-byte LDS row per tile row), STAGES the depth
+// of the LDS ring: STAGES-1 tiles are in flight (global_load_lds) while one is multiplied.
+// MODE: 0 plain GEMM rows, 1 implicit conv, 2 implicit conv with ReLU applied to A on load
+template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int MODE, bool PP = false>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins exist in the device pass only; the host pass needs just the stub
+    constexpr bool CONV = MODE != 0;
+    constexpr bool RELU_A = MODE == 2;
+    constexpr int NT = WM * WN * 64;
+    constexpr int ROWB = BK * 2;        // bytes per LDS row
+    constexpr int LPR = ROWB / 16;      // lanes (16-byte chunks) per row: 8 (BK 64) or 4 (BK 32)
+    constexpr int RPR = NT / LPR;       // rows staged per DMA round
+    constexpr int RPW = 64 / LPR;       // rows per wave-instruction (1 KiB)
+    constexpr int RA = BM / RPR, RB = BN / RPR;
+    static_assert(BK == 64 || BK == 32, "BK");
+    static_assert(BM % RPR == 0 && BN % RPR == 0, "tile rows must be a multiple of the DMA round");
+    constexpr int GL = RA + RB;         // LDS-DMA instructions per wave per stage
+    static_assert(GL * (STAGES - 1) <= 63, "vmcnt range");
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int FM = TM / 16, FN = TN / 16;
+    static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be a multiple of 16");
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int LDS_BYTES = STAGES * STAGE;
+    constexpr unsigned OOB = 0x80000000u;   // voffset sentinel: beyond every descriptor (num_records < 2^31) -> the DMA writes zeros
+    typedef typename T16<T>::v8 v8;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // ---- work id -> tile, XCD-aware (blocks b and b+8 share an XCD; give each XCD a contiguous
+    // run of work ids so that the N-tiles of one M-tile hit the same L2)
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + loc;
+    const int tm = wg / p.ntn, tn = wg - tm * p.ntn;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int srow = tid / LPR;
+    // LDS image: 16-byte chunk c of row r sits at chunk position c ^ swz(r); swz(r) = r & 7 (128-byte rows) or
+    // (-(r >> 2)) & 3 (64-byte rows): conflict-free ds_read_b128 for the 16x16x32 operand pattern in both cases
+    // (the b128 lane groups pair rows {0-3,12-15} at chunk c with rows {4-11} at chunk c^1).
+    const int sswz = (BK == 64) ? (srow & 7) : ((0 - (srow >> 2)) & 3);
+    const int cs16 = ((tid & (LPR - 1)) ^ sswz) * 16;  // byte offset of the SOURCE chunk this lane fetches
+
+    // ---- buffer descriptors (wave-uniform): A window starting at this tile's first image / row, W whole.
+    // Out-of-range lanes of a `buffer_load ... lds` write ZEROS to LDS (probed: tools/probes/lds_dma_oob.hip):
+    // that is the convolution's zero padding -- no zero page, no per-lane pointer select, 32-bit offsets only.
+    const int m0 = tm * BM;
+    long long a_base_el;
+    int img0 = 0;
+    if (CONV) {
+        img0 = m0 / (p.Hout * p.Wout);
+        a_base_el = (long long)img0 * p.Hin * p.Win * p.lda;
+    } else {
+        a_base_el = (long long)m0 * p.lda;
+    }
+    long long a_left = p.a_bytes - a_base_el * 2;
+    a_left = a_left > 0x7FFFFFF0ll ? 0x7FFFFFF0ll : a_left;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(reinterpret_cast<const T*>(p.A)) + a_base_el, 0, (int)a_left, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.W), 0, (int)((long long)p.N * p.K * 2), 0x00020000);
+
+    // ---- per-lane row bookkeeping for the DMA rounds: a 32-bit byte offset and (conv) a tap-validity bitmask
+    unsigned a_off[RA];
+    unsigned a_mask[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        int m = m0 + j * RPR + srow;
+        m = m < p.M ? m : p.M - 1;
+        if (CONV) {
+            const int hw = p.Hout * p.Wout;
+            const int b = m / hw, rem = m - b * hw;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            const int iy0 = oy * p.stride - p.pad_h, ix0 = ox * p.stride - p.pad_w;
+            // offset of tap (0,0); may be "negative" (wraps): it is only used where the tap is valid, where the sum is in range
+            a_off[j] = (unsigned)((((b - img0) * p.Hin + iy0) * p.Win + ix0) * p.lda * 2 + cs16);
+            unsigned mk = 0;
+            for (int ky = 0; ky < p.KH; ++ky)
+                for (int kx = 0; kx < p.KW; ++kx) {
+                    const bool ok = (unsigned)(iy0 + ky) < (unsigned)p.Hin && (unsigned)(ix0 + kx) < (unsigned)p.Win;
+                    mk |= (ok ? 1u : 0u) << (ky * p.KW + kx);
+                }
+            a_mask[j] = mk;
+        } else {
+            a_off[j] = (unsigned)((m - m0) * p.lda * 2 + cs16);
+            a_mask[j] = 1u;
+        }
+    }
+    unsigned w_off[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        int n = tn * BN + j * RPR + srow;
+        n = n < p.N ? n : p.N - 1;
+        w_off[j] = (unsigned)(n * p.K * 2 + cs16);
+    }
+
+    // running state of the NEXT tile to stage: tap index / tap byte offset / channel byte offset (conv), k byte offset
+    int s_tap = 0, s_kx = 0, s_tapoff = 0, s_c0 = 0, s_k = 0;
+
+    auto stage = [&](int buf) {
+        char* sa = smem + buf * STAGE;
+        char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            unsigned vo;
+            if (CONV) {
+                vo = ((a_mask[j] >> s_tap) & 1u) ? a_off[j] + (unsigned)s_tapoff : OOB;
+            } else {
+                vo = a_off[j];
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(sa + (j * RPR + wave * RPW) * ROWB), 16, vo,
+                                                     CONV ? s_c0 : s_k, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(sb + (j * RPR + wave * RPW) * ROWB), 16, w_off[j],
+                                                     s_k, 0, 0);
+        s_k += BK * 2;
+        if (CONV) {
+            s_c0 += BK * 2;
+            if (s_c0 >= p.Cin * 2) {
+                s_c0 = 0;
+                ++s_tap;
+                s_tapoff += p.lda * 2;
+                if (++s_kx >= p.KW) {
+                    s_kx = 0;
+                    s_tapoff += (p.Win - p.KW) * p.lda * 2;
+                }
+            }
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets: row = 16-row fragment base + (lane & 15)
+    const int frow = lane & 15, fq = lane >> 4;
+    const int fswz = (BK == 64) ? (lane & 7) : ((0 - ((lane & 15) >> 2)) & 3);
+    const int koff0 = ((0 + fq) ^ fswz) << 4, koff1 = (BK == 64) ? (((4 + fq) ^ fswz) << 4) : 0;
+    const int a_base = (wm * TM + frow) * ROWB, b_base = (wn * TN + frow) * ROWB;
+
+    const int nt = p.K / BK;
+    if constexpr (!PP) {
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s)
+            if (s < nt) stage(s);
+        int cbuf = 0, sbuf = STAGES - 1;   // buffer multiplied this iteration / buffer staged this iteration
+        v8 af[FM], bf[FN];
+        for (int t = 0; t < nt; ++t) {
+            // my own DMA for tile t has landed once at most (tiles issued after t) x GL operations are outstanding
+            const int younger = nt - 1 - t;
+            if (STAGES >= 4 && younger >= 2) wait_vmcnt<(STAGES >= 4 ? 2 : 0) * GL>();
+            else if (STAGES >= 3 && younger >= 1) wait_vmcnt<(STAGES >= 3 ? 1 : 0) * GL>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();   // everyone's tile t has landed; everyone is done reading buffer sbuf (tile t-1)
+            asm volatile("" ::: "memory");
+            if (t + STAGES - 1 < nt && !(p.ablate & 1)) stage(sbuf);
+            const char* sa = smem + cbuf * STAGE;
+            const char* sb = sa + A_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < BK / 32; ++kk) {
+                const int ko = kk ? koff1 : koff0;
+                if (!(p.ablate & 2) || t == 0) {
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+                        af[i] = *reinterpret_cast<const v8*>(sa + a_base + i * 16 * ROWB + ko);
+                        if (RELU_A) af[i] = relu8<T>(af[i]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const v8*>(sb + b_base + j * 16 * ROWB + ko);
+                }
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = T16<T>::mfma16(bf[j], af[i], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            cbuf = cbuf + 1 == STAGES ? 0 : cbuf + 1;
+            sbuf = sbuf + 1 == STAGES ? 0 : sbuf + 1;
+        }
+    } else {
+        // ---- ping-pong schedule (BK = 32, 4-stage ring, 8 waves = two groups of four, one wave of each group per
+        // SIMD).  A wave alternates a LOAD phase (issue its 4 LDS-DMA pieces of tile t+3, read ALL 12 fragments of
+        // its tile into registers) with a COMPUTE phase (32 MFMAs from registers, nothing else); the groups run half a
+        // tile apart, so on every SIMD one wave feeds the matrix pipe while its partner moves data.
+        //   phase 2t   : group 0 computes tile t          | group 1 issues DMA(t+3), loads tile t
+        //   phase 2t+1 : group 0 issues DMA(t+3), loads t+1 | group 1 computes tile t
+        // One barrier per phase.  Before the barrier that opens an odd phase every wave waits (counted vmcnt) for its
+        // own pieces of the tile that group 0 is about to read; the ring slot of tile t+3 was last read two phases ago.
+        static_assert(BK == 32 && STAGES == 4 && WM == 2 && NW_CHECK(WM, WN) == 8, "ping-pong variant: 256x256x32, 8 waves");
+        const int grp = wm;
+        v8 af[FM], bf[FN];
+        auto load_frags = [&](int buf) {
+            const char* sa = smem + buf * STAGE;
+            const char* sb = sa + A_BYTES;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                af[i] = *reinterpret_cast<const v8*>(sa + a_base + i * 16 * ROWB + koff0);
+                if (RELU_A) af[i] = relu8<T>(af[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const v8*>(sb + b_base + j * 16 * ROWB + koff0);
+        };
+        auto compute = [&]() {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = T16<T>::mfma16(bf[j], af[i], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto wait_tiles = [&](int younger) {   // leave `younger` of my tiles (GL pieces each) in flight
+            if (younger >= 2) wait_vmcnt<2 * GL>();
+            else if (younger == 1) wait_vmcnt<GL>();
+            else wait_vmcnt<0>();
+        };
+        auto phase_barrier = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            if (s < nt) stage(s);
+        wait_tiles((nt - 1 < 2 ? nt - 1 : 2));
+        phase_barrier();                       // tile 0 has landed everywhere
+        // Both groups run the SAME loop; group 1 runs it one phase later (it sits out phase -1 and issues tile 3 on
+        // entering phase 0), group 0 sits out the last phase.
+        int issued = nt - 1 < 2 ? nt - 1 : 2;  // highest tile this wave has issued
+        if (grp == 1) {
+            phase_barrier();
+            if (3 < nt) { stage(3); issued = 3; }
+        }
+        load_frags(0);
+        int buf = 0;                           // ring slot of tile t
+        const int last = nt - 1;
+        for (int t = 0; t < nt; ++t) {
+            const int nbuf = buf == 3 ? 0 : buf + 1;
+            // group 1: this barrier opens the odd phase in which group 0 reads tile t+1 -> my pieces of t+1 must have landed
+            if (grp == 1 && t + 1 < nt) wait_tiles(issued - (t + 1));
+            phase_barrier();
+            compute();
+            if (grp == 0 && t + 1 < nt) wait_tiles(issued - (t + 1));
+            phase_barrier();
+            if (t + 1 < nt) {
+                if (issued < last) { ++issued; stage(issued & 3); }
+                load_frags(nbuf);
+            }
+            buf = nbuf;
+        }
+        if (grp == 0) phase_barrier();
+    }
+
+    // ---- epilogue.  A lane holds, per 16x16 fragment, 4 CONSECUTIVE n of one row m (operands were swapped), so it
+    // stores 8 bytes (16-bit out) or 16 bytes (fp32 out) straight from registers: no LDS round trip, no barrier.
+    // Everything that depends only on the column (bias, layer-scale, head / tap decomposition) is hoisted per fragment
+    // column j, everything that depends only on the row (regrouped row, image / token / pixel decomposition) per fragment
+    // row i; the activation is selected once, outside the fragment loops.  Only the V third of the fused QKV projection
+    // still goes through LDS: it is written TRANSPOSED (V^T [B,nh,64,Sp]), consecutive lanes taking consecutive tokens.
+    //   lane: m = tm*BM + wm*TM + i*16 + (lane & 15),  n = tn*BN + wn*TN + j*16 + (lane >> 4)*4 + 0..3
+    const int n_wave = tn * BN + wn * TN;
+    const bool v_tile = (p.out_mode == BS_OUT_QKV) && (tn * BN >= 2 * p.qkv_hidden);
+    if (p.ablate & 4) {
+        if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.out)[0] = 1.f;   // keep the accumulators live
+        return;
+    }
+    if (!v_tile) {
+        auto epi = [&](auto act_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
+            f32x4 bj[FN], sj[FN];
+            int n0j[FN];
+            int64_t coff[FN];        // column part of the store offset (elements)
+            int which[FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n0 = n_wave + j * 16 + fq * 4;
+                n0j[j] = n0;
+                const bool ok = n0 < p.N;
+                bj[j] = (p.bias && !p.bias_group_rows && ok) ? *reinterpret_cast<const f32x4*>(p.bias + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
+                sj[j] = (p.scale && ok) ? *reinterpret_cast<const f32x4*>(p.scale + n0) : f32x4{1.f, 1.f, 1.f, 1.f};
+                which[j] = 0;
+                if (p.out_mode == BS_OUT_PLAIN) {
+                    coff[j] = n0;
+                } else if (p.out_mode == BS_OUT_SHUFFLE) {
+                    const int s = p.shuffle_s;
+                    const int tap = n0 / p.shuffle_cout, co = n0 - tap * p.shuffle_cout;
+                    const int ky = tap / s, kx = tap - ky * s;
+                    coff[j] = ((int64_t)ky * (p.Wout * s) + kx) * p.ldo + co;
+                } else {
+                    const int w_ = n0 / p.qkv_hidden, rem = n0 - w_ * p.qkv_hidden;
+                    which[j] = w_;
+                    coff[j] = (int64_t)(rem >> 6) * p.qkv_sp * 64 + (rem & 63);
+                    if (w_ == 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { sj[j][e] *= p.q_scale; bj[j][e] *= 1.0f; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = tm * BM + wm * TM + i * 16 + frow;
+                if (m >= p.M) continue;
+                int64_t orow = m;        // row in the output / residual geometry
+                int64_t roff;            // row part of the store offset (elements)
+                const float* brow = nullptr;
+                if (p.bias && p.bias_group_rows) brow = p.bias + (int64_t)(m / p.bias_group_rows) * p.N;
+                if (p.out_mode == BS_OUT_PLAIN) {
+                    if (p.out_group_rows) {
+                        const int g = m / p.out_group_rows;
+                        orow = (int64_t)g * p.out_group_stride + (m - g * p.out_group_rows) + p.out_row_offset;
+                    }
+                    roff = orow * p.ldo;
+                } else if (p.out_mode == BS_OUT_SHUFFLE) {
+                    const int hw = p.Hout * p.Wout;
+                    const int ob = m / hw, rem = m - ob * hw;
+                    const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+                    const int s = p.shuffle_s;
+                    roff = (((int64_t)(ob * p.Hout + oy) * s) * (p.Wout * s) + ox * s) * p.ldo;
+                } else {
+                    const int ob = m / p.qkv_tokens, otok = m - ob * p.qkv_tokens;
+                    roff = ((int64_t)ob * (p.qkv_hidden >> 6) * p.qkv_sp + otok) * 64;
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    if (n0j[j] >= p.N) continue;
+                    float y[4];
+                    if (brow) {
+                        const f32x4 bb = *reinterpret_cast<const f32x4*>(brow + n0j[j]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = acc[i][j][e] + bb[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = acc[i][j][e] + bj[j][e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (ACT == BS_ACT_RELU) y[e] = fmaxf(y[e], 0.0f);
+                        else if (ACT == BS_ACT_GELU) y[e] = gelu_erf(y[e]);
+                        else if (ACT == BS_ACT_SOFTPLUS) y[e] = softplus20(y[e]);
+                        y[e] *= sj[j][e];
+                    }
+                    if (p.res) {
+                        const int64_t ro = orow * p.ldr + n0j[j];   // residuals live in the OUTPUT row geometry
+                        if (p.res_dtype == BS_F32) {
+                            const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + ro);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[e] += rr[e];
+                        } else {
+                            const typename T16<T>::v4 rr = *reinterpret_cast<const typename T16<T>::v4*>(reinterpret_cast<const T*>(p.res) + ro);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[e] += T16<T>::to_f32(rr[e]);
+                        }
+                        if (p.res2) {   // second residual, 16-bit (fusion: fused + residual_unit(skip))
+                            const typename T16<T>::v4 rr = *reinterpret_cast<const typename T16<T>::v4*>(reinterpret_cast<const T*>(p.res2) + ro);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[e] += T16<T>::to_f32(rr[e]);
+                        }
+                    }
+                    void* dst = (p.out_mode == BS_OUT_QKV && which[j] == 1) ? p.out2 : p.out;
+                    store4<T>(dst, roff + coff[j], p.out_dtype, y);
+                }
+            }
+        };
+        if (p.act == BS_ACT_GELU) epi(std::integral_constant<int, BS_ACT_GELU>{});
+        else if (p.act == BS_ACT_RELU) epi(std::integral_constant<int, BS_ACT_RELU>{});
+        else if (p.act == BS_ACT_SOFTPLUS) epi(std::integral_constant<int, BS_ACT_SOFTPLUS>{});
+        else epi(std::integral_constant<int, BS_ACT_NONE>{});
+    } else {
+        // V part: per-wave LDS transpose, then consecutive lanes store consecutive tokens of one (head, d) row
+        constexpr int NW = WM * WN;
+        constexpr int S4 = TN / 4;
+        constexpr int MAXR = LDS_BYTES / (NW * TN * 4);
+        constexpr int PASS_R = MAXR >= TM ? TM : (MAXR >= TM / 2 ? TM / 2 : (MAXR >= TM / 4 ? TM / 4 : TM / 8));
+        static_assert(PASS_R >= 16 && PASS_R % 16 == 0 && NW * PASS_R * TN * 4 <= LDS_BYTES, "epilogue staging does not fit the main-loop LDS");
+        constexpr int PASSES = TM / PASS_R;
+        float* sc = reinterpret_cast<float*>(smem) + wave * (PASS_R * TN);
+        T* vt = reinterpret_cast<T*>(p.out3);
+        const int nh = p.qkv_hidden >> 6;
+        __syncthreads();  // every wave is done reading the main-loop LDS
+        for (int ps = 0; ps < PASSES; ++ps) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                if ((i * 16) / PASS_R == ps) {
+                    const int r = i * 16 - ps * PASS_R + frow;
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) *reinterpret_cast<f32x4*>(sc + r * TN + (((j * 4 + fq) ^ (r & (S4 - 1))) << 2)) = acc[i][j];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int m_base = tm * BM + wm * TM + ps * PASS_R;
+            // lane -> row r (token), loop over the TN columns; PASS_R is 32 or 64 rows: 1 or 2 columns per sweep
+            constexpr int CPS = 64 / PASS_R >= 1 ? 64 / PASS_R : 1;     // columns per 64-lane sweep
+            const int r = lane % PASS_R, csub = lane / PASS_R;
+            const int m = m_base + r;
+            const int ob = m / p.qkv_tokens, otok = m - ob * p.qkv_tokens;
+            if (m < p.M) {
+                for (int c0 = 0; c0 < TN; c0 += CPS) {
+                    const int c = c0 + csub;
+                    const int n = n_wave + c;
+                    if (n >= p.N) continue;
+                    float y = sc[r * TN + ((((c >> 2) ^ (r & (S4 - 1))) << 2) | (c & 3))];
+                    if (p.bias) y += p.bias[n];
+                    const int rem = n - 2 * p.qkv_hidden;
+                    vt[(((int64_t)ob * nh + (rem >> 6)) * 64 + (rem & 63)) * p.qkv_sp + otok] = T16<T>::from_f32(y);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // the next pass overwrites this wave's region
+        }
+    }
+#endif
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int MODE, bool PP = false>
+inline int launch_mode(const IgemmParams& p, hipStream_t st) {
+    constexpr int smem = STAGES * (BM + BN) * BK * 2;
+    dim3 grid(p.ntm * p.ntn), block(WM * WN * 64);
+    auto k = igemm_kernel<T, BM, BN, WM, WN, BK, STAGES, MODE, PP>;
+    static bool attr = false;
+    if (!attr) {
+        BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr = true;
+    }
+    hipLaunchKernelGGL(k, grid, block, smem, st, p);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, bool PP = false>
+inline int launch_variant(const IgemmParams& p, bool conv, hipStream_t st) {
+    if (!conv) return launch_mode<T, BM, BN, WM, WN, BK, STAGES, 0, PP>(p, st);
+    if (p.relu_a) return launch_mode<T, BM, BN, WM, WN, BK, STAGES, 2, PP>(p, st);
+    return launch_mode<T, BM, BN, WM, WN, BK, STAGES, 1, PP>(p, st);
+}
+
+}  // namespace bs

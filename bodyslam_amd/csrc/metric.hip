@@ -36,15 +36,17 @@ __device__ __forceinline__ Lerp2 lerp_ac(int oy, int ox, int Hin, int Win, float
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attractor_kernel(const float* A, const float* bins_prev, float* bins_out, const int32_t* route,
                                                          int B, int Hp, int Wp, int H, int W, int G, int nb, int na, float sy, float sx) {
+    // grid.y = (image, output row); grid.x covers (column, group, bin quad) of that row: no 64-bit div/mod per thread
     const int q4 = nb >> 2;
-    const int64_t total = (int64_t)B * H * W * G * q4;
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    const int q = (int)(gid % q4);
-    const int g = (int)((gid / q4) % G);
-    const int64_t pix = gid / ((int64_t)q4 * G);
-    const int ox = (int)(pix % W), oy = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+    const unsigned per_row = (unsigned)W * G * q4;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= per_row) return;
+    const int b = blockIdx.y / H, oy = blockIdx.y - b * H;
+    const int q = idx % q4;
+    const int g = (idx / q4) % G;
+    const int ox = idx / (q4 * G);
     if (route && route[b] != g) return;
+    const int64_t pix = ((int64_t)b * H + oy) * W + ox;
     const Lerp2 l = lerp_ac(oy, ox, Hp, Wp, sy, sx);
     const int CB = G * nb, CA = G * na;
     const float* pb = bins_prev + (int64_t)b * Hp * Wp * CB + g * nb + q * 4;
@@ -56,13 +58,16 @@ __global__ __launch_bounds__(256) void attractor_kernel(const float* A, const fl
 #pragma unroll
     for (int e = 0; e < 4; ++e) c[e] = l.hy * (l.hx * p00[e] + l.lx * p01[e]) + l.ly * (l.hx * p10[e] + l.lx * p11[e]);
     const float* pa = A + pix * CA + g * na;
-    for (int a = 0; a < na; ++a) {
-        const float av = pa[a];
+    for (int a4 = 0; a4 < na; a4 += 4) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(pa + a4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float dx = av - c[e];
-            dsum[e] += dx / (1.0f + 300.0f * (dx * dx));  // inv_attractor defaults alpha=300, gamma=2
-        }
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dx = av[k] - c[e];
+                // inv_attractor defaults alpha=300, gamma=2; v_rcp-based division (1 ulp) instead of the IEEE sequence
+                dsum[e] += __fdividef(dx, 1.0f + 300.0f * (dx * dx));
+            }
     }
     f32x4 o;
 #pragma unroll
@@ -77,21 +82,44 @@ __global__ __launch_bounds__(256) void attractor_kernel(const float* A, const fl
 //   y_k = logC(n-1,k) + k log p + (n-1-k) log(1-p); depth = sum_k softmax(y/T)_k * interp(bins)_k
 // ---------------------------------------------------------------------------------------------
 constexpr int LB_HID = 40, LB_IN = 32, LB_BINS = 64;
+constexpr int LB_T = 16;                 // output tile edge (256 threads = 16 x 16 pixels)
+constexpr int LB_MAXSRC = 12;            // low-res rows / columns a 16-pixel span can touch at >= 1.5x upsampling (+1 neighbour, +slack)
 
 template <typename T>
 __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const float* Eh, const float* bins, const float* w0_last,
                                                         const float* w2, const float* b2, const int32_t* route, float* depth, int B, int H,
                                                         int W, int He, int We, float sy, float sx, float min_temp, float max_temp) {
-    __shared__ float s_w0[2][LB_HID][LB_IN + 1];
-    __shared__ float s_w2[2][4][LB_HID];
-    __shared__ float s_b2[2][4];
+    // LDS: the block's low-res patch of bin centres [rows][cols][64] and of Eh [rows][cols][40] for the routed head only,
+    // loaded once (coalesced) instead of 4 x (256 + 160) bytes per output pixel; plus the small MLP weights.
+    __shared__ float s_bins[LB_MAXSRC * LB_MAXSRC * LB_BINS];
+    __shared__ float s_eh[LB_MAXSRC * LB_MAXSRC * LB_HID];
+    __shared__ float s_w0[LB_HID][LB_IN + 1];
+    __shared__ float s_w2[4][LB_HID];
+    __shared__ float s_b2[4];
     __shared__ float s_lb[LB_BINS];
-    for (int i = threadIdx.x; i < 2 * LB_HID * LB_IN; i += blockDim.x) {
-        const int g = i / (LB_HID * LB_IN), r = (i / LB_IN) % LB_HID, c = i % LB_IN;
-        s_w0[g][r][c] = w0_last[i];
+    const int b = blockIdx.z;
+    const int g = route[b];
+    const int ty0 = blockIdx.y * LB_T, tx0 = blockIdx.x * LB_T;
+    // low-res window covered by this tile (align_corners=True: src = scale * dst)
+    const int ty1 = min(ty0 + LB_T - 1, H - 1), tx1 = min(tx0 + LB_T - 1, W - 1);
+    const int sy0 = min((int)(sy * (float)ty0), He - 1), sx0 = min((int)(sx * (float)tx0), We - 1);
+    const int sy1 = min((int)(sy * (float)ty1) + 1, He - 1), sx1 = min((int)(sx * (float)tx1) + 1, We - 1);
+    const int nr = sy1 - sy0 + 1, nc = sx1 - sx0 + 1;        // <= LB_MAXSRC (checked by the launcher's scale test)
+    for (int i = threadIdx.x; i < nr * nc * (LB_BINS / 4); i += 256) {
+        const int k4 = i % (LB_BINS / 4), cell = i / (LB_BINS / 4);
+        const int rr = cell / nc, cc = cell - rr * nc;
+        const float* src = bins + (((int64_t)b * He + sy0 + rr) * We + sx0 + cc) * (2 * LB_BINS) + g * LB_BINS + k4 * 4;
+        *reinterpret_cast<f32x4*>(s_bins + cell * LB_BINS + k4 * 4) = *reinterpret_cast<const f32x4*>(src);
     }
-    for (int i = threadIdx.x; i < 2 * 4 * LB_HID; i += blockDim.x) s_w2[i / (4 * LB_HID)][(i / LB_HID) % 4][i % LB_HID] = w2[i];
-    if (threadIdx.x < 8) s_b2[threadIdx.x / 4][threadIdx.x % 4] = b2[threadIdx.x];
+    for (int i = threadIdx.x; i < nr * nc * (LB_HID / 4); i += 256) {
+        const int k4 = i % (LB_HID / 4), cell = i / (LB_HID / 4);
+        const int rr = cell / nc, cc = cell - rr * nc;
+        const float* src = Eh + (((int64_t)b * He + sy0 + rr) * We + sx0 + cc) * (2 * LB_HID) + g * LB_HID + k4 * 4;
+        *reinterpret_cast<f32x4*>(s_eh + cell * LB_HID + k4 * 4) = *reinterpret_cast<const f32x4*>(src);
+    }
+    for (int i = threadIdx.x; i < LB_HID * LB_IN; i += 256) s_w0[i / LB_IN][i % LB_IN] = w0_last[g * LB_HID * LB_IN + i];
+    for (int i = threadIdx.x; i < 4 * LB_HID; i += 256) s_w2[i / LB_HID][i % LB_HID] = w2[g * 4 * LB_HID + i];
+    if (threadIdx.x < 4) s_b2[threadIdx.x] = b2[g * 4 + threadIdx.x];
     if (threadIdx.x < LB_BINS) {
         // log_binom(n = 63, k) with the reference's eps placement (modeling_zoedepth.py:376-381)
         const float e = 1e-7f;
@@ -99,15 +127,12 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
         s_lb[threadIdx.x] = n * logf(n) - k * logf(k) - (n - k) * logf(n - k + e);
     }
     __syncthreads();
-    const int64_t total = (int64_t)B * H * W;
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    const int ox = (int)(gid % W), oy = (int)((gid / W) % H), b = (int)(gid / ((int64_t)W * H));
-    const int g = route[b];
+    const int oy = ty0 + (threadIdx.x >> 4), ox = tx0 + (threadIdx.x & 15);
+    if (oy >= H || ox >= W) return;
+    const int64_t gid = ((int64_t)b * H + oy) * W + ox;
     const Lerp2 l = lerp_ac(oy, ox, He, We, sy, sx);
-    const float w00 = l.hy * l.hx, w01 = l.hy * l.lx, w10 = l.ly * l.hx, w11 = l.ly * l.lx;
-    const int64_t e00 = ((int64_t)b * He + l.y0) * We + l.x0, e01 = ((int64_t)b * He + l.y0) * We + l.x1;
-    const int64_t e10 = ((int64_t)b * He + l.y1) * We + l.x0, e11 = ((int64_t)b * He + l.y1) * We + l.x1;
+    const int c00 = (l.y0 - sy0) * nc + (l.x0 - sx0), c01 = (l.y0 - sy0) * nc + (l.x1 - sx0);
+    const int c10 = (l.y1 - sy0) * nc + (l.x0 - sx0), c11 = (l.y1 - sy0) * nc + (l.x1 - sx0);
 
     // the 32 `last` features of this pixel
     float xin[LB_IN];
@@ -121,19 +146,17 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
             for (int e = 0; e < 8; ++e) xin[v * 8 + e] = (float)t[e];
         }
     }
-    float pt[4] = {s_b2[g][0], s_b2[g][1], s_b2[g][2], s_b2[g][3]};
-    const int EC = 2 * LB_HID;
+    float pt[4] = {s_b2[0], s_b2[1], s_b2[2], s_b2[3]};
     for (int h = 0; h < LB_HID; ++h) {
-        const int ch = g * LB_HID + h;
         // same bilinear operation order as torch: hy*(hx*p00 + lx*p01) + ly*(hx*p10 + lx*p11)
-        float a = l.hy * (l.hx * Eh[e00 * EC + ch] + l.lx * Eh[e01 * EC + ch]) + l.ly * (l.hx * Eh[e10 * EC + ch] + l.lx * Eh[e11 * EC + ch]);
+        float a = l.hy * (l.hx * s_eh[c00 * LB_HID + h] + l.lx * s_eh[c01 * LB_HID + h]) +
+                  l.ly * (l.hx * s_eh[c10 * LB_HID + h] + l.lx * s_eh[c11 * LB_HID + h]);
 #pragma unroll
-        for (int c = 0; c < LB_IN; ++c) a += s_w0[g][h][c] * xin[c];
+        for (int c = 0; c < LB_IN; ++c) a += s_w0[h][c] * xin[c];
         a = gelu_erf(a);
 #pragma unroll
-        for (int o = 0; o < 4; ++o) pt[o] += s_w2[g][o][h] * a;
+        for (int o = 0; o < 4; ++o) pt[o] += s_w2[o][h] * a;
     }
-    (void)w00; (void)w01; (void)w10; (void)w11;
 #pragma unroll
     for (int o = 0; o < 4; ++o) pt[o] = softplus20(pt[o]);
     const float eps = 1e-4f;
@@ -144,26 +167,25 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
     omp = fminf(fmaxf(omp, eps), 1.0f);
     p = fminf(fmaxf(p, eps), 1.0f);
     const float lp_ = logf(p), lomp = logf(omp);
-    // pass 1: max of y/T
+    // y_k / T for all 64 bins, kept in registers (one evaluation; the softmax max needs them all first)
+    float y[LB_BINS];
     float mx = -3.0e38f;
+#pragma unroll
     for (int k = 0; k < LB_BINS; ++k) {
-        const float y = (s_lb[k] + (float)k * lp_ + (float)(LB_BINS - 1 - k) * lomp) / t;
-        mx = fmaxf(mx, y);
+        y[k] = (s_lb[k] + (float)k * lp_ + (float)(LB_BINS - 1 - k) * lomp) / t;
+        mx = fmaxf(mx, y[k]);
     }
-    const int CB = 2 * LB_BINS;
-    const float* bb = bins + g * LB_BINS;
     float den = 0.f, num = 0.f;
+#pragma unroll
     for (int k4 = 0; k4 < LB_BINS / 4; ++k4) {
-        const f32x4 c00 = *reinterpret_cast<const f32x4*>(bb + e00 * CB + k4 * 4);
-        const f32x4 c01 = *reinterpret_cast<const f32x4*>(bb + e01 * CB + k4 * 4);
-        const f32x4 c10 = *reinterpret_cast<const f32x4*>(bb + e10 * CB + k4 * 4);
-        const f32x4 c11 = *reinterpret_cast<const f32x4*>(bb + e11 * CB + k4 * 4);
+        const f32x4 b00 = *reinterpret_cast<const f32x4*>(s_bins + c00 * LB_BINS + k4 * 4);
+        const f32x4 b01 = *reinterpret_cast<const f32x4*>(s_bins + c01 * LB_BINS + k4 * 4);
+        const f32x4 b10 = *reinterpret_cast<const f32x4*>(s_bins + c10 * LB_BINS + k4 * 4);
+        const f32x4 b11 = *reinterpret_cast<const f32x4*>(s_bins + c11 * LB_BINS + k4 * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int k = k4 * 4 + e;
-            const float y = (s_lb[k] + (float)k * lp_ + (float)(LB_BINS - 1 - k) * lomp) / t;
-            const float w = expf(y - mx);
-            const float c = l.hy * (l.hx * c00[e] + l.lx * c01[e]) + l.ly * (l.hx * c10[e] + l.lx * c11[e]);
+            const float w = __expf(y[k4 * 4 + e] - mx);
+            const float c = l.hy * (l.hx * b00[e] + l.lx * b01[e]) + l.ly * (l.hx * b10[e] + l.lx * b11[e]);
             den += w;
             num += w * c;
         }
@@ -241,8 +263,9 @@ extern "C" int bs_attractor_step(const float* A, const float* bins_prev, float* 
                "bs_attractor_step: bad argument");
     if (B == 0) return BS_OK;
     const float sy = H > 1 ? (float)(Hp - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(Wp - 1) / (float)(W - 1) : 0.f;
-    const int64_t total = (int64_t)B * H * W * groups * (n_bins / 4);
-    hipLaunchKernelGGL(attractor_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A,
+    BS_REQUIRE(n_attr % 4 == 0, "bs_attractor_step: n_attr must be a multiple of 4");
+    const unsigned per_row = (unsigned)W * groups * (n_bins / 4);
+    hipLaunchKernelGGL(attractor_kernel, dim3(cdiv((int)per_row, 256), B * H), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A,
                        bins_prev, bins_out, route, B, Hp, Wp, H, W, groups, n_bins, n_attr, sy, sx);
     BS_CHECK_LAUNCH();
     return BS_OK;
@@ -257,14 +280,17 @@ extern "C" int bs_logbinom_depth(const void* last, const float* Eh, const float*
     BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_logbinom_depth: dtype");
     if (B == 0) return BS_OK;
     const float sy = H > 1 ? (float)(He - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(We - 1) / (float)(W - 1) : 0.f;
-    const int64_t total = (int64_t)B * H * W;
+    // a 16-pixel output span must fit the LDS patch: span * scale + 2 <= LB_MAXSRC
+    BS_REQUIRE(sy * (LB_T - 1) + 3.0f <= (float)LB_MAXSRC && sx * (LB_T - 1) + 3.0f <= (float)LB_MAXSRC,
+               "bs_logbinom_depth: the bins map must be upsampled by at least ~1.7x (He,We=%d,%d -> H,W=%d,%d)", He, We, H, W);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid(cdiv(W, LB_T), cdiv(H, LB_T), B);
     if (dtype == BS_F16)
-        hipLaunchKernelGGL(logbinom_kernel<f16>, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, (const f16*)last, Eh, bins, w0_last,
-                           w2, b2, route, depth, B, H, W, He, We, sy, sx, min_temp, max_temp);
+        hipLaunchKernelGGL(logbinom_kernel<f16>, grid, dim3(256), 0, st, (const f16*)last, Eh, bins, w0_last, w2, b2, route, depth, B, H, W,
+                           He, We, sy, sx, min_temp, max_temp);
     else
-        hipLaunchKernelGGL(logbinom_kernel<bf16>, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, (const bf16*)last, Eh, bins,
-                           w0_last, w2, b2, route, depth, B, H, W, He, We, sy, sx, min_temp, max_temp);
+        hipLaunchKernelGGL(logbinom_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)last, Eh, bins, w0_last, w2, b2, route, depth, B, H,
+                           W, He, We, sy, sx, min_temp, max_temp);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }

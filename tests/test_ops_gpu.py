@@ -48,9 +48,9 @@ def tol(dtype, k):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M,N,K,tile", [(128, 128, 64, 1), (300, 256, 192, 1), (257, 64, 128, 2), (1000, 32, 256, 3),
-                                        (513, 384, 1024, 4), (64, 8, 64, 0), (2049, 1024, 512, 0), (40000, 256, 256, 0),
-                                        (1000, 384, 1024, 5), (1000, 640, 448, 6), (777, 256, 64, 6), (1000, 384, 320, 7),
-                                        (1000, 384, 1056 - 32, 8), (300, 128, 64, 8), (1000, 640, 448, 9), (5000, 256, 128, 9)])
+                                        (513, 384, 1024, 11), (64, 8, 64, 0), (2049, 1024, 512, 0), (40000, 256, 256, 0),
+                                        (1000, 384, 320, 11), (300, 128, 64, 11), (1000, 640, 448, 9), (5000, 256, 128, 9), (777, 256, 64, 9),
+                                        (1000, 640, 448, 10), (5000, 256, 64, 10), (700, 512, 64, 10), (3000, 256, 128, 10), (3000, 1024, 1024, 10)])
 def test_gemm_plain(L, dtype, M, N, K, tile):
     A = rnd(M, K, seed=1, dtype=dtype)
     W = rnd(N, K, seed=2, scale=1 / math.sqrt(K), dtype=dtype)
@@ -92,10 +92,11 @@ def test_gemm_epilogue_gelu_scale_residual_groups(L, dtype):
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,relu_a,tile", [(2, 12, 16, 64, 64, 1, False, 0), (1, 24, 32, 256, 256, 1, True, 0),
                                                                 (3, 17, 19, 128, 32, 1, False, 0), (2, 32, 32, 64, 128, 2, False, 0),
                                                                 (1, 48, 64, 512, 256, 1, False, 0), (1, 24, 32, 1024, 1024, 2, False, 0),
-                                                                (2, 24, 32, 256, 256, 1, True, 5), (2, 24, 32, 256, 256, 1, True, 6),
-                                                                (3, 17, 19, 128, 256, 1, False, 6), (2, 24, 32, 64, 256, 1, False, 7),
-                                                                (2, 24, 32, 128, 128, 1, True, 8), (2, 31, 33, 64, 128, 2, False, 6),
-                                                                (2, 24, 32, 256, 256, 1, True, 9), (3, 17, 19, 128, 256, 1, False, 9)])
+                                                                (2, 24, 32, 256, 256, 1, True, 11), (2, 24, 32, 64, 256, 1, False, 11),
+                                                                (2, 24, 32, 128, 128, 1, True, 11), (2, 31, 33, 64, 128, 2, False, 11),
+                                                                (2, 24, 32, 256, 256, 1, True, 9), (3, 17, 19, 128, 256, 1, False, 9),
+                                                                (2, 24, 32, 256, 256, 1, True, 10), (3, 17, 19, 128, 256, 1, False, 10),
+                                                                (2, 31, 33, 64, 256, 2, False, 10)])
 def test_conv3x3(L, dtype, B, H, W, Cin, Cout, stride, relu_a, tile):
     x = rnd(B, H, W, Cin, seed=1, dtype=dtype)                       # NHWC
     w = rnd(Cout, Cin, 3, 3, seed=2, scale=1 / math.sqrt(9 * Cin), dtype=dtype)
