@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU (8 steps x 32 = the 256-frame config)")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
@@ -59,8 +59,10 @@ def main():
         args.gpus = world
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ        # under torch.distributed.run the RCCL path is exercised even at N=1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from bodyslam_amd import _lib as L
@@ -95,14 +97,14 @@ def main():
         pplan.frames.copy_(chunk)
         pplan.pairs.copy_(pairs)
         pplan.plan.run()
-        t_all = gather_relative_poses(pplan.T, counts) if world > 1 else pplan.T
+        t_all = gather_relative_poses(pplan.T, counts) if use_dist else pplan.T
         g_abs = geom3d.pose_chain(t_all, device=local_rank)
         xyz, idx, cnt = geom3d.backproject(zplan.depth_u16, pipe.K, pipe.depth_scale, pipe.depth_trunc,
                                            poses=g_abs[rank * B + 1: (rank + 1) * B + 1])
         return cnt
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -114,7 +116,7 @@ def main():
         cnt = step(k, not args.no_kernel_timing)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = te.item()
@@ -184,7 +186,7 @@ def main():
             "depth_l1_vs_oracle_m": l1, "kernels": kern_table,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

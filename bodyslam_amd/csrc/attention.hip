@@ -14,6 +14,8 @@
 // k-step are 8 CONSECUTIVE keys, i.e. one 16-byte read of the V^T image.
 // K and V^T tiles (64 keys) are staged by global_load_lds into double-buffered, XOR-swizzled LDS
 // images shared by the QW waves of a block.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace bs {
@@ -21,7 +23,7 @@ namespace bs {
 template <typename T, int QW>
 __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ Vt,
                                                              const float* __restrict__ bias, T* __restrict__ out, int B, int nh, int S,
-                                                             int Sp, int nqt, int nqb) {
+                                                             int Sp, int nqt, int nqb, int ablate) {
     typedef typename T16<T>::v8 v8;
     constexpr int STAGE = 16 * 1024;  // K tile 8 KiB + V^T tile 8 KiB
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict_
     stage(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();
-        if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
+        if (kt + 1 < nkt && !(ablate & 2)) stage(kt + 1, (kt + 1) & 1);
         const char* sk = smem + (kt & 1) * STAGE;
         const char* sv = sk + 8 * 1024;
 #pragma unroll
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict_
                     sacc[8 * s + e] = bnext[2 * s][e] - m_run;
                     sacc[8 * s + 4 + e] = bnext[2 * s + 1][e] - m_run;
                 }
-            if (key0 + 32 < Sp) load_bias(key0 + 32);
+            if (key0 + 32 < Sp && !(ablate & 1)) load_bias(key0 + 32);
             // ---- S^T = K Q^T (+ bias - m_run)
             const int krow = sub * 32 + kap;
 #pragma unroll
@@ -148,10 +150,15 @@ __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict_
             }
             float p[16];
             float psum = 0.f;
+            if (ablate & 4) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                p[i] = __builtin_amdgcn_exp2f(sacc[i]);
-                psum += p[i];
+                for (int i = 0; i < 16; ++i) p[i] = sacc[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    p[i] = __builtin_amdgcn_exp2f(sacc[i]);
+                    psum += p[i];
+                }
             }
             l_run += psum;
             // ---- O^T += V^T P^T
@@ -194,7 +201,7 @@ static int launch_attn(const void* q, const void* k, const void* vt, const float
                        hipStream_t st) {
     const int nqt = cdiv(S, 32), nqb = cdiv(nqt, QW);
     hipLaunchKernelGGL((attention_kernel<T, QW>), dim3(B * nh * nqb), dim3(QW * 64), 32 * 1024, st, (const T*)q, (const T*)k,
-                       (const T*)vt, bias, (T*)out, B, nh, S, Sp, nqt, nqb);
+                       (const T*)vt, bias, (T*)out, B, nh, S, Sp, nqt, nqb, getenv("BS_ATTN_ABLATE") ? atoi(getenv("BS_ATTN_ABLATE")) : 0);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }

@@ -44,9 +44,9 @@ def gather_relative_poses(t_local: torch.Tensor, counts: Sequence[int], group=No
     """All-gather the per-rank relative poses [P_r,16] into the full [sum P_r,16] in rank order.
     Ranks own different pair counts (rank 0 has one fewer), so blocks are padded to the maximum."""
     import torch.distributed as dist
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return t_local
+    world = dist.get_world_size(group)
     pmax = max(counts)
     buf = torch.zeros(pmax, 16, dtype=torch.float32, device=t_local.device)
     buf[: t_local.shape[0]] = t_local

@@ -64,6 +64,17 @@ def main():
             pl = L.Plan()
             pl.gemm(name, x, w, out, M=NB * H * W_, N=Co, K=9 * Ci, lda=Ci, conv=geom, bias=bias, act=L.ACT_RELU, tile=t)
             results.append((name, t, 2.0 * NB * H * W_ * Co * 9 * Ci, pl.run))
+    if not a.only or "attn" in a.only:
+        Sp = 832
+        q = torch.randn(NB, 16, Sp, 64, device=dev).to(dt) * 0.2
+        k = torch.randn(NB, 16, Sp, 64, device=dev).to(dt)
+        vt = torch.randn(NB, 16, 64, Sp, device=dev).to(dt)
+        bias = torch.randn(16, Sp, Sp, device=dev)
+        bias[:, :, S:] = -1e30
+        ao = torch.empty(NB * S, 1024, device=dev, dtype=dt)
+        pl = L.Plan()
+        pl.add("attn", "bs_attention", q, k, vt, bias, ao, NB, 16, S, Sp, L.dt(q))
+        results.append(("attn  769 tokens x16 heads", 0, 4.0 * NB * 16 * S * S * 64, pl.run))
     # warm up, then interleaved rounds
     for _, _, _, fn in results:
         fn()
