@@ -42,7 +42,7 @@ class GemmDesc(C.Structure):
         ("out_group_rows", C.c_int32), ("out_group_stride", C.c_int32), ("out_row_offset", C.c_int32),
         ("shuffle_s", C.c_int32), ("shuffle_cout", C.c_int32),
         ("qkv_hidden", C.c_int32), ("qkv_tokens", C.c_int32), ("qkv_sp", C.c_int32), ("q_scale", C.c_float),
-        ("tile", C.c_int32),
+        ("tile", C.c_int32), ("seg1", C.c_int32), ("out_split_off", C.c_int32), ("res_split_off", C.c_int32),
     ]
 
 
@@ -57,6 +57,8 @@ _SIGS = {
     "bs_layernorm": [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p],
     "bs_cast": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p],
     "bs_copy_f32": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    "bs_cast_split": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p],
+    "bs_relu_split": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p],
     "bs_preprocess_patches": [C.c_void_p, C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p],
     "bs_preprocess_image": [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p],
     "bs_fill_rows": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
@@ -139,7 +141,8 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
                    conv=None, relu_a: bool = False, bias: Optional[torch.Tensor] = None, bias_group_rows: int = 0,
                    act: int = ACT_NONE, scale: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
                    res2: Optional[torch.Tensor] = None, ldr: int = 0, ldo: Optional[int] = None, out_group=None,
-                   shuffle=None, qkv=None, a_offset: int = 0, tile: int = 0) -> GemmDesc:
+                   shuffle=None, qkv=None, a_offset: int = 0, tile: int = 0, seg1: int = 0, out_split_off: int = 0,
+                   res_split_off: int = 0) -> GemmDesc:
     """Fill a bs_gemm_desc.  conv = (Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_h, pad_w) or None;
     out_group = (rows, stride, offset); shuffle = (s, Cout, Hgrid, Wgrid);
     qkv = (hidden, tokens, Sp, q_scale, out_k, out_vt); a_offset in elements."""
@@ -183,6 +186,7 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
         d.out2 = out_k.data_ptr()
         d.out3 = out_vt.data_ptr()
     d.tile = tile
+    d.seg1, d.out_split_off, d.res_split_off = seg1, out_split_off, res_split_off
     return d
 
 
@@ -204,13 +208,17 @@ class Plan:
         self.gemm_info = {}  # call index -> dict(tile, conv, flops, bytes)
 
     def gemm(self, name, A, W, out, **kw):
+        passes = kw.pop("precision_passes", 1)
         d = make_gemm_desc(A, W, out, **kw)
+        kw["precision_passes"] = passes
         self.keep.append((d, A, W, out, kw))
         self.calls.append((load_library().bs_gemm, (C.byref(d),)))
         self.names.append(name)
         # bookkeeping for the roofline: which kernel instantiation and how many algorithmic FLOPs
         self.gemm_info[len(self.calls) - 1] = dict(
             name=name, tile=load_library().bs_gemm_tile(C.byref(d)), conv=bool(d.conv), flops=2.0 * d.M * d.N * d.K,
+            # algorithmic FLOPs exclude the extra passes of a split-precision product
+            alg_flops=2.0 * d.M * d.N * (d.K / kw.get("precision_passes", 1)),
             bytes=float(d.M) * (d.Cin if d.conv else d.K) * 2 + float(d.N) * d.K * 2 + float(d.M) * d.N * (4 if d.out_dtype == F32 else 2))
 
     def add(self, name, fn_name, *args):
@@ -278,6 +286,16 @@ def cast(x, out):
     check(load_library().bs_cast(p(x), p(out), x.numel(), dt(out), stream_ptr()), "bs_cast")
 
 
+def cast_split(x, out, rows, cols):
+    """fp32 [rows, cols] -> 16-bit [rows, 2*cols] = (hi | lo),  hi = round16(x), lo = round16(x - hi)."""
+    check(load_library().bs_cast_split(p(x), p(out), rows, cols, dt(out), stream_ptr()), "bs_cast_split")
+
+
+def relu_split(x, out, rows, cols):
+    """(hi | lo) [rows, 2*cols] -> re-split relu(hi + lo)."""
+    check(load_library().bs_relu_split(p(x), p(out), rows, cols, dt(out), stream_ptr()), "bs_relu_split")
+
+
 def preprocess_patches(frames, out, B, H, W, nh, nw, flip):
     check(load_library().bs_preprocess_patches(p(frames), p(out), B, H, W, nh, nw, int(flip), dt(out), stream_ptr()),
           "bs_preprocess_patches")
@@ -291,8 +309,8 @@ def fill_rows(x, v, B, rows_per_image, cols):
     check(load_library().bs_fill_rows(p(x), p(v), B, rows_per_image, cols, stream_ptr()), "bs_fill_rows")
 
 
-def resize_bilinear_nhwc(x, out, B, Hin, Win, Cch, Hout, Wout, align_corners=True):
-    check(load_library().bs_resize_bilinear_nhwc(p(x), p(out), B, Hin, Win, Cch, Hout, Wout, int(align_corners), dt(x),
+def resize_bilinear_nhwc(x, out, B, Hin, Win, Cch, Hout, Wout, align_corners=True, split=False):
+    check(load_library().bs_resize_bilinear_nhwc(p(x), p(out), B, Hin, Win, Cch, Hout, Wout, int(align_corners) | (2 if split else 0), dt(x),
                                                  stream_ptr()), "bs_resize_bilinear_nhwc")
 
 
@@ -301,8 +319,9 @@ def attractor_step(A, bins_prev, bins_out, route, B, Hp, Wp, H, W, groups, n_bin
                                            stream_ptr()), "bs_attractor_step")
 
 
-def add_resized(x, prev, out, B, Hp, Wp, H, W, Cch):
-    check(load_library().bs_add_resized(p(x), p(prev), p(out), B, Hp, Wp, H, W, Cch, dt(x), stream_ptr()), "bs_add_resized")
+def add_resized(x, prev, out, B, Hp, Wp, H, W, Cch, split=False):
+    check(load_library().bs_add_resized(p(x), p(prev), p(out), B, Hp, Wp, H, W, Cch, dt(x) | (16 if split else 0), stream_ptr()),
+          "bs_add_resized")
 
 
 def logbinom_depth(last, Eh, bins, w0_last, w2, b2, route, depth, B, H, W, He, We, min_temp, max_temp):

@@ -94,6 +94,45 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* x, T* out, int64
     }
 }
 
+// fp32 [rows, C] -> 16-bit (hi | lo) pairs [rows, 2C]: x = hi + lo to ~22 bits (split-precision operands)
+template <typename T>
+__global__ __launch_bounds__(256) void cast_split_kernel(const float* x, T* out, int64_t rows, int C) {
+    const int c4n = C >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows * c4n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c4n;
+        const int c = (int)(i - r * c4n) * 4;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(x + r * C + c);
+        typename T16<T>::v4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = T16<T>::from_f32(t[e]);
+            l[e] = T16<T>::from_f32(t[e] - T16<T>::to_f32(h[e]));
+        }
+        *reinterpret_cast<typename T16<T>::v4*>(out + r * 2 * C + c) = h;
+        *reinterpret_cast<typename T16<T>::v4*>(out + r * 2 * C + C + c) = l;
+    }
+}
+
+// ReLU of a (hi | lo) tensor [rows, 2C]: the sign of hi + lo is the sign of hi (|lo| <= ulp(hi)/2)
+template <typename T>
+__global__ __launch_bounds__(256) void relu_split_kernel(const T* x, T* out, int64_t rows, int C) {
+    typedef typename T16<T>::v8 v8;
+    const int c8n = C >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows * c8n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c8n;
+        const int c = (int)(i - r * c8n) * 8;
+        v8 h = *reinterpret_cast<const v8*>(x + r * 2 * C + c), l = *reinterpret_cast<const v8*>(x + r * 2 * C + C + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool pos = (float)h[e] > 0.0f;
+            h[e] = pos ? h[e] : T16<T>::from_f32(0.0f);
+            l[e] = pos ? l[e] : T16<T>::from_f32(0.0f);
+        }
+        *reinterpret_cast<v8*>(out + r * 2 * C + c) = h;
+        *reinterpret_cast<v8*>(out + r * 2 * C + C + c) = l;
+    }
+}
+
 __global__ void fill_rows_kernel(float* x, const float* v, int rows_per_image, int cols) {
     const int b = blockIdx.x;
     for (int i = threadIdx.x; i < cols; i += blockDim.x) x[(int64_t)b * rows_per_image * cols + i] = v[i];
@@ -164,9 +203,10 @@ __global__ __launch_bounds__(256) void pre_image_kernel(const uint8_t* frames, f
 // ---------------------------------------------------------------------------------------------
 // NHWC bilinear resize (+ optional add): thread = one 8-channel group of one output pixel
 // ---------------------------------------------------------------------------------------------
-template <typename T, bool ADD>
+template <typename T, bool ADD, bool SPLIT>
 __global__ __launch_bounds__(256) void resize_nhwc_kernel(const T* x, const T* addend, T* out, int B, int Hin, int Win, int C, int Hout,
                                                            int Wout, float sy, float sx, int align) {
+    // SPLIT: the tensors hold (hi | lo) pairs, C channels each (pixel stride 2C); the value hi + lo is resampled and re-split
     // grid.y = (image, output row); grid.x covers (column, 8-channel group) of that row
     const int c8n = C >> 3;
     const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -188,21 +228,34 @@ __global__ __launch_bounds__(256) void resize_nhwc_kernel(const T* x, const T* a
     const int y1 = y0 + (y0 < Hin - 1 ? 1 : 0), x1 = x0 + (x0 < Win - 1 ? 1 : 0);
     const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
     typedef typename T16<T>::v8 v8;
-    const T* xb = x + (int64_t)b * Hin * Win * C + c8 * 8;
-    const v8 p00 = *reinterpret_cast<const v8*>(xb + ((int64_t)y0 * Win + x0) * C);
-    const v8 p01 = *reinterpret_cast<const v8*>(xb + ((int64_t)y0 * Win + x1) * C);
-    const v8 p10 = *reinterpret_cast<const v8*>(xb + ((int64_t)y1 * Win + x0) * C);
-    const v8 p11 = *reinterpret_cast<const v8*>(xb + ((int64_t)y1 * Win + x1) * C);
-    v8 a;
-    if (ADD) a = *reinterpret_cast<const v8*>(addend + pix * C + c8 * 8);
-    v8 o;
+    constexpr int PS = SPLIT ? 2 : 1;                       // pixel stride in units of C
+    const T* xb = x + (int64_t)b * Hin * Win * C * PS + c8 * 8;
+    float q00[8], q01[8], q10[8], q11[8], av[8];
+    auto ld = [&](const T* ptr, float (&dst)[8]) {
+        const v8 h = *reinterpret_cast<const v8*>(ptr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dst[e] = (float)h[e];
+        if (SPLIT) {
+            const v8 l = *reinterpret_cast<const v8*>(ptr + C);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dst[e] += (float)l[e];
+        }
+    };
+    ld(xb + ((int64_t)y0 * Win + x0) * C * PS, q00);
+    ld(xb + ((int64_t)y0 * Win + x1) * C * PS, q01);
+    ld(xb + ((int64_t)y1 * Win + x0) * C * PS, q10);
+    ld(xb + ((int64_t)y1 * Win + x1) * C * PS, q11);
+    if (ADD) ld(addend + pix * C * PS + c8 * 8, av);
+    v8 o, ol;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        float v = hy * (hx * (float)p00[e] + lx * (float)p01[e]) + ly * (hx * (float)p10[e] + lx * (float)p11[e]);
-        if (ADD) v += (float)a[e];
+        float v = hy * (hx * q00[e] + lx * q01[e]) + ly * (hx * q10[e] + lx * q11[e]);
+        if (ADD) v += av[e];
         o[e] = T16<T>::from_f32(v);
+        if (SPLIT) ol[e] = T16<T>::from_f32(v - (float)o[e]);
     }
-    *reinterpret_cast<v8*>(out + pix * C + c8 * 8) = o;
+    *reinterpret_cast<v8*>(out + pix * C * PS + c8 * 8) = o;
+    if (SPLIT) *reinterpret_cast<v8*>(out + pix * C * PS + C + c8 * 8) = ol;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -353,7 +406,7 @@ extern "C" int bs_preprocess_image(const uint8_t* frames, float* out, int32_t B,
 
 template <typename T>
 static int launch_resize(const void* x, const void* addend, void* out, int B, int Hin, int Win, int C, int Hout, int Wout, int align,
-                         hipStream_t st) {
+                         hipStream_t st, bool split = false) {
     float sy, sx;
     if (align) {
         sy = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f;
@@ -363,11 +416,21 @@ static int launch_resize(const void* x, const void* addend, void* out, int B, in
         sx = (float)Win / (float)Wout;
     }
     const dim3 blocks(cdiv(Wout * (C / 8), 256), B * Hout);
+    if (split) {
+        if (addend)
+            hipLaunchKernelGGL((resize_nhwc_kernel<T, true, true>), blocks, dim3(256), 0, st, (const T*)x, (const T*)addend, (T*)out, B, Hin, Win,
+                               C, Hout, Wout, sy, sx, align);
+        else
+            hipLaunchKernelGGL((resize_nhwc_kernel<T, false, true>), blocks, dim3(256), 0, st, (const T*)x, (const T*)nullptr, (T*)out, B, Hin,
+                               Win, C, Hout, Wout, sy, sx, align);
+        BS_CHECK_LAUNCH();
+        return BS_OK;
+    }
     if (addend)
-        hipLaunchKernelGGL((resize_nhwc_kernel<T, true>), blocks, dim3(256), 0, st, (const T*)x, (const T*)addend, (T*)out, B, Hin,
+        hipLaunchKernelGGL((resize_nhwc_kernel<T, true, false>), blocks, dim3(256), 0, st, (const T*)x, (const T*)addend, (T*)out, B, Hin,
                            Win, C, Hout, Wout, sy, sx, align);
     else
-        hipLaunchKernelGGL((resize_nhwc_kernel<T, false>), blocks, dim3(256), 0, st, (const T*)x, (const T*)nullptr, (T*)out, B,
+        hipLaunchKernelGGL((resize_nhwc_kernel<T, false, false>), blocks, dim3(256), 0, st, (const T*)x, (const T*)nullptr, (T*)out, B,
                            Hin, Win, C, Hout, Wout, sy, sx, align);
     BS_CHECK_LAUNCH();
     return BS_OK;
@@ -380,19 +443,23 @@ extern "C" int bs_resize_bilinear_nhwc(const void* x, void* out, int32_t B, int3
     BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_resize_bilinear_nhwc: dtype");
     if (B == 0) return BS_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    return dtype == BS_F16 ? launch_resize<f16>(x, nullptr, out, B, Hin, Win, C, Hout, Wout, align_corners, st)
-                           : launch_resize<bf16>(x, nullptr, out, B, Hin, Win, C, Hout, Wout, align_corners, st);
+    const bool split = (align_corners & 2) != 0;      // bit 1: the tensors hold (hi | lo) pairs of C channels each
+    const int ac = align_corners & 1;
+    return dtype == BS_F16 ? launch_resize<f16>(x, nullptr, out, B, Hin, Win, C, Hout, Wout, ac, st, split)
+                           : launch_resize<bf16>(x, nullptr, out, B, Hin, Win, C, Hout, Wout, ac, st, split);
 }
 
 extern "C" int bs_add_resized(const void* x, const void* prev, void* out, int32_t B, int32_t Hp, int32_t Wp, int32_t H, int32_t W,
                               int32_t C, int32_t dtype, void* stream) {
     BS_ENTRY("bs_add_resized");
     BS_REQUIRE(x && prev && out && B >= 0 && Hp > 0 && Wp > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "bs_add_resized: bad argument");
+    const bool split = (dtype & 16) != 0;             // bit 4: x, prev and out hold (hi | lo) pairs of C channels each
+    dtype &= 15;
     BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_add_resized: dtype");
     if (B == 0) return BS_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    return dtype == BS_F16 ? launch_resize<f16>(prev, x, out, B, Hp, Wp, C, H, W, 1, st)
-                           : launch_resize<bf16>(prev, x, out, B, Hp, Wp, C, H, W, 1, st);
+    return dtype == BS_F16 ? launch_resize<f16>(prev, x, out, B, Hp, Wp, C, H, W, 1, st, split)
+                           : launch_resize<bf16>(prev, x, out, B, Hp, Wp, C, H, W, 1, st, split);
 }
 
 extern "C" int bs_postprocess_depth(const float* depth_net, float* depth_m, uint16_t* depth_u16, int32_t B, int32_t H, int32_t W,
@@ -406,6 +473,38 @@ extern "C" int bs_postprocess_depth(const float* depth_net, float* depth_m, uint
     const int64_t total = (int64_t)B * H * W;
     hipLaunchKernelGGL(postprocess_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        depth_net, depth_m, depth_u16, B, H, W, nh, nw, g.ph, g.pw, sy, sx, flip);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+extern "C" int bs_cast_split(const float* x, void* out, int64_t rows, int32_t cols, int32_t out_dtype, void* stream) {
+    BS_ENTRY("bs_cast_split");
+    BS_REQUIRE(x && out && rows >= 0 && cols > 0 && cols % 4 == 0, "bs_cast_split: cols must be a multiple of 4");
+    BS_REQUIRE(out_dtype == BS_F16 || out_dtype == BS_BF16, "bs_cast_split: dtype");
+    if (rows == 0) return BS_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t n = rows * (cols / 4);
+    const unsigned blocks = (unsigned)(cdiv64(n, 256) < 8192 ? cdiv64(n, 256) : 8192);
+    if (out_dtype == BS_F16)
+        hipLaunchKernelGGL(cast_split_kernel<f16>, dim3(blocks), dim3(256), 0, st, x, (f16*)out, rows, cols);
+    else
+        hipLaunchKernelGGL(cast_split_kernel<bf16>, dim3(blocks), dim3(256), 0, st, x, (bf16*)out, rows, cols);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+extern "C" int bs_relu_split(const void* x, void* out, int64_t rows, int32_t cols, int32_t dtype, void* stream) {
+    BS_ENTRY("bs_relu_split");
+    BS_REQUIRE(x && out && rows >= 0 && cols > 0 && cols % 8 == 0, "bs_relu_split: cols must be a multiple of 8");
+    BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_relu_split: dtype");
+    if (rows == 0) return BS_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t n = rows * (cols / 8);
+    const unsigned blocks = (unsigned)(cdiv64(n, 256) < 16384 ? cdiv64(n, 256) : 16384);
+    if (dtype == BS_F16)
+        hipLaunchKernelGGL(relu_split_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const f16*)x, (f16*)out, rows, cols);
+    else
+        hipLaunchKernelGGL(relu_split_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)x, (bf16*)out, rows, cols);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }

@@ -69,14 +69,14 @@ extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
     IgemmParams p{};
     p.A = d->A; p.W = d->W; p.zero = zero_page();
     p.a_bytes = d->conv ? (long long)(d->M / (d->Hout > 0 && d->Wout > 0 ? d->Hout * d->Wout : 1)) * d->Hin * d->Win * d->lda * 2
-                        : ((long long)(d->M - 1) * d->lda + d->K) * 2;
+                        : ((long long)(d->M - 1) * d->lda + (d->K - d->seg1)) * 2;
     BS_REQUIRE((long long)d->N * d->K * 2 < 0x7FFFFFF0ll, "bs_gemm: weight matrix too large for one descriptor");
     p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda;
     p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin; p.Hout = d->Hout; p.Wout = d->Wout;
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
     if (d->conv) {
         BS_REQUIRE(d->Cin > 0 && d->Cin % 64 == 0, "bs_gemm: conv Cin=%d must be a multiple of 64", d->Cin);
-        BS_REQUIRE(d->K == d->KH * d->KW * d->Cin, "bs_gemm: conv K=%d != KH*KW*Cin", d->K);
+        BS_REQUIRE(d->K == d->KH * d->KW * (d->Cin + d->seg1), "bs_gemm: conv K=%d != KH*KW*(Cin+seg1)", d->K);
         BS_REQUIRE(d->Hout > 0 && d->Wout > 0 && d->M % (d->Hout * d->Wout) == 0, "bs_gemm: conv M=%d not a multiple of Hout*Wout", d->M);
         BS_REQUIRE(d->stride > 0 && d->lda >= d->Cin, "bs_gemm: bad conv stride/lda");
         BS_REQUIRE(d->KH > 0 && d->KW > 0 && d->KH * d->KW <= 32, "bs_gemm: conv window %dx%d: at most 32 taps", d->KH, d->KW);
@@ -84,6 +84,13 @@ extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
         p.tiles_per_tap = d->Cin / 64;
     }
     p.relu_a = d->relu_a;
+    p.cin1 = d->seg1;
+    p.split_off = d->out_split_off;
+    p.res_split_off = d->res_split_off;
+    BS_REQUIRE(d->seg1 >= 0 && d->seg1 % 64 == 0, "bs_gemm: seg1=%d must be a multiple of 64", d->seg1);
+    BS_REQUIRE(d->conv || d->seg1 < d->K, "bs_gemm: seg1 must be smaller than K");
+    BS_REQUIRE(d->out_split_off == 0 || (d->out_mode != BS_OUT_QKV && d->out_dtype == d->dtype), "bs_gemm: split output needs a plain / shuffle 16-bit output");
+    BS_REQUIRE(d->res_split_off == 0 || (d->res && d->res_dtype == d->dtype), "bs_gemm: split residual must be 16-bit");
     p.ablate = d->tile >= 100 ? d->tile / 100 : 0;
     BS_REQUIRE(!d->relu_a || d->conv, "bs_gemm: relu_a is only built for conv mode");
     p.bias = d->bias; p.bias_group_rows = d->bias_group_rows; p.act = d->act; p.scale = d->scale;

@@ -35,6 +35,9 @@ struct IgemmParams {
     int M, N, K, lda;
     int Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_h, pad_w;
     int tiles_per_tap;
+    int cin1;            // second K segment: channels per tap (conv) / K extent (plain); 0 = none.  Segment 0 is Cin (conv) / K - cin1 (plain)
+    int split_off;       // > 0: 16-bit output is written as a (hi, lo) pair, lo at +split_off elements (PLAIN mode)
+    int res_split_off;   // > 0: the 16-bit residual(s) are (hi, lo) pairs, lo at +res_split_off elements
     int relu_a;
     const float* bias;
     int bias_group_rows;
@@ -65,7 +68,18 @@ __device__ __forceinline__ typename T16<T>::v8 relu8(typename T16<T>::v8 x) {
 }
 
 template <typename T>
-__device__ __forceinline__ void store4(void* base, int64_t off, int out_dtype, const float (&y)[4]) {
+__device__ __forceinline__ void store4(void* base, int64_t off, int out_dtype, const float (&y)[4], int split_off = 0) {
+    if (split_off > 0) {   // (hi, lo) pair: y = hi + lo to ~22 bits
+        typename T16<T>::v4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = T16<T>::from_f32(y[e]);
+            l[e] = T16<T>::from_f32(y[e] - T16<T>::to_f32(h[e]));
+        }
+        *reinterpret_cast<typename T16<T>::v4*>(reinterpret_cast<T*>(base) + off) = h;
+        *reinterpret_cast<typename T16<T>::v4*>(reinterpret_cast<T*>(base) + off + split_off) = l;
+        return;
+    }
     if (out_dtype == BS_F32) {
         f32x4 v = {y[0], y[1], y[2], y[3]};
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off) = v;
@@ -184,8 +198,13 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
         w_off[j] = (unsigned)(n * p.K * 2 + cs16);
     }
 
-    // running state of the NEXT tile to stage: tap index / tap byte offset / channel byte offset (conv), k byte offset
-    int s_tap = 0, s_kx = 0, s_tapoff = 0, s_c0 = 0, s_k = 0;
+    // running state of the NEXT tile to stage.  W side: s_k (byte offset along K, runs straight through).  A side: the
+    // K axis is up to two SEGMENTS that both walk the same rows of A -- segment 0 with seg0 bytes per tap, then segment 1
+    // with seg1 bytes per tap (taps restart).  This is how split-precision products are expressed without a second
+    // kernel: A = [hi | lo] channels, W' = [W_hi | W_hi] then [W_lo] against the hi channels again (Numerics).
+    const int seg0 = (CONV ? p.Cin : p.K - p.cin1) * 2, seg1 = p.cin1 * 2;
+    const int ntaps = CONV ? p.KH * p.KW : 1;
+    int s_tap = 0, s_kx = 0, s_tapoff = 0, s_c0 = 0, s_k = 0, s_seg = seg0;
 
     auto stage = [&](int buf) {
         char* sa = smem + buf * STAGE;
@@ -199,23 +218,29 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                 vo = a_off[j];
             }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(sa + (j * RPR + wave * RPW) * ROWB), 16, vo,
-                                                     CONV ? s_c0 : s_k, 0, 0);
+                                                     s_c0, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(sb + (j * RPR + wave * RPW) * ROWB), 16, w_off[j],
                                                      s_k, 0, 0);
         s_k += BK * 2;
-        if (CONV) {
-            s_c0 += BK * 2;
-            if (s_c0 >= p.Cin * 2) {
-                s_c0 = 0;
+        s_c0 += BK * 2;
+        if (s_c0 >= s_seg) {
+            s_c0 = 0;
+            if (CONV) {
                 ++s_tap;
                 s_tapoff += p.lda * 2;
                 if (++s_kx >= p.KW) {
                     s_kx = 0;
                     s_tapoff += (p.Win - p.KW) * p.lda * 2;
                 }
+            }
+            if (!CONV || s_tap >= ntaps) {   // segment 0 finished: restart the taps for segment 1
+                s_tap = 0;
+                s_kx = 0;
+                s_tapoff = 0;
+                s_seg = seg1;
             }
         }
     };
@@ -443,15 +468,25 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                             const typename T16<T>::v4 rr = *reinterpret_cast<const typename T16<T>::v4*>(reinterpret_cast<const T*>(p.res) + ro);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) y[e] += T16<T>::to_f32(rr[e]);
+                            if (p.res_split_off > 0) {
+                                const typename T16<T>::v4 rl = *reinterpret_cast<const typename T16<T>::v4*>(reinterpret_cast<const T*>(p.res) + ro + p.res_split_off);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) y[e] += T16<T>::to_f32(rl[e]);
+                            }
                         }
                         if (p.res2) {   // second residual, 16-bit (fusion: fused + residual_unit(skip))
                             const typename T16<T>::v4 rr = *reinterpret_cast<const typename T16<T>::v4*>(reinterpret_cast<const T*>(p.res2) + ro);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) y[e] += T16<T>::to_f32(rr[e]);
+                            if (p.res_split_off > 0) {
+                                const typename T16<T>::v4 rl = *reinterpret_cast<const typename T16<T>::v4*>(reinterpret_cast<const T*>(p.res2) + ro + p.res_split_off);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) y[e] += T16<T>::to_f32(rl[e]);
+                            }
                         }
                     }
                     void* dst = (p.out_mode == BS_OUT_QKV && which[j] == 1) ? p.out2 : p.out;
-                    store4<T>(dst, roff + coff[j], p.out_dtype, y);
+                    store4<T>(dst, roff + coff[j], p.out_dtype, y, p.out_mode != BS_OUT_QKV ? p.split_off : 0);
                 }
             }
         };

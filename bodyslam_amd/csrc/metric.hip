@@ -85,7 +85,7 @@ constexpr int LB_HID = 40, LB_IN = 32, LB_BINS = 64;
 constexpr int LB_T = 16;                 // output tile edge (256 threads = 16 x 16 pixels)
 constexpr int LB_MAXSRC = 12;            // low-res rows / columns a 16-pixel span can touch at >= 1.5x upsampling (+1 neighbour, +slack)
 
-template <typename T>
+template <typename T, bool LSPLIT>
 __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const float* Eh, const float* bins, const float* w0_last,
                                                         const float* w2, const float* b2, const int32_t* route, float* depth, int B, int H,
                                                         int W, int He, int We, float sy, float sx, float min_temp, float max_temp) {
@@ -138,12 +138,17 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
     float xin[LB_IN];
     {
         typedef typename T16<T>::v8 v8;
-        const T* lp = last + gid * LB_IN;
+        const T* lp = last + gid * LB_IN * (LSPLIT ? 2 : 1);     // LSPLIT: (hi | lo) pairs, 32 + 32 values per pixel
 #pragma unroll
         for (int v = 0; v < LB_IN / 8; ++v) {
             const v8 t = *reinterpret_cast<const v8*>(lp + v * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) xin[v * 8 + e] = (float)t[e];
+            if (LSPLIT) {
+                const v8 tl = *reinterpret_cast<const v8*>(lp + LB_IN + v * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xin[v * 8 + e] += (float)tl[e];
+            }
         }
     }
     float pt[4] = {s_b2[0], s_b2[1], s_b2[2], s_b2[3]};
@@ -277,7 +282,7 @@ extern "C" int bs_logbinom_depth(const void* last, const float* Eh, const float*
     BS_ENTRY("bs_logbinom_depth");
     BS_REQUIRE(last && Eh && bins && w0_last && w2 && b2 && route && depth && B >= 0 && H > 0 && W > 0 && He > 0 && We > 0,
                "bs_logbinom_depth: bad argument");
-    BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_logbinom_depth: dtype");
+    BS_REQUIRE((dtype & 15) == BS_F16 || (dtype & 15) == BS_BF16, "bs_logbinom_depth: dtype");
     if (B == 0) return BS_OK;
     const float sy = H > 1 ? (float)(He - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(We - 1) / (float)(W - 1) : 0.f;
     // a 16-pixel output span must fit the LDS patch: span * scale + 2 <= LB_MAXSRC
@@ -285,11 +290,19 @@ extern "C" int bs_logbinom_depth(const void* last, const float* Eh, const float*
                "bs_logbinom_depth: the bins map must be upsampled by at least ~1.7x (He,We=%d,%d -> H,W=%d,%d)", He, We, H, W);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(cdiv(W, LB_T), cdiv(H, LB_T), B);
-    if (dtype == BS_F16)
-        hipLaunchKernelGGL(logbinom_kernel<f16>, grid, dim3(256), 0, st, (const f16*)last, Eh, bins, w0_last, w2, b2, route, depth, B, H, W,
+    const bool lsplit = (dtype & 16) != 0;   // bit 4: `last` holds (hi | lo) pairs
+    dtype &= 15;
+    if (dtype == BS_F16 && !lsplit)
+        hipLaunchKernelGGL((logbinom_kernel<f16, false>), grid, dim3(256), 0, st, (const f16*)last, Eh, bins, w0_last, w2, b2, route, depth, B, H, W,
                            He, We, sy, sx, min_temp, max_temp);
+    else if (dtype == BS_F16)
+        hipLaunchKernelGGL((logbinom_kernel<f16, true>), grid, dim3(256), 0, st, (const f16*)last, Eh, bins, w0_last, w2, b2, route, depth, B, H, W,
+                           He, We, sy, sx, min_temp, max_temp);
+    else if (!lsplit)
+        hipLaunchKernelGGL((logbinom_kernel<bf16, false>), grid, dim3(256), 0, st, (const bf16*)last, Eh, bins, w0_last, w2, b2, route, depth, B, H,
+                           W, He, We, sy, sx, min_temp, max_temp);
     else
-        hipLaunchKernelGGL(logbinom_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)last, Eh, bins, w0_last, w2, b2, route, depth, B, H,
+        hipLaunchKernelGGL((logbinom_kernel<bf16, true>), grid, dim3(256), 0, st, (const bf16*)last, Eh, bins, w0_last, w2, b2, route, depth, B, H,
                            W, He, We, sy, sx, min_temp, max_temp);
     BS_CHECK_LAUNCH();
     return BS_OK;

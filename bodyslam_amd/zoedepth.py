@@ -102,8 +102,13 @@ class ZoeDepthEngine:
     """
 
     def __init__(self, weights: Dict[str, torch.Tensor], cfg: Optional[ZoeConfig] = None, dtype=torch.float16,
-                 device: int = 0, target_hw: Tuple[int, int] = (384, 512)):
+                 device: int = 0, target_hw: Tuple[int, int] = (384, 512), precision: str = "fast"):
+        """precision: "fast" = one MFMA pass per product (16-bit operands, fp32 accumulate);
+        "accurate" = split-precision products where they matter (Numerics): backbone weights as
+        (hi, lo) pairs (2 passes), DPT neck + relative head with weights AND activations as (hi, lo) pairs (3 passes)."""
         L.init(device)
+        assert precision in ("fast", "accurate")
+        self.acc = precision == "accurate"
         self.target_hw = target_hw       # the processor's resize target (384x512 for every released checkpoint)
         self.cfg = cfg or ZoeConfig()
         assert dtype in (torch.float16, torch.bfloat16)
@@ -129,55 +134,83 @@ class ZoeDepthEngine:
         """[O, I, kh, kw] -> [O][kh][kw][I] (K-major over (ky, kx, ci))."""
         return self._h(t.permute(0, 2, 3, 1).reshape(t.shape[0], -1))
 
+    def _split(self, t: torch.Tensor):
+        hi = t.to(self.dtype)
+        lo = (t - hi.float()).to(self.dtype)
+        return hi, lo
+
+    def _wb(self, t: torch.Tensor) -> torch.Tensor:
+        """backbone GEMM weight [N, K]; accurate: [N, 2K] = [W_hi | W_lo] (A is walked twice: bs_gemm seg1 = K)."""
+        if not self.acc:
+            return self._h(t)
+        hi, lo = self._split(t)
+        return torch.cat([hi, lo], 1).to(self.dev).contiguous()
+
+    def _wn(self, t: torch.Tensor) -> torch.Tensor:
+        """neck / relative-head plain weight [N, K]; accurate: [N, 3K] = [W_hi | W_hi | W_lo] against A = [hi | lo], then hi."""
+        if not self.acc:
+            return self._h(t)
+        hi, lo = self._split(t)
+        return torch.cat([hi, hi, lo], 1).to(self.dev).contiguous()
+
+    def _wn_conv(self, t: torch.Tensor) -> torch.Tensor:
+        """neck conv weight [O, I, kh, kw]; accurate: per tap [W_hi | W_hi] (2I), then all taps of W_lo (I)."""
+        if not self.acc:
+            return self._conv_w(t)
+        k = t.permute(0, 2, 3, 1)                                   # [O, kh, kw, I]
+        hi, lo = self._split(k)
+        seg0 = torch.cat([hi, hi], -1).reshape(t.shape[0], -1)
+        return torch.cat([seg0, lo.reshape(t.shape[0], -1)], 1).to(self.dev).contiguous()
+
     def _ingest(self, sd: Dict[str, torch.Tensor]):
         c, w = self.cfg, self.w
         g = lambda k: sd[k].detach().float()
         pe = "backbone.beit.embeddings."
-        w["pe.w"] = self._h(g(pe + "patch_embeddings.projection.weight").reshape(c.hidden, -1))
+        w["pe.w"] = self._wb(g(pe + "patch_embeddings.projection.weight").reshape(c.hidden, -1))
         w["pe.b"] = self._f(g(pe + "patch_embeddings.projection.bias"))
         w["cls"] = self._f(g(pe + "cls_token").reshape(-1))
         for l in range(c.layers):
             p = f"backbone.beit.layers.{l}."
             w[f"l{l}.ln1.g"], w[f"l{l}.ln1.b"] = self._f(g(p + "layernorm_before.weight")), self._f(g(p + "layernorm_before.bias"))
             w[f"l{l}.ln2.g"], w[f"l{l}.ln2.b"] = self._f(g(p + "layernorm_after.weight")), self._f(g(p + "layernorm_after.bias"))
-            w[f"l{l}.qkv.w"] = self._h(torch.cat([g(p + "attention.q_proj.weight"), g(p + "attention.k_proj.weight"),
-                                                  g(p + "attention.v_proj.weight")], 0))
+            w[f"l{l}.qkv.w"] = self._wb(torch.cat([g(p + "attention.q_proj.weight"), g(p + "attention.k_proj.weight"),
+                                                   g(p + "attention.v_proj.weight")], 0))
             # k_proj has no bias (HF modeling_beit.py:305-307)
             w[f"l{l}.qkv.b"] = self._f(torch.cat([g(p + "attention.q_proj.bias"), torch.zeros(c.hidden),
                                                   g(p + "attention.v_proj.bias")], 0))
-            w[f"l{l}.o.w"], w[f"l{l}.o.b"] = self._h(g(p + "attention.o_proj.weight")), self._f(g(p + "attention.o_proj.bias"))
-            w[f"l{l}.fc1.w"], w[f"l{l}.fc1.b"] = self._h(g(p + "mlp.fc1.weight")), self._f(g(p + "mlp.fc1.bias"))
-            w[f"l{l}.fc2.w"], w[f"l{l}.fc2.b"] = self._h(g(p + "mlp.fc2.weight")), self._f(g(p + "mlp.fc2.bias"))
+            w[f"l{l}.o.w"], w[f"l{l}.o.b"] = self._wb(g(p + "attention.o_proj.weight")), self._f(g(p + "attention.o_proj.bias"))
+            w[f"l{l}.fc1.w"], w[f"l{l}.fc1.b"] = self._wb(g(p + "mlp.fc1.weight")), self._f(g(p + "mlp.fc1.bias"))
+            w[f"l{l}.fc2.w"], w[f"l{l}.fc2.b"] = self._wb(g(p + "mlp.fc2.weight")), self._f(g(p + "mlp.fc2.bias"))
             w[f"l{l}.lam1"], w[f"l{l}.lam2"] = self._f(g(p + "lambda_1")), self._f(g(p + "lambda_2"))
             self._raw_tables.append(g(p + "relative_position_bias.relative_position_bias_table"))
         factors = (4, 2, 1, 0.5)
         for i, (ch, f) in enumerate(zip(c.neck_hidden, factors)):
             ro = g(f"neck.reassemble_stage.readout_projects.{i}.0.weight")
-            w[f"ro{i}.w_tok"] = self._h(ro[:, :c.hidden])          # concat(token, cls) @ W^T = token @ W1^T + cls @ W2^T
-            w[f"ro{i}.w_cls"] = self._h(ro[:, c.hidden:])
+            w[f"ro{i}.w_tok"] = self._wn(ro[:, :c.hidden])          # concat(token, cls) @ W^T = token @ W1^T + cls @ W2^T
+            w[f"ro{i}.w_cls"] = self._wn(ro[:, c.hidden:])
             w[f"ro{i}.b"] = self._f(g(f"neck.reassemble_stage.readout_projects.{i}.0.bias"))
             p = f"neck.reassemble_stage.layers.{i}."
-            w[f"ra{i}.proj.w"] = self._h(g(p + "projection.weight").reshape(ch, c.hidden))
+            w[f"ra{i}.proj.w"] = self._wn(g(p + "projection.weight").reshape(ch, c.hidden))
             w[f"ra{i}.proj.b"] = self._f(g(p + "projection.bias"))
             if f > 1:
                 s = int(f)
                 wt = g(p + "resize.weight")                         # ConvTranspose2d [Cin, Cout, s, s]
-                w[f"ra{i}.up.w"] = self._h(wt.permute(2, 3, 1, 0).reshape(s * s * ch, ch))   # n = (ky*s+kx)*Cout + co
+                w[f"ra{i}.up.w"] = self._wn(wt.permute(2, 3, 1, 0).reshape(s * s * ch, ch))  # n = (ky*s+kx)*Cout + co
                 w[f"ra{i}.up.b"] = self._f(g(p + "resize.bias").repeat(s * s))
             elif f < 1:
-                w[f"ra{i}.down.w"] = self._conv_w(g(p + "resize.weight"))
+                w[f"ra{i}.down.w"] = self._wn_conv(g(p + "resize.weight"))
                 w[f"ra{i}.down.b"] = self._f(g(p + "resize.bias"))
-            w[f"nc{i}.w"] = self._conv_w(g(f"neck.convs.{i}.weight"))
+            w[f"nc{i}.w"] = self._wn_conv(g(f"neck.convs.{i}.weight"))
         for i in range(4):
             p = f"neck.fusion_stage.layers.{i}."
-            w[f"fu{i}.proj.w"] = self._h(g(p + "projection.weight").reshape(c.fusion, c.fusion))
+            w[f"fu{i}.proj.w"] = self._wn(g(p + "projection.weight").reshape(c.fusion, c.fusion))
             w[f"fu{i}.proj.b"] = self._f(g(p + "projection.bias"))
             for r in (1, 2):
                 for cv in (1, 2):
-                    w[f"fu{i}.r{r}.c{cv}.w"] = self._conv_w(g(p + f"residual_layer{r}.convolution{cv}.weight"))
+                    w[f"fu{i}.r{r}.c{cv}.w"] = self._wn_conv(g(p + f"residual_layer{r}.convolution{cv}.weight"))
                     w[f"fu{i}.r{r}.c{cv}.b"] = self._f(g(p + f"residual_layer{r}.convolution{cv}.bias"))
         for n in ("projection", "conv1", "conv2"):
-            w[f"rh.{n}.w"] = self._conv_w(g(f"relative_head.{n}.weight"))
+            w[f"rh.{n}.w"] = self._wn_conv(g(f"relative_head.{n}.weight"))
             w[f"rh.{n}.b"] = self._f(g(f"relative_head.{n}.bias"))
         # ---- metric head
         mh = "metric_head."
@@ -197,8 +230,8 @@ class ZoeDepthEngine:
         w["seedproj.c2.b"] = self._f(g(mh + "seed_projector.conv2.bias"))
         for i in range(4):
             p = mh + f"projectors.{i}."
-            w[f"pj{i}.c1.w"], w[f"pj{i}.c1.b"] = self._h(sq(p + "conv1.weight")), self._f(g(p + "conv1.bias"))
-            w[f"pj{i}.c2.w"], w[f"pj{i}.c2.b"] = self._h(sq(p + "conv2.weight")), self._f(g(p + "conv2.bias"))
+            w[f"pj{i}.c1.w"], w[f"pj{i}.c1.b"] = self._wn(sq(p + "conv1.weight")), self._f(g(p + "conv1.bias"))
+            w[f"pj{i}.c2.w"], w[f"pj{i}.c2.b"] = self._wn(sq(p + "conv2.weight")), self._f(g(p + "conv2.bias"))
             a0, a1 = mh + f"attractors.{n0}.{i}.", mh + f"attractors.{n1}.{i}."
             w[f"at{i}.c1.w"] = self._h(torch.cat([sq(a0 + "conv1.weight"), sq(a1 + "conv1.weight")], 0))      # [256, 128]
             w[f"at{i}.c1.b"] = self._f(torch.cat([g(a0 + "conv1.bias"), g(a1 + "conv1.bias")]))
@@ -207,7 +240,7 @@ class ZoeDepthEngine:
         clb = [mh + f"conditional_log_binomial.{n}.mlp." for n in (n0, n1)]
         R = c.rel_features
         w0 = [sq(p + "0.weight") for p in clb]                                                                # [40, 160] = [last 32 | emb 128]
-        w["clb.emb.w"] = self._h(torch.cat([w0[0][:, R:], w0[1][:, R:]], 0))                                   # [80, 128]
+        w["clb.emb.w"] = self._wn(torch.cat([w0[0][:, R:], w0[1][:, R:]], 0))                                   # [80, 128]
         w["clb.emb.b"] = self._f(torch.cat([g(clb[0] + "0.bias"), g(clb[1] + "0.bias")]))
         w["clb.w0_last"] = self._f(torch.stack([w0[0][:, :R], w0[1][:, :R]]))                                  # [2, 40, 32]
         w["clb.w2"] = self._f(torch.stack([sq(p + "2.weight") for p in clb]))                                  # [2, 4, 40]
@@ -294,6 +327,10 @@ class _ZoePlan:
         e32 = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         bias = eng._rel_bias(hp, wp, Sp)
 
+        acc = eng.acc
+        m2 = 2 if acc else 1          # channel multiplier of (hi | lo) activations in the neck / relative head
+        bp = 2 if acc else 1          # K passes of a backbone GEMM (weights split)
+        np3 = 3 if acc else 1         # K passes of a neck GEMM (weights and activations split)
         self.frames = torch.empty(B, H, W, 3, device=dev, dtype=torch.uint8)
         patches = e16(NB * T0, 3 * c.patch * c.patch)
         x = e32(NB * S, Hd)
@@ -301,60 +338,83 @@ class _ZoePlan:
         q, k, vt = z16(NB, c.heads, Sp, 64), z16(NB, c.heads, Sp, 64), z16(NB, c.heads, 64, Sp)
         ao = e16(NB * S, Hd)
         hid = e16(NB * S, c.intermediate)
-        taps16 = [e16(NB * S, Hd) for _ in c.taps]
+        taps16 = [e16(NB * S, Hd * m2) for _ in c.taps]
+
+        def bgemm(name, A, Wt, out, M, N, K, **kw):
+            """backbone GEMM: accurate mode walks A twice against [W_hi | W_lo]."""
+            P.gemm(name, A, Wt, out, M=M, N=N, K=K * bp, lda=K, seg1=K if acc else 0, precision_passes=bp, **kw)
 
         # ---- Z1 + Z2: pre-processing fused with the patch gather, patch embedding, cls token
         P.add("preprocess", "bs_preprocess_patches", self.frames, patches, B, H, W, nh_, nw_, int(flip), L.dt(patches))
         P.add("cls", "bs_fill_rows", x, w["cls"], NB, S, Hd)
-        P.gemm("patch_embed", patches, w["pe.w"], x, M=NB * T0, N=Hd, K=patches.shape[1], lda=patches.shape[1], bias=w["pe.b"],
-               out_group=(T0, S, 1))
+        bgemm("patch_embed", patches, w["pe.w"], x, NB * T0, Hd, patches.shape[1], bias=w["pe.b"], out_group=(T0, S, 1))
         P.mark("embed", x, ("tokens", NB, S, Hd))
         # ---- Z3: BEiT layers
         ti = 0
         for l in range(c.layers):
             P.add(f"l{l}.ln1", "bs_layernorm", x, w[f"l{l}.ln1.g"], w[f"l{l}.ln1.b"], xn, None, NB * S, Hd, c.ln_eps, L.dt(xn))
-            P.gemm(f"l{l}.qkv", xn, w[f"l{l}.qkv.w"], q, M=NB * S, N=3 * Hd, K=Hd, lda=Hd, bias=w[f"l{l}.qkv.b"],
-                   qkv=(Hd, S, Sp, LOG2E / math.sqrt(64.0), k, vt))
+            bgemm(f"l{l}.qkv", xn, w[f"l{l}.qkv.w"], q, NB * S, 3 * Hd, Hd, bias=w[f"l{l}.qkv.b"], qkv=(Hd, S, Sp, LOG2E / math.sqrt(64.0), k, vt))
             P.add(f"l{l}.attn", "bs_attention", q, k, vt, bias[l], ao, NB, c.heads, S, Sp, L.dt(q))
-            P.gemm(f"l{l}.o", ao, w[f"l{l}.o.w"], x, M=NB * S, N=Hd, K=Hd, lda=Hd, bias=w[f"l{l}.o.b"], scale=w[f"l{l}.lam1"], res=x, ldr=Hd)
+            bgemm(f"l{l}.o", ao, w[f"l{l}.o.w"], x, NB * S, Hd, Hd, bias=w[f"l{l}.o.b"], scale=w[f"l{l}.lam1"], res=x, ldr=Hd)
             P.add(f"l{l}.ln2", "bs_layernorm", x, w[f"l{l}.ln2.g"], w[f"l{l}.ln2.b"], xn, None, NB * S, Hd, c.ln_eps, L.dt(xn))
-            P.gemm(f"l{l}.fc1", xn, w[f"l{l}.fc1.w"], hid, M=NB * S, N=c.intermediate, K=Hd, lda=Hd, bias=w[f"l{l}.fc1.b"], act=L.ACT_GELU)
-            P.gemm(f"l{l}.fc2", hid, w[f"l{l}.fc2.w"], x, M=NB * S, N=Hd, K=c.intermediate, lda=c.intermediate, bias=w[f"l{l}.fc2.b"],
-                   scale=w[f"l{l}.lam2"], res=x, ldr=Hd)
+            bgemm(f"l{l}.fc1", xn, w[f"l{l}.fc1.w"], hid, NB * S, c.intermediate, Hd, bias=w[f"l{l}.fc1.b"], act=L.ACT_GELU)
+            bgemm(f"l{l}.fc2", hid, w[f"l{l}.fc2.w"], x, NB * S, Hd, c.intermediate, bias=w[f"l{l}.fc2.b"], scale=w[f"l{l}.lam2"], res=x, ldr=Hd)
             P.mark(f"layer{l + 1}", x, ("tokens", NB, S, Hd))
             if (l + 1) in c.taps:
-                P.add(f"tap{ti}", "bs_cast", x, taps16[ti], x.numel(), L.dt(xn))
+                if acc:
+                    P.add(f"tap{ti}", "bs_cast_split", x, taps16[ti], NB * S, Hd, L.dt(xn))
+                else:
+                    P.add(f"tap{ti}", "bs_cast", x, taps16[ti], x.numel(), L.dt(xn))
                 ti += 1
+
+        # ---- neck helpers.  Activations are NHWC 16-bit; in accurate mode every tensor carries (hi | lo) channel pairs
+        # (pixel stride 2C) and every product is A_hi W_hi + A_lo W_hi + A_hi W_lo in ONE launch (bs_gemm segments).
+        def nplain(name, A, Wt, out, M, N, K, shuffle=None, **kw):
+            ldo = kw.pop("ldo", N * m2)
+            so = kw.pop("split_off", N)
+            P.gemm(name, A, Wt, out, M=M, N=N, K=K * np3, lda=K * m2, seg1=K if acc else 0, ldo=ldo, out_split_off=so if acc else 0,
+                   shuffle=shuffle, precision_passes=np3, **kw)
+
+        def nconv(name, A, Wt, out, hh, ww, Ci, Co, stride=1, out_f32=False, **kw):
+            g_ = L.conv_geom(hh, ww, Ci * m2, 3, 3, stride, 1)
+            ho, wo = g_[3], g_[4]
+            if "res" in kw and acc:
+                kw["res_split_off"] = Co
+            P.gemm(name, A, Wt, out, M=NB * ho * wo, N=Co, K=9 * Ci * np3, lda=Ci * m2, conv=g_, seg1=Ci if acc else 0,
+                   ldo=Co * m2, ldr=Co * m2 if "res" in kw else 0, out_split_off=Co if acc else 0, precision_passes=np3, **kw)
+            return ho, wo
+
         # ---- Z4: reassemble (readout project, 1x1 projection, resize) + neck 3x3 convs
         feats, fshape = [], []
         cb = e32(NB, Hd)
-        r16 = e16(NB * T0, Hd)
+        r16 = e16(NB * T0, Hd * m2)
         for i, ch in enumerate(c.neck_hidden):
             t16 = taps16[i]
             # cls half of the readout: per-image bias vector  c_b = cls_b @ W_cls^T + b
-            P.gemm(f"ro{i}.cls", t16, w[f"ro{i}.w_cls"], cb, M=NB, N=Hd, K=Hd, lda=S * Hd, bias=w[f"ro{i}.b"])
+            P.gemm(f"ro{i}.cls", t16, w[f"ro{i}.w_cls"], cb, M=NB, N=Hd, K=Hd * np3, lda=S * Hd * m2, seg1=Hd if acc else 0, bias=w[f"ro{i}.b"],
+                   precision_passes=np3)
             # token half: rows 1..S-1 of every image (a 1-row "conv" with a -1 column crop), + c_b, GELU
-            P.gemm(f"ro{i}.tok", t16, w[f"ro{i}.w_tok"], r16, M=NB * T0, N=Hd, K=Hd, lda=Hd, conv=(1, S, Hd, 1, T0, 1, 1, 1, 0, -1),
-                   bias=cb, bias_group_rows=T0, act=L.ACT_GELU)
-            pr = e16(NB * T0, ch)
-            P.gemm(f"ra{i}.proj", r16, w[f"ra{i}.proj.w"], pr, M=NB * T0, N=ch, K=Hd, lda=Hd, bias=w[f"ra{i}.proj.b"])
+            P.gemm(f"ro{i}.tok", t16, w[f"ro{i}.w_tok"], r16, M=NB * T0, N=Hd, K=Hd * np3, lda=Hd * m2, conv=(1, S, Hd * m2, 1, T0, 1, 1, 1, 0, -1),
+                   seg1=Hd if acc else 0, bias=cb, bias_group_rows=T0, act=L.ACT_GELU, ldo=Hd * m2, out_split_off=Hd if acc else 0,
+                   precision_passes=np3)
+            pr = e16(NB * T0, ch * m2)
+            nplain(f"ra{i}.proj", r16, w[f"ra{i}.proj.w"], pr, NB * T0, ch, Hd, bias=w[f"ra{i}.proj.b"])
             if i == 0 or i == 1:
-                s = 4 if i == 0 else 2
-                up = e16(NB, hp * s, wp * s, ch)
-                P.gemm(f"ra{i}.up", pr, w[f"ra{i}.up.w"], up, M=NB * T0, N=s * s * ch, K=ch, lda=ch, bias=w[f"ra{i}.up.b"], ldo=ch,
-                       shuffle=(s, ch, hp, wp))
-                fh, fw, src = hp * s, wp * s, up
+                s_ = 4 if i == 0 else 2
+                up = e16(NB, hp * s_, wp * s_, ch * m2)
+                nplain(f"ra{i}.up", pr, w[f"ra{i}.up.w"], up, NB * T0, s_ * s_ * ch, ch, shuffle=(s_, ch, hp, wp), bias=w[f"ra{i}.up.b"],
+                       ldo=ch * m2, split_off=ch)
+                fh, fw, src = hp * s_, wp * s_, up
             elif i == 2:
                 fh, fw, src = hp, wp, pr
             else:
-                g_ = L.conv_geom(hp, wp, ch, 3, 3, 2, 1)
-                fh, fw = g_[3], g_[4]
-                src = e16(NB, fh, fw, ch)
-                P.gemm(f"ra{i}.down", pr, w[f"ra{i}.down.w"], src, M=NB * fh * fw, N=ch, K=9 * ch, lda=ch, conv=g_, bias=w[f"ra{i}.down.b"])
-            P.mark(f"reassemble{i}", src, ("nhwc", NB, fh, fw, ch))
-            f16_ = e16(NB, fh, fw, c.fusion)
-            P.gemm(f"nc{i}", src, w[f"nc{i}.w"], f16_, M=NB * fh * fw, N=c.fusion, K=9 * ch, lda=ch, conv=L.conv_geom(fh, fw, ch, 3, 3, 1, 1))
-            P.mark(f"neckconv{i}", f16_, ("nhwc", NB, fh, fw, c.fusion))
+                fh, fw = (hp + 2 - 3) // 2 + 1, (wp + 2 - 3) // 2 + 1
+                src = e16(NB, fh, fw, ch * m2)
+                nconv(f"ra{i}.down", pr, w[f"ra{i}.down.w"], src, hp, wp, ch, ch, stride=2, bias=w[f"ra{i}.down.b"])
+            P.mark(f"reassemble{i}", src, ("nhwc", NB, fh, fw, ch, acc))
+            f16_ = e16(NB, fh, fw, c.fusion * m2)
+            nconv(f"nc{i}", src, w[f"nc{i}.w"], f16_, fh, fw, ch, c.fusion)
+            P.mark(f"neckconv{i}", f16_, ("nhwc", NB, fh, fw, c.fusion, acc))
             feats.append(f16_)
             fshape.append((fh, fw))
         # ---- Z5: fusion stage (pre-activation residual units, x2 bilinear, 1x1 projection)
@@ -362,12 +422,15 @@ class _ZoePlan:
 
         def res_unit(name, xin, hh, ww, other=None):
             """y = conv2(relu(conv1(relu(x)))) + x (+ other)."""
-            g_ = L.conv_geom(hh, ww, Fc, 3, 3, 1, 1)
-            t = e16(NB, hh, ww, Fc)
-            y = e16(NB, hh, ww, Fc)
-            M_ = NB * hh * ww
-            P.gemm(name + ".c1", xin, w[name + ".c1.w"], t, M=M_, N=Fc, K=9 * Fc, lda=Fc, conv=g_, relu_a=True, bias=w[name + ".c1.b"], act=L.ACT_RELU)
-            P.gemm(name + ".c2", t, w[name + ".c2.w"], y, M=M_, N=Fc, K=9 * Fc, lda=Fc, conv=g_, bias=w[name + ".c2.b"], res=xin, res2=other, ldr=Fc)
+            t = e16(NB, hh, ww, Fc * m2)
+            y = e16(NB, hh, ww, Fc * m2)
+            if acc:
+                xr = e16(NB, hh, ww, Fc * m2)
+                P.add(name + ".relu", "bs_relu_split", xin, xr, NB * hh * ww, Fc, L.dt(xr))
+                nconv(name + ".c1", xr, w[name + ".c1.w"], t, hh, ww, Fc, Fc, bias=w[name + ".c1.b"], act=L.ACT_RELU)
+            else:
+                nconv(name + ".c1", xin, w[name + ".c1.w"], t, hh, ww, Fc, Fc, relu_a=True, bias=w[name + ".c1.b"], act=L.ACT_RELU)
+            nconv(name + ".c2", t, w[name + ".c2.w"], y, hh, ww, Fc, Fc, bias=w[name + ".c2.b"], res=xin, res2=other)
             return y
 
         fused_list = []
@@ -380,30 +443,28 @@ class _ZoePlan:
             else:
                 cur = res_unit(f"fu{li}.r1", feat, fh, fw, other=fused)     # fused + residual_layer1(feat)
             cur = res_unit(f"fu{li}.r2", cur, fh, fw)
-            up = e16(NB, 2 * fh, 2 * fw, Fc)
-            P.add(f"fu{li}.up", "bs_resize_bilinear_nhwc", cur, up, NB, fh, fw, Fc, 2 * fh, 2 * fw, 1, L.dt(up))
-            fused = e16(NB, 2 * fh, 2 * fw, Fc)
-            P.gemm(f"fu{li}.proj", up, w[f"fu{li}.proj.w"], fused, M=NB * 4 * fh * fw, N=Fc, K=Fc, lda=Fc, bias=w[f"fu{li}.proj.b"])
-            P.mark(f"fused{li}", fused, ("nhwc", NB, 2 * fh, 2 * fw, Fc))
+            up = e16(NB, 2 * fh, 2 * fw, Fc * m2)
+            P.add(f"fu{li}.up", "bs_resize_bilinear_nhwc", cur, up, NB, fh, fw, Fc, 2 * fh, 2 * fw, 1 | (2 if acc else 0), L.dt(up))
+            fused = e16(NB, 2 * fh, 2 * fw, Fc * m2)
+            nplain(f"fu{li}.proj", up, w[f"fu{li}.proj.w"], fused, NB * 4 * fh * fw, Fc, Fc, bias=w[f"fu{li}.proj.b"])
+            P.mark(f"fused{li}", fused, ("nhwc", NB, 2 * fh, 2 * fw, Fc, acc))
             fused_list.append((fused, 2 * fh, 2 * fw))
         bott, (bh_, bw_) = feats[3], fshape[3]
         # ---- Z6: relative head (conv3 + ReLU -> relative depth is dead code for the NK output and not launched)
         f3, h3, w3 = fused_list[3]
-        g_ = L.conv_geom(h3, w3, Fc, 3, 3, 1, 1)
-        rp = e16(NB, h3, w3, Fc)
-        P.gemm("rh.projection", f3, w["rh.projection.w"], rp, M=NB * h3 * w3, N=Fc, K=9 * Fc, lda=Fc, conv=g_, bias=w["rh.projection.b"], act=L.ACT_RELU)
-        r1 = e16(NB, h3, w3, Fc // 2)
-        P.gemm("rh.conv1", rp, w["rh.conv1.w"], r1, M=NB * h3 * w3, N=Fc // 2, K=9 * Fc, lda=Fc, conv=g_, bias=w["rh.conv1.b"])
-        r1u = e16(NB, 2 * h3, 2 * w3, Fc // 2)
-        P.add("rh.up", "bs_resize_bilinear_nhwc", r1, r1u, NB, h3, w3, Fc // 2, 2 * h3, 2 * w3, 1, L.dt(r1))
-        last = e16(NB, 2 * h3, 2 * w3, c.rel_features)
-        P.gemm("rh.conv2", r1u, w["rh.conv2.w"], last, M=NB * 4 * h3 * w3, N=c.rel_features, K=9 * (Fc // 2), lda=Fc // 2,
-               conv=L.conv_geom(2 * h3, 2 * w3, Fc // 2, 3, 3, 1, 1), bias=w["rh.conv2.b"], act=L.ACT_RELU)
-        P.mark("rel_features", last, ("nhwc", NB, 2 * h3, 2 * w3, c.rel_features))
+        rp = e16(NB, h3, w3, Fc * m2)
+        nconv("rh.projection", f3, w["rh.projection.w"], rp, h3, w3, Fc, Fc, bias=w["rh.projection.b"], act=L.ACT_RELU)
+        r1 = e16(NB, h3, w3, (Fc // 2) * m2)
+        nconv("rh.conv1", rp, w["rh.conv1.w"], r1, h3, w3, Fc, Fc // 2, bias=w["rh.conv1.b"])
+        r1u = e16(NB, 2 * h3, 2 * w3, (Fc // 2) * m2)
+        P.add("rh.up", "bs_resize_bilinear_nhwc", r1, r1u, NB, h3, w3, Fc // 2, 2 * h3, 2 * w3, 1 | (2 if acc else 0), L.dt(r1))
+        last = e16(NB, 2 * h3, 2 * w3, c.rel_features * m2)
+        nconv("rh.conv2", r1u, w["rh.conv2.w"], last, 2 * h3, 2 * w3, Fc // 2, c.rel_features, bias=w["rh.conv2.b"], act=L.ACT_RELU)
+        P.mark("rel_features", last, ("nhwc", NB, 2 * h3, 2 * w3, c.rel_features, acc))
         # ---- Z7: metric-bins head
         Mb = NB * bh_ * bw_
         xb = e16(Mb, c.bottleneck)
-        P.gemm("mh.conv2", bott, w["mh.conv2.w"], xb, M=Mb, N=c.bottleneck, K=c.bottleneck, lda=c.bottleneck, bias=w["mh.conv2.b"])
+        P.gemm("mh.conv2", bott, w["mh.conv2.w"], xb, M=Mb, N=c.bottleneck, K=c.bottleneck, lda=c.bottleneck * m2, bias=w["mh.conv2.b"])   # hi half of a split map
         # router: 4-layer post-norm transformer over (1 + bh*bw) tokens, classifier on token 0
         D, St = c.pt_hidden, bh_ * bw_ + 1
         pos = torch.arange(0, St, dtype=torch.float32).unsqueeze(1)
@@ -443,20 +504,22 @@ class _ZoePlan:
         P.gemm("seed.c1", xb, w["seed.c1.w"], sh, M=Mb, N=3 * (E // 2), K=c.bottleneck, lda=c.bottleneck, bias=w["seed.c1.b"], act=L.ACT_RELU)
         bins_prev = e32(NB, bh_, bw_, 2 * nb)
         P.gemm("seed.c2", sh, w["seed.c2.w"], bins_prev, M=Mb, N=2 * nb, K=E, lda=3 * (E // 2), bias=w["seed.c2.b"], act=L.ACT_SOFTPLUS)
-        emb_prev = e16(Mb, E)
-        P.gemm("seedproj.c2", sh, w["seedproj.c2.w"], emb_prev, M=Mb, N=E, K=E // 2, lda=3 * (E // 2), a_offset=E, bias=w["seedproj.c2.b"])
+        # projector embeddings feed the last 1x1 convs of the head almost directly, so accurate mode keeps them as (hi | lo) pairs too
+        emb_prev = e16(Mb, E * m2)
+        P.gemm("seedproj.c2", sh, w["seedproj.c2.w"], emb_prev, M=Mb, N=E, K=E // 2, lda=3 * (E // 2), a_offset=E, bias=w["seedproj.c2.b"],
+               ldo=E * m2, out_split_off=E if acc else 0)
         ph_, pw_ = bh_, bw_
         for i in range(4):
             feat, fh, fw = fused_list[i]
             Mi = NB * fh * fw
-            e1 = e16(Mi, E // 2)
-            P.gemm(f"pj{i}.c1", feat, w[f"pj{i}.c1.w"], e1, M=Mi, N=E // 2, K=Fc, lda=Fc, bias=w[f"pj{i}.c1.b"], act=L.ACT_RELU)
-            emb = e16(Mi, E)
-            P.gemm(f"pj{i}.c2", e1, w[f"pj{i}.c2.w"], emb, M=Mi, N=E, K=E // 2, lda=E // 2, bias=w[f"pj{i}.c2.b"])
-            y = e16(Mi, E)
-            P.add(f"at{i}.add", "bs_add_resized", emb, emb_prev, y, NB, ph_, pw_, fh, fw, E, L.dt(y))
+            e1 = e16(Mi, (E // 2) * m2)
+            nplain(f"pj{i}.c1", feat, w[f"pj{i}.c1.w"], e1, Mi, E // 2, Fc, bias=w[f"pj{i}.c1.b"], act=L.ACT_RELU)
+            emb = e16(Mi, E * m2)
+            nplain(f"pj{i}.c2", e1, w[f"pj{i}.c2.w"], emb, Mi, E, E // 2, bias=w[f"pj{i}.c2.b"])
+            y = e16(Mi, E * m2)
+            P.add(f"at{i}.add", "bs_add_resized", emb, emb_prev, y, NB, ph_, pw_, fh, fw, E, L.dt(y) | (16 if acc else 0))
             a1 = e16(Mi, 2 * E)
-            P.gemm(f"at{i}.c1", y, w[f"at{i}.c1.w"], a1, M=Mi, N=2 * E, K=E, lda=E, bias=w[f"at{i}.c1.b"], act=L.ACT_RELU)
+            P.gemm(f"at{i}.c1", y, w[f"at{i}.c1.w"], a1, M=Mi, N=2 * E, K=E, lda=E * m2, bias=w[f"at{i}.c1.b"], act=L.ACT_RELU)
             A = e32(Mi, 2 * na)
             P.gemm(f"at{i}.c2", a1, w[f"at{i}.c2.w"], A, M=Mi, N=2 * na, K=2 * E, lda=2 * E, bias=w[f"at{i}.c2.b"], act=L.ACT_SOFTPLUS)
             bins = e32(NB, fh, fw, 2 * nb)
@@ -464,11 +527,12 @@ class _ZoePlan:
             P.mark(f"bins{i}", bins, ("nhwc_route", NB, fh, fw, 2 * nb))
             bins_prev, emb_prev, ph_, pw_ = bins, emb, fh, fw
         Eh = e32(NB * ph_ * pw_, 2 * 40)
-        P.gemm("clb.emb", emb_prev, w["clb.emb.w"], Eh, M=NB * ph_ * pw_, N=80, K=E, lda=E, bias=w["clb.emb.b"])
+        P.gemm("clb.emb", emb_prev, w["clb.emb.w"], Eh, M=NB * ph_ * pw_, N=80, K=E * np3, lda=E * m2, seg1=E if acc else 0, bias=w["clb.emb.b"],
+               precision_passes=np3)
         self.depth_net = e32(NB, nh_, nw_)
         assert (nh_, nw_) == (2 * h3, 2 * w3)
         P.add("logbinom", "bs_logbinom_depth", last, Eh, bins_prev, w["clb.w0_last"], w["clb.w2"], w["clb.b2"], self.route, self.depth_net,
-              NB, nh_, nw_, ph_, pw_, c.min_temp, c.max_temp, L.dt(last))
+              NB, nh_, nw_, ph_, pw_, c.min_temp, c.max_temp, L.dt(last) | (16 if acc else 0))
         P.mark("depth_net", self.depth_net, ("raw",))
         # ---- Z8: flip average + bicubic + crop + x256 -> uint16
         self.depth_m = e32(B, H, W)

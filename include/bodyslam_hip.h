@@ -85,6 +85,14 @@ typedef struct bs_gemm_desc {
     int32_t qkv_hidden, qkv_tokens, qkv_sp;
     float q_scale;
     int32_t tile;                  /* 0 = auto; else forces a tile variant (tests / tuning) */
+    /* split-precision support (Numerics).  The K axis may consist of two segments that walk the SAME rows of A:
+     * segment 0 (Cin channels per tap for conv, K - seg1 for plain) then segment 1 (seg1 channels per tap / K columns);
+     * W holds both segments back to back along K.  With A = [hi | lo] and W = [W_hi | W_hi | W_lo] one launch evaluates
+     * A_hi W_hi + A_lo W_hi + A_hi W_lo.  out_split_off > 0 stores the 16-bit output as a (hi, lo) pair, lo at that
+     * element offset; res_split_off > 0 reads the 16-bit residual(s) as such pairs. */
+    int32_t seg1;
+    int32_t out_split_off;
+    int32_t res_split_off;
 } bs_gemm_desc;
 int bs_gemm(const bs_gemm_desc* d, void* stream);
 /* the tile variant bs_gemm will pick for this descriptor (1: 128x128, 2: 128x64, 3: 128x32, 4: 256x128) */
@@ -106,6 +114,12 @@ int bs_layernorm(const float* x, const float* gamma, const float* beta, void* ou
 
 /* device-to-device copy on the stream (re-arming the router's positional-encoding buffer) */
 int bs_copy_f32(const float* src, float* dst, int64_t n, void* stream);
+
+/* split-precision helpers: fp32 [rows, cols] -> 16-bit (hi | lo) pairs [rows, 2*cols] with x = hi + lo to ~22 bits; ReLU of such a
+ * tensor (the pre-activation residual units, HF modeling_zoedepth.py:225-241).  bs_resize_bilinear_nhwc takes such tensors when
+ * bit 1 of align_corners is set; bs_logbinom_depth takes a (hi | lo) `last` when bit 4 of dtype is set. */
+int bs_cast_split(const float* x, void* out, int64_t rows, int32_t cols, int32_t out_dtype, void* stream);
+int bs_relu_split(const void* x, void* out, int64_t rows, int32_t cols, int32_t dtype, void* stream);
 
 /* fp32 -> fp16/bf16 cast (tap copies of the residual stream) */
 int bs_cast(const float* x, void* out, int64_t n, int32_t out_dtype, void* stream);
@@ -142,7 +156,8 @@ int bs_resize_bilinear_nhwc(const void* x, void* out, int32_t B, int32_t Hin, in
 int bs_attractor_step(const float* A, const float* bins_prev, float* bins_out, const int32_t* route, int32_t B,
                       int32_t Hp, int32_t Wp, int32_t H, int32_t W, int32_t groups, int32_t n_bins, int32_t n_attr,
                       void* stream);
-/* out[b,y,x,:] = x[b,y,x,:] + bilinear_align_corners(prev)[b,y,x,:] (fp16/bf16 NHWC); HF :726-730 */
+/* out[b,y,x,:] = x[b,y,x,:] + bilinear_align_corners(prev)[b,y,x,:] (fp16/bf16 NHWC); HF :726-730.
+ * dtype bit 4 (| 16): x, prev and out hold (hi | lo) pairs of C channels each (pixel stride 2C), see bs_cast_split. */
 int bs_add_resized(const void* x, const void* prev, void* out, int32_t B, int32_t Hp, int32_t Wp, int32_t H,
                    int32_t W, int32_t C, int32_t dtype, void* stream);
 /* conditional log-binomial + expectation, HF modeling_zoedepth.py:376-491,1086-1101, per output pixel:

@@ -116,6 +116,68 @@ def test_conv3x3(L, dtype, B, H, W, Cin, Cout, stride, relu_a, tile):
     assert err < tol(dtype, 9 * Cin) * max(1.0, ref.abs().max().item())
 
 
+def _split(x, dtype):
+    hi = x.to(dtype)
+    lo = (x - hi.float()).to(dtype)
+    return hi, lo
+
+
+@pytest.mark.parametrize("tile", [1, 9, 10, 2])
+def test_split_precision_plain(L, tile):
+    """A = [hi | lo], W' = [W_hi | W_hi | W_lo]: one launch evaluates A_hi W_hi + A_lo W_hi + A_hi W_lo (segments),
+    the output is stored as a (hi, lo) pair.  Error vs the fp32 product must be ~1e-6 relative instead of ~5e-4."""
+    dtype = torch.float16
+    M, N, C = 700, 256 if tile != 2 else 64, 192
+    A = rnd(M, C, seed=1)
+    W = rnd(N, C, seed=2, scale=1 / math.sqrt(C))
+    ah, al = _split(A, dtype)
+    wh, wl = _split(W, dtype)
+    A2 = torch.cat([ah, al], 1).contiguous()
+    W3 = torch.cat([wh, wh, wl], 1).contiguous()
+    out = torch.zeros(M, 2 * N, device=dev(), dtype=dtype)
+    L.gemm(A2, W3, out, M=M, N=N, K=3 * C, lda=2 * C, seg1=C, ldo=2 * N, out_split_off=N, tile=tile)
+    ref = A.double() @ W.double().t()
+    got = out[:, :N].double() + out[:, N:].double()
+    err = (got - ref).abs().max().item()
+    single = torch.empty(M, N, device=dev())
+    L.gemm(ah, wh, single, M=M, N=N, K=C, lda=C, tile=tile)
+    err1 = (single.double() - ref).abs().max().item()
+    report(f"split plain tile{tile}: max|err| split {err:.2e} vs single-pass {err1:.2e}")
+    assert err < 2e-5 and err < err1 / 20
+    # weights-only split: A single, W' = [W_hi | W_lo]
+    W2 = torch.cat([wh, wl], 1).contiguous()
+    o32 = torch.empty(M, N, device=dev())
+    L.gemm(ah, W2, o32, M=M, N=N, K=2 * C, lda=C, seg1=C, tile=tile)
+    refw = ah.double() @ W.double().t()
+    assert (o32.double() - refw).abs().max().item() < 2e-5
+
+
+def test_split_precision_conv(L):
+    dtype = torch.float16
+    B, H, Wd, C, Co = 2, 24, 32, 64, 256
+    x = rnd(B, H, Wd, C, seed=1)
+    w = rnd(Co, C, 3, 3, seed=2, scale=1 / math.sqrt(9 * C))
+    res = rnd(B, H, Wd, Co, seed=3)
+    xh, xl = _split(x, dtype)
+    rh, rl = _split(res, dtype)
+    x2 = torch.cat([xh, xl], -1).contiguous()                       # NHWC with [hi | lo] channels
+    r2 = torch.cat([rh, rl], -1).contiguous()
+    wk = w.permute(0, 2, 3, 1)                                       # [O][kh][kw][I]
+    wh, wl = _split(wk, dtype)
+    seg0 = torch.cat([wh, wh], -1).reshape(Co, -1)                   # per tap [W_hi | W_hi] against [hi | lo]
+    W3 = torch.cat([seg0, wl.reshape(Co, -1)], 1).contiguous()       # then all taps of W_lo against hi
+    out = torch.zeros(B, H, Wd, 2 * Co, device=dev(), dtype=dtype)
+    g = L.conv_geom(H, Wd, 2 * C, 3, 3, 1, 1)
+    for tile in (1, 9):
+        L.gemm(x2, W3, out, M=B * H * Wd, N=Co, K=9 * 3 * C, lda=2 * C, conv=g, seg1=C, res=r2, ldr=2 * Co, res_split_off=Co,
+               ldo=2 * Co, out_split_off=Co, tile=tile)
+        ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1) + res.double()
+        got = out[..., :Co].double() + out[..., Co:].double()
+        err = (got - ref).abs().max().item()
+        report(f"split conv tile{tile}: max|err|={err:.2e}")
+        assert err < 3e-5
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("s,C", [(2, 64), (4, 128)])
 def test_conv_transpose_shuffle(L, dtype, s, C):
@@ -235,6 +297,35 @@ def test_resize_and_add(L, dtype):
     L.resize_bilinear_nhwc(x, o3, B, H, W, C, 17, 23, False)
     ref3 = F.interpolate(x.float().permute(0, 3, 1, 2), size=(17, 23), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
     assert (o3.float() - ref3).abs().max().item() < tol(dtype, 1) * 4
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_split_pointwise(L, dtype):
+    """(hi | lo) carriers of accurate mode: cast_split, relu_split, split resize and split add_resized keep ~2x the mantissa."""
+    B, H, W, C = 2, 12, 16, 64
+    x = rnd(B, H, W, C, seed=1)                                         # fp32 values
+    xs = torch.empty(B, H, W, 2 * C, device=dev(), dtype=dtype)
+    L.cast_split(x, xs, B * H * W, C)
+    hi = x.to(dtype)
+    assert torch.equal(xs[..., :C], hi) and torch.equal(xs[..., C:], (x - hi.float()).to(dtype))
+    val = lambda t: t[..., :C].double() + t[..., C:].double()
+    t2 = tol(dtype, 1) ** 2 * 8                                         # two mantissas' worth
+    assert (val(xs) - x.double()).abs().max().item() < t2
+    r = torch.empty_like(xs)
+    L.relu_split(xs, r, B * H * W, C)
+    assert (val(r) - val(xs).clamp(min=0)).abs().max().item() < t2
+    assert (r[..., :C].float() >= 0).all()
+    up = torch.empty(B, 2 * H, 2 * W, 2 * C, device=dev(), dtype=dtype)
+    L.resize_bilinear_nhwc(xs, up, B, H, W, C, 2 * H, 2 * W, True, split=True)
+    ref = F.interpolate(val(xs).permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    t3 = 4e-6 if dtype == torch.float16 else 2e-4                       # fp32 interpolation arithmetic + the re-split
+    assert (val(up) - ref).abs().max().item() < t3
+    y = rnd(B, 2 * H, 2 * W, C, seed=2)
+    ys = torch.empty_like(up)
+    L.cast_split(y, ys, B * 4 * H * W, C)
+    o = torch.empty_like(up)
+    L.add_resized(ys, xs, o, B, H, W, 2 * H, 2 * W, C, split=True)
+    assert (val(o) - (ref + val(ys))).abs().max().item() < 2 * t3
 
 
 def test_attractor_step(L):

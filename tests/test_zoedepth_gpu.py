@@ -39,6 +39,10 @@ def to_nchw(t, meta):
     t = t.float().cpu()
     if kind == "tokens":
         return t.view(meta[1], meta[2], meta[3])
+    if kind == "nhwc" and len(meta) > 5 and meta[5]:
+        # accurate mode: (hi | lo) channel pairs; the value is their sum
+        t = t.view(meta[1], meta[2], meta[3], 2, meta[4])
+        return (t[..., 0, :] + t[..., 1, :]).permute(0, 3, 1, 2)
     if kind in ("nhwc", "nhwc_route"):
         return t.view(meta[1], meta[2], meta[3], meta[4]).permute(0, 3, 1, 2)
     return t
@@ -100,11 +104,11 @@ def oracle_case(cfg_o, B, H, W, target_hw, seed, route_bias, flip):
     return _ORACLE_CACHE[key]
 
 
-def run_case(cfg_o, dtype, B, H, W, target_hw, seed, route_bias=0.0, flip=True):
+def run_case(cfg_o, dtype, B, H, W, target_hw, seed, route_bias=0.0, flip=True, precision="fast"):
     from bodyslam_amd.zoedepth import ZoeDepthEngine
     from oracle import zoedepth_ref as Z
     w, frames, taps_o, logits, ref, t_or = oracle_case(cfg_o, B, H, W, target_hw, seed, route_bias, flip)
-    eng = ZoeDepthEngine(w, product_cfg(cfg_o), dtype=dtype, target_hw=target_hw)
+    eng = ZoeDepthEngine(w, product_cfg(cfg_o), dtype=dtype, target_hw=target_hw, precision=precision)
     taps_p = {}
     dm, du = eng.infer(frames.cuda(), flip_aug=flip, taps=taps_p)
     torch.cuda.synchronize()
@@ -129,6 +133,21 @@ def test_small_backbone_full_head(dtype, route_bias):
     assert l1 < (2e-3 if dtype == torch.float16 else 2e-2)
     lsb = np.abs(r["du"].astype(np.int32) - r["Z"].to_uint16(r["ref"]).astype(np.int32))
     report(f"[{tag}] u16: max |diff| = {lsb.max()} LSB, mean {lsb.mean():.3f}")
+
+
+def test_small_accurate_mode():
+    """precision="accurate" (split-precision products in the neck / heads, split weights in the backbone) on the small case:
+    every split code path (cast_split, relu_split, split resize / add_resized / logbinom, 2- and 3-segment GEMMs) runs and must
+    beat the single-pass result by a wide margin."""
+    kw = dict(B=2, H=120, W=160, target_hw=(96, 128), seed=3, route_bias=3.0)
+    fast = run_case(small_oracle_cfg(), torch.float16, **kw)
+    r = run_case(small_oracle_cfg(), torch.float16, precision="accurate", **kw)
+    compare_taps(r["taps_p"], r["taps_o"], None, "small f16 accurate")
+    l1 = (r["dm"] - r["ref"]).abs().mean().item()
+    l1_fast = (fast["dm"] - fast["ref"]).abs().mean().item()
+    report(f"[small f16 accurate] depth L1={l1:.3e} (fast mode {l1_fast:.3e})")
+    assert torch.equal(torch.argmax(r["logits_o"], -1).int(), r["route_p"])
+    assert l1 < 0.5 * l1_fast and l1 < 5e-4
 
 
 def test_batch_and_noflip_invariance():
@@ -167,3 +186,19 @@ def test_full_size_zoed_nk(dtype):
     assert torch.equal(route_o.int(), r["route_p"])
     # stated tolerance (DESIGN.md "Numerics"): fp16 operands / fp32 accumulate through 24 layers
     assert l1 < (1e-3 if dtype == torch.float16 else 1e-2)
+
+
+def test_full_size_zoed_nk_accurate():
+    """precision="accurate" at the real configuration.  Tolerance: the north star's depth L1 <= 1e-4 m against the fp32
+    oracle (DESIGN.md "Numerics"), which single-pass fp16 (3e-4) does not reach."""
+    from oracle import zoedepth_ref as Z
+    r = run_case(Z.ZOED_NK, torch.float16, B=1, H=480, W=640, target_hw=(384, 512), seed=1, precision="accurate")
+    tag = "ZoeD_NK f16 accurate"
+    compare_taps(r["taps_p"], r["taps_o"], None, tag)
+    l1 = (r["dm"] - r["ref"]).abs().mean().item()
+    mx = (r["dm"] - r["ref"]).abs().max().item()
+    report(f"[{tag}] 640x480 depth L1={l1:.3e} m, max={mx:.3e} m")
+    lsb = np.abs(r["du"].astype(np.int32) - Z.to_uint16(r["ref"]).astype(np.int32))
+    report(f"[{tag}] u16: max |diff| = {lsb.max()} LSB, mean {lsb.mean():.3f} LSB")
+    assert torch.equal(torch.argmax(r["logits_o"], -1).int(), r["route_p"])
+    assert l1 <= 1e-4
