@@ -2,7 +2,7 @@
 """Benchmark of the BodySLAM hot path on MI355X: frames/s of depth (ZoeD_NK, flip-aug) + relative pose
 (CyclePose) + pose chain + back-projection on synthetic 640x480 sequences.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype f16|bf16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype f16|bf16] [--precision accurate|fast]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -46,6 +46,10 @@ def main():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--precision", default="accurate", choices=["accurate", "fast"],
+                    help="accurate: split-precision products, depth L1 <= 1e-4 m vs the fp32 oracle (the north star's tolerance); "
+                         "fast: one 16-bit MFMA pass per product (L1 ~3e-4 m).  The other mode is measured too and reported beside it.")
+    ap.add_argument("--single-mode", action="store_true", help="measure only --precision")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (pure throughput run)")
     args = ap.parse_args()
@@ -78,90 +82,111 @@ def main():
     cfg = ZoeConfig()
     wz = random_zoedepth_weights(cfg, seed=0)
     wp = random_cyclepose_weights(seed=0)
-    pipe = BodySlamPipeline(wz, wp, cfg, dtype=dtype, device=local_rank, batch=B)
     n_frames = (K + Wm) * B + 1
     frames = torch.from_numpy(make_sequence(n_frames, H, W, seed=rank)).to(dev)     # resident in HBM
     pairs = torch.tensor([[i, i + 1] for i in range(B)], dtype=torch.int32, device=dev)
-    zplan = pipe.zoe.plan_for(B, H, W, True)
-    pplan = pipe.pose.plan_for(B + 1, B, H, W)
     counts = [B] * world
-    events = []
-
-    def step(k, timed_kernels):
-        chunk = frames[k * B: (k + 1) * B + 1]                                       # halo frame + B frames
-        zplan.frames.copy_(chunk[1:])
-        if timed_kernels:
-            zplan.plan.run_timed(events)
-        else:
-            zplan.plan.run()
-        pplan.frames.copy_(chunk)
-        pplan.pairs.copy_(pairs)
-        pplan.plan.run()
-        t_all = gather_relative_poses(pplan.T, counts) if use_dist else pplan.T
-        g_abs = geom3d.pose_chain(t_all, device=local_rank)
-        xyz, idx, cnt = geom3d.backproject(zplan.depth_u16, pipe.K, pipe.depth_scale, pipe.depth_trunc,
-                                           poses=g_abs[rank * B + 1: (rank + 1) * B + 1])
-        return cnt
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(Wm):
-        step(k, False)
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(Wm, Wm + K):
-        cnt = step(k, not args.no_kernel_timing)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = te.item()
-    total_frames = world * K * B
-    fps = total_frames / elapsed
+    def measure(precision):
+        """W warm-up + K timed steps of the whole loop in one precision mode -> (pipeline, plan, fps, elapsed, rooflines, table)."""
+        pipe = BodySlamPipeline(wz, wp, cfg, dtype=dtype, device=local_rank, batch=B, precision=precision)
+        zplan = pipe.zoe.plan_for(B, H, W, True)
+        pplan = pipe.pose.plan_for(B + 1, B, H, W)
+        events = []
 
-    # ---- per-kernel roofline from the HIP events of the timed steps (rank 0's view)
-    roof, roof_conv, kern_table = None, None, {}
-    if events:
-        agg = {}
-        for (ci, e0, e1) in events:
-            gi = zplan.plan.gemm_info[ci]
-            key = ("conv" if gi["conv"] else "gemm", gi["tile"])
-            a = agg.setdefault(key, dict(ms=0.0, flops=0.0, n=0))
-            a["ms"] += e0.elapsed_time(e1)
-            a["flops"] += gi["flops"]
-            a["n"] += 1
-        for (kind, tile), a in agg.items():
-            kern_table[f"igemm_{kind}_{TILE_NAMES[tile]}"] = dict(
-                launches=a["n"], avg_us=1e3 * a["ms"] / a["n"], tflops=a["flops"] / (a["ms"] * 1e-3) / 1e12,
-                gflop_per_launch=a["flops"] / a["n"] / 1e9, share_of_step=a["ms"] / (elapsed * 1e3))
-        dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
-        (kind, tile), a = dom
-        ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
-        # HBM bytes per launch of that kernel from the committed PMC collection (separate --pmc passes, FETCH_SIZE doubled as
-        # the microarch guide prescribes for gfx950); only valid for the batch it was collected at
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
-            mode = {"gemm": "ELi0E", "conv": "ELi1E"}[kind]
-            dims = TILE_NAMES[tile].split("s")[0].split("x")
-            for name, v in pm["kernels"].items():
-                if "igemm_kernel" in name and f"Li{dims[0]}ELi{dims[1]}E" in name and f"Li{dims[2]}E" in name and mode in name and ("DF16_" in name) == (args.dtype == "f16") and B == 32:
-                    traffic = round(v["hbm_bytes_per_launch_corrected"])
-                    break
-        except Exception:
+        def step(k, timed_kernels):
+            chunk = frames[k * B: (k + 1) * B + 1]                                       # halo frame + B frames
+            zplan.frames.copy_(chunk[1:])
+            if timed_kernels:
+                zplan.plan.run_timed(events)
+            else:
+                zplan.plan.run()
+            pplan.frames.copy_(chunk)
+            pplan.pairs.copy_(pairs)
+            pplan.plan.run()
+            t_all = gather_relative_poses(pplan.T, counts) if use_dist else pplan.T
+            g_abs = geom3d.pose_chain(t_all, device=local_rank)
+            xyz, idx, cnt = geom3d.backproject(zplan.depth_u16, pipe.K, pipe.depth_scale, pipe.depth_trunc,
+                                               poses=g_abs[rank * B + 1: (rank + 1) * B + 1])
+            return cnt
+
+        for k in range(Wm):
+            step(k, False)
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(Wm, Wm + K):
+            step(k, not args.no_kernel_timing)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            elapsed = te.item()
+        fps = world * K * B / elapsed
+
+        # ---- per-kernel roofline from the HIP events of the timed steps (rank 0's view).  "achieved" counts ALGORITHMIC FLOPs
+        # (2*M*N*K of the convolution / GEMM being computed); "executed" counts the MFMA work actually issued, which in
+        # accurate mode is 2x (backbone) or 3x (neck, heads) larger because every product is a sum of split-precision passes.
+        roof, roof_conv, kern_table = None, None, {}
+        if events:
+            agg = {}
+            for (ci, e0, e1) in events:
+                gi = zplan.plan.gemm_info[ci]
+                key = ("conv" if gi["conv"] else "gemm", gi["tile"])
+                a = agg.setdefault(key, dict(ms=0.0, flops=0.0, alg=0.0, n=0))
+                a["ms"] += e0.elapsed_time(e1)
+                a["flops"] += gi["flops"]
+                a["alg"] += gi["alg_flops"]
+                a["n"] += 1
+            for (kind, tile), a in agg.items():
+                kern_table[f"igemm_{kind}_{TILE_NAMES[tile]}"] = dict(
+                    launches=a["n"], avg_us=1e3 * a["ms"] / a["n"], tflops=a["alg"] / (a["ms"] * 1e-3) / 1e12,
+                    executed_tflops=a["flops"] / (a["ms"] * 1e-3) / 1e12,
+                    gflop_per_launch=a["alg"] / a["n"] / 1e9, share_of_step=a["ms"] / (elapsed * 1e3))
+            dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+            (kind, tile), a = dom
+            ach = a["alg"] / (a["ms"] * 1e-3) / 1e12
+            exe = a["flops"] / (a["ms"] * 1e-3) / 1e12
+            # HBM bytes per launch of that kernel from the committed PMC collection (separate --pmc passes, FETCH_SIZE doubled as
+            # the microarch guide prescribes for gfx950); only valid for the batch / mode it was collected at
             traffic = None
-        roof = dict(bound="mfma", kernel=f"igemm_kernel<{args.dtype},{TILE_NAMES[tile]},{kind}>", achieved=round(ach, 1),
-                    peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=traffic,
-                    avg_launch_us=round(1e3 * a["ms"] / a["n"], 2), gflop_per_launch=round(a["flops"] / a["n"] / 1e9, 3))
-        cms = sum(a["ms"] for (kd, _), a in agg.items() if kd == "conv")
-        cfl = sum(a["flops"] for (kd, _), a in agg.items() if kd == "conv")
-        if cms > 0:
-            roof_conv = dict(bound="mfma", what="ZoeDepth conv stack (all conv-mode igemm launches)", achieved=round(cfl / (cms * 1e-3) / 1e12, 1),
-                             peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(cfl / (cms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4))
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+                mode = {"gemm": "ELi0E", "conv": "ELi1E"}[kind]
+                dims = TILE_NAMES[tile].split("s")[0].split("x")
+                for name, v in pm["kernels"].items():
+                    if ("igemm_kernel" in name and f"Li{dims[0]}ELi{dims[1]}E" in name and f"Li{dims[2]}E" in name and mode in name
+                            and ("DF16_" in name) == (args.dtype == "f16") and B == 32 and pm.get("precision", "fast") == precision):
+                        traffic = round(v["hbm_bytes_per_launch_corrected"])
+                        break
+            except Exception:
+                traffic = None
+            roof = dict(bound="mfma", kernel=f"igemm_kernel<{args.dtype},{TILE_NAMES[tile]},{kind}>", achieved=round(ach, 1),
+                        peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=traffic,
+                        executed=round(exe, 1), executed_frac=round(exe / MFMA_PEAK_TFLOPS, 4),
+                        avg_launch_us=round(1e3 * a["ms"] / a["n"], 2), gflop_per_launch=round(a["alg"] / a["n"] / 1e9, 3))
+            cms = sum(a["ms"] for (kd, _), a in agg.items() if kd == "conv")
+            cfl = sum(a["alg"] for (kd, _), a in agg.items() if kd == "conv")
+            cex = sum(a["flops"] for (kd, _), a in agg.items() if kd == "conv")
+            if cms > 0:
+                roof_conv = dict(bound="mfma", what="ZoeDepth conv stack (all conv-mode igemm launches)",
+                                 achieved=round(cfl / (cms * 1e-3) / 1e12, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                                 frac=round(cfl / (cms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                 executed=round(cex / (cms * 1e-3) / 1e12, 1), executed_frac=round(cex / (cms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4))
+        return dict(pipe=pipe, zplan=zplan, fps=fps, elapsed=elapsed, roof=roof, roof_conv=roof_conv, kern=kern_table)
+
+    main_run = measure(args.precision)
+    pipe, zplan, fps, elapsed = main_run["pipe"], main_run["zplan"], main_run["fps"], main_run["elapsed"]
+    roof, roof_conv, kern_table = main_run["roof"], main_run["roof_conv"], main_run["kern"]
+    other = None
+    if not args.single_mode:
+        other_name = "fast" if args.precision == "accurate" else "accurate"
+        other = measure(other_name)
 
     # ---- CPU baseline (rank 0): the oracle on one frame of the same sequence, all host cores
     cpu = None
@@ -176,6 +201,7 @@ def main():
         f2 = frames[:2].cpu()
         gd, _ = pipe.zoe.infer(frames[1:2])
         gd = gd.cpu().clone()
+        gd_other = other["pipe"].zoe.infer(frames[1:2])[0].cpu().clone() if other else None
         tc = time.perf_counter()
         with torch.no_grad():
             d_ref = Z.infer_depth(wz, Z.ZOED_NK, f2[1:2], flip_aug=True)
@@ -184,6 +210,8 @@ def main():
         G.backproject(Z.to_uint16(d_ref)[0], pose=g_ref[1])
         tcpu = time.perf_counter() - tc
         l1 = float((gd - d_ref).abs().mean())
+        if other:
+            other["l1"] = float((gd_other - d_ref).abs().mean())
         cpu = dict(value=round(1.0 / tcpu, 4), unit="frames/s", cores=ncores, kind="port",
                    sample="1 frame 640x480: ZoeD_NK x2 (flip-aug) + 1 CyclePose pair + chain + back-projection, torch fp32 oracle")
 
@@ -196,8 +224,12 @@ def main():
                                    f"batch {B} frames/step", "frames_per_step_per_gpu": B, "net_input": list(zplan.geom[k] for k in ("nh", "nw")),
                        "sharding": "contiguous frame blocks per rank, one RCCL all-gather of relative poses per step" if world > 1 else "single GPU"},
             "roofline": roof, "roofline_conv_stack": roof_conv, "cpu_baseline": cpu,
-            "depth_l1_vs_oracle_m": l1, "kernels": kern_table,
+            "precision": args.precision, "depth_l1_vs_oracle_m": l1, "kernels": kern_table,
         }
+        if other:
+            out["other_mode"] = {"precision": other_name, "value": round(other["fps"], 2), "unit": "frames/s",
+                                 "ms_per_step": round(1e3 * other["elapsed"] / K, 3), "depth_l1_vs_oracle_m": other.get("l1"),
+                                 "roofline": other["roof"], "roofline_conv_stack": other["roof_conv"]}
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

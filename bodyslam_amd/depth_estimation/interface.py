@@ -20,11 +20,12 @@ class DepthEstimator:
     SUPPORTED_MODELS = ['ZoeD_N', 'ZoeD_K', 'ZoeD_NK']
     DEFAULT_MODEL = 'ZoeD_NK'
 
-    def __init__(self, model_type: str = DEFAULT_MODEL, weights=None, dtype=torch.float16):
-        """``weights``: a state-dict path, a loaded HF-named state dict, or None (BODYSLAM_ZOEDEPTH_WEIGHTS)."""
-        self.model = self._initialize_model(model_type, weights, dtype)
+    def __init__(self, model_type: str = DEFAULT_MODEL, weights=None, dtype=torch.float16, precision: str = "accurate"):
+        """``weights``: a state-dict path, a loaded HF-named state dict, or None (BODYSLAM_ZOEDEPTH_WEIGHTS).
+        ``precision``: "accurate" (split-precision products, depth within 1e-4 m of the fp32 reference) or "fast"."""
+        self.model = self._initialize_model(model_type, weights, dtype, precision)
 
-    def _initialize_model(self, model_type: str, weights=None, dtype=torch.float16) -> ZoeDepthEngine:
+    def _initialize_model(self, model_type: str, weights=None, dtype=torch.float16, precision: str = "accurate") -> ZoeDepthEngine:
         if model_type not in self.SUPPORTED_MODELS:
             # interface.py:37-40: warn and fall back to the default
             warnings.warn(
@@ -34,7 +35,7 @@ class DepthEstimator:
             raise NotImplementedError("only the two-head ZoeD_NK variant (the reference's default) is built so far")
         sd = weights if isinstance(weights, dict) else load_zoedepth_weights(weights)
         print("[INFO] Model loaded on cuda (MI355X, HIP)")
-        return ZoeDepthEngine(sd, dtype=dtype)
+        return ZoeDepthEngine(sd, dtype=dtype, precision=precision)
 
     def infer_depth_map(self, path_to_frame: str) -> Image.Image:
         """path -> PIL 'I;16' depth map (metres x 256, as upstream infer_pil(output_type="pil"))."""

@@ -11,10 +11,10 @@ from .zoedepth import ZoeDepthEngine
 
 
 class MDEMInterface:
-    def __init__(self, model_type: str = "ZoeD_NK", weights=None, dtype=torch.float16):
-        self.zoe = self._initialize_ZOE(model_type, weights, dtype)
+    def __init__(self, model_type: str = "ZoeD_NK", weights=None, dtype=torch.float16, precision: str = "accurate"):
+        self.zoe = self._initialize_ZOE(model_type, weights, dtype, precision)
 
-    def _initialize_ZOE(self, model_type: str, weights=None, dtype=torch.float16):
+    def _initialize_ZOE(self, model_type: str, weights=None, dtype=torch.float16, precision: str = "accurate"):
         if model_type not in ("ZoeD_N", "ZoeD_K", "ZoeD_NK"):
             # mdem_interface.py:42-44 warns (and then still asks the hub for the bad name); here: warn + default
             warnings.warn(f"The model type selected [{model_type}], does not exist! Using default model [ZoeD_NK]")
@@ -23,7 +23,7 @@ class MDEMInterface:
             raise NotImplementedError("only ZoeD_NK is built so far")
         sd = weights if isinstance(weights, dict) else load_zoedepth_weights(weights)
         print("[INFO] model loaded on cuda (MI355X, HIP)")
-        return ZoeDepthEngine(sd, dtype=dtype)
+        return ZoeDepthEngine(sd, dtype=dtype, precision=precision)
 
     def infer_monocular_depth_map(self, path_to_frame: str) -> Image.Image:
         image = Image.open(path_to_frame).convert("RGB")

@@ -72,12 +72,15 @@ class BodySlamPipeline:
                  zoe_cfg: Optional[ZoeConfig] = None, dtype=torch.float16, device: int = 0, batch: int = 8,
                  K: Sequence[float] = geom3d.REF_INTRINSICS, depth_scale: float = geom3d.REF_DEPTH_SCALE,
                  depth_trunc: float = geom3d.REF_DEPTH_TRUNC, flip_aug: bool = True,
-                 target_hw: Tuple[int, int] = (384, 512)):
+                 target_hw: Tuple[int, int] = (384, 512), precision: str = "accurate"):
+        """precision: ZoeDepthEngine's -- "accurate" keeps depth within 1e-4 m (L1) of the fp32 reference, "fast" is one
+        16-bit MFMA pass per product (L1 ~3e-4 m at fp16)."""
         L.init(device)
         self.dev = torch.device("cuda", device)
         self.batch = batch
         self.K, self.depth_scale, self.depth_trunc, self.flip = tuple(K), depth_scale, depth_trunc, flip_aug
-        self.zoe = ZoeDepthEngine(zoe_weights, zoe_cfg, dtype=dtype, device=device, target_hw=target_hw)
+        self.zoe = ZoeDepthEngine(zoe_weights, zoe_cfg, dtype=dtype, device=device, target_hw=target_hw, precision=precision)
+        self.precision = precision
         self.pose = CyclePoseEngine(pose_weights, dtype=dtype, device=device)
 
     # -- stage 1+2 for one block of frames ----------------------------------------------------------
