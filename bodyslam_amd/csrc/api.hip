@@ -19,6 +19,8 @@ void set_error(const char* fmt, ...) {
 }
 const void* zero_page() { return g_zero; }
 bool initialized() { return g_zero != nullptr; }
+static int g_cus = 256;
+int cu_count() { return g_cus; }
 
 }  // namespace bs
 
@@ -37,6 +39,7 @@ extern "C" int bs_init(int device) {
         BS_CHECK_HIP(hipMemset(g_zero, 0, 4096));
     }
     g_device = device;
+    g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     return BS_OK;
 }
 

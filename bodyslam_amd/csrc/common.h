@@ -22,6 +22,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 void set_error(const char* fmt, ...);
 const void* zero_page();          // 4 KiB of device zeros (allocated by bs_init)
 bool initialized();
+int cu_count();                   // compute units of the device bs_init bound (256 on MI355X)
 
 #define BS_CHECK_HIP(expr)                                                             \
     do {                                                                               \

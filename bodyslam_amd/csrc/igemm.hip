@@ -34,11 +34,10 @@ static void tile_dims(int tile, int& BM, int& BN) {
     }
 }
 
-static int dispatch(IgemmParams& p, int dtype, bool conv, int tile, hipStream_t st) {
-    tile = auto_tile(p.M, p.N, p.K, tile, conv);
+static int launch_tile(IgemmParams& p, int dtype, bool conv, int tile, hipStream_t st) {
     int BM, BN;
     tile_dims(tile, BM, BN);
-    p.ntm = cdiv(p.M, BM);
+    p.ntm = cdiv(p.M - p.m_begin, BM);
     p.ntn = cdiv(p.N, BN);
     switch (tile) {
         case 1: return igemm_launch_tile1(p, dtype, conv, st);
@@ -49,6 +48,31 @@ static int dispatch(IgemmParams& p, int dtype, bool conv, int tile, hipStream_t 
         case 11: return igemm_launch_tile11(p, dtype, conv, st);
         default: set_error("bs_gemm: tile %d is not built (1, 2, 3, 9, 10, 11)", tile); return BS_ERR_INVALID;
     }
+}
+
+// Tail split.  A 256-row tile grid over M = 64 x 769 token rows is 192.25 tiles tall: the quarter-full last tile row costs a
+// whole extra round of the chip (772 blocks on 256 CUs = 4 rounds for 3.02 rounds of work in o_proj / fc2).  When dropping the
+// ragged rows saves a round, the full tiles go out as one launch and the <= 128 ragged rows as a second, small-tile launch
+// on the same stream (same kernel family; IgemmParams::m_begin offsets its rows).
+static int dispatch(IgemmParams& p, int dtype, bool conv, int tile, hipStream_t st) {
+    tile = auto_tile(p.M, p.N, p.K, tile, conv);
+    int BM, BN;
+    tile_dims(tile, BM, BN);
+    const int rem = p.M % BM, full = p.M / BM, ntn = cdiv(p.N, BN), cus = cu_count();
+    // (measured, tools/bench_kernels.py tiles 9 vs 809: -8 % on fc2 (K = 4096); neutral to slightly negative for K = 1024, where a
+    // block is short and the second launch costs as much as the saved blocks)
+    if (!(p.ablate & 8) && !conv && BM == 256 && p.K >= 2048 && full > 0 && rem > 0 && rem <= 128 && p.N % 128 == 0 &&
+        cdiv(full * ntn, cus) < cdiv((full + 1) * ntn, cus)) {
+        IgemmParams main = p;
+        main.M = full * BM;                    // rows [0, full*BM): the kernel clamps and masks against M
+        main.m_begin = 0;
+        const int rc = launch_tile(main, dtype, conv, tile, st);
+        if (rc != BS_OK) return rc;
+        p.m_begin = full * BM;                 // rows [full*BM, M)
+        return launch_tile(p, dtype, conv, 1, st);
+    }
+    p.m_begin = 0;
+    return launch_tile(p, dtype, conv, tile, st);
 }
 
 }  // namespace bs

@@ -55,7 +55,8 @@ struct IgemmParams {
     int qkv_hidden, qkv_tokens, qkv_sp;
     float q_scale;
     int ntm, ntn;
-    int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue
+    int m_begin;        // first output row this launch covers (a GEMM may be issued as a main launch + a tail launch)
+    int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue, 8 = no tail split (host side)
 };
 
 template <typename T>
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
     // ---- buffer descriptors (wave-uniform): A window starting at this tile's first image / row, W whole.
     // Out-of-range lanes of a `buffer_load ... lds` write ZEROS to LDS (probed: tools/probes/lds_dma_oob.hip):
     // that is the convolution's zero padding -- no zero page, no per-lane pointer select, 32-bit offsets only.
-    const int m0 = tm * BM;
+    const int m0 = p.m_begin + tm * BM;
     long long a_base_el;
     int img0 = 0;
     if (CONV) {
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
             }
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                const int m = tm * BM + wm * TM + i * 16 + frow;
+                const int m = m0 + wm * TM + i * 16 + frow;
                 if (m >= p.M) continue;
                 int64_t orow = m;        // row in the output / residual geometry
                 int64_t roff;            // row part of the store offset (elements)
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const int m_base = tm * BM + wm * TM + ps * PASS_R;
+            const int m_base = m0 + wm * TM + ps * PASS_R;
             // lane -> row r (token), loop over the TN columns; PASS_R is 32 or 64 rows: 1 or 2 columns per sweep
             constexpr int CPS = 64 / PASS_R >= 1 ? 64 / PASS_R : 1;     // columns per 64-lane sweep
             const int r = lane % PASS_R, csub = lane / PASS_R;

@@ -122,6 +122,23 @@ def _split(x, dtype):
     return hi, lo
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", [(256 * 192 + 64, 1024, 128), (256 * 128 + 1, 768, 64), (256 * 64 + 128, 4096, 64)])
+def test_gemm_tail_split(L, dtype, M, N, K):
+    """Auto tile choice with a ragged last 256-row tile: the full tiles and the <= 128 ragged rows go out as two launches
+    (igemm.hip dispatch); every row must still be written, with the fp32-residual epilogue the backbone uses."""
+    A = rnd(M, K, seed=1, dtype=dtype)
+    W = rnd(N, K, seed=2, scale=1 / math.sqrt(K), dtype=dtype)
+    bias = rnd(N, seed=3)
+    res = rnd(M, N, seed=4)
+    out = res.clone()
+    L.gemm(A, W, out, M=M, N=N, K=K, lda=K, bias=bias, res=out, ldr=N)
+    ref = A.float() @ W.float().t() + bias + res
+    err = (out - ref).abs().max().item()
+    report(f"gemm tail split {dtype} M{M} N{N} K{K}: max|err|={err:.3e}")
+    assert err < 1e-4 * math.sqrt(K)
+
+
 @pytest.mark.parametrize("tile", [1, 9, 10, 2])
 def test_split_precision_plain(L, tile):
     """A = [hi | lo], W' = [W_hi | W_hi | W_lo]: one launch evaluates A_hi W_hi + A_lo W_hi + A_hi W_lo (segments),
