@@ -267,6 +267,13 @@ class Plan:
                 check(fn(*args, st), self.names[i])
 
 
+def conv_weight(w_ohwi: torch.Tensor) -> torch.Tensor:
+    """[O, kh, kw, I] -> the K order bs_gemm's conv mode walks: [O][I/64 chunks][kh][kw][64] flattened to [O, kh*kw*I]."""
+    O, kh, kw, I = w_ohwi.shape
+    assert I % 64 == 0, I
+    return w_ohwi.reshape(O, kh, kw, I // 64, 64).permute(0, 3, 1, 2, 4).reshape(O, -1).contiguous()
+
+
 def conv_geom(Hin, Win, Cin, KH, KW, stride, pad):
     Hout = (Hin + 2 * pad - KH) // stride + 1
     Wout = (Win + 2 * pad - KW) // stride + 1

@@ -94,6 +94,33 @@ __device__ __forceinline__ void store4(void* base, int64_t off, int out_dtype, c
     }
 }
 
+// 8 consecutive outputs from one lane (two fragments whose columns interleave, see the W-row permutation in igemm_kernel):
+// one 16-byte store for 16-bit outputs, two for fp32 or (hi, lo) pairs
+template <typename T>
+__device__ __forceinline__ void store8(void* base, int64_t off, int out_dtype, const float (&y)[8], int split_off = 0) {
+    typedef typename T16<T>::v8 v8;
+    if (split_off > 0) {
+        v8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            h[e] = T16<T>::from_f32(y[e]);
+            l[e] = T16<T>::from_f32(y[e] - T16<T>::to_f32(h[e]));
+        }
+        *reinterpret_cast<v8*>(reinterpret_cast<T*>(base) + off) = h;
+        *reinterpret_cast<v8*>(reinterpret_cast<T*>(base) + off + split_off) = l;
+        return;
+    }
+    if (out_dtype == BS_F32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off) = f32x4{y[0], y[1], y[2], y[3]};
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off + 4) = f32x4{y[4], y[5], y[6], y[7]};
+    } else {
+        v8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = T16<T>::from_f32(y[e]);
+        *reinterpret_cast<v8*>(reinterpret_cast<T*>(base) + off) = v;
+    }
+}
+
 constexpr int NW_CHECK(int a, int b) { return a * b; }
 
 template <int N>
@@ -191,10 +218,15 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
             a_mask[j] = 1u;
         }
     }
+    // LDS row r of the W tile holds output column perm(r): inside every group of 32 rows the two 16-row fragments take
+    // INTERLEAVED groups of 4 columns (fragment e, MFMA column c -> column 8*(c>>2) + 4*e + (c&3)), so that a lane's 4+4
+    // accumulator values of a fragment pair are 8 CONSECUTIVE output columns: one 16-byte store, 64 contiguous bytes per row.
+    static_assert(BN % 32 == 0 && TN % 32 == 0, "column permutation works on 32-column groups");
     unsigned w_off[RB];
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
-        int n = tn * BN + j * RPR + srow;
+        const int r = j * RPR + srow;
+        int n = tn * BN + ((r & ~31) | ((r & 12) << 1) | ((r & 16) >> 2) | (r & 3));
         n = n < p.N ? n : p.N - 1;
         w_off[j] = (unsigned)(n * p.K * 2 + cs16);
     }
@@ -203,13 +235,20 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
     // K axis is up to two SEGMENTS that both walk the same rows of A -- segment 0 with seg0 bytes per tap, then segment 1
     // with seg1 bytes per tap (taps restart).  This is how split-precision products are expressed without a second
     // kernel: A = [hi | lo] channels, W' = [W_hi | W_hi] then [W_lo] against the hi channels again (Numerics).
+    //
+    // Order of K inside a segment: 64-channel CHUNK outermost, filter tap inside it, the chunk's 64 channels innermost
+    // (W is laid out to match: [N][segment][chunk][tap][64]).  Tiles that run side by side on an XCD walk K in step, so
+    // the three kernel rows a tap triple (ky = 0,1,2) needs from one input row are requested within 3 K-steps of each other
+    // and by neighbouring tiles within a few more: the re-reads hit the XCD's 4 MiB L2.  (Tap-outermost order spreads them a
+    // whole Cin apart: 9x the L2 miss traffic on the 256-channel, 192x256 feature maps.)
     const int seg0 = (CONV ? p.Cin : p.K - p.cin1) * 2, seg1 = p.cin1 * 2;
     const int ntaps = CONV ? p.KH * p.KW : 1;
-    int s_tap = 0, s_kx = 0, s_tapoff = 0, s_c0 = 0, s_k = 0, s_seg = seg0;
+    int s_tap = 0, s_kx = 0, s_tapoff = 0, s_cb = 0, s_sub = 0, s_k = 0, s_seg = seg0;
 
     auto stage = [&](int buf) {
         char* sa = smem + buf * STAGE;
         char* sb = sa + A_BYTES;
+        const int s_c0 = s_cb + s_sub;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             unsigned vo;
@@ -226,21 +265,25 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(sb + (j * RPR + wave * RPW) * ROWB), 16, w_off[j],
                                                      s_k, 0, 0);
         s_k += BK * 2;
-        s_c0 += BK * 2;
-        if (s_c0 >= s_seg) {
-            s_c0 = 0;
-            if (CONV) {
-                ++s_tap;
-                s_tapoff += p.lda * 2;
-                if (++s_kx >= p.KW) {
-                    s_kx = 0;
-                    s_tapoff += (p.Win - p.KW) * p.lda * 2;
-                }
-            }
-            if (!CONV || s_tap >= ntaps) {   // segment 0 finished: restart the taps for segment 1
-                s_tap = 0;
+        if (BK == 32) {
+            s_sub ^= 64;                       // second half of the 64-channel chunk, same tap
+            if (s_sub) return;
+        }
+        if (CONV) {                            // next tap of this chunk
+            ++s_tap;
+            s_tapoff += p.lda * 2;
+            if (++s_kx >= p.KW) {
                 s_kx = 0;
-                s_tapoff = 0;
+                s_tapoff += (p.Win - p.KW) * p.lda * 2;
+            }
+        }
+        if (!CONV || s_tap >= ntaps) {         // chunk finished: next chunk, taps restart
+            s_tap = 0;
+            s_kx = 0;
+            s_tapoff = 0;
+            s_cb += 128;
+            if (s_cb >= s_seg) {               // segment 0 finished: segment 1 walks the same rows again
+                s_cb = 0;
                 s_seg = seg1;
             }
         }
@@ -377,7 +420,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
     // column j, everything that depends only on the row (regrouped row, image / token / pixel decomposition) per fragment
     // row i; the activation is selected once, outside the fragment loops.  Only the V third of the fused QKV projection
     // still goes through LDS: it is written TRANSPOSED (V^T [B,nh,64,Sp]), consecutive lanes taking consecutive tokens.
-    //   lane: m = tm*BM + wm*TM + i*16 + (lane & 15),  n = tn*BN + wn*TN + j*16 + (lane >> 4)*4 + 0..3
+    //   lane: m = m0 + wm*TM + i*16 + (lane & 15),  n = tn*BN + wn*TN + (j>>1)*32 + (lane >> 4)*8 + (j&1)*4 + 0..3
     const int n_wave = tn * BN + wn * TN;
     const bool v_tile = (p.out_mode == BS_OUT_QKV) && (tn * BN >= 2 * p.qkv_hidden);
     if (p.ablate & 4) {
@@ -393,7 +436,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
             int which[FN];
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const int n0 = n_wave + j * 16 + fq * 4;
+                const int n0 = n_wave + (j >> 1) * 32 + fq * 8 + (j & 1) * 4;
                 n0j[j] = n0;
                 const bool ok = n0 < p.N;
                 bj[j] = (p.bias && !p.bias_group_rows && ok) ? *reinterpret_cast<const f32x4*>(p.bias + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -416,6 +459,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                     }
                 }
             }
+            // 16-byte stores need every row start and the split offset on an 8-element boundary (always true for the plans in
+            // zoedepth.py; the 4-wide path stays for odd leading dimensions)
+            const bool wide_ok = (p.out_mode == BS_OUT_QKV) || (p.ldo % 8 == 0 && p.split_off % 8 == 0);
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int m = m0 + wm * TM + i * 16 + frow;
@@ -441,53 +487,72 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                     roff = ((int64_t)ob * (p.qkv_hidden >> 6) * p.qkv_sp + otok) * 64;
                 }
 #pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    if (n0j[j] >= p.N) continue;
-                    float y[4];
-                    if (brow) {
-                        const f32x4 bb = *reinterpret_cast<const f32x4*>(brow + n0j[j]);
+                for (int jp = 0; jp < FN / 2; ++jp) {
+                    float y8[8];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = acc[i][j][e] + bb[e];
-                    } else {
+                    for (int h = 0; h < 2; ++h) {
+                        const int j = jp * 2 + h;
+                        float* y = y8 + h * 4;
+                        if (n0j[j] >= p.N) continue;
+                        if (brow) {
+                            const f32x4 bb = *reinterpret_cast<const f32x4*>(brow + n0j[j]);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = acc[i][j][e] + bj[j][e];
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (ACT == BS_ACT_RELU) y[e] = fmaxf(y[e], 0.0f);
-                        else if (ACT == BS_ACT_GELU) y[e] = gelu_erf(y[e]);
-                        else if (ACT == BS_ACT_SOFTPLUS) y[e] = softplus20(y[e]);
-                        y[e] *= sj[j][e];
-                    }
-                    if (p.res) {
-                        const int64_t ro = orow * p.ldr + n0j[j];   // residuals live in the OUTPUT row geometry
-                        if (p.res_dtype == BS_F32) {
-                            const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + ro);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) y[e] += rr[e];
+                            for (int e = 0; e < 4; ++e) y[e] = acc[i][j][e] + bb[e];
                         } else {
-                            const typename T16<T>::v4 rr = *reinterpret_cast<const typename T16<T>::v4*>(reinterpret_cast<const T*>(p.res) + ro);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) y[e] += T16<T>::to_f32(rr[e]);
-                            if (p.res_split_off > 0) {
-                                const typename T16<T>::v4 rl = *reinterpret_cast<const typename T16<T>::v4*>(reinterpret_cast<const T*>(p.res) + ro + p.res_split_off);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) y[e] += T16<T>::to_f32(rl[e]);
-                            }
+                            for (int e = 0; e < 4; ++e) y[e] = acc[i][j][e] + bj[j][e];
                         }
-                        if (p.res2) {   // second residual, 16-bit (fusion: fused + residual_unit(skip))
-                            const typename T16<T>::v4 rr = *reinterpret_cast<const typename T16<T>::v4*>(reinterpret_cast<const T*>(p.res2) + ro);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) y[e] += T16<T>::to_f32(rr[e]);
-                            if (p.res_split_off > 0) {
-                                const typename T16<T>::v4 rl = *reinterpret_cast<const typename T16<T>::v4*>(reinterpret_cast<const T*>(p.res2) + ro + p.res_split_off);
+                        for (int e = 0; e < 4; ++e) {
+                            if (ACT == BS_ACT_RELU) y[e] = fmaxf(y[e], 0.0f);
+                            else if (ACT == BS_ACT_GELU) y[e] = gelu_erf(y[e]);
+                            else if (ACT == BS_ACT_SOFTPLUS) y[e] = softplus20(y[e]);
+                            y[e] *= sj[j][e];
+                        }
+                        if (p.res) {
+                            const int64_t ro = orow * p.ldr + n0j[j];   // residuals live in the OUTPUT row geometry
+                            if (p.res_dtype == BS_F32) {
+                                const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + ro);
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) y[e] += T16<T>::to_f32(rl[e]);
+                                for (int e = 0; e < 4; ++e) y[e] += rr[e];
+                            } else {
+                                const typename T16<T>::v4 rr = *reinterpret_cast<const typename T16<T>::v4*>(reinterpret_cast<const T*>(p.res) + ro);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) y[e] += T16<T>::to_f32(rr[e]);
+                                if (p.res_split_off > 0) {
+                                    const typename T16<T>::v4 rl = *reinterpret_cast<const typename T16<T>::v4*>(reinterpret_cast<const T*>(p.res) + ro + p.res_split_off);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) y[e] += T16<T>::to_f32(rl[e]);
+                                }
+                            }
+                            if (p.res2) {   // second residual, 16-bit (fusion: fused + residual_unit(skip))
+                                const typename T16<T>::v4 rr = *reinterpret_cast<const typename T16<T>::v4*>(reinterpret_cast<const T*>(p.res2) + ro);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) y[e] += T16<T>::to_f32(rr[e]);
+                                if (p.res_split_off > 0) {
+                                    const typename T16<T>::v4 rl = *reinterpret_cast<const typename T16<T>::v4*>(reinterpret_cast<const T*>(p.res2) + ro + p.res_split_off);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) y[e] += T16<T>::to_f32(rl[e]);
+                                }
                             }
                         }
                     }
-                    void* dst = (p.out_mode == BS_OUT_QKV && which[j] == 1) ? p.out2 : p.out;
-                    store4<T>(dst, roff + coff[j], p.out_dtype, y, p.out_mode != BS_OUT_QKV ? p.split_off : 0);
+                    const int j0 = jp * 2, j1 = j0 + 1;
+                    if (n0j[j0] >= p.N) continue;
+                    void* dst = (p.out_mode == BS_OUT_QKV && which[j0] == 1) ? p.out2 : p.out;
+                    const int so = p.out_mode != BS_OUT_QKV ? p.split_off : 0;
+                    // the pair is one 8-wide store when both halves exist, are adjacent in the output and 16-byte aligned
+                    if (wide_ok && n0j[j1] < p.N && coff[j1] == coff[j0] + 4 && which[j1] == which[j0]) {
+                        store8<T>(dst, roff + coff[j0], p.out_dtype, y8, so);
+                    } else {
+                        const float(&ya)[4] = *reinterpret_cast<const float(*)[4]>(y8);
+                        store4<T>(dst, roff + coff[j0], p.out_dtype, ya, so);
+                        if (n0j[j1] < p.N) {
+                            const float(&yb)[4] = *reinterpret_cast<const float(*)[4]>(y8 + 4);
+                            void* dst1 = (p.out_mode == BS_OUT_QKV && which[j1] == 1) ? p.out2 : p.out;
+                            store4<T>(dst1, roff + coff[j1], p.out_dtype, yb, so);
+                        }
+                    }
                 }
             }
         };
@@ -513,7 +578,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                 if ((i * 16) / PASS_R == ps) {
                     const int r = i * 16 - ps * PASS_R + frow;
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) *reinterpret_cast<f32x4*>(sc + r * TN + (((j * 4 + fq) ^ (r & (S4 - 1))) << 2)) = acc[i][j];
+                    for (int j = 0; j < FN; ++j)   // group-of-4 index of this lane's columns in the wave tile (permuted columns, see w_off)
+                        *reinterpret_cast<f32x4*>(sc + r * TN + ((((j >> 1) * 8 + fq * 2 + (j & 1)) ^ (r & (S4 - 1))) << 2)) = acc[i][j];
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

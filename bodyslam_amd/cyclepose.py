@@ -42,7 +42,7 @@ class CyclePoseEngine:
         w["c0.w"] = h(torch.cat([w0, torch.zeros(w0.shape[0], K0 - w0.shape[1])], 1))
         w["c0.b"] = f(g("initial_model.1.bias"))
         for name, key in (("c1", "downsampling.0"), ("c2", "downsampling.3"), ("c3", "pose_conv.0")):
-            w[name + ".w"] = h(cw(g(key + ".weight")))
+            w[name + ".w"] = h(L.conv_weight(g(key + ".weight").permute(0, 2, 3, 1)))   # conv mode K order: chunk, tap, channel
             w[name + ".b"] = f(g(key + ".bias"))
         if "skip_linear.weight" not in weights:
             raise KeyError("skip_linear.weight missing: the reference would silently use a random layer here "

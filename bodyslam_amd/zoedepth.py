@@ -10,7 +10,7 @@ models/zoedepth/image_processing_pil_zoedepth.py).  Parameter names are HF state
 
 Data layout in HBM (B frames, flip-aug doubles the image batch: NB = 2B):
   residual stream      fp32 [NB*S, hidden]            S = 1 + hp*wp tokens (cls first)
-  GEMM operands        fp16/bf16, K-major weights [N, K]; conv weights [O][kh][kw][I]
+  GEMM operands        fp16/bf16, K-major weights [N, K]; conv weights [O][I/64][kh][kw][64]
   Q, K / V^T           [NB, heads, Sp, 64] / [NB, heads, 64, Sp], Sp = S rounded up to 64, zero padded
   rel-pos bias         fp32 [layers][heads, Sp, Sp], -1e30 in padded key columns (built once per window)
   conv activations     NHWC 16-bit
@@ -131,8 +131,8 @@ class ZoeDepthEngine:
         return t.to(self.dev, dtype=torch.float32).contiguous()
 
     def _conv_w(self, t: torch.Tensor) -> torch.Tensor:
-        """[O, I, kh, kw] -> [O][kh][kw][I] (K-major over (ky, kx, ci))."""
-        return self._h(t.permute(0, 2, 3, 1).reshape(t.shape[0], -1))
+        """[O, I, kh, kw] -> [O][I/64][kh][kw][64] (the K order of bs_gemm's conv mode: chunk, tap, channel)."""
+        return self._h(L.conv_weight(t.permute(0, 2, 3, 1)))
 
     def _split(self, t: torch.Tensor):
         hi = t.to(self.dtype)
@@ -154,13 +154,14 @@ class ZoeDepthEngine:
         return torch.cat([hi, hi, lo], 1).to(self.dev).contiguous()
 
     def _wn_conv(self, t: torch.Tensor) -> torch.Tensor:
-        """neck conv weight [O, I, kh, kw]; accurate: per tap [W_hi | W_hi] (2I), then all taps of W_lo (I)."""
+        """neck conv weight [O, I, kh, kw]; accurate: segment 0 = [W_hi | W_hi] against the 2I (hi | lo) channels,
+        segment 1 = W_lo against the hi channels again; each segment in conv K order (chunk, tap, channel)."""
         if not self.acc:
             return self._conv_w(t)
         k = t.permute(0, 2, 3, 1)                                   # [O, kh, kw, I]
         hi, lo = self._split(k)
-        seg0 = torch.cat([hi, hi], -1).reshape(t.shape[0], -1)
-        return torch.cat([seg0, lo.reshape(t.shape[0], -1)], 1).to(self.dev).contiguous()
+        seg0 = L.conv_weight(torch.cat([hi, hi], -1))
+        return torch.cat([seg0, L.conv_weight(lo)], 1).to(self.dev).contiguous()
 
     def _ingest(self, sd: Dict[str, torch.Tensor]):
         c, w = self.cfg, self.w

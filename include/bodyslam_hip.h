@@ -45,8 +45,10 @@ int bs_version(void);
  *   metric-head 1x1 convs                 HF modeling_zoedepth.py:494-547,665-772
  *   CyclePose Conv7x7 / Conv3x3 s2        MPEM/architecture_v3.py:120-147
  * conv == 0: A is [M, K] with row stride lda.   conv == 1: A is an NHWC batch [B, Hin, Win, lda>=Cin],
- * K = KH*KW*Cin ordered (ky, kx, ci), M = B*Hout*Wout, zero padding pad_h/pad_w (may be negative:
- * a crop), W is [N][KH][KW][Cin].  Cin (conv) / K (plain) must be a multiple of 64.
+ * K = KH*KW*Cin, M = B*Hout*Wout, zero padding pad_h/pad_w (may be negative: a crop).  K order, conv mode:
+ * 64-channel chunk outermost, then the filter tap, then the chunk's channels -- W is [N][Cin/64][KH][KW][64]
+ * (bodyslam_amd/_lib.py conv_weight()); this keeps the taps that re-read one input row a few K-steps apart, inside
+ * the XCD's L2.  Cin (conv) / K (plain) must be a multiple of 64.
  * epilogue: y = acc + bias[(m / bias_group_rows) * N + n]  (bias_group_rows == 0: bias[n]);
  *           y = act(y); y *= scale[n]; y += res[orow * ldr + n] (orow = m unless regrouped, below); store.
  * out_mode BS_OUT_PLAIN  : out[orow * ldo + n], orow = (m / out_group_rows) * out_group_stride

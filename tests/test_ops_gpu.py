@@ -101,7 +101,7 @@ def test_conv3x3(L, dtype, B, H, W, Cin, Cout, stride, relu_a, tile):
     x = rnd(B, H, W, Cin, seed=1, dtype=dtype)                       # NHWC
     w = rnd(Cout, Cin, 3, 3, seed=2, scale=1 / math.sqrt(9 * Cin), dtype=dtype)
     bias = rnd(Cout, seed=3)
-    wk = w.permute(0, 2, 3, 1).contiguous()                          # [O][kh][kw][I]
+    wk = L.conv_weight(w.permute(0, 2, 3, 1))                        # [O][I/64][kh][kw][64]
     g = L.conv_geom(H, W, Cin, 3, 3, stride, 1)
     Ho, Wo = g[3], g[4]
     res = rnd(B, Ho, Wo, Cout, seed=4, dtype=dtype)
@@ -181,8 +181,8 @@ def test_split_precision_conv(L):
     r2 = torch.cat([rh, rl], -1).contiguous()
     wk = w.permute(0, 2, 3, 1)                                       # [O][kh][kw][I]
     wh, wl = _split(wk, dtype)
-    seg0 = torch.cat([wh, wh], -1).reshape(Co, -1)                   # per tap [W_hi | W_hi] against [hi | lo]
-    W3 = torch.cat([seg0, wl.reshape(Co, -1)], 1).contiguous()       # then all taps of W_lo against hi
+    seg0 = L.conv_weight(torch.cat([wh, wh], -1))                    # segment 0: [W_hi | W_hi] against [hi | lo]
+    W3 = torch.cat([seg0, L.conv_weight(wl)], 1).contiguous()        # segment 1: W_lo against hi
     out = torch.zeros(B, H, Wd, 2 * Co, device=dev(), dtype=dtype)
     g = L.conv_geom(H, Wd, 2 * C, 3, 3, 1, 1)
     for tile in (1, 9):
