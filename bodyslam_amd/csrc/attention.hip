@@ -22,7 +22,7 @@ namespace bs {
 
 template <typename T, int QW>
 __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ Vt,
-                                                             const float* __restrict__ bias, T* __restrict__ out, int B, int nh, int S,
+                                                             const float* __restrict__ bias, T* __restrict__ out, int split, int B, int nh, int S,
                                                              int Sp, int nqt, int nqb, int ablate) {
     typedef typename T16<T>::v8 v8;
     constexpr int STAGE = 16 * 1024;  // K tile 8 KiB + V^T tile 8 KiB
@@ -183,36 +183,42 @@ __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict_
     const float inv = 1.0f / l_tot;
     const int q = q0 + r;
     if (active && q < S) {
-        T* orow = out + ((int64_t)b * S + q) * (nh * 64) + head * 64;
+        // split: rows of (hi | lo) pairs [., 2*nh*64], o = hi + lo to ~22 bits (operand of a split-precision o_proj)
+        T* orow = out + ((int64_t)b * S + q) * (nh * 64) * (split ? 2 : 1) + head * 64;
 #pragma unroll
         for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
             for (int gg = 0; gg < 4; ++gg) {
-                typename T16<T>::v4 o;
+                typename T16<T>::v4 o, ol;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(oacc[dh][gg * 4 + e] * inv);
+                for (int e = 0; e < 4; ++e) {
+                    const float y = oacc[dh][gg * 4 + e] * inv;
+                    o[e] = T16<T>::from_f32(y);
+                    ol[e] = T16<T>::from_f32(y - T16<T>::to_f32(o[e]));
+                }
                 *reinterpret_cast<typename T16<T>::v4*>(orow + dh * 32 + 8 * gg + 4 * h2) = o;
+                if (split) *reinterpret_cast<typename T16<T>::v4*>(orow + nh * 64 + dh * 32 + 8 * gg + 4 * h2) = ol;
             }
     }
 }
 
 template <typename T, int QW>
-static int launch_attn(const void* q, const void* k, const void* vt, const float* bias, void* out, int B, int nh, int S, int Sp,
+static int launch_attn(const void* q, const void* k, const void* vt, const float* bias, void* out, int split, int B, int nh, int S, int Sp,
                        hipStream_t st) {
     const int nqt = cdiv(S, 32), nqb = cdiv(nqt, QW);
     hipLaunchKernelGGL((attention_kernel<T, QW>), dim3(B * nh * nqb), dim3(QW * 64), 32 * 1024, st, (const T*)q, (const T*)k,
-                       (const T*)vt, bias, (T*)out, B, nh, S, Sp, nqt, nqb, getenv("BS_ATTN_ABLATE") ? atoi(getenv("BS_ATTN_ABLATE")) : 0);
+                       (const T*)vt, bias, (T*)out, split, B, nh, S, Sp, nqt, nqb, getenv("BS_ATTN_ABLATE") ? atoi(getenv("BS_ATTN_ABLATE")) : 0);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }
 
 template <typename T>
-static int dispatch_attn(const void* q, const void* k, const void* vt, const float* bias, void* out, int B, int nh, int S, int Sp,
+static int dispatch_attn(const void* q, const void* k, const void* vt, const float* bias, void* out, int split, int B, int nh, int S, int Sp,
                          hipStream_t st) {
     const int nqt = cdiv(S, 32);
-    if (nqt % 5 == 0) return launch_attn<T, 5>(q, k, vt, bias, out, B, nh, S, Sp, st);
-    if (nqt % 3 == 0) return launch_attn<T, 3>(q, k, vt, bias, out, B, nh, S, Sp, st);
-    return launch_attn<T, 4>(q, k, vt, bias, out, B, nh, S, Sp, st);
+    if (nqt % 5 == 0) return launch_attn<T, 5>(q, k, vt, bias, out, split, B, nh, S, Sp, st);
+    if (nqt % 3 == 0) return launch_attn<T, 3>(q, k, vt, bias, out, split, B, nh, S, Sp, st);
+    return launch_attn<T, 4>(q, k, vt, bias, out, split, B, nh, S, Sp, st);
 }
 
 }  // namespace bs
@@ -223,9 +229,11 @@ extern "C" int bs_attention(const void* q, const void* k, const void* vt, const 
     if (!initialized()) { set_error("bs_attention: call bs_init first"); return BS_ERR_NOT_INIT; }
     BS_REQUIRE(q && k && vt && bias && out && B >= 0 && nh > 0 && S > 0, "bs_attention: bad argument");
     BS_REQUIRE(Sp % 64 == 0 && Sp >= S, "bs_attention: Sp=%d must be a multiple of 64 and >= S=%d", Sp, S);
+    const int split = (dtype & 16) ? 1 : 0;            // bit 4: out holds (hi | lo) pairs, [B*S, 2*nh*64]
+    dtype &= 15;
     BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_attention: dtype");
     if (B == 0) return BS_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    return dtype == BS_F16 ? dispatch_attn<f16>(q, k, vt, bias, out, B, nh, S, Sp, st)
-                           : dispatch_attn<bf16>(q, k, vt, bias, out, B, nh, S, Sp, st);
+    return dtype == BS_F16 ? dispatch_attn<f16>(q, k, vt, bias, out, split, B, nh, S, Sp, st)
+                           : dispatch_attn<bf16>(q, k, vt, bias, out, split, B, nh, S, Sp, st);
 }

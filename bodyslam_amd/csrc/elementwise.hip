@@ -12,7 +12,8 @@ namespace bs {
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* gamma, const float* beta, T* out16, float* out32,
-                                                         int rows, int cols, float eps) {
+                                                         int rows, int cols, float eps, int split) {
+    // split: out16 is [rows, 2*cols] = (hi | lo) pairs, y = hi + lo to ~22 bits (operand of a split-precision GEMM)
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + (int64_t)row * cols;
@@ -77,7 +78,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
             typename T16<T>::v4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(y[e]);
-            *reinterpret_cast<typename T16<T>::v4*>(out16 + (int64_t)row * cols + vi * 4) = o;
+            if (split) {
+                typename T16<T>::v4 ol;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ol[e] = T16<T>::from_f32(y[e] - T16<T>::to_f32(o[e]));
+                *reinterpret_cast<typename T16<T>::v4*>(out16 + (int64_t)row * cols * 2 + vi * 4) = o;
+                *reinterpret_cast<typename T16<T>::v4*>(out16 + (int64_t)row * cols * 2 + cols + vi * 4) = ol;
+            } else {
+                *reinterpret_cast<typename T16<T>::v4*>(out16 + (int64_t)row * cols + vi * 4) = o;
+            }
         }
         if (out32) *reinterpret_cast<f32x4*>(out32 + (int64_t)row * cols + vi * 4) = f32x4{y[0], y[1], y[2], y[3]};
     }
@@ -173,7 +182,7 @@ __device__ __forceinline__ float pre_sample(const uint8_t* frame, const PreGeom&
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void pre_patches_kernel(const uint8_t* frames, T* out, int B, int nimg, PreGeom g) {
+__global__ __launch_bounds__(256) void pre_patches_kernel(const uint8_t* frames, T* out, int B, int nimg, PreGeom g, int split) {
     const int hp = g.nh / 16, wp = g.nw / 16;
     const int64_t total = (int64_t)nimg * hp * wp * 768;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -186,7 +195,14 @@ __global__ __launch_bounds__(256) void pre_patches_kernel(const uint8_t* frames,
     int x = px * 16 + kx;
     const int b = img >= B ? img - B : img;
     if (img >= B) x = g.nw - 1 - x;  // torch.flip(x, dims=[3]) of the network input
-    out[gid] = T16<T>::from_f32(pre_sample(frames + (int64_t)b * g.H * g.W * 3, g, c, y, x));
+    const float v = pre_sample(frames + (int64_t)b * g.H * g.W * 3, g, c, y, x);
+    const T hi = T16<T>::from_f32(v);
+    if (split) {   // rows of [768 hi | 768 lo]
+        out[r * 1536 + k] = hi;
+        out[r * 1536 + 768 + k] = T16<T>::from_f32(v - T16<T>::to_f32(hi));
+    } else {
+        out[gid] = hi;
+    }
 }
 
 __global__ __launch_bounds__(256) void pre_image_kernel(const uint8_t* frames, float* out, int B, int nimg, PreGeom g) {
@@ -332,14 +348,16 @@ extern "C" int bs_layernorm(const float* x, const float* gamma, const float* bet
                             int32_t cols, float eps, int32_t dtype, void* stream) {
     BS_ENTRY("bs_layernorm");
     BS_REQUIRE(x && gamma && beta && (out16 || out32) && rows >= 0 && cols > 0 && cols % 4 == 0, "bs_layernorm: bad argument");
+    const int split = (dtype & 16) ? 1 : 0;            // bit 4: out16 holds (hi | lo) pairs, [rows, 2*cols]
+    dtype &= 15;
     BS_REQUIRE(!out16 || dtype == BS_F16 || dtype == BS_BF16, "bs_layernorm: dtype");
     if (rows == 0) return BS_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(cdiv(rows, 4));
     if (dtype == BS_BF16)
-        hipLaunchKernelGGL(layernorm_kernel<bf16>, grid, dim3(256), 0, st, x, gamma, beta, (bf16*)out16, out32, rows, cols, eps);
+        hipLaunchKernelGGL(layernorm_kernel<bf16>, grid, dim3(256), 0, st, x, gamma, beta, (bf16*)out16, out32, rows, cols, eps, split);
     else
-        hipLaunchKernelGGL(layernorm_kernel<f16>, grid, dim3(256), 0, st, x, gamma, beta, (f16*)out16, out32, rows, cols, eps);
+        hipLaunchKernelGGL(layernorm_kernel<f16>, grid, dim3(256), 0, st, x, gamma, beta, (f16*)out16, out32, rows, cols, eps, split);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }
@@ -374,6 +392,8 @@ extern "C" int bs_preprocess_patches(const uint8_t* frames, void* out, int32_t B
     BS_ENTRY("bs_preprocess_patches");
     BS_REQUIRE(frames && out && B >= 0 && H > 1 && W > 1 && nh % 16 == 0 && nw % 16 == 0 && nh > 0 && nw > 0,
                "bs_preprocess_patches: bad geometry");
+    const int split = (out_dtype & 16) ? 1 : 0;        // bit 4: rows are (hi | lo) pairs, [., 2*768]
+    out_dtype &= 15;
     BS_REQUIRE(out_dtype == BS_F16 || out_dtype == BS_BF16, "bs_preprocess_patches: dtype");
     if (B == 0) return BS_OK;
     const PreGeom g = make_geom(H, W, nh, nw);
@@ -382,9 +402,9 @@ extern "C" int bs_preprocess_patches(const uint8_t* frames, void* out, int32_t B
     const int64_t total = (int64_t)nimg * (nh / 16) * (nw / 16) * 768;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (out_dtype == BS_F16)
-        hipLaunchKernelGGL(pre_patches_kernel<f16>, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, frames, (f16*)out, B, nimg, g);
+        hipLaunchKernelGGL(pre_patches_kernel<f16>, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, frames, (f16*)out, B, nimg, g, split);
     else
-        hipLaunchKernelGGL(pre_patches_kernel<bf16>, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, frames, (bf16*)out, B, nimg, g);
+        hipLaunchKernelGGL(pre_patches_kernel<bf16>, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, frames, (bf16*)out, B, nimg, g, split);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }

@@ -37,15 +37,16 @@ __device__ __forceinline__ Lerp2 lerp_ac(int oy, int ox, int Hin, int Win, float
 __global__ __launch_bounds__(256) void attractor_kernel(const float* A, const float* bins_prev, float* bins_out, const int32_t* route,
                                                          int B, int Hp, int Wp, int H, int W, int G, int nb, int na, float sy, float sx) {
     // grid.y = (image, output row); grid.x covers (column, group, bin quad) of that row: no 64-bit div/mod per thread
+    // with `route` the grid covers the routed group only (no idle lanes for the head that is not computed)
     const int q4 = nb >> 2;
-    const unsigned per_row = (unsigned)W * G * q4;
+    const int GG = route ? 1 : G;
+    const unsigned per_row = (unsigned)W * GG * q4;
     const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= per_row) return;
     const int b = blockIdx.y / H, oy = blockIdx.y - b * H;
     const int q = idx % q4;
-    const int g = (idx / q4) % G;
-    const int ox = idx / (q4 * G);
-    if (route && route[b] != g) return;
+    const int g = route ? route[b] : (int)((idx / q4) % G);
+    const int ox = idx / (q4 * GG);
     const int64_t pix = ((int64_t)b * H + oy) * W + ox;
     const Lerp2 l = lerp_ac(oy, ox, Hp, Wp, sy, sx);
     const int CB = G * nb, CA = G * na;
@@ -93,9 +94,6 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
     // loaded once (coalesced) instead of 4 x (256 + 160) bytes per output pixel; plus the small MLP weights.
     __shared__ float s_bins[LB_MAXSRC * LB_MAXSRC * LB_BINS];
     __shared__ float s_eh[LB_MAXSRC * LB_MAXSRC * LB_HID];
-    __shared__ float s_w0[LB_HID][LB_IN + 1];
-    __shared__ float s_w2[4][LB_HID];
-    __shared__ float s_b2[4];
     __shared__ float s_lb[LB_BINS];
     const int b = blockIdx.z;
     const int g = route[b];
@@ -117,9 +115,6 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
         const float* src = Eh + (((int64_t)b * He + sy0 + rr) * We + sx0 + cc) * (2 * LB_HID) + g * LB_HID + k4 * 4;
         *reinterpret_cast<f32x4*>(s_eh + cell * LB_HID + k4 * 4) = *reinterpret_cast<const f32x4*>(src);
     }
-    for (int i = threadIdx.x; i < LB_HID * LB_IN; i += 256) s_w0[i / LB_IN][i % LB_IN] = w0_last[g * LB_HID * LB_IN + i];
-    for (int i = threadIdx.x; i < 4 * LB_HID; i += 256) s_w2[i / LB_HID][i % LB_HID] = w2[g * 4 * LB_HID + i];
-    if (threadIdx.x < 4) s_b2[threadIdx.x] = b2[g * 4 + threadIdx.x];
     if (threadIdx.x < LB_BINS) {
         // log_binom(n = 63, k) with the reference's eps placement (modeling_zoedepth.py:376-381)
         const float e = 1e-7f;
@@ -151,16 +146,22 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
             }
         }
     }
-    float pt[4] = {s_b2[0], s_b2[1], s_b2[2], s_b2[3]};
+    // The MLP weights are the same for every thread of the block (g is block-uniform): they are read straight from global
+    // memory with uniform addresses, i.e. through the scalar cache into SGPRs (s_load + v_fmac with a scalar operand), not
+    // through 1280 LDS broadcast reads per pixel.
+    const float* __restrict__ gw0 = w0_last + g * LB_HID * LB_IN;
+    const float* __restrict__ gw2 = w2 + g * 4 * LB_HID;
+    float pt[4] = {b2[g * 4 + 0], b2[g * 4 + 1], b2[g * 4 + 2], b2[g * 4 + 3]};
+#pragma unroll 4
     for (int h = 0; h < LB_HID; ++h) {
         // same bilinear operation order as torch: hy*(hx*p00 + lx*p01) + ly*(hx*p10 + lx*p11)
         float a = l.hy * (l.hx * s_eh[c00 * LB_HID + h] + l.lx * s_eh[c01 * LB_HID + h]) +
                   l.ly * (l.hx * s_eh[c10 * LB_HID + h] + l.lx * s_eh[c11 * LB_HID + h]);
 #pragma unroll
-        for (int c = 0; c < LB_IN; ++c) a += s_w0[h][c] * xin[c];
-        a = gelu_erf(a);
+        for (int c = 0; c < LB_IN; ++c) a += gw0[h * LB_IN + c] * xin[c];
+        a = gelu_erf_as(a);
 #pragma unroll
-        for (int o = 0; o < 4; ++o) pt[o] += s_w2[o][h] * a;
+        for (int o = 0; o < 4; ++o) pt[o] += gw2[o * LB_HID + h] * a;
     }
 #pragma unroll
     for (int o = 0; o < 4; ++o) pt[o] = softplus20(pt[o]);
@@ -269,7 +270,7 @@ extern "C" int bs_attractor_step(const float* A, const float* bins_prev, float* 
     if (B == 0) return BS_OK;
     const float sy = H > 1 ? (float)(Hp - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(Wp - 1) / (float)(W - 1) : 0.f;
     BS_REQUIRE(n_attr % 4 == 0, "bs_attractor_step: n_attr must be a multiple of 4");
-    const unsigned per_row = (unsigned)W * groups * (n_bins / 4);
+    const unsigned per_row = (unsigned)W * (route ? 1 : groups) * (n_bins / 4);
     hipLaunchKernelGGL(attractor_kernel, dim3(cdiv((int)per_row, 256), B * H), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A,
                        bins_prev, bins_out, route, B, Hp, Wp, H, W, groups, n_bins, n_attr, sy, sx);
     BS_CHECK_LAUNCH();

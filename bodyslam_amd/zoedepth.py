@@ -104,8 +104,9 @@ class ZoeDepthEngine:
     def __init__(self, weights: Dict[str, torch.Tensor], cfg: Optional[ZoeConfig] = None, dtype=torch.float16,
                  device: int = 0, target_hw: Tuple[int, int] = (384, 512), precision: str = "fast"):
         """precision: "fast" = one MFMA pass per product (16-bit operands, fp32 accumulate);
-        "accurate" = split-precision products where they matter (Numerics): backbone weights as
-        (hi, lo) pairs (2 passes), DPT neck + relative head with weights AND activations as (hi, lo) pairs (3 passes)."""
+        "accurate" = split-precision products (Numerics): every GEMM / conv operand of the backbone, the DPT neck,
+        the relative head and the projector path of the bins head is a (hi, lo) pair of 16-bit values; one launch evaluates
+        A_hi W_hi + A_lo W_hi + A_hi W_lo (3 MFMA passes).  Attention (Q, K, V, P) and the small bins-head MLPs stay single."""
         L.init(device)
         assert precision in ("fast", "accurate")
         self.acc = precision == "accurate"
@@ -139,15 +140,8 @@ class ZoeDepthEngine:
         lo = (t - hi.float()).to(self.dtype)
         return hi, lo
 
-    def _wb(self, t: torch.Tensor) -> torch.Tensor:
-        """backbone GEMM weight [N, K]; accurate: [N, 2K] = [W_hi | W_lo] (A is walked twice: bs_gemm seg1 = K)."""
-        if not self.acc:
-            return self._h(t)
-        hi, lo = self._split(t)
-        return torch.cat([hi, lo], 1).to(self.dev).contiguous()
-
     def _wn(self, t: torch.Tensor) -> torch.Tensor:
-        """neck / relative-head plain weight [N, K]; accurate: [N, 3K] = [W_hi | W_hi | W_lo] against A = [hi | lo], then hi."""
+        """plain GEMM weight [N, K]; accurate: [N, 3K] = [W_hi | W_hi | W_lo] against A = [hi | lo], then hi again."""
         if not self.acc:
             return self._h(t)
         hi, lo = self._split(t)
@@ -167,21 +161,21 @@ class ZoeDepthEngine:
         c, w = self.cfg, self.w
         g = lambda k: sd[k].detach().float()
         pe = "backbone.beit.embeddings."
-        w["pe.w"] = self._wb(g(pe + "patch_embeddings.projection.weight").reshape(c.hidden, -1))
+        w["pe.w"] = self._wn(g(pe + "patch_embeddings.projection.weight").reshape(c.hidden, -1))
         w["pe.b"] = self._f(g(pe + "patch_embeddings.projection.bias"))
         w["cls"] = self._f(g(pe + "cls_token").reshape(-1))
         for l in range(c.layers):
             p = f"backbone.beit.layers.{l}."
             w[f"l{l}.ln1.g"], w[f"l{l}.ln1.b"] = self._f(g(p + "layernorm_before.weight")), self._f(g(p + "layernorm_before.bias"))
             w[f"l{l}.ln2.g"], w[f"l{l}.ln2.b"] = self._f(g(p + "layernorm_after.weight")), self._f(g(p + "layernorm_after.bias"))
-            w[f"l{l}.qkv.w"] = self._wb(torch.cat([g(p + "attention.q_proj.weight"), g(p + "attention.k_proj.weight"),
+            w[f"l{l}.qkv.w"] = self._wn(torch.cat([g(p + "attention.q_proj.weight"), g(p + "attention.k_proj.weight"),
                                                    g(p + "attention.v_proj.weight")], 0))
             # k_proj has no bias (HF modeling_beit.py:305-307)
             w[f"l{l}.qkv.b"] = self._f(torch.cat([g(p + "attention.q_proj.bias"), torch.zeros(c.hidden),
                                                   g(p + "attention.v_proj.bias")], 0))
-            w[f"l{l}.o.w"], w[f"l{l}.o.b"] = self._wb(g(p + "attention.o_proj.weight")), self._f(g(p + "attention.o_proj.bias"))
-            w[f"l{l}.fc1.w"], w[f"l{l}.fc1.b"] = self._wb(g(p + "mlp.fc1.weight")), self._f(g(p + "mlp.fc1.bias"))
-            w[f"l{l}.fc2.w"], w[f"l{l}.fc2.b"] = self._wb(g(p + "mlp.fc2.weight")), self._f(g(p + "mlp.fc2.bias"))
+            w[f"l{l}.o.w"], w[f"l{l}.o.b"] = self._wn(g(p + "attention.o_proj.weight")), self._f(g(p + "attention.o_proj.bias"))
+            w[f"l{l}.fc1.w"], w[f"l{l}.fc1.b"] = self._wn(g(p + "mlp.fc1.weight")), self._f(g(p + "mlp.fc1.bias"))
+            w[f"l{l}.fc2.w"], w[f"l{l}.fc2.b"] = self._wn(g(p + "mlp.fc2.weight")), self._f(g(p + "mlp.fc2.bias"))
             w[f"l{l}.lam1"], w[f"l{l}.lam2"] = self._f(g(p + "lambda_1")), self._f(g(p + "lambda_2"))
             self._raw_tables.append(g(p + "relative_position_bias.relative_position_bias_table"))
         factors = (4, 2, 1, 0.5)
@@ -329,36 +323,39 @@ class _ZoePlan:
         bias = eng._rel_bias(hp, wp, Sp)
 
         acc = eng.acc
-        m2 = 2 if acc else 1          # channel multiplier of (hi | lo) activations in the neck / relative head
-        bp = 2 if acc else 1          # K passes of a backbone GEMM (weights split)
-        np3 = 3 if acc else 1         # K passes of a neck GEMM (weights and activations split)
+        m2 = 2 if acc else 1          # channel multiplier of (hi | lo) activations
+        np3 = 3 if acc else 1         # K passes of a GEMM whose weights AND activations are split
+        SP = 16 if acc else 0         # "split" flag (bit 4 of the dtype argument) of the pointwise producers
         self.frames = torch.empty(B, H, W, 3, device=dev, dtype=torch.uint8)
-        patches = e16(NB * T0, 3 * c.patch * c.patch)
+        patches = e16(NB * T0, 3 * c.patch * c.patch * m2)
         x = e32(NB * S, Hd)
-        xn = e16(NB * S, Hd)
+        xn = e16(NB * S, Hd * m2)
         q, k, vt = z16(NB, c.heads, Sp, 64), z16(NB, c.heads, Sp, 64), z16(NB, c.heads, 64, Sp)
-        ao = e16(NB * S, Hd)
-        hid = e16(NB * S, c.intermediate)
+        ao = e16(NB * S, Hd * m2)
+        hid = e16(NB * S, c.intermediate * m2)
         taps16 = [e16(NB * S, Hd * m2) for _ in c.taps]
 
         def bgemm(name, A, Wt, out, M, N, K, **kw):
-            """backbone GEMM: accurate mode walks A twice against [W_hi | W_lo]."""
-            P.gemm(name, A, Wt, out, M=M, N=N, K=K * bp, lda=K, seg1=K if acc else 0, precision_passes=bp, **kw)
+            """backbone GEMM.  Accurate mode: A = (hi | lo) [M, 2K] against [W_hi | W_hi | W_lo] -- one launch evaluates
+            A_hi W_hi + A_lo W_hi + A_hi W_lo (bs_gemm K segments)."""
+            P.gemm(name, A, Wt, out, M=M, N=N, K=K * np3, lda=K * m2, seg1=K if acc else 0, precision_passes=np3, **kw)
 
         # ---- Z1 + Z2: pre-processing fused with the patch gather, patch embedding, cls token
-        P.add("preprocess", "bs_preprocess_patches", self.frames, patches, B, H, W, nh_, nw_, int(flip), L.dt(patches))
+        PK = 3 * c.patch * c.patch
+        P.add("preprocess", "bs_preprocess_patches", self.frames, patches, B, H, W, nh_, nw_, int(flip), L.dt(patches) | SP)
         P.add("cls", "bs_fill_rows", x, w["cls"], NB, S, Hd)
-        bgemm("patch_embed", patches, w["pe.w"], x, NB * T0, Hd, patches.shape[1], bias=w["pe.b"], out_group=(T0, S, 1))
+        bgemm("patch_embed", patches, w["pe.w"], x, NB * T0, Hd, PK, bias=w["pe.b"], out_group=(T0, S, 1))
         P.mark("embed", x, ("tokens", NB, S, Hd))
         # ---- Z3: BEiT layers
         ti = 0
         for l in range(c.layers):
-            P.add(f"l{l}.ln1", "bs_layernorm", x, w[f"l{l}.ln1.g"], w[f"l{l}.ln1.b"], xn, None, NB * S, Hd, c.ln_eps, L.dt(xn))
+            P.add(f"l{l}.ln1", "bs_layernorm", x, w[f"l{l}.ln1.g"], w[f"l{l}.ln1.b"], xn, None, NB * S, Hd, c.ln_eps, L.dt(xn) | SP)
             bgemm(f"l{l}.qkv", xn, w[f"l{l}.qkv.w"], q, NB * S, 3 * Hd, Hd, bias=w[f"l{l}.qkv.b"], qkv=(Hd, S, Sp, LOG2E / math.sqrt(64.0), k, vt))
-            P.add(f"l{l}.attn", "bs_attention", q, k, vt, bias[l], ao, NB, c.heads, S, Sp, L.dt(q))
+            P.add(f"l{l}.attn", "bs_attention", q, k, vt, bias[l], ao, NB, c.heads, S, Sp, L.dt(q) | SP)
             bgemm(f"l{l}.o", ao, w[f"l{l}.o.w"], x, NB * S, Hd, Hd, bias=w[f"l{l}.o.b"], scale=w[f"l{l}.lam1"], res=x, ldr=Hd)
-            P.add(f"l{l}.ln2", "bs_layernorm", x, w[f"l{l}.ln2.g"], w[f"l{l}.ln2.b"], xn, None, NB * S, Hd, c.ln_eps, L.dt(xn))
-            bgemm(f"l{l}.fc1", xn, w[f"l{l}.fc1.w"], hid, NB * S, c.intermediate, Hd, bias=w[f"l{l}.fc1.b"], act=L.ACT_GELU)
+            P.add(f"l{l}.ln2", "bs_layernorm", x, w[f"l{l}.ln2.g"], w[f"l{l}.ln2.b"], xn, None, NB * S, Hd, c.ln_eps, L.dt(xn) | SP)
+            bgemm(f"l{l}.fc1", xn, w[f"l{l}.fc1.w"], hid, NB * S, c.intermediate, Hd, bias=w[f"l{l}.fc1.b"], act=L.ACT_GELU,
+                  ldo=c.intermediate * m2, out_split_off=c.intermediate if acc else 0)
             bgemm(f"l{l}.fc2", hid, w[f"l{l}.fc2.w"], x, NB * S, Hd, c.intermediate, bias=w[f"l{l}.fc2.b"], scale=w[f"l{l}.lam2"], res=x, ldr=Hd)
             P.mark(f"layer{l + 1}", x, ("tokens", NB, S, Hd))
             if (l + 1) in c.taps:

@@ -122,6 +122,22 @@ def _split(x, dtype):
     return hi, lo
 
 
+def test_gelu_epilogue_accuracy(L):
+    """The epilogue's erf-GELU against a float64 evaluation: x passes through an identity GEMM, fp32 output.
+    Tolerance 1e-6 absolute (the 16-bit outputs it feeds round at >= 2.4e-4 relative)."""
+    M = 4096
+    x = torch.linspace(-9.0, 9.0, M * 64, dtype=torch.float64).view(M, 64).to(torch.float16).to(dev())
+    eye = torch.eye(64, dtype=torch.float16, device=dev())
+    out = torch.empty(M, 64, device=dev())
+    L.gemm(x, eye, out, M=M, N=64, K=64, lda=64, act=L.ACT_GELU)
+    xd = x.double()
+    ref = 0.5 * xd * (1.0 + torch.erf(xd / math.sqrt(2.0)))
+    err = (out.double() - ref).abs()
+    i = err.argmax()
+    report(f"gelu epilogue: max|err|={err.max().item():.3e} at x={xd.flatten()[i].item():.4f}")
+    assert err.max().item() < 1e-6
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M,N,K", [(256 * 192 + 64, 1024, 128), (256 * 128 + 1, 768, 64), (256 * 64 + 128, 4096, 64)])
 def test_gemm_tail_split(L, dtype, M, N, K):

@@ -197,7 +197,7 @@ def test_full_size_zoed_nk_accurate():
     compare_taps(r["taps_p"], r["taps_o"], None, tag)
     l1 = (r["dm"] - r["ref"]).abs().mean().item()
     mx = (r["dm"] - r["ref"]).abs().max().item()
-    report(f"[{tag}] 640x480 depth L1={l1:.3e} m, max={mx:.3e} m")
+    report(f"[{tag}] 640x480 depth L1={l1:.3e} m, max={mx:.3e} m, mean signed {(r['dm'] - r['ref']).mean().item():+.3e} m")
     lsb = np.abs(r["du"].astype(np.int32) - Z.to_uint16(r["ref"]).astype(np.int32))
     report(f"[{tag}] u16: max |diff| = {lsb.max()} LSB, mean {lsb.mean():.3f} LSB")
     assert torch.equal(torch.argmax(r["logits_o"], -1).int(), r["route_p"])

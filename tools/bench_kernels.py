@@ -28,7 +28,8 @@ def main():
     shapes = []
     M = NB * S
     shapes += [("qkv   K1024 N3072", dict(M=M, N=3072, K=1024), None), ("oproj K1024 N1024 f32res", dict(M=M, N=1024, K=1024), "res"),
-               ("fc1   K1024 N4096 gelu", dict(M=M, N=4096, K=1024), "gelu"), ("fc2   K4096 N1024 f32res", dict(M=M, N=1024, K=4096), "res")]
+               ("fc1   K1024 N4096 gelu", dict(M=M, N=4096, K=1024), "gelu"), ("fc1x  K1024 N4096 noact", dict(M=M, N=4096, K=1024), None),
+               ("fc2   K4096 N1024 f32res", dict(M=M, N=1024, K=4096), "res")]
     convs = [("conv 256->256 @96x128", 96, 128, 256, 256), ("conv 256->256 @192x256", 192, 256, 256, 256), ("conv 256->128 @192x256", 192, 256, 256, 128),
              ("conv 256->256 @48x64", 48, 64, 256, 256), ("conv 1024->256 @24x32", 24, 32, 1024, 256), ("conv 128->32 @384x512", 384, 512, 128, 32)]
     tiles = [int(t) for t in a.tiles.split(",")]
