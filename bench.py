@@ -159,9 +159,9 @@ def main():
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
                 mode = {"gemm": "ELi0E", "conv": "ELi1E"}[kind]
                 dims = TILE_NAMES[tile].split("s")[0].split("x")
-                for name, v in pm["kernels"].items():
+                for name, v in pm["modes"][precision]["kernels"].items():
                     if ("igemm_kernel" in name and f"Li{dims[0]}ELi{dims[1]}E" in name and f"Li{dims[2]}E" in name and mode in name
-                            and ("DF16_" in name) == (args.dtype == "f16") and B == 32 and pm.get("precision", "fast") == precision):
+                            and ("DF16_" in name) == (args.dtype == "f16") and B == 32):
                         traffic = round(v["hbm_bytes_per_launch_corrected"])
                         break
             except Exception:
