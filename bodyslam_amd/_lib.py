@@ -43,6 +43,7 @@ class GemmDesc(C.Structure):
         ("shuffle_s", C.c_int32), ("shuffle_cout", C.c_int32),
         ("qkv_hidden", C.c_int32), ("qkv_tokens", C.c_int32), ("qkv_sp", C.c_int32), ("q_scale", C.c_float),
         ("tile", C.c_int32), ("seg1", C.c_int32), ("out_split_off", C.c_int32), ("res_split_off", C.c_int32),
+        ("f8_seg", C.c_int32), ("f8_scales", C.c_uint32), ("out_f8", C.c_int32),
     ]
 
 
@@ -142,7 +143,7 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
                    act: int = ACT_NONE, scale: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
                    res2: Optional[torch.Tensor] = None, ldr: int = 0, ldo: Optional[int] = None, out_group=None,
                    shuffle=None, qkv=None, a_offset: int = 0, tile: int = 0, seg1: int = 0, out_split_off: int = 0,
-                   res_split_off: int = 0) -> GemmDesc:
+                   res_split_off: int = 0, f8_seg: int = 0, f8_scales=(127, 127, 127, 127), out_f8=None) -> GemmDesc:
     """Fill a bs_gemm_desc.  conv = (Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_h, pad_w) or None;
     out_group = (rows, stride, offset); shuffle = (s, Cout, Hgrid, Wgrid);
     qkv = (hidden, tokens, Sp, q_scale, out_k, out_vt); a_offset in elements."""
@@ -187,6 +188,9 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
         d.out3 = out_vt.data_ptr()
     d.tile = tile
     d.seg1, d.out_split_off, d.res_split_off = seg1, out_split_off, res_split_off
+    d.f8_seg = f8_seg
+    d.f8_scales = f8_scales[0] | (f8_scales[1] << 8) | (f8_scales[2] << 16) | (f8_scales[3] << 24)
+    d.out_f8 = 0 if out_f8 is None else ((out_f8[0] & 0xff) | ((out_f8[1] & 0xff) << 8))
     return d
 
 
@@ -216,7 +220,9 @@ class Plan:
         self.names.append(name)
         # bookkeeping for the roofline: which kernel instantiation and how many algorithmic FLOPs
         self.gemm_info[len(self.calls) - 1] = dict(
-            name=name, tile=load_library().bs_gemm_tile(C.byref(d)), conv=bool(d.conv), flops=2.0 * d.M * d.N * d.K,
+            name=name, tile=load_library().bs_gemm_tile(C.byref(d)), conv=bool(d.conv),
+            # executed work in 16-bit-MFMA-equivalents: an FP8 correction stage covers 128 k in the time of 64
+            flops=2.0 * d.M * d.N * (d.K + d.f8_seg / 2),
             # algorithmic FLOPs exclude the extra passes of a split-precision product
             alg_flops=2.0 * d.M * d.N * (d.K / kw.get("precision_passes", 1)),
             bytes=float(d.M) * (d.Cin if d.conv else d.K) * 2 + float(d.N) * d.K * 2 + float(d.M) * d.N * (4 if d.out_dtype == F32 else 2))
@@ -265,6 +271,30 @@ class Plan:
             if i < len(self.calls):
                 fn, args = self.calls[i]
                 check(fn(*args, st), self.names[i])
+
+
+def f8_weight(w: torch.Tensor, dtype) -> tuple:
+    """fp32 [N, K] -> ([N, 2K] `dtype`-typed rows of [W_hi16 | W_lo8 | W_hi8] bytes, (sb0, sb1)): the weight side of bs_gemm's
+    FP8 correction segment.  W_hi8 = e4m3(W_hi * 2^e_hi), W_lo8 = e4m3((W - W_hi) * 2^e_lo) with per-matrix power-of-two
+    scales that put the largest magnitude just under e4m3's 448; sb0 / sb1 are the E8M0 exponents bs_gemm applies to the
+    lo / hi plane (127 - e)."""
+    import math
+    w = w.detach().float().cpu()
+    hi = w.to(dtype)
+    lo = w - hi.float()
+
+    def plane(t):
+        mx = float(t.abs().max())
+        e = 0 if mx == 0.0 else min(int(math.floor(math.log2(448.0 / mx))), 100)
+        return (t * (2.0 ** e)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8), e
+
+    hi8, e_hi = plane(hi.float())
+    lo8, e_lo = plane(lo)
+    row = torch.cat([hi.contiguous().view(torch.uint8).view(w.shape[0], -1), lo8, hi8], 1).contiguous()
+    return row.view(dtype), (127 - e_lo, 127 - e_hi)
+
+
+F8_ACT_HI_EXP, F8_ACT_LO_EXP = 0, 11          # include/bodyslam_hip.h BS_F8_ACT_*_EXP
 
 
 def conv_weight(w_ohwi: torch.Tensor) -> torch.Tensor:

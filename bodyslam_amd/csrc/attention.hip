@@ -197,7 +197,20 @@ __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict_
                     ol[e] = T16<T>::from_f32(y - T16<T>::to_f32(o[e]));
                 }
                 *reinterpret_cast<typename T16<T>::v4*>(orow + dh * 32 + 8 * gg + 4 * h2) = o;
-                if (split) *reinterpret_cast<typename T16<T>::v4*>(orow + nh * 64 + dh * 32 + 8 * gg + 4 * h2) = ol;
+                if (split == 2) {      // (hi16 | hi8 | lo8) planes of a 4*nh*64-byte row
+                    const int col = head * 64 + dh * 32 + 8 * gg + 4 * h2;
+                    char* planes = reinterpret_cast<char*>(orow - head * 64 + nh * 64);
+                    const float sh = __builtin_ldexpf(1.0f, F8_ACT_HI_EXP), sl = __builtin_ldexpf(1.0f, F8_ACT_LO_EXP);
+                    float yv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) yv[e] = oacc[dh][gg * 4 + e] * inv;
+                    *reinterpret_cast<int*>(planes + col) = f8_pack4(yv[0] * sh, yv[1] * sh, yv[2] * sh, yv[3] * sh);
+                    *reinterpret_cast<int*>(planes + nh * 64 + col) =
+                        f8_pack4((yv[0] - T16<T>::to_f32(o[0])) * sl, (yv[1] - T16<T>::to_f32(o[1])) * sl, (yv[2] - T16<T>::to_f32(o[2])) * sl,
+                                 (yv[3] - T16<T>::to_f32(o[3])) * sl);
+                } else if (split) {
+                    *reinterpret_cast<typename T16<T>::v4*>(orow + nh * 64 + dh * 32 + 8 * gg + 4 * h2) = ol;
+                }
             }
     }
 }
@@ -229,7 +242,7 @@ extern "C" int bs_attention(const void* q, const void* k, const void* vt, const 
     if (!initialized()) { set_error("bs_attention: call bs_init first"); return BS_ERR_NOT_INIT; }
     BS_REQUIRE(q && k && vt && bias && out && B >= 0 && nh > 0 && S > 0, "bs_attention: bad argument");
     BS_REQUIRE(Sp % 64 == 0 && Sp >= S, "bs_attention: Sp=%d must be a multiple of 64 and >= S=%d", Sp, S);
-    const int split = (dtype & 16) ? 1 : 0;            // bit 4: out holds (hi | lo) pairs, [B*S, 2*nh*64]
+    const int split = (dtype & 32) ? 2 : ((dtype & 16) ? 1 : 0);   // bit 4: (hi | lo) 16-bit pairs; bit 5: (hi16 | hi8 | lo8); [B*S, 2*nh*64]
     dtype &= 15;
     BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_attention: dtype");
     if (B == 0) return BS_OK;

@@ -109,6 +109,17 @@ __device__ __forceinline__ float apply_act(float y, int act) {
     return y;
 }
 
+// four floats -> four OCP e4m3 bytes (round to nearest even, saturating at +-448), element 0 in the low byte
+__device__ __forceinline__ int f8_pack4(float a, float b, float c, float d) {
+    auto cl = [](float v) { return fminf(fmaxf(v, -448.0f), 448.0f); };
+    int r = 0;
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(cl(a), cl(b), r, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(cl(c), cl(d), r, true);
+    return r;
+}
+// exponents of the (hi16 | hi8 | lo8) activation format: hi8 = e4m3(y * 2^BS_F8_ACT_HI_EXP), lo8 = e4m3((y - hi16) * 2^BS_F8_ACT_LO_EXP)
+constexpr int F8_ACT_HI_EXP = BS_F8_ACT_HI_EXP, F8_ACT_LO_EXP = BS_F8_ACT_LO_EXP;
+
 // async global -> LDS, 16 bytes per lane; LDS destination = wave-uniform base + lane*16
 __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,

@@ -78,7 +78,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
             typename T16<T>::v4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(y[e]);
-            if (split) {
+            if (split == 2) {          // (hi16 | hi8 | lo8) planes of a 4*cols-byte row
+                T* rowp = out16 + (int64_t)row * cols * 2;
+                *reinterpret_cast<typename T16<T>::v4*>(rowp + vi * 4) = o;
+                const float sh = __builtin_ldexpf(1.0f, F8_ACT_HI_EXP), sl = __builtin_ldexpf(1.0f, F8_ACT_LO_EXP);
+                char* planes = reinterpret_cast<char*>(rowp + cols);
+                *reinterpret_cast<int*>(planes + vi * 4) = f8_pack4(y[0] * sh, y[1] * sh, y[2] * sh, y[3] * sh);
+                *reinterpret_cast<int*>(planes + cols + vi * 4) =
+                    f8_pack4((y[0] - T16<T>::to_f32(o[0])) * sl, (y[1] - T16<T>::to_f32(o[1])) * sl, (y[2] - T16<T>::to_f32(o[2])) * sl,
+                             (y[3] - T16<T>::to_f32(o[3])) * sl);
+            } else if (split) {
                 typename T16<T>::v4 ol;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ol[e] = T16<T>::from_f32(y[e] - T16<T>::to_f32(o[e]));
@@ -197,7 +206,12 @@ __global__ __launch_bounds__(256) void pre_patches_kernel(const uint8_t* frames,
     if (img >= B) x = g.nw - 1 - x;  // torch.flip(x, dims=[3]) of the network input
     const float v = pre_sample(frames + (int64_t)b * g.H * g.W * 3, g, c, y, x);
     const T hi = T16<T>::from_f32(v);
-    if (split) {   // rows of [768 hi | 768 lo]
+    if (split == 2) {   // rows of [768 hi16 | 768 hi8 | 768 lo8]
+        out[r * 1536 + k] = hi;
+        char* planes = reinterpret_cast<char*>(out + r * 1536 + 768);
+        planes[k] = (char)(f8_pack4(v * __builtin_ldexpf(1.0f, F8_ACT_HI_EXP), 0.f, 0.f, 0.f) & 0xff);
+        planes[768 + k] = (char)(f8_pack4((v - T16<T>::to_f32(hi)) * __builtin_ldexpf(1.0f, F8_ACT_LO_EXP), 0.f, 0.f, 0.f) & 0xff);
+    } else if (split) {   // rows of [768 hi | 768 lo]
         out[r * 1536 + k] = hi;
         out[r * 1536 + 768 + k] = T16<T>::from_f32(v - T16<T>::to_f32(hi));
     } else {
@@ -348,7 +362,7 @@ extern "C" int bs_layernorm(const float* x, const float* gamma, const float* bet
                             int32_t cols, float eps, int32_t dtype, void* stream) {
     BS_ENTRY("bs_layernorm");
     BS_REQUIRE(x && gamma && beta && (out16 || out32) && rows >= 0 && cols > 0 && cols % 4 == 0, "bs_layernorm: bad argument");
-    const int split = (dtype & 16) ? 1 : 0;            // bit 4: out16 holds (hi | lo) pairs, [rows, 2*cols]
+    const int split = (dtype & 32) ? 2 : ((dtype & 16) ? 1 : 0);   // bit 4: (hi | lo) 16-bit pairs; bit 5: (hi16 | hi8 | lo8)
     dtype &= 15;
     BS_REQUIRE(!out16 || dtype == BS_F16 || dtype == BS_BF16, "bs_layernorm: dtype");
     if (rows == 0) return BS_OK;
@@ -392,7 +406,7 @@ extern "C" int bs_preprocess_patches(const uint8_t* frames, void* out, int32_t B
     BS_ENTRY("bs_preprocess_patches");
     BS_REQUIRE(frames && out && B >= 0 && H > 1 && W > 1 && nh % 16 == 0 && nw % 16 == 0 && nh > 0 && nw > 0,
                "bs_preprocess_patches: bad geometry");
-    const int split = (out_dtype & 16) ? 1 : 0;        // bit 4: rows are (hi | lo) pairs, [., 2*768]
+    const int split = (out_dtype & 32) ? 2 : ((out_dtype & 16) ? 1 : 0);   // bit 4: (hi | lo) pairs, bit 5: (hi16 | hi8 | lo8); [., 2*768]
     out_dtype &= 15;
     BS_REQUIRE(out_dtype == BS_F16 || out_dtype == BS_BF16, "bs_preprocess_patches: dtype");
     if (B == 0) return BS_OK;

@@ -56,6 +56,7 @@ static int launch_tile(IgemmParams& p, int dtype, bool conv, int tile, hipStream
 // on the same stream (same kernel family; IgemmParams::m_begin offsets its rows).
 static int dispatch(IgemmParams& p, int dtype, bool conv, int tile, hipStream_t st) {
     tile = auto_tile(p.M, p.N, p.K, tile, conv);
+    if (p.f8_seg > 0 && (tile == 10 || tile == 11)) tile = 9;    // the FP8 stage is built for the BK = 64 ring tiles
     int BM, BN;
     tile_dims(tile, BM, BN);
     const int rem = p.M % BM, full = p.M / BM, ntn = cdiv(p.N, BN), cus = cu_count();
@@ -77,7 +78,11 @@ static int dispatch(IgemmParams& p, int dtype, bool conv, int tile, hipStream_t 
 
 }  // namespace bs
 
-extern "C" int bs_gemm_tile(const bs_gemm_desc* d) { return d ? bs::auto_tile(d->M, d->N, d->K, d->tile % 100, d->conv != 0) : BS_ERR_INVALID; }
+extern "C" int bs_gemm_tile(const bs_gemm_desc* d) {
+    if (!d) return BS_ERR_INVALID;
+    const int tile = bs::auto_tile(d->M, d->N, d->K + d->f8_seg / 2, d->tile % 100, d->conv != 0);
+    return (d->f8_seg > 0 && (tile == 10 || tile == 11)) ? 9 : tile;
+}
 
 extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
     using namespace bs;
@@ -93,9 +98,16 @@ extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
     IgemmParams p{};
     p.A = d->A; p.W = d->W; p.zero = zero_page();
     p.a_bytes = d->conv ? (long long)(d->M / (d->Hout > 0 && d->Wout > 0 ? d->Hout * d->Wout : 1)) * d->Hin * d->Win * d->lda * 2
-                        : ((long long)(d->M - 1) * d->lda + (d->K - d->seg1)) * 2;
-    BS_REQUIRE((long long)d->N * d->K * 2 < 0x7FFFFFF0ll, "bs_gemm: weight matrix too large for one descriptor");
-    p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda;
+                        : ((long long)(d->M - 1) * d->lda + (d->K + d->f8_seg / 2 - d->seg1)) * 2;
+    BS_REQUIRE((long long)d->N * (d->K + d->f8_seg / 2) * 2 < 0x7FFFFFF0ll, "bs_gemm: weight matrix too large for one descriptor");
+    p.M = d->M; p.N = d->N; p.K = d->K + d->f8_seg / 2; p.lda = d->lda;     // kernel K: 128-byte stages x 64
+    p.f8_seg = d->f8_seg;
+    p.f8_sa0 = d->f8_scales & 0xff; p.f8_sb0 = (d->f8_scales >> 8) & 0xff; p.f8_sa1 = (d->f8_scales >> 16) & 0xff; p.f8_sb1 = d->f8_scales >> 24;
+    p.out_f8 = d->out_f8;
+    BS_REQUIRE(d->f8_seg >= 0 && d->f8_seg % 256 == 0, "bs_gemm: f8_seg=%d must be a multiple of 256 (two halves of whole 128-byte stages)", d->f8_seg);
+    BS_REQUIRE(d->f8_seg == 0 || (!d->conv && d->seg1 == 0), "bs_gemm: the FP8 segment is built for plain single-segment GEMMs");
+    BS_REQUIRE(d->out_f8 == 0 || (d->out_mode == BS_OUT_PLAIN && d->out_split_off == d->N && d->N % 8 == 0 && d->ldo % 8 == 0 && d->out_dtype == d->dtype),
+               "bs_gemm: out_f8 needs a plain 16-bit output with out_split_off = N, N %% 8 == 0");
     p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin; p.Hout = d->Hout; p.Wout = d->Wout;
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
     if (d->conv) {

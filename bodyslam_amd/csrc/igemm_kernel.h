@@ -56,6 +56,11 @@ struct IgemmParams {
     float q_scale;
     int ntm, ntn;
     int m_begin;        // first output row this launch covers (a GEMM may be issued as a main launch + a tail launch)
+    int f8_seg;          // > 0: the last f8_seg K-ELEMENTS of every A / W row are FP8 (e4m3) bytes, multiplied on the block-scaled
+                         //      FP8 MFMA (2x the 16-bit rate): the correction products of a split-precision GEMM.  Two halves of
+                         //      f8_seg / 2 elements each with their own power-of-two scales (E8M0 exponents, 127 = 1.0)
+    int f8_sa0, f8_sb0, f8_sa1, f8_sb1;
+    int out_f8;          // > 0 with split_off: the output pair is (hi16 | hi8 | lo8), see store8_f8
     int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue, 8 = no tail split (host side)
 };
 
@@ -119,6 +124,38 @@ __device__ __forceinline__ void store8(void* base, int64_t off, int out_dtype, c
         for (int e = 0; e < 8; ++e) v[e] = T16<T>::from_f32(y[e]);
         *reinterpret_cast<v8*>(reinterpret_cast<T*>(base) + off) = v;
     }
+}
+
+// (hi16 | hi8 | lo8) output pair of 8 consecutive columns: hi = round16(y) at off; e4m3(y * 2^ea) at byte n of the hi8 plane,
+// e4m3((y - hi) * 2^el) in the lo8 plane.  Planes (in 16-bit element units from the row start): hi16 [0, N), hi8 [N, N + N/2),
+// lo8 [N + N/2, 2N).  `off` = row start + n, plane_off = N (= split_off).
+template <typename T>
+__device__ __forceinline__ void store8_f8(void* base, int64_t row_off, int n, int plane_off, const float (&y)[8], int ea, int el) {
+    typedef typename T16<T>::v8 v8;
+    v8 h;
+    float yl[8], yh[8];
+    const float sa = __builtin_ldexpf(1.0f, ea), sl = __builtin_ldexpf(1.0f, el);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h[e] = T16<T>::from_f32(y[e]);
+        yh[e] = fminf(fmaxf(y[e] * sa, -448.0f), 448.0f);
+        yl[e] = fminf(fmaxf((y[e] - T16<T>::to_f32(h[e])) * sl, -448.0f), 448.0f);
+    }
+    T* rowp = reinterpret_cast<T*>(base) + row_off;
+    *reinterpret_cast<v8*>(rowp + n) = h;
+    int ph0 = 0, ph1 = 0, pl0 = 0, pl1 = 0;
+    ph0 = __builtin_amdgcn_cvt_pk_fp8_f32(yh[0], yh[1], ph0, false);
+    ph0 = __builtin_amdgcn_cvt_pk_fp8_f32(yh[2], yh[3], ph0, true);
+    ph1 = __builtin_amdgcn_cvt_pk_fp8_f32(yh[4], yh[5], ph1, false);
+    ph1 = __builtin_amdgcn_cvt_pk_fp8_f32(yh[6], yh[7], ph1, true);
+    pl0 = __builtin_amdgcn_cvt_pk_fp8_f32(yl[0], yl[1], pl0, false);
+    pl0 = __builtin_amdgcn_cvt_pk_fp8_f32(yl[2], yl[3], pl0, true);
+    pl1 = __builtin_amdgcn_cvt_pk_fp8_f32(yl[4], yl[5], pl1, false);
+    pl1 = __builtin_amdgcn_cvt_pk_fp8_f32(yl[6], yl[7], pl1, true);
+    char* bytes = reinterpret_cast<char*>(rowp + plane_off);
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<i32x2*>(bytes + n) = i32x2{ph0, ph1};
+    *reinterpret_cast<i32x2*>(bytes + plane_off + n) = i32x2{pl0, pl1};
 }
 
 constexpr int NW_CHECK(int a, int b) { return a * b; }
@@ -302,13 +339,17 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
     const int a_base = (wm * TM + frow) * ROWB, b_base = (wn * TN + frow) * ROWB;
 
     const int nt = p.K / BK;
+    const int nt16 = nt - p.f8_seg / 128;     // stages multiplied as 16-bit data; the rest are FP8 correction stages (BK = 64 tiles)
     if constexpr (!PP) {
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s)
             if (s < nt) stage(s);
         int cbuf = 0, sbuf = STAGES - 1;   // buffer multiplied this iteration / buffer staged this iteration
         v8 af[FM], bf[FN];
-        for (int t = 0; t < nt; ++t) {
+        // one iteration of the ring; F8 selects the multiply of the stage (two plain loops, not a branch inside one: a branch
+        // made the register allocator spill the accumulators)
+        auto iteration = [&](int t, auto f8_tag) {
+            constexpr bool F8 = decltype(f8_tag)::value;
             // my own DMA for tile t has landed once at most (tiles issued after t) x GL operations are outstanding
             const int younger = nt - 1 - t;
             if (STAGES >= 4 && younger >= 2) wait_vmcnt<(STAGES >= 4 ? 2 : 0) * GL>();
@@ -319,27 +360,59 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
             if (t + STAGES - 1 < nt && !(p.ablate & 1)) stage(sbuf);
             const char* sa = smem + cbuf * STAGE;
             const char* sb = sa + A_BYTES;
+            if constexpr (F8) {
+                // ---- FP8 correction stage: the 128-byte LDS rows hold 128 e4m3 values.  A lane supplies 32 of them per
+                // row: the same two 16-byte chunks (fq and 4 + fq) the 16-bit path reads -- A and W use the same
+                // permutation of k, so the product is unchanged -- as one 8-register operand of the 16x16x128 MFMA.
+                typedef int i32x4 __attribute__((ext_vector_type(4)));
+                typedef int i32x8 __attribute__((ext_vector_type(8)));
+                const bool second = t >= nt16 + ((nt - nt16) >> 1);
+                const int sca = (second ? p.f8_sa1 : p.f8_sa0) * 0x01010101, scb = (second ? p.f8_sb1 : p.f8_sb0) * 0x01010101;
+                auto ld8 = [&](const char* base) {
+                    const i32x4 lo = *reinterpret_cast<const i32x4*>(base + koff0);
+                    const i32x4 hi = *reinterpret_cast<const i32x4*>(base + koff1);
+                    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                };
+                i32x8 b8[FN];
 #pragma unroll
-            for (int kk = 0; kk < BK / 32; ++kk) {
-                const int ko = kk ? koff1 : koff0;
-                if (!(p.ablate & 2) || t == 0) {
-#pragma unroll
-                    for (int i = 0; i < FM; ++i) {
-                        af[i] = *reinterpret_cast<const v8*>(sa + a_base + i * 16 * ROWB + ko);
-                        if (RELU_A) af[i] = relu8<T>(af[i]);
-                    }
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const v8*>(sb + b_base + j * 16 * ROWB + ko);
-                }
+                for (int j = 0; j < FN; ++j) b8[j] = ld8(sb + b_base + j * 16 * ROWB);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int i = 0; i < FM; ++i)
+                for (int i = 0; i < FM; ++i) {     // one A fragment (8 registers) at a time: the kernel is at the 256-VGPR line
+                    const i32x8 a8 = ld8(sa + a_base + i * 16 * ROWB);
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) acc[i][j] = T16<T>::mfma16(bf[j], af[i], acc[i][j]);
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b8[j], a8, acc[i][j], 0, 0, 0, scb, 0, sca);
+                }
                 __builtin_amdgcn_s_setprio(0);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < BK / 32; ++kk) {
+                    const int ko = kk ? koff1 : koff0;
+                    if (!(p.ablate & 2) || t == 0) {
+#pragma unroll
+                        for (int i = 0; i < FM; ++i) {
+                            af[i] = *reinterpret_cast<const v8*>(sa + a_base + i * 16 * ROWB + ko);
+                            if (RELU_A) af[i] = relu8<T>(af[i]);
+                        }
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const v8*>(sb + b_base + j * 16 * ROWB + ko);
+                    }
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) acc[i][j] = T16<T>::mfma16(bf[j], af[i], acc[i][j]);
+                    __builtin_amdgcn_s_setprio(0);
+                }
             }
             cbuf = cbuf + 1 == STAGES ? 0 : cbuf + 1;
             sbuf = sbuf + 1 == STAGES ? 0 : sbuf + 1;
+        };
+        int t = 0;
+        for (; t < nt16; ++t) iteration(t, std::false_type{});
+        if constexpr (!CONV && BK == 64) {
+            for (; t < nt; ++t) iteration(t, std::true_type{});
         }
     } else {
         // ---- ping-pong schedule (BK = 32, 4-stage ring, 8 waves = two groups of four, one wave of each group per
@@ -542,7 +615,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                     void* dst = (p.out_mode == BS_OUT_QKV && which[j0] == 1) ? p.out2 : p.out;
                     const int so = p.out_mode != BS_OUT_QKV ? p.split_off : 0;
                     // the pair is one 8-wide store when both halves exist, are adjacent in the output and 16-byte aligned
-                    if (wide_ok && n0j[j1] < p.N && coff[j1] == coff[j0] + 4 && which[j1] == which[j0]) {
+                    if (p.out_f8) {     // PLAIN mode, N % 8 == 0 (checked on the host): (hi16 | hi8 | lo8) row planes
+                        store8_f8<T>(dst, roff, n0j[j0], so, y8, p.out_f8 & 0xff, (p.out_f8 >> 8) & 0xff);
+                    } else if (wide_ok && n0j[j1] < p.N && coff[j1] == coff[j0] + 4 && which[j1] == which[j0]) {
                         store8<T>(dst, roff + coff[j0], p.out_dtype, y8, so);
                     } else {
                         const float(&ya)[4] = *reinterpret_cast<const float(*)[4]>(y8);

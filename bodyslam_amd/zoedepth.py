@@ -119,6 +119,7 @@ class ZoeDepthEngine:
         self._bias_cache: Dict[Tuple[int, int], list] = {}
         self._plans: Dict[Tuple, "_ZoePlan"] = {}
         self._raw_tables = []
+        self.f8s: Dict[str, Tuple[int, int]] = {}
         with torch.no_grad():
             self._ingest(weights)
 
@@ -139,6 +140,17 @@ class ZoeDepthEngine:
         hi = t.to(self.dtype)
         lo = (t - hi.float()).to(self.dtype)
         return hi, lo
+
+    def _w8(self, key: str, t: torch.Tensor) -> torch.Tensor:
+        """backbone GEMM weight [N, K]; accurate: rows of [W_hi16 | W_lo8 | W_hi8] bytes (bs_gemm's FP8 correction segment);
+        the two plane scales go to self.f8s[key]."""
+        if not self.acc:
+            return self._h(t)
+        if t.shape[1] % 128 != 0:        # the FP8 segment walks whole 128-byte stages per plane: fall back to three 16-bit passes
+            return self._wn(t)
+        w8, sb = L.f8_weight(t, self.dtype)
+        self.f8s[key] = sb
+        return w8.to(self.dev)
 
     def _wn(self, t: torch.Tensor) -> torch.Tensor:
         """plain GEMM weight [N, K]; accurate: [N, 3K] = [W_hi | W_hi | W_lo] against A = [hi | lo], then hi again."""
@@ -161,21 +173,21 @@ class ZoeDepthEngine:
         c, w = self.cfg, self.w
         g = lambda k: sd[k].detach().float()
         pe = "backbone.beit.embeddings."
-        w["pe.w"] = self._wn(g(pe + "patch_embeddings.projection.weight").reshape(c.hidden, -1))
+        w["pe.w"] = self._w8("pe.w", g(pe + "patch_embeddings.projection.weight").reshape(c.hidden, -1))
         w["pe.b"] = self._f(g(pe + "patch_embeddings.projection.bias"))
         w["cls"] = self._f(g(pe + "cls_token").reshape(-1))
         for l in range(c.layers):
             p = f"backbone.beit.layers.{l}."
             w[f"l{l}.ln1.g"], w[f"l{l}.ln1.b"] = self._f(g(p + "layernorm_before.weight")), self._f(g(p + "layernorm_before.bias"))
             w[f"l{l}.ln2.g"], w[f"l{l}.ln2.b"] = self._f(g(p + "layernorm_after.weight")), self._f(g(p + "layernorm_after.bias"))
-            w[f"l{l}.qkv.w"] = self._wn(torch.cat([g(p + "attention.q_proj.weight"), g(p + "attention.k_proj.weight"),
-                                                   g(p + "attention.v_proj.weight")], 0))
+            w[f"l{l}.qkv.w"] = self._w8(f"l{l}.qkv.w", torch.cat([g(p + "attention.q_proj.weight"), g(p + "attention.k_proj.weight"),
+                                                                  g(p + "attention.v_proj.weight")], 0))
             # k_proj has no bias (HF modeling_beit.py:305-307)
             w[f"l{l}.qkv.b"] = self._f(torch.cat([g(p + "attention.q_proj.bias"), torch.zeros(c.hidden),
                                                   g(p + "attention.v_proj.bias")], 0))
-            w[f"l{l}.o.w"], w[f"l{l}.o.b"] = self._wn(g(p + "attention.o_proj.weight")), self._f(g(p + "attention.o_proj.bias"))
-            w[f"l{l}.fc1.w"], w[f"l{l}.fc1.b"] = self._wn(g(p + "mlp.fc1.weight")), self._f(g(p + "mlp.fc1.bias"))
-            w[f"l{l}.fc2.w"], w[f"l{l}.fc2.b"] = self._wn(g(p + "mlp.fc2.weight")), self._f(g(p + "mlp.fc2.bias"))
+            w[f"l{l}.o.w"], w[f"l{l}.o.b"] = self._w8(f"l{l}.o.w", g(p + "attention.o_proj.weight")), self._f(g(p + "attention.o_proj.bias"))
+            w[f"l{l}.fc1.w"], w[f"l{l}.fc1.b"] = self._w8(f"l{l}.fc1.w", g(p + "mlp.fc1.weight")), self._f(g(p + "mlp.fc1.bias"))
+            w[f"l{l}.fc2.w"], w[f"l{l}.fc2.b"] = self._w8(f"l{l}.fc2.w", g(p + "mlp.fc2.weight")), self._f(g(p + "mlp.fc2.bias"))
             w[f"l{l}.lam1"], w[f"l{l}.lam2"] = self._f(g(p + "lambda_1")), self._f(g(p + "lambda_2"))
             self._raw_tables.append(g(p + "relative_position_bias.relative_position_bias_table"))
         factors = (4, 2, 1, 0.5)
@@ -335,28 +347,47 @@ class _ZoePlan:
         hid = e16(NB * S, c.intermediate * m2)
         taps16 = [e16(NB * S, Hd * m2) for _ in c.taps]
 
-        def bgemm(name, A, Wt, out, M, N, K, **kw):
-            """backbone GEMM.  Accurate mode: A = (hi | lo) [M, 2K] against [W_hi | W_hi | W_lo] -- one launch evaluates
-            A_hi W_hi + A_lo W_hi + A_hi W_lo (bs_gemm K segments)."""
-            P.gemm(name, A, Wt, out, M=M, N=N, K=K * np3, lda=K * m2, seg1=K if acc else 0, precision_passes=np3, **kw)
+        f8s = eng.f8s
+
+        def fmt(*wkeys):
+            """producer format flag of an activation: 32 = (hi16 | hi8 | lo8) when every consumer GEMM runs its corrections on
+            the FP8 MFMA, 16 = (hi | lo) 16-bit pairs otherwise (accurate mode), 0 = single (fast mode)."""
+            if not acc:
+                return 0
+            return 32 if all(k_ in f8s for k_ in wkeys) else 16
+
+        def bgemm(name, A, wkey, out, M, N, K, **kw):
+            """backbone GEMM.  Accurate mode: A_hi W_hi + A_hi W_lo + A_lo W_hi in one launch -- the two corrections on the
+            block-scaled FP8 MFMA where the weight was packed for it (A = [hi16 | hi8 | lo8], 2 pass-equivalents), else as
+            K segments of 16-bit (hi | lo) pairs (3 passes)."""
+            if acc and wkey in f8s:
+                sb0, sb1 = f8s[wkey]
+                P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=2 * K, f8_seg=2 * K,
+                       f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1), precision_passes=1, **kw)
+            else:
+                P.gemm(name, A, w[wkey], out, M=M, N=N, K=K * np3, lda=K * m2, seg1=K if acc else 0, precision_passes=np3, **kw)
 
         # ---- Z1 + Z2: pre-processing fused with the patch gather, patch embedding, cls token
         PK = 3 * c.patch * c.patch
-        P.add("preprocess", "bs_preprocess_patches", self.frames, patches, B, H, W, nh_, nw_, int(flip), L.dt(patches) | SP)
+        P.add("preprocess", "bs_preprocess_patches", self.frames, patches, B, H, W, nh_, nw_, int(flip), L.dt(patches) | fmt("pe.w"))
         P.add("cls", "bs_fill_rows", x, w["cls"], NB, S, Hd)
-        bgemm("patch_embed", patches, w["pe.w"], x, NB * T0, Hd, PK, bias=w["pe.b"], out_group=(T0, S, 1))
+        bgemm("patch_embed", patches, "pe.w", x, NB * T0, Hd, PK, bias=w["pe.b"], out_group=(T0, S, 1))
         P.mark("embed", x, ("tokens", NB, S, Hd))
         # ---- Z3: BEiT layers
         ti = 0
         for l in range(c.layers):
-            P.add(f"l{l}.ln1", "bs_layernorm", x, w[f"l{l}.ln1.g"], w[f"l{l}.ln1.b"], xn, None, NB * S, Hd, c.ln_eps, L.dt(xn) | SP)
-            bgemm(f"l{l}.qkv", xn, w[f"l{l}.qkv.w"], q, NB * S, 3 * Hd, Hd, bias=w[f"l{l}.qkv.b"], qkv=(Hd, S, Sp, LOG2E / math.sqrt(64.0), k, vt))
-            P.add(f"l{l}.attn", "bs_attention", q, k, vt, bias[l], ao, NB, c.heads, S, Sp, L.dt(q) | SP)
-            bgemm(f"l{l}.o", ao, w[f"l{l}.o.w"], x, NB * S, Hd, Hd, bias=w[f"l{l}.o.b"], scale=w[f"l{l}.lam1"], res=x, ldr=Hd)
-            P.add(f"l{l}.ln2", "bs_layernorm", x, w[f"l{l}.ln2.g"], w[f"l{l}.ln2.b"], xn, None, NB * S, Hd, c.ln_eps, L.dt(xn) | SP)
-            bgemm(f"l{l}.fc1", xn, w[f"l{l}.fc1.w"], hid, NB * S, c.intermediate, Hd, bias=w[f"l{l}.fc1.b"], act=L.ACT_GELU,
-                  ldo=c.intermediate * m2, out_split_off=c.intermediate if acc else 0)
-            bgemm(f"l{l}.fc2", hid, w[f"l{l}.fc2.w"], x, NB * S, Hd, c.intermediate, bias=w[f"l{l}.fc2.b"], scale=w[f"l{l}.lam2"], res=x, ldr=Hd)
+            P.add(f"l{l}.ln1", "bs_layernorm", x, w[f"l{l}.ln1.g"], w[f"l{l}.ln1.b"], xn, None, NB * S, Hd, c.ln_eps,
+                  L.dt(xn) | fmt(f"l{l}.qkv.w"))
+            bgemm(f"l{l}.qkv", xn, f"l{l}.qkv.w", q, NB * S, 3 * Hd, Hd, bias=w[f"l{l}.qkv.b"], qkv=(Hd, S, Sp, LOG2E / math.sqrt(64.0), k, vt))
+            P.add(f"l{l}.attn", "bs_attention", q, k, vt, bias[l], ao, NB, c.heads, S, Sp, L.dt(q) | fmt(f"l{l}.o.w"))
+            bgemm(f"l{l}.o", ao, f"l{l}.o.w", x, NB * S, Hd, Hd, bias=w[f"l{l}.o.b"], scale=w[f"l{l}.lam1"], res=x, ldr=Hd)
+            P.add(f"l{l}.ln2", "bs_layernorm", x, w[f"l{l}.ln2.g"], w[f"l{l}.ln2.b"], xn, None, NB * S, Hd, c.ln_eps,
+                  L.dt(xn) | fmt(f"l{l}.fc1.w"))
+            hid8 = fmt(f"l{l}.fc2.w") == 32
+            bgemm(f"l{l}.fc1", xn, f"l{l}.fc1.w", hid, NB * S, c.intermediate, Hd, bias=w[f"l{l}.fc1.b"], act=L.ACT_GELU,
+                  ldo=c.intermediate * m2, out_split_off=c.intermediate if acc else 0,
+                  out_f8=(L.F8_ACT_HI_EXP, L.F8_ACT_LO_EXP) if hid8 else None)
+            bgemm(f"l{l}.fc2", hid, f"l{l}.fc2.w", x, NB * S, Hd, c.intermediate, bias=w[f"l{l}.fc2.b"], scale=w[f"l{l}.lam2"], res=x, ldr=Hd)
             P.mark(f"layer{l + 1}", x, ("tokens", NB, S, Hd))
             if (l + 1) in c.taps:
                 if acc:

@@ -59,6 +59,12 @@ int bs_version(void);
  *                          out -> Q [B,nh,Sp,64] (scaled by q_scale), out2 -> K [B,nh,Sp,64],
  *                          out3 -> V^T [B,nh,64,Sp]
  */
+/* The (hi16 | hi8 | lo8) operand format of accurate mode's FP8 correction passes: a row of C features is
+ * [round16(y) x C | e4m3(y * 2^BS_F8_ACT_HI_EXP) x C | e4m3((y - round16(y)) * 2^BS_F8_ACT_LO_EXP) x C] = 4C bytes.
+ * Producers take the flag `| 32` on their dtype argument (bs_layernorm, bs_attention, bs_preprocess_patches) or
+ * bs_gemm_desc.out_f8; the consumer is bs_gemm with f8_seg = 2C. */
+#define BS_F8_ACT_HI_EXP 0
+#define BS_F8_ACT_LO_EXP 11
 typedef struct bs_gemm_desc {
     const void* A;
     const void* W;
@@ -95,6 +101,16 @@ typedef struct bs_gemm_desc {
     int32_t seg1;
     int32_t out_split_off;
     int32_t res_split_off;
+    /* FP8 correction segment (plain GEMMs).  f8_seg > 0: every A row and every W row continues, after its K 16-bit values, with
+     * f8_seg bytes of OCP e4m3 values that are multiplied on the block-scaled FP8 MFMA (2x the 16-bit rate).  They come in
+     * two halves of f8_seg / 2 (a multiple of 128) each; half h contributes 2^(sa_h - 127 + sb_h - 127) * sum_k A8[k] W8[k].
+     * f8_scales packs the four E8M0 exponents: sa0 | sb0 << 8 | sa1 << 16 | sb1 << 24.  With A = [hi16 | hi8 | lo8] and
+     * W = [W_hi16 | W_lo8 | W_hi8] this is A_hi W_hi + A_hi W_lo + A_lo W_hi at 2 pass-equivalents instead of 3.
+     * out_f8 != 0 (with out_split_off = N, ldo = 2N, N % 8 == 0): the output row is written in that A format,
+     * [hi16 x N | e4m3(y * 2^ea) x N | e4m3((y - hi) * 2^el) x N], out_f8 = ea | el << 8. */
+    int32_t f8_seg;
+    uint32_t f8_scales;
+    int32_t out_f8;
 } bs_gemm_desc;
 int bs_gemm(const bs_gemm_desc* d, void* stream);
 /* the tile variant bs_gemm will pick for this descriptor (1: 128x128, 2: 128x64, 3: 128x32, 4: 256x128) */

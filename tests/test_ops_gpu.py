@@ -185,6 +185,44 @@ def test_split_precision_plain(L, tile):
     assert (o32.double() - refw).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("tile", [0, 9, 1])
+def test_f8_correction_gemm(L, dtype, tile):
+    """Split-precision product with the correction passes on the FP8 MFMA: A = [hi16 | hi8 | lo8] (written by LayerNorm's
+    `| 32` format), W = [W_hi16 | W_lo8 | W_hi8] (f8_weight).  Must land within a few 1e-5 relative of the fp64 product
+    (single pass: ~3e-4 fp16 / 2e-3 bf16), and the fc1-style epilogue must re-emit the same operand format."""
+    M, N, K = 700, 512, 256
+    x = rnd(M, K, seed=1)                                # fp32 rows; LayerNorm with gamma 1 / beta 0 makes the A operand
+    g, b = torch.ones(K, device=dev()), torch.zeros(K, device=dev())
+    A8 = torch.empty(M, 2 * K, device=dev(), dtype=dtype)
+    check = L.load_library().bs_layernorm(L.p(x), L.p(g), L.p(b), L.p(A8), None, M, K, 1e-6, L.dt(A8) | 32, L.stream_ptr())
+    assert check == 0
+    xn = F.layer_norm(x.double(), (K,), eps=1e-6)
+    w = rnd(N, K, seed=2, scale=1 / math.sqrt(K))
+    W8, (sb0, sb1) = L.f8_weight(w, dtype)
+    W8 = W8.to(dev())
+    out = torch.empty(M, N, device=dev())
+    L.gemm(A8, W8, out, M=M, N=N, K=K, lda=2 * K, f8_seg=2 * K, f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1), tile=tile)
+    ref = xn @ w.double().t()
+    err = (out.double() - ref).abs().max().item()
+    single = torch.empty(M, N, device=dev())
+    L.gemm(A8, w.to(dtype), single, M=M, N=N, K=K, lda=2 * K, tile=tile)
+    err1 = (single.double() - ref).abs().max().item()
+    report(f"f8 correction gemm {dtype} tile{tile}: max|err|={err:.2e} vs single-pass {err1:.2e}")
+    assert err < (1e-4 if dtype == torch.float16 else 8e-4) and err < 0.15 * err1
+    # epilogue re-emitting the operand format: out row = [hi16 x N | hi8 x N | lo8 x N]
+    o8 = torch.zeros(M, 2 * N, device=dev(), dtype=dtype)
+    L.gemm(A8, W8, o8, M=M, N=N, K=K, lda=2 * K, f8_seg=2 * K, f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1),
+           ldo=2 * N, out_split_off=N, out_f8=(L.F8_ACT_HI_EXP, L.F8_ACT_LO_EXP), tile=tile)
+    hi = o8[:, :N].float()
+    planes = o8[:, N:].contiguous().view(torch.uint8).view(M, 2 * N)
+    hi8 = planes[:, :N].contiguous().view(torch.float8_e4m3fn).float() * 2.0 ** -L.F8_ACT_HI_EXP
+    lo8 = planes[:, N:].contiguous().view(torch.float8_e4m3fn).float() * 2.0 ** -L.F8_ACT_LO_EXP
+    assert torch.equal(hi, out.to(dtype).float())
+    assert ((hi8 - out).abs() <= out.abs() * 2.0 ** -4 + 2.0 ** -9).all()
+    assert ((hi + lo8 - out).abs() <= out.abs() * (2.0 ** -15 if dtype == torch.float16 else 2.0 ** -12) + 2.0 ** -20).all()
+
+
 def test_split_precision_conv(L):
     dtype = torch.float16
     B, H, Wd, C, Co = 2, 24, 32, 64, 256
