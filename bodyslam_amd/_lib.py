@@ -43,7 +43,7 @@ class GemmDesc(C.Structure):
         ("shuffle_s", C.c_int32), ("shuffle_cout", C.c_int32),
         ("qkv_hidden", C.c_int32), ("qkv_tokens", C.c_int32), ("qkv_sp", C.c_int32), ("q_scale", C.c_float),
         ("tile", C.c_int32), ("seg1", C.c_int32), ("out_split_off", C.c_int32), ("res_split_off", C.c_int32),
-        ("f8_seg", C.c_int32), ("f8_scales", C.c_uint32), ("out_f8", C.c_int32),
+        ("f8_seg", C.c_int32), ("f8_scales", C.c_uint32), ("out_f8", C.c_int32), ("res_f8", C.c_int32),
     ]
 
 
@@ -143,7 +143,7 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
                    act: int = ACT_NONE, scale: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
                    res2: Optional[torch.Tensor] = None, ldr: int = 0, ldo: Optional[int] = None, out_group=None,
                    shuffle=None, qkv=None, a_offset: int = 0, tile: int = 0, seg1: int = 0, out_split_off: int = 0,
-                   res_split_off: int = 0, f8_seg: int = 0, f8_scales=(127, 127, 127, 127), out_f8=None) -> GemmDesc:
+                   res_split_off: int = 0, f8_seg: int = 0, f8_scales=(127, 127, 127, 127), out_f8=None, res_f8: bool = False) -> GemmDesc:
     """Fill a bs_gemm_desc.  conv = (Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_h, pad_w) or None;
     out_group = (rows, stride, offset); shuffle = (s, Cout, Hgrid, Wgrid);
     qkv = (hidden, tokens, Sp, q_scale, out_k, out_vt); a_offset in elements."""
@@ -191,6 +191,7 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
     d.f8_seg = f8_seg
     d.f8_scales = f8_scales[0] | (f8_scales[1] << 8) | (f8_scales[2] << 16) | (f8_scales[3] << 24)
     d.out_f8 = 0 if out_f8 is None else ((out_f8[0] & 0xff) | ((out_f8[1] & 0xff) << 8))
+    d.res_f8 = int(res_f8)
     return d
 
 
@@ -222,7 +223,7 @@ class Plan:
         self.gemm_info[len(self.calls) - 1] = dict(
             name=name, tile=load_library().bs_gemm_tile(C.byref(d)), conv=bool(d.conv),
             # executed work in 16-bit-MFMA-equivalents: an FP8 correction stage covers 128 k in the time of 64
-            flops=2.0 * d.M * d.N * (d.K + d.f8_seg / 2),
+            flops=2.0 * d.M * d.N * (d.K + (d.KH * d.KW if d.conv else 1) * d.f8_seg / 2),
             # algorithmic FLOPs exclude the extra passes of a split-precision product
             alg_flops=2.0 * d.M * d.N * (d.K / kw.get("precision_passes", 1)),
             bytes=float(d.M) * (d.Cin if d.conv else d.K) * 2 + float(d.N) * d.K * 2 + float(d.M) * d.N * (4 if d.out_dtype == F32 else 2))
@@ -291,6 +292,29 @@ def f8_weight(w: torch.Tensor, dtype) -> tuple:
     hi8, e_hi = plane(hi.float())
     lo8, e_lo = plane(lo)
     row = torch.cat([hi.contiguous().view(torch.uint8).view(w.shape[0], -1), lo8, hi8], 1).contiguous()
+    return row.view(dtype), (127 - e_lo, 127 - e_hi)
+
+
+def f8_conv_weight(w_ohwi: torch.Tensor, dtype) -> tuple:
+    """fp32 [O, kh, kw, I] -> the conv-mode counterpart of f8_weight: K order [W_hi16: chunk64, tap, 64][W_lo8: chunk128, tap, 128]
+    [W_hi8: chunk128, tap, 128] (the kernel's chunk walk continues from the 16-bit channels through the two FP8 planes)."""
+    import math
+    w = w_ohwi.detach().float().cpu()
+    O, kh, kw, I = w.shape
+    assert I % 128 == 0, I
+    hi = w.to(dtype)
+    lo = w - hi.float()
+
+    def plane(t):
+        mx = float(t.abs().max())
+        e = 0 if mx == 0.0 else min(int(math.floor(math.log2(448.0 / mx))), 100)
+        q = (t * (2.0 ** e)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+        return q.reshape(O, kh, kw, I // 128, 128).permute(0, 3, 1, 2, 4).reshape(O, -1), e
+
+    hi8, e_hi = plane(hi.float())
+    lo8, e_lo = plane(lo)
+    hi16 = conv_weight(hi).view(torch.uint8).view(O, -1)
+    row = torch.cat([hi16, lo8, hi8], 1).contiguous()
     return row.view(dtype), (127 - e_lo, 127 - e_hi)
 
 

@@ -117,6 +117,12 @@ __device__ __forceinline__ int f8_pack4(float a, float b, float c, float d) {
     r = __builtin_amdgcn_cvt_pk_fp8_f32(cl(c), cl(d), r, true);
     return r;
 }
+// four e4m3 bytes -> floats
+__device__ __forceinline__ void f8_unpack4(int packed, float (&o)[4]) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(packed, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(packed, true);
+    o[0] = a[0]; o[1] = a[1]; o[2] = b[0]; o[3] = b[1];
+}
 // exponents of the (hi16 | hi8 | lo8) activation format: hi8 = e4m3(y * 2^BS_F8_ACT_HI_EXP), lo8 = e4m3((y - hi16) * 2^BS_F8_ACT_LO_EXP)
 constexpr int F8_ACT_HI_EXP = BS_F8_ACT_HI_EXP, F8_ACT_LO_EXP = BS_F8_ACT_LO_EXP;
 

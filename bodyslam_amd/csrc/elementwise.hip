@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* x, T* out, int64
 
 // fp32 [rows, C] -> 16-bit (hi | lo) pairs [rows, 2C]: x = hi + lo to ~22 bits (split-precision operands)
 template <typename T>
-__global__ __launch_bounds__(256) void cast_split_kernel(const float* x, T* out, int64_t rows, int C) {
+__global__ __launch_bounds__(256) void cast_split_kernel(const float* x, T* out, int64_t rows, int C, int f8) {
     const int c4n = C >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows * c4n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / c4n;
@@ -127,18 +127,43 @@ __global__ __launch_bounds__(256) void cast_split_kernel(const float* x, T* out,
             l[e] = T16<T>::from_f32(t[e] - T16<T>::to_f32(h[e]));
         }
         *reinterpret_cast<typename T16<T>::v4*>(out + r * 2 * C + c) = h;
-        *reinterpret_cast<typename T16<T>::v4*>(out + r * 2 * C + C + c) = l;
+        if (f8) {     // (hi16 | hi8 | lo8)
+            const float sh = __builtin_ldexpf(1.0f, F8_ACT_HI_EXP), sl = __builtin_ldexpf(1.0f, F8_ACT_LO_EXP);
+            char* planes = reinterpret_cast<char*>(out + r * 2 * C + C);
+            *reinterpret_cast<int*>(planes + c) = f8_pack4(t[0] * sh, t[1] * sh, t[2] * sh, t[3] * sh);
+            *reinterpret_cast<int*>(planes + C + c) = f8_pack4((t[0] - T16<T>::to_f32(h[0])) * sl, (t[1] - T16<T>::to_f32(h[1])) * sl,
+                                                                (t[2] - T16<T>::to_f32(h[2])) * sl, (t[3] - T16<T>::to_f32(h[3])) * sl);
+        } else {
+            *reinterpret_cast<typename T16<T>::v4*>(out + r * 2 * C + C + c) = l;
+        }
     }
 }
 
 // ReLU of a (hi | lo) tensor [rows, 2C]: the sign of hi + lo is the sign of hi (|lo| <= ulp(hi)/2)
 template <typename T>
-__global__ __launch_bounds__(256) void relu_split_kernel(const T* x, T* out, int64_t rows, int C) {
+__global__ __launch_bounds__(256) void relu_split_kernel(const T* x, T* out, int64_t rows, int C, int f8) {
     typedef typename T16<T>::v8 v8;
     const int c8n = C >> 3;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows * c8n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / c8n;
         const int c = (int)(i - r * c8n) * 8;
+        if (f8) {     // (hi16 | hi8 | lo8): the three planes are masked bytewise, nothing is decoded
+            v8 h = *reinterpret_cast<const v8*>(x + r * 2 * C + c);
+            const unsigned char* pin = reinterpret_cast<const unsigned char*>(x + r * 2 * C + C);
+            unsigned char* pout = reinterpret_cast<unsigned char*>(out + r * 2 * C + C);
+            unsigned long long h8 = *reinterpret_cast<const unsigned long long*>(pin + c), l8 = *reinterpret_cast<const unsigned long long*>(pin + C + c);
+            unsigned long long mask = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool pos = (float)h[e] > 0.0f;
+                h[e] = pos ? h[e] : T16<T>::from_f32(0.0f);
+                mask |= pos ? (0xffull << (8 * e)) : 0ull;
+            }
+            *reinterpret_cast<v8*>(out + r * 2 * C + c) = h;
+            *reinterpret_cast<unsigned long long*>(pout + c) = h8 & mask;
+            *reinterpret_cast<unsigned long long*>(pout + C + c) = l8 & mask;
+            continue;
+        }
         v8 h = *reinterpret_cast<const v8*>(x + r * 2 * C + c), l = *reinterpret_cast<const v8*>(x + r * 2 * C + C + c);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -233,7 +258,7 @@ __global__ __launch_bounds__(256) void pre_image_kernel(const uint8_t* frames, f
 // ---------------------------------------------------------------------------------------------
 // NHWC bilinear resize (+ optional add): thread = one 8-channel group of one output pixel
 // ---------------------------------------------------------------------------------------------
-template <typename T, bool ADD, bool SPLIT>
+template <typename T, bool ADD, int SPLIT>
 __global__ __launch_bounds__(256) void resize_nhwc_kernel(const T* x, const T* addend, T* out, int B, int Hin, int Win, int C, int Hout,
                                                            int Wout, float sy, float sx, int align) {
     // SPLIT: the tensors hold (hi | lo) pairs, C channels each (pixel stride 2C); the value hi + lo is resampled and re-split
@@ -258,17 +283,29 @@ __global__ __launch_bounds__(256) void resize_nhwc_kernel(const T* x, const T* a
     const int y1 = y0 + (y0 < Hin - 1 ? 1 : 0), x1 = x0 + (x0 < Win - 1 ? 1 : 0);
     const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
     typedef typename T16<T>::v8 v8;
-    constexpr int PS = SPLIT ? 2 : 1;                       // pixel stride in units of C
+    constexpr int PS = SPLIT ? 2 : 1;                       // pixel stride in units of C (both pair formats are 4C bytes per pixel)
     const T* xb = x + (int64_t)b * Hin * Win * C * PS + c8 * 8;
     float q00[8], q01[8], q10[8], q11[8], av[8];
     auto ld = [&](const T* ptr, float (&dst)[8]) {
         const v8 h = *reinterpret_cast<const v8*>(ptr);
 #pragma unroll
         for (int e = 0; e < 8; ++e) dst[e] = (float)h[e];
-        if (SPLIT) {
+        if (SPLIT == 1) {
             const v8 l = *reinterpret_cast<const v8*>(ptr + C);
 #pragma unroll
             for (int e = 0; e < 8; ++e) dst[e] += (float)l[e];
+        } else if (SPLIT == 2) {      // (hi16 | hi8 | lo8) pixel: ptr points at the 8 hi16 values of channel group c8
+            const char* lo8 = reinterpret_cast<const char*>(ptr - c8 * 8 + C + (C >> 1)) + c8 * 8;
+            const int p0 = *reinterpret_cast<const int*>(lo8), p1 = *reinterpret_cast<const int*>(lo8 + 4);
+            float l0[4], l1[4];
+            f8_unpack4(p0, l0);
+            f8_unpack4(p1, l1);
+            const float sc = __builtin_ldexpf(1.0f, -F8_ACT_LO_EXP);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dst[e] += l0[e] * sc;
+                dst[4 + e] += l1[e] * sc;
+            }
         }
     };
     ld(xb + ((int64_t)y0 * Win + x0) * C * PS, q00);
@@ -277,15 +314,27 @@ __global__ __launch_bounds__(256) void resize_nhwc_kernel(const T* x, const T* a
     ld(xb + ((int64_t)y1 * Win + x1) * C * PS, q11);
     if (ADD) ld(addend + pix * C * PS + c8 * 8, av);
     v8 o, ol;
+    float vv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         float v = hy * (hx * q00[e] + lx * q01[e]) + ly * (hx * q10[e] + lx * q11[e]);
         if (ADD) v += av[e];
+        vv[e] = v;
         o[e] = T16<T>::from_f32(v);
-        if (SPLIT) ol[e] = T16<T>::from_f32(v - (float)o[e]);
+        if (SPLIT == 1) ol[e] = T16<T>::from_f32(v - (float)o[e]);
     }
     *reinterpret_cast<v8*>(out + pix * C * PS + c8 * 8) = o;
-    if (SPLIT) *reinterpret_cast<v8*>(out + pix * C * PS + C + c8 * 8) = ol;
+    if (SPLIT == 1) *reinterpret_cast<v8*>(out + pix * C * PS + C + c8 * 8) = ol;
+    if (SPLIT == 2) {
+        const float sh = __builtin_ldexpf(1.0f, F8_ACT_HI_EXP), sl = __builtin_ldexpf(1.0f, F8_ACT_LO_EXP);
+        char* planes = reinterpret_cast<char*>(out + pix * C * 2 + C);
+        typedef int i32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<i32x2*>(planes + c8 * 8) = i32x2{f8_pack4(vv[0] * sh, vv[1] * sh, vv[2] * sh, vv[3] * sh),
+                                                           f8_pack4(vv[4] * sh, vv[5] * sh, vv[6] * sh, vv[7] * sh)};
+        *reinterpret_cast<i32x2*>(planes + C + c8 * 8) =
+            i32x2{f8_pack4((vv[0] - (float)o[0]) * sl, (vv[1] - (float)o[1]) * sl, (vv[2] - (float)o[2]) * sl, (vv[3] - (float)o[3]) * sl),
+                  f8_pack4((vv[4] - (float)o[4]) * sl, (vv[5] - (float)o[5]) * sl, (vv[6] - (float)o[6]) * sl, (vv[7] - (float)o[7]) * sl)};
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -440,7 +489,7 @@ extern "C" int bs_preprocess_image(const uint8_t* frames, float* out, int32_t B,
 
 template <typename T>
 static int launch_resize(const void* x, const void* addend, void* out, int B, int Hin, int Win, int C, int Hout, int Wout, int align,
-                         hipStream_t st, bool split = false) {
+                         hipStream_t st, int split = 0) {
     float sy, sx;
     if (align) {
         sy = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f;
@@ -450,21 +499,27 @@ static int launch_resize(const void* x, const void* addend, void* out, int B, in
         sx = (float)Win / (float)Wout;
     }
     const dim3 blocks(cdiv(Wout * (C / 8), 256), B * Hout);
+    if (split == 2) {      // (hi16 | hi8 | lo8) pixels (no add variant: the bins head's embeddings stay 16-bit pairs)
+        hipLaunchKernelGGL((resize_nhwc_kernel<T, false, 2>), blocks, dim3(256), 0, st, (const T*)x, (const T*)nullptr, (T*)out, B, Hin, Win,
+                           C, Hout, Wout, sy, sx, align);
+        BS_CHECK_LAUNCH();
+        return BS_OK;
+    }
     if (split) {
         if (addend)
-            hipLaunchKernelGGL((resize_nhwc_kernel<T, true, true>), blocks, dim3(256), 0, st, (const T*)x, (const T*)addend, (T*)out, B, Hin, Win,
+            hipLaunchKernelGGL((resize_nhwc_kernel<T, true, 1>), blocks, dim3(256), 0, st, (const T*)x, (const T*)addend, (T*)out, B, Hin, Win,
                                C, Hout, Wout, sy, sx, align);
         else
-            hipLaunchKernelGGL((resize_nhwc_kernel<T, false, true>), blocks, dim3(256), 0, st, (const T*)x, (const T*)nullptr, (T*)out, B, Hin,
+            hipLaunchKernelGGL((resize_nhwc_kernel<T, false, 1>), blocks, dim3(256), 0, st, (const T*)x, (const T*)nullptr, (T*)out, B, Hin,
                                Win, C, Hout, Wout, sy, sx, align);
         BS_CHECK_LAUNCH();
         return BS_OK;
     }
     if (addend)
-        hipLaunchKernelGGL((resize_nhwc_kernel<T, true, false>), blocks, dim3(256), 0, st, (const T*)x, (const T*)addend, (T*)out, B, Hin,
+        hipLaunchKernelGGL((resize_nhwc_kernel<T, true, 0>), blocks, dim3(256), 0, st, (const T*)x, (const T*)addend, (T*)out, B, Hin,
                            Win, C, Hout, Wout, sy, sx, align);
     else
-        hipLaunchKernelGGL((resize_nhwc_kernel<T, false, false>), blocks, dim3(256), 0, st, (const T*)x, (const T*)nullptr, (T*)out, B,
+        hipLaunchKernelGGL((resize_nhwc_kernel<T, false, 0>), blocks, dim3(256), 0, st, (const T*)x, (const T*)nullptr, (T*)out, B,
                            Hin, Win, C, Hout, Wout, sy, sx, align);
     BS_CHECK_LAUNCH();
     return BS_OK;
@@ -477,8 +532,9 @@ extern "C" int bs_resize_bilinear_nhwc(const void* x, void* out, int32_t B, int3
     BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_resize_bilinear_nhwc: dtype");
     if (B == 0) return BS_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const bool split = (align_corners & 2) != 0;      // bit 1: the tensors hold (hi | lo) pairs of C channels each
+    const int split = (align_corners & 4) ? 2 : ((align_corners & 2) ? 1 : 0);   // bit 1: (hi | lo) 16-bit pairs; bit 2: (hi16 | hi8 | lo8)
     const int ac = align_corners & 1;
+    BS_REQUIRE(split != 2 || C % 16 == 0, "bs_resize_bilinear_nhwc: the FP8 pair format needs C %% 16 == 0");
     return dtype == BS_F16 ? launch_resize<f16>(x, nullptr, out, B, Hin, Win, C, Hout, Wout, ac, st, split)
                            : launch_resize<bf16>(x, nullptr, out, B, Hin, Win, C, Hout, Wout, ac, st, split);
 }
@@ -487,7 +543,7 @@ extern "C" int bs_add_resized(const void* x, const void* prev, void* out, int32_
                               int32_t C, int32_t dtype, void* stream) {
     BS_ENTRY("bs_add_resized");
     BS_REQUIRE(x && prev && out && B >= 0 && Hp > 0 && Wp > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "bs_add_resized: bad argument");
-    const bool split = (dtype & 16) != 0;             // bit 4: x, prev and out hold (hi | lo) pairs of C channels each
+    const int split = (dtype & 16) ? 1 : 0;           // bit 4: x, prev and out hold (hi | lo) pairs of C channels each
     dtype &= 15;
     BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_add_resized: dtype");
     if (B == 0) return BS_OK;
@@ -514,15 +570,17 @@ extern "C" int bs_postprocess_depth(const float* depth_net, float* depth_m, uint
 extern "C" int bs_cast_split(const float* x, void* out, int64_t rows, int32_t cols, int32_t out_dtype, void* stream) {
     BS_ENTRY("bs_cast_split");
     BS_REQUIRE(x && out && rows >= 0 && cols > 0 && cols % 4 == 0, "bs_cast_split: cols must be a multiple of 4");
+    const int f8 = (out_dtype & 32) ? 1 : 0;          // bit 5: (hi16 | hi8 | lo8) instead of (hi | lo) 16-bit pairs
+    out_dtype &= 15;
     BS_REQUIRE(out_dtype == BS_F16 || out_dtype == BS_BF16, "bs_cast_split: dtype");
     if (rows == 0) return BS_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int64_t n = rows * (cols / 4);
     const unsigned blocks = (unsigned)(cdiv64(n, 256) < 8192 ? cdiv64(n, 256) : 8192);
     if (out_dtype == BS_F16)
-        hipLaunchKernelGGL(cast_split_kernel<f16>, dim3(blocks), dim3(256), 0, st, x, (f16*)out, rows, cols);
+        hipLaunchKernelGGL(cast_split_kernel<f16>, dim3(blocks), dim3(256), 0, st, x, (f16*)out, rows, cols, f8);
     else
-        hipLaunchKernelGGL(cast_split_kernel<bf16>, dim3(blocks), dim3(256), 0, st, x, (bf16*)out, rows, cols);
+        hipLaunchKernelGGL(cast_split_kernel<bf16>, dim3(blocks), dim3(256), 0, st, x, (bf16*)out, rows, cols, f8);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }
@@ -530,15 +588,17 @@ extern "C" int bs_cast_split(const float* x, void* out, int64_t rows, int32_t co
 extern "C" int bs_relu_split(const void* x, void* out, int64_t rows, int32_t cols, int32_t dtype, void* stream) {
     BS_ENTRY("bs_relu_split");
     BS_REQUIRE(x && out && rows >= 0 && cols > 0 && cols % 8 == 0, "bs_relu_split: cols must be a multiple of 8");
+    const int f8 = (dtype & 32) ? 1 : 0;              // bit 5: (hi16 | hi8 | lo8) rows
+    dtype &= 15;
     BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_relu_split: dtype");
     if (rows == 0) return BS_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int64_t n = rows * (cols / 8);
     const unsigned blocks = (unsigned)(cdiv64(n, 256) < 16384 ? cdiv64(n, 256) : 16384);
     if (dtype == BS_F16)
-        hipLaunchKernelGGL(relu_split_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const f16*)x, (f16*)out, rows, cols);
+        hipLaunchKernelGGL(relu_split_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const f16*)x, (f16*)out, rows, cols, f8);
     else
-        hipLaunchKernelGGL(relu_split_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)x, (bf16*)out, rows, cols);
+        hipLaunchKernelGGL(relu_split_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)x, (bf16*)out, rows, cols, f8);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }

@@ -56,7 +56,7 @@ static int launch_tile(IgemmParams& p, int dtype, bool conv, int tile, hipStream
 // on the same stream (same kernel family; IgemmParams::m_begin offsets its rows).
 static int dispatch(IgemmParams& p, int dtype, bool conv, int tile, hipStream_t st) {
     tile = auto_tile(p.M, p.N, p.K, tile, conv);
-    if (p.f8_seg > 0 && (tile == 10 || tile == 11)) tile = 9;    // the FP8 stage is built for the BK = 64 ring tiles
+    if ((p.f8_seg > 0 || p.out_f8 || p.res_f8) && (tile == 10 || tile == 11)) tile = 9;    // the FP8 paths are built for the BK = 64 ring tiles
     int BM, BN;
     tile_dims(tile, BM, BN);
     const int rem = p.M % BM, full = p.M / BM, ntn = cdiv(p.N, BN), cus = cu_count();
@@ -81,7 +81,7 @@ static int dispatch(IgemmParams& p, int dtype, bool conv, int tile, hipStream_t 
 extern "C" int bs_gemm_tile(const bs_gemm_desc* d) {
     if (!d) return BS_ERR_INVALID;
     const int tile = bs::auto_tile(d->M, d->N, d->K + d->f8_seg / 2, d->tile % 100, d->conv != 0);
-    return (d->f8_seg > 0 && (tile == 10 || tile == 11)) ? 9 : tile;
+    return ((d->f8_seg > 0 || d->out_f8 || d->res_f8) && (tile == 10 || tile == 11)) ? 9 : tile;
 }
 
 extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
@@ -104,10 +104,15 @@ extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
     p.f8_seg = d->f8_seg;
     p.f8_sa0 = d->f8_scales & 0xff; p.f8_sb0 = (d->f8_scales >> 8) & 0xff; p.f8_sa1 = (d->f8_scales >> 16) & 0xff; p.f8_sb1 = d->f8_scales >> 24;
     p.out_f8 = d->out_f8;
+    p.res_f8 = d->res_f8;
+    BS_REQUIRE(!d->res_f8 || (d->res && d->res_dtype == d->dtype && d->res_split_off == 0 && d->ldr >= 2 * d->N && d->N % 8 == 0), "bs_gemm: res_f8 needs a 16-bit residual in (hi16 | hi8 | lo8) rows, ldr >= 2N");
     BS_REQUIRE(d->f8_seg >= 0 && d->f8_seg % 256 == 0, "bs_gemm: f8_seg=%d must be a multiple of 256 (two halves of whole 128-byte stages)", d->f8_seg);
-    BS_REQUIRE(d->f8_seg == 0 || (!d->conv && d->seg1 == 0), "bs_gemm: the FP8 segment is built for plain single-segment GEMMs");
-    BS_REQUIRE(d->out_f8 == 0 || (d->out_mode == BS_OUT_PLAIN && d->out_split_off == d->N && d->N % 8 == 0 && d->ldo % 8 == 0 && d->out_dtype == d->dtype),
-               "bs_gemm: out_f8 needs a plain 16-bit output with out_split_off = N, N %% 8 == 0");
+    BS_REQUIRE(d->f8_seg == 0 || (d->seg1 == 0 && !d->relu_a), "bs_gemm: the FP8 segment excludes seg1 and relu_a");
+    p.f8_stages = d->f8_seg / 128;
+    BS_REQUIRE(d->out_f8 == 0 || (d->out_dtype == d->dtype && d->ldo % 8 == 0 &&
+                                  ((d->out_mode == BS_OUT_PLAIN && d->out_split_off == d->N && d->N % 8 == 0) ||
+                                   (d->out_mode == BS_OUT_SHUFFLE && d->out_split_off == d->shuffle_cout && d->shuffle_cout % 8 == 0))),
+               "bs_gemm: out_f8 needs a plain / shuffle 16-bit output with out_split_off = channels, channels %% 8 == 0");
     p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin; p.Hout = d->Hout; p.Wout = d->Wout;
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
     if (d->conv) {
@@ -118,6 +123,14 @@ extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
         BS_REQUIRE(d->KH > 0 && d->KW > 0 && d->KH * d->KW <= 32, "bs_gemm: conv window %dx%d: at most 32 taps", d->KH, d->KW);
         BS_REQUIRE((long long)d->Hin * d->Win * d->lda * 2 * 4 < 0x7FFFFFF0ll, "bs_gemm: image too large for the 2 GiB tile window");
         p.tiles_per_tap = d->Cin / 64;
+        if (d->f8_seg > 0) {
+            // pixel vector = [hi16 x Cin | hi8 x Cin | lo8 x Cin]: the chunk walk simply continues through the two FP8 planes
+            BS_REQUIRE(d->f8_seg == 2 * d->Cin && d->Cin % 128 == 0 && d->lda >= 2 * d->Cin, "bs_gemm: conv FP8 segment needs f8_seg = 2*Cin, Cin %% 128 == 0, lda >= 2*Cin");
+            p.Cin = 2 * d->Cin;
+            p.K = d->KH * d->KW * p.Cin;
+            p.f8_stages = d->KH * d->KW * (d->f8_seg / 128);
+            BS_REQUIRE((long long)d->N * p.K * 2 < 0x7FFFFFF0ll, "bs_gemm: weight matrix too large for one descriptor");
+        }
     }
     p.relu_a = d->relu_a;
     p.cin1 = d->seg1;

@@ -60,6 +60,8 @@ struct IgemmParams {
                          //      FP8 MFMA (2x the 16-bit rate): the correction products of a split-precision GEMM.  Two halves of
                          //      f8_seg / 2 elements each with their own power-of-two scales (E8M0 exponents, 127 = 1.0)
     int f8_sa0, f8_sb0, f8_sa1, f8_sb1;
+    int f8_stages;       // number of trailing 128-byte K stages that are FP8 (host: f8_seg / 128, times the taps for a conv)
+    int res_f8;          // != 0: the 16-bit residual(s) are (hi16 | hi8 | lo8) rows of N channels; value = hi16 + lo8 * 2^-BS_F8_ACT_LO_EXP
     int out_f8;          // > 0 with split_off: the output pair is (hi16 | hi8 | lo8), see store8_f8
     int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue, 8 = no tail split (host side)
 };
@@ -158,6 +160,17 @@ __device__ __forceinline__ void store8_f8(void* base, int64_t row_off, int n, in
     *reinterpret_cast<i32x2*>(bytes + plane_off + n) = i32x2{pl0, pl1};
 }
 
+// y[0..3] += the lo8 plane of a (hi16 | hi8 | lo8) row of C channels at columns n..n+3
+template <typename T>
+__device__ __forceinline__ void add_lo8(float* y, const void* base, int64_t row_off, int C, int n) {
+    const char* lp = reinterpret_cast<const char*>(reinterpret_cast<const T*>(base) + row_off + C + (C >> 1)) + n;
+    const int packed = *reinterpret_cast<const int*>(lp);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(packed, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(packed, true);
+    const float sc = __builtin_ldexpf(1.0f, -BS_F8_ACT_LO_EXP);
+    y[0] += a[0] * sc; y[1] += a[1] * sc; y[2] += b[0] * sc; y[3] += b[1] * sc;
+}
+
 constexpr int NW_CHECK(int a, int b) { return a * b; }
 
 template <int N>
@@ -168,7 +181,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // Tile variants.  BK is the K slice per stage (one 64- or 128-byte LDS row per tile row), STAGES the depth
 // of the LDS ring: STAGES-1 tiles are in flight (global_load_lds) while one is multiplied.
 // MODE: 0 plain GEMM rows, 1 implicit conv, 2 implicit conv with ReLU applied to A on load
-template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int MODE, bool PP = false>
+// F8: the instantiation that knows the FP8 correction stages and the (hi16 | hi8 | lo8) epilogue formats (accurate mode);
+// the plain instantiation carries none of that code, so fast-mode launches are not affected by its register pressure.
+template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int MODE, bool PP = false, bool F8 = false>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins exist in the device pass only; the host pass needs just the stub
     constexpr bool CONV = MODE != 0;
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
     const int a_base = (wm * TM + frow) * ROWB, b_base = (wn * TN + frow) * ROWB;
 
     const int nt = p.K / BK;
-    const int nt16 = nt - p.f8_seg / 128;     // stages multiplied as 16-bit data; the rest are FP8 correction stages (BK = 64 tiles)
+    const int nt16 = F8 ? nt - p.f8_stages : nt;   // stages multiplied as 16-bit data; the rest are FP8 correction stages (BK = 64 tiles)
     if constexpr (!PP) {
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s)
@@ -349,7 +364,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
         // one iteration of the ring; F8 selects the multiply of the stage (two plain loops, not a branch inside one: a branch
         // made the register allocator spill the accumulators)
         auto iteration = [&](int t, auto f8_tag) {
-            constexpr bool F8 = decltype(f8_tag)::value;
+            constexpr bool F8S = decltype(f8_tag)::value;
             // my own DMA for tile t has landed once at most (tiles issued after t) x GL operations are outstanding
             const int younger = nt - 1 - t;
             if (STAGES >= 4 && younger >= 2) wait_vmcnt<(STAGES >= 4 ? 2 : 0) * GL>();
@@ -360,7 +375,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
             if (t + STAGES - 1 < nt && !(p.ablate & 1)) stage(sbuf);
             const char* sa = smem + cbuf * STAGE;
             const char* sb = sa + A_BYTES;
-            if constexpr (F8) {
+            if constexpr (F8S) {
                 // ---- FP8 correction stage: the 128-byte LDS rows hold 128 e4m3 values.  A lane supplies 32 of them per
                 // row: the same two 16-byte chunks (fq and 4 + fq) the 16-bit path reads -- A and W use the same
                 // permutation of k, so the product is unchanged -- as one 8-register operand of the 16x16x128 MFMA.
@@ -411,7 +426,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
         };
         int t = 0;
         for (; t < nt16; ++t) iteration(t, std::false_type{});
-        if constexpr (!CONV && BK == 64) {
+        if constexpr (F8 && BK == 64 && !RELU_A) {
             for (; t < nt; ++t) iteration(t, std::true_type{});
         }
     } else {
@@ -596,6 +611,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                                     const typename T16<T>::v4 rl = *reinterpret_cast<const typename T16<T>::v4*>(reinterpret_cast<const T*>(p.res) + ro + p.res_split_off);
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) y[e] += T16<T>::to_f32(rl[e]);
+                                } else if (F8 && p.res_f8) {
+                                    add_lo8<T>(y, p.res, orow * p.ldr, p.N, n0j[j]);
                                 }
                             }
                             if (p.res2) {   // second residual, 16-bit (fusion: fused + residual_unit(skip))
@@ -606,6 +623,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                                     const typename T16<T>::v4 rl = *reinterpret_cast<const typename T16<T>::v4*>(reinterpret_cast<const T*>(p.res2) + ro + p.res_split_off);
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) y[e] += T16<T>::to_f32(rl[e]);
+                                } else if (F8 && p.res_f8) {
+                                    add_lo8<T>(y, p.res2, orow * p.ldr, p.N, n0j[j]);
                                 }
                             }
                         }
@@ -615,8 +634,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                     void* dst = (p.out_mode == BS_OUT_QKV && which[j0] == 1) ? p.out2 : p.out;
                     const int so = p.out_mode != BS_OUT_QKV ? p.split_off : 0;
                     // the pair is one 8-wide store when both halves exist, are adjacent in the output and 16-byte aligned
-                    if (p.out_f8) {     // PLAIN mode, N % 8 == 0 (checked on the host): (hi16 | hi8 | lo8) row planes
-                        store8_f8<T>(dst, roff, n0j[j0], so, y8, p.out_f8 & 0xff, (p.out_f8 >> 8) & 0xff);
+                    if (F8 && p.out_f8) {     // PLAIN / SHUFFLE, channels % 8 == 0 (checked on the host): (hi16 | hi8 | lo8) planes per row / pixel
+                        const int nloc = p.out_mode == BS_OUT_SHUFFLE ? n0j[j0] % p.shuffle_cout : n0j[j0];
+                        store8_f8<T>(dst, roff + coff[j0] - nloc, nloc, so, y8, p.out_f8 & 0xff, (p.out_f8 >> 8) & 0xff);
                     } else if (wide_ok && n0j[j1] < p.N && coff[j1] == coff[j0] + 4 && which[j1] == which[j0]) {
                         store8<T>(dst, roff + coff[j0], p.out_dtype, y8, so);
                     } else {
@@ -683,11 +703,11 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
 #endif
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int MODE, bool PP = false>
+template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int MODE, bool PP = false, bool F8 = false>
 inline int launch_mode(const IgemmParams& p, hipStream_t st) {
     constexpr int smem = STAGES * (BM + BN) * BK * 2;
     dim3 grid(p.ntm * p.ntn), block(WM * WN * 64);
-    auto k = igemm_kernel<T, BM, BN, WM, WN, BK, STAGES, MODE, PP>;
+    auto k = igemm_kernel<T, BM, BN, WM, WN, BK, STAGES, MODE, PP, F8>;
     static bool attr = false;
     if (!attr) {
         BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -700,6 +720,12 @@ inline int launch_mode(const IgemmParams& p, hipStream_t st) {
 
 template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, bool PP = false>
 inline int launch_variant(const IgemmParams& p, bool conv, hipStream_t st) {
+    if constexpr (BK == 64 && !PP) {
+        if (p.f8_stages > 0 || p.out_f8 || p.res_f8) {      // accurate mode's FP8-correction instantiations (never with relu_a)
+            if (!conv) return launch_mode<T, BM, BN, WM, WN, BK, STAGES, 0, PP, true>(p, st);
+            return launch_mode<T, BM, BN, WM, WN, BK, STAGES, 1, PP, true>(p, st);
+        }
+    }
     if (!conv) return launch_mode<T, BM, BN, WM, WN, BK, STAGES, 0, PP>(p, st);
     if (p.relu_a) return launch_mode<T, BM, BN, WM, WN, BK, STAGES, 2, PP>(p, st);
     return launch_mode<T, BM, BN, WM, WN, BK, STAGES, 1, PP>(p, st);

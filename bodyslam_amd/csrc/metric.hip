@@ -86,7 +86,7 @@ constexpr int LB_HID = 40, LB_IN = 32, LB_BINS = 64;
 constexpr int LB_T = 16;                 // output tile edge (256 threads = 16 x 16 pixels)
 constexpr int LB_MAXSRC = 12;            // low-res rows / columns a 16-pixel span can touch at >= 1.5x upsampling (+1 neighbour, +slack)
 
-template <typename T, bool LSPLIT>
+template <typename T, int LSPLIT>
 __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const float* Eh, const float* bins, const float* w0_last,
                                                         const float* w2, const float* b2, const int32_t* route, float* depth, int B, int H,
                                                         int W, int He, int We, float sy, float sx, float min_temp, float max_temp) {
@@ -139,10 +139,21 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
             const v8 t = *reinterpret_cast<const v8*>(lp + v * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) xin[v * 8 + e] = (float)t[e];
-            if (LSPLIT) {
+            if (LSPLIT == 1) {
                 const v8 tl = *reinterpret_cast<const v8*>(lp + LB_IN + v * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) xin[v * 8 + e] += (float)tl[e];
+            } else if (LSPLIT == 2) {     // (hi16 | hi8 | lo8): the lo8 plane starts 1.5 * 32 elements into the pixel
+                const char* l8 = reinterpret_cast<const char*>(lp + LB_IN + LB_IN / 2) + v * 8;
+                float l0[4], l1[4];
+                f8_unpack4(*reinterpret_cast<const int*>(l8), l0);
+                f8_unpack4(*reinterpret_cast<const int*>(l8 + 4), l1);
+                const float sc = __builtin_ldexpf(1.0f, -F8_ACT_LO_EXP);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xin[v * 8 + e] += l0[e] * sc;
+                    xin[v * 8 + 4 + e] += l1[e] * sc;
+                }
             }
         }
     }
@@ -291,20 +302,21 @@ extern "C" int bs_logbinom_depth(const void* last, const float* Eh, const float*
                "bs_logbinom_depth: the bins map must be upsampled by at least ~1.7x (He,We=%d,%d -> H,W=%d,%d)", He, We, H, W);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(cdiv(W, LB_T), cdiv(H, LB_T), B);
-    const bool lsplit = (dtype & 16) != 0;   // bit 4: `last` holds (hi | lo) pairs
+    const int lsplit = (dtype & 32) ? 2 : ((dtype & 16) ? 1 : 0);   // bit 4: `last` holds (hi | lo) 16-bit pairs; bit 5: (hi16 | hi8 | lo8)
     dtype &= 15;
-    if (dtype == BS_F16 && !lsplit)
-        hipLaunchKernelGGL((logbinom_kernel<f16, false>), grid, dim3(256), 0, st, (const f16*)last, Eh, bins, w0_last, w2, b2, route, depth, B, H, W,
-                           He, We, sy, sx, min_temp, max_temp);
-    else if (dtype == BS_F16)
-        hipLaunchKernelGGL((logbinom_kernel<f16, true>), grid, dim3(256), 0, st, (const f16*)last, Eh, bins, w0_last, w2, b2, route, depth, B, H, W,
-                           He, We, sy, sx, min_temp, max_temp);
-    else if (!lsplit)
-        hipLaunchKernelGGL((logbinom_kernel<bf16, false>), grid, dim3(256), 0, st, (const bf16*)last, Eh, bins, w0_last, w2, b2, route, depth, B, H,
-                           W, He, We, sy, sx, min_temp, max_temp);
-    else
-        hipLaunchKernelGGL((logbinom_kernel<bf16, true>), grid, dim3(256), 0, st, (const bf16*)last, Eh, bins, w0_last, w2, b2, route, depth, B, H,
-                           W, He, We, sy, sx, min_temp, max_temp);
+#define BS_LB_LAUNCH(TT, LS)                                                                                                          \
+    hipLaunchKernelGGL((logbinom_kernel<TT, LS>), grid, dim3(256), 0, st, (const TT*)last, Eh, bins, w0_last, w2, b2, route, depth, B, H, W, \
+                       He, We, sy, sx, min_temp, max_temp)
+    if (dtype == BS_F16) {
+        if (lsplit == 2) BS_LB_LAUNCH(f16, 2);
+        else if (lsplit == 1) BS_LB_LAUNCH(f16, 1);
+        else BS_LB_LAUNCH(f16, 0);
+    } else {
+        if (lsplit == 2) BS_LB_LAUNCH(bf16, 2);
+        else if (lsplit == 1) BS_LB_LAUNCH(bf16, 1);
+        else BS_LB_LAUNCH(bf16, 0);
+    }
+#undef BS_LB_LAUNCH
     BS_CHECK_LAUNCH();
     return BS_OK;
 }

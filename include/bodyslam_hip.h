@@ -106,11 +106,14 @@ typedef struct bs_gemm_desc {
      * two halves of f8_seg / 2 (a multiple of 128) each; half h contributes 2^(sa_h - 127 + sb_h - 127) * sum_k A8[k] W8[k].
      * f8_scales packs the four E8M0 exponents: sa0 | sb0 << 8 | sa1 << 16 | sb1 << 24.  With A = [hi16 | hi8 | lo8] and
      * W = [W_hi16 | W_lo8 | W_hi8] this is A_hi W_hi + A_hi W_lo + A_lo W_hi at 2 pass-equivalents instead of 3.
-     * out_f8 != 0 (with out_split_off = N, ldo = 2N, N % 8 == 0): the output row is written in that A format,
+     * Conv mode: the pixel vector is [hi16 x Cin | hi8 x Cin | lo8 x Cin] (f8_seg = 2*Cin, Cin % 128 == 0) and W is
+     * [W_hi16: chunk64, tap, 64][W_lo8: chunk128, tap, 128][W_hi8: ...] (bodyslam_amd/_lib.py f8_conv_weight()).
+     * out_f8 != 0 (with out_split_off = channels, ldo = 2*channels, channels % 8 == 0): the output row / pixel is written in that A format,
      * [hi16 x N | e4m3(y * 2^ea) x N | e4m3((y - hi) * 2^el) x N], out_f8 = ea | el << 8. */
     int32_t f8_seg;
     uint32_t f8_scales;
     int32_t out_f8;
+    int32_t res_f8;                /* != 0: res / res2 are rows in that format too (N channels, ldr >= 2N) */
 } bs_gemm_desc;
 int bs_gemm(const bs_gemm_desc* d, void* stream);
 /* the tile variant bs_gemm will pick for this descriptor (1: 128x128, 2: 128x64, 3: 128x32, 4: 256x128) */

@@ -223,6 +223,56 @@ def test_f8_correction_gemm(L, dtype, tile):
     assert ((hi + lo8 - out).abs() <= out.abs() * (2.0 ** -15 if dtype == torch.float16 else 2.0 ** -12) + 2.0 ** -20).all()
 
 
+def to_f8_pairs(x, dtype):
+    """fp32 [..., C] -> [..., 2C] `dtype`-typed rows of (hi16 | hi8 | lo8) -- the torch statement of the operand format."""
+    import bodyslam_amd._lib as L_
+    hi = x.to(dtype)
+    lo = x - hi.float()
+    hi8 = (x * 2.0 ** L_.F8_ACT_HI_EXP).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    lo8 = (lo * 2.0 ** L_.F8_ACT_LO_EXP).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    C2 = x.shape[-1] * 2
+    row = torch.cat([hi.contiguous().view(torch.uint8).view(*x.shape[:-1], C2), hi8, lo8], -1).contiguous()
+    return row.view(dtype)
+
+
+def from_f8_pairs(t, C):
+    """[..., 2C] 16-bit rows of (hi16 | hi8 | lo8) -> (hi fp32, value = hi + lo8 * 2^-LO_EXP)."""
+    import bodyslam_amd._lib as L_
+    hi = t[..., :C].float()
+    planes = t[..., C:].contiguous().view(torch.uint8).view(*t.shape[:-1], 2 * C)
+    lo = planes[..., C:].contiguous().view(torch.float8_e4m3fn).float() * 2.0 ** -L_.F8_ACT_LO_EXP
+    return hi, hi + lo
+
+
+@pytest.mark.parametrize("tile", [0, 9, 1])
+def test_f8_correction_conv(L, tile):
+    """3x3 conv with the correction products on the FP8 MFMA: NHWC pixels [hi16 | hi8 | lo8], weights f8_conv_weight, a residual in
+    the same format, output re-emitted in it."""
+    dtype = torch.float16
+    B, H, Wd, C, Co = 2, 20, 24, 128, 256
+    x = rnd(B, H, Wd, C, seed=1)
+    w = rnd(Co, C, 3, 3, seed=2, scale=1 / math.sqrt(9 * C))
+    res = rnd(B, H, Wd, Co, seed=3)
+    x8 = to_f8_pairs(x, dtype)
+    r8 = to_f8_pairs(res, dtype)
+    W8, (sb0, sb1) = L.f8_conv_weight(w.permute(0, 2, 3, 1), dtype)
+    W8 = W8.to(dev())
+    g = L.conv_geom(H, Wd, C, 3, 3, 1, 1)
+    sc = (127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1)
+    out = torch.zeros(B, H, Wd, 2 * Co, device=dev(), dtype=dtype)
+    L.gemm(x8, W8, out, M=B * H * Wd, N=Co, K=9 * C, lda=2 * C, conv=g, f8_seg=2 * C, f8_scales=sc, res=r8, ldr=2 * Co, res_f8=True,
+           ldo=2 * Co, out_split_off=Co, out_f8=(L.F8_ACT_HI_EXP, L.F8_ACT_LO_EXP), tile=tile)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1) + from_f8_pairs(r8, Co)[1].double()
+    hi, val = from_f8_pairs(out, Co)
+    err = (val.double() - ref).abs().max().item()
+    single = torch.empty(B, H, Wd, Co, device=dev())
+    L.gemm(x.to(dtype), L.conv_weight(w.permute(0, 2, 3, 1)).to(dtype), single, M=B * H * Wd, N=Co, K=9 * C, lda=C,
+           conv=L.conv_geom(H, Wd, C, 3, 3, 1, 1), tile=tile)
+    err1 = (single.double() - (ref - from_f8_pairs(r8, Co)[1].double())).abs().max().item()
+    report(f"f8 correction conv tile{tile}: max|err|={err:.2e} vs single-pass {err1:.2e}")
+    assert err < 2e-4 and err < 0.2 * err1
+
+
 def test_split_precision_conv(L):
     dtype = torch.float16
     B, H, Wd, C, Co = 2, 24, 32, 64, 256

@@ -36,9 +36,19 @@ def product_cfg(ocfg):
 
 def to_nchw(t, meta):
     kind = meta[0]
+    t_raw = t
     t = t.float().cpu()
     if kind == "tokens":
         return t.view(meta[1], meta[2], meta[3])
+    if kind == "nhwc" and len(meta) > 5 and meta[5] == 2:
+        # accurate mode, FP8 pair format: (hi16 | hi8 | lo8) per pixel; the value is hi16 + lo8 * 2^-LO_EXP
+        from bodyslam_amd import _lib as L
+        C = meta[4]
+        raw = t_raw.cpu().view(meta[1], meta[2], meta[3], 2 * C)
+        hi = raw[..., :C].float()
+        planes = raw[..., C:].contiguous().view(torch.uint8).view(meta[1], meta[2], meta[3], 2 * C)
+        lo = planes[..., C:].contiguous().view(torch.float8_e4m3fn).float() * 2.0 ** -L.F8_ACT_LO_EXP
+        return (hi + lo).permute(0, 3, 1, 2)
     if kind == "nhwc" and len(meta) > 5 and meta[5]:
         # accurate mode: (hi | lo) channel pairs; the value is their sum
         t = t.view(meta[1], meta[2], meta[3], 2, meta[4])
