@@ -347,14 +347,15 @@ def cast(x, out):
     check(load_library().bs_cast(p(x), p(out), x.numel(), dt(out), stream_ptr()), "bs_cast")
 
 
-def cast_split(x, out, rows, cols):
-    """fp32 [rows, cols] -> 16-bit [rows, 2*cols] = (hi | lo),  hi = round16(x), lo = round16(x - hi)."""
-    check(load_library().bs_cast_split(p(x), p(out), rows, cols, dt(out), stream_ptr()), "bs_cast_split")
+def cast_split(x, out, rows, cols, f8=False):
+    """fp32 [rows, cols] -> 16-bit [rows, 2*cols] = (hi | lo),  hi = round16(x), lo = round16(x - hi);
+    f8: (hi16 | hi8 | lo8), the operand format of the FP8 correction passes."""
+    check(load_library().bs_cast_split(p(x), p(out), rows, cols, dt(out) | (32 if f8 else 0), stream_ptr()), "bs_cast_split")
 
 
-def relu_split(x, out, rows, cols):
-    """(hi | lo) [rows, 2*cols] -> re-split relu(hi + lo)."""
-    check(load_library().bs_relu_split(p(x), p(out), rows, cols, dt(out), stream_ptr()), "bs_relu_split")
+def relu_split(x, out, rows, cols, f8=False):
+    """(hi | lo) [rows, 2*cols] -> re-split relu(hi + lo); f8: the same on (hi16 | hi8 | lo8) rows."""
+    check(load_library().bs_relu_split(p(x), p(out), rows, cols, dt(out) | (32 if f8 else 0), stream_ptr()), "bs_relu_split")
 
 
 def preprocess_patches(frames, out, B, H, W, nh, nw, flip):
@@ -371,7 +372,7 @@ def fill_rows(x, v, B, rows_per_image, cols):
 
 
 def resize_bilinear_nhwc(x, out, B, Hin, Win, Cch, Hout, Wout, align_corners=True, split=False):
-    check(load_library().bs_resize_bilinear_nhwc(p(x), p(out), B, Hin, Win, Cch, Hout, Wout, int(align_corners) | (2 if split else 0), dt(x),
+    check(load_library().bs_resize_bilinear_nhwc(p(x), p(out), B, Hin, Win, Cch, Hout, Wout, int(align_corners) | (4 if split == 2 else (2 if split else 0)), dt(x),
                                                  stream_ptr()), "bs_resize_bilinear_nhwc")
 
 

@@ -449,6 +449,29 @@ def test_split_pointwise(L, dtype):
     assert (val(o) - (ref + val(ys))).abs().max().item() < 2 * t3
 
 
+def test_f8_pair_pointwise(L):
+    """(hi16 | hi8 | lo8) carriers: cast_split, relu_split and the bilinear resize in that format against the torch statement of
+    the format (to_f8_pairs / from_f8_pairs)."""
+    dtype = torch.float16
+    B, H, W, C = 2, 12, 16, 128
+    x = rnd(B, H, W, C, seed=1)
+    xs = torch.empty(B, H, W, 2 * C, device=dev(), dtype=dtype)
+    L.cast_split(x, xs, B * H * W, C, f8=True)
+    assert torch.equal(xs.view(torch.int16), to_f8_pairs(x, dtype).view(torch.int16))           # byte-exact format
+    hi, val = from_f8_pairs(xs, C)
+    assert (val - x).abs().max().item() < 2.0 ** -14 * x.abs().max().item()
+    r = torch.empty_like(xs)
+    L.relu_split(xs, r, B * H * W, C, f8=True)
+    rhi, rval = from_f8_pairs(r, C)
+    assert torch.equal(rval, torch.where(hi > 0, val, torch.zeros_like(val)))
+    up = torch.empty(B, 2 * H, 2 * W, 2 * C, device=dev(), dtype=dtype)
+    L.resize_bilinear_nhwc(xs, up, B, H, W, C, 2 * H, 2 * W, True, split=2)
+    ref = F.interpolate(val.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    uhi, uval = from_f8_pairs(up, C)
+    assert (uval - ref).abs().max().item() < 2.0 ** -13 * ref.abs().max().item()
+    assert torch.equal(up.view(torch.int16)[..., :C], ref.to(dtype).view(torch.int16)) or (uhi - ref).abs().max().item() < 2e-3
+
+
 def test_attractor_step(L):
     B, Hp, Wp, H, W = 2, 6, 8, 12, 16
     A = F.softplus(rnd(B, H, W, 32, seed=1, scale=2.0))
