@@ -212,3 +212,17 @@ def test_full_size_zoed_nk_accurate():
     report(f"[{tag}] u16: max |diff| = {lsb.max()} LSB, mean {lsb.mean():.3f} LSB")
     assert torch.equal(torch.argmax(r["logits_o"], -1).int(), r["route_p"])
     assert l1 <= 1e-4
+
+
+@pytest.mark.parametrize("H,W", [(480, 600), (1024, 1280)])
+def test_other_frame_geometries(H, W):
+    """BASELINE config 1 (the reference's own 600x480 example image) and config 5 (1280x1024): both resolve to a 416x512
+    network input (833 tokens, rel-pos window 26x32) -- another attention tiling, other pads and resize ratios."""
+    from oracle import zoedepth_ref as Z
+    r = run_case(Z.ZOED_NK, torch.float16, B=1, H=H, W=W, target_hw=(384, 512), seed=2, precision="accurate")
+    l1 = (r["dm"] - r["ref"]).abs().mean().item()
+    mx = (r["dm"] - r["ref"]).abs().max().item()
+    report(f"[ZoeD_NK f16 accurate {W}x{H}] depth L1={l1:.3e} m, max={mx:.3e} m")
+    lsb = np.abs(r["du"].astype(np.int32) - Z.to_uint16(r["ref"]).astype(np.int32))
+    assert torch.equal(torch.argmax(r["logits_o"], -1).int(), r["route_p"])
+    assert l1 <= 1e-4 and lsb.max() <= 1
