@@ -134,36 +134,3 @@ class BodySlamPipeline:
                 for j in range(b1 - b0):
                     points.append((xyz[j, :c[j]].clone(), idx[j, :c[j]].clone()))
         return SequenceResult(start, end, depth, t_all.view(-1, 4, 4), g_abs, cnt_all, points, depth_m)
-
-
-def smoke() -> None:
-    """One tiny end-to-end invocation checked against the oracle (called by __graft_entry__.smoke())."""
-    import dataclasses
-    from oracle import cyclepose_ref as CP
-    from oracle import geom3d_ref as G
-    from oracle import zoedepth_ref as Z
-    from .synthetic import make_sequence
-    cfg_o = Z.ZoeConfig(hidden=128, layers=4, heads=2, intermediate=256, taps=(1, 2, 3, 4), image_size=64)
-    names = {f.name for f in dataclasses.fields(ZoeConfig)}
-    cfg_p = ZoeConfig(**{k: v for k, v in dataclasses.asdict(cfg_o).items() if k in names})
-    wz, wp = Z.synth_weights(cfg_o, seed=2), CP.synth_weights(seed=2)
-    frames = make_sequence(3, 160, 192, seed=5)
-    pipe = BodySlamPipeline(wz, wp, cfg_p, batch=2, target_hw=(64, 96))
-    res = pipe.run_sequence(frames, keep_points=True, keep_depth_m=True)
-    ft = torch.from_numpy(frames)
-    ref_d = Z.infer_depth(wz, cfg_o, ft, out_hw=(64, 96))
-    l1 = (res.depth_m.cpu() - ref_d).abs().mean().item()
-    assert l1 < 2e-3, f"depth L1 vs oracle {l1}"
-    pairs = torch.tensor([[0, 1], [1, 2]])
-    ref_T = CP.forward_pose(wp, CP.center_crop_pair(ft, pairs)).numpy()
-    et = np.abs(res.t_rel.cpu().numpy() - ref_T).max()
-    assert et < 5e-3, f"relative pose error vs oracle {et}"
-    ref_g = G.pose_chain(res.t_rel.cpu().numpy())
-    assert np.abs(res.g_abs.cpu().numpy() - ref_g).max() < 1e-10
-    du = res.depth_u16.cpu().numpy().view(np.uint16)
-    for j in range(3):
-        rx, ri = G.backproject(du[j], pose=ref_g[j])
-        xyz, idx = res.points[j]
-        assert np.array_equal(idx.cpu().numpy(), ri), "point indices differ from the oracle"
-        assert np.allclose(xyz.cpu().numpy(), rx, atol=1e-5)
-    print(f"pipeline smoke ok: depth L1 {l1:.2e} m, pose max err {et:.2e}")
