@@ -159,11 +159,11 @@ def main():
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
                 mode = {"gemm": "ELi0E", "conv": "ELi1E"}[kind]
                 dims = TILE_NAMES[tile].split("s")[0].split("x")
-                for name, v in pm["modes"][precision]["kernels"].items():
-                    if ("igemm_kernel" in name and f"Li{dims[0]}ELi{dims[1]}E" in name and f"Li{dims[2]}E" in name and mode in name
-                            and ("DF16_" in name) == (args.dtype == "f16") and B == 32):
-                        traffic = round(v["hbm_bytes_per_launch_corrected"])
-                        break
+                cands = [v for name, v in pm["modes"][precision]["kernels"].items()
+                         if ("igemm_kernel" in name and f"Li{dims[0]}ELi{dims[1]}E" in name and f"Li{dims[2]}E" in name and mode in name
+                             and ("DF16_" in name) == (args.dtype == "f16") and B == 32)]
+                if cands:       # the F8 / plain instantiation with the most launches is the one the events timed
+                    traffic = round(max(cands, key=lambda v: v["launches"])["hbm_bytes_per_launch_corrected"])
             except Exception:
                 traffic = None
             roof = dict(bound="mfma", kernel=f"igemm_kernel<{args.dtype},{TILE_NAMES[tile]},{kind}>", achieved=round(ach, 1),

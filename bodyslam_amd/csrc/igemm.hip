@@ -1,5 +1,7 @@
 // Dispatcher + C entry point of the implicit GEMM (the kernel template lives in igemm_kernel.h, the tile variants in
 // igemm_tile*.hip).
+#include <stdlib.h>
+
 #include "igemm_kernel.h"
 
 namespace bs {
@@ -62,7 +64,8 @@ static int dispatch(IgemmParams& p, int dtype, bool conv, int tile, hipStream_t 
     const int rem = p.M % BM, full = p.M / BM, ntn = cdiv(p.N, BN), cus = cu_count();
     // (measured, tools/bench_kernels.py tiles 9 vs 809: -8 % on fc2 (K = 4096); neutral to slightly negative for K = 1024, where a
     // block is short and the second launch costs as much as the saved blocks)
-    if (!(p.ablate & 8) && !conv && BM == 256 && p.K >= 2048 && full > 0 && rem > 0 && rem <= 128 && p.N % 128 == 0 &&
+    static const bool no_split = getenv("BS_NO_TAIL_SPLIT") != nullptr;   // diagnostics
+    if (!no_split && !(p.ablate & 8) && !conv && BM == 256 && p.K >= 2048 && full > 0 && rem > 0 && rem <= 128 && p.N % 128 == 0 &&
         cdiv(full * ntn, cus) < cdiv((full + 1) * ntn, cus)) {
         IgemmParams main = p;
         main.M = full * BM;                    // rows [0, full*BM): the kernel clamps and masks against M

@@ -214,6 +214,17 @@ def test_full_size_zoed_nk_accurate():
     assert l1 <= 1e-4
 
 
+def test_full_size_zoed_nk_accurate_bf16():
+    """accurate mode on bf16 storage: hi has 8 significant bits, the e4m3 correction planes add ~4: 2e-4 m measured (bf16
+    single-pass: 4.8e-3).  Stated tolerance 5e-4 m; fp16 is the type that meets the north star's 1e-4."""
+    from oracle import zoedepth_ref as Z
+    r = run_case(Z.ZOED_NK, torch.bfloat16, B=1, H=480, W=640, target_hw=(384, 512), seed=1, precision="accurate")
+    l1 = (r["dm"] - r["ref"]).abs().mean().item()
+    report(f"[ZoeD_NK bf16 accurate] 640x480 depth L1={l1:.3e} m")
+    assert torch.equal(torch.argmax(r["logits_o"], -1).int(), r["route_p"])
+    assert l1 <= 5e-4
+
+
 @pytest.mark.parametrize("H,W", [(480, 600), (1024, 1280)])
 def test_other_frame_geometries(H, W):
     """BASELINE config 1 (the reference's own 600x480 example image) and config 5 (1280x1024): both resolve to a 416x512
