@@ -125,13 +125,13 @@ int bs_gemm_tile(const bs_gemm_desc* d);
  * log2(e)/sqrt(64) and bias pre-multiplied by log2(e).  k [B,nh,Sp,64], vt [B,nh,64,Sp], Sp % 64 == 0,
  * rows/cols >= S zero; bias fp32 [nh,Sp,Sp] with <= -1e30 in key columns >= S.
  * out [B*S, nh*64] token-major (the o_proj GEMM's A operand).
- * dtype | 16: out holds (hi | lo) pairs, [B*S, 2*nh*64]. */
+ * dtype | 16: out holds (hi | lo) pairs, [B*S, 2*nh*64]; dtype | 32: (hi16 | hi8 | lo8) rows of the same size. */
 int bs_attention(const void* q, const void* k, const void* vt, const float* bias, void* out,
                  int32_t B, int32_t nh, int32_t S, int32_t Sp, int32_t dtype, void* stream);
 
 /* LayerNorm over the last dim, fp32 in; out16 (fp16/bf16, nullable) and out32 (fp32, nullable, may
  * alias x) -- HF modeling_beit.py:418,432; post-norm of the router HF modeling_zoedepth.py:876-881
- * dtype | 16: out16 holds (hi | lo) pairs, [rows, 2*cols] (bs_cast_split's format). */
+ * dtype | 16: out16 holds (hi | lo) pairs, [rows, 2*cols] (bs_cast_split's format); dtype | 32: (hi16 | hi8 | lo8) rows. */
 int bs_layernorm(const float* x, const float* gamma, const float* beta, void* out16, float* out32, int32_t rows,
                  int32_t cols, float eps, int32_t dtype, void* stream);
 
@@ -140,7 +140,9 @@ int bs_copy_f32(const float* src, float* dst, int64_t n, void* stream);
 
 /* split-precision helpers: fp32 [rows, cols] -> 16-bit (hi | lo) pairs [rows, 2*cols] with x = hi + lo to ~22 bits; ReLU of such a
  * tensor (the pre-activation residual units, HF modeling_zoedepth.py:225-241).  bs_resize_bilinear_nhwc takes such tensors when
- * bit 1 of align_corners is set; bs_logbinom_depth takes a (hi | lo) `last` when bit 4 of dtype is set. */
+ * bit 1 of align_corners is set; bs_logbinom_depth takes a (hi | lo) `last` when bit 4 of dtype is set.
+ * With `| 32` on the dtype argument (bit 2 of align_corners for the resize) the same calls work on the (hi16 | hi8 | lo8)
+ * format of the FP8 correction passes (BS_F8_ACT_*_EXP above). */
 int bs_cast_split(const float* x, void* out, int64_t rows, int32_t cols, int32_t out_dtype, void* stream);
 int bs_relu_split(const void* x, void* out, int64_t rows, int32_t cols, int32_t dtype, void* stream);
 
@@ -152,7 +154,7 @@ int bs_cast(const float* x, void* out, int64_t n, int32_t out_dtype, void* strea
  * bilinear align_corners=True resize to (nh, nw), (x-0.5)/0.5; fused with the 16x16 patch gather
  * of HF modeling_beit.py:83-90.  frames [B,H,W,3] u8; out [2B or B][(nh/16)*(nw/16)][3*16*16]
  * (k = c*256 + ky*16 + kx); images B..2B-1 are the W-flipped copies when flip != 0.
- * out_dtype | 16: rows are (hi | lo) pairs, [., 2*768]. */
+ * out_dtype | 16: rows are (hi | lo) pairs, [., 2*768]; out_dtype | 32: (hi16 | hi8 | lo8) rows. */
 int bs_preprocess_patches(const uint8_t* frames, void* out, int32_t B, int32_t H, int32_t W, int32_t nh,
                           int32_t nw, int32_t flip, int32_t out_dtype, void* stream);
 /* the same pre-processing to a plain NCHW fp32 image (tests) */
