@@ -70,10 +70,31 @@ static int dispatch(IgemmParams& p, int dtype, bool conv, int tile, hipStream_t 
         IgemmParams main = p;
         main.M = full * BM;                    // rows [0, full*BM): the kernel clamps and masks against M
         main.m_begin = 0;
-        const int rc = launch_tile(main, dtype, conv, tile, st);
-        if (rc != BS_OK) return rc;
         p.m_begin = full * BM;                 // rows [full*BM, M)
-        return launch_tile(p, dtype, conv, 1, st);
+        // The two launches touch disjoint rows, so the short, latency-bound tail (8-32 small blocks, ~60 us on its own) runs on
+        // a side stream beside the main launch and fills CUs the main grid leaves idle in its last round: fork / join by events.
+        static const bool side_ok = getenv("BS_NO_TAIL_STREAM") == nullptr;
+        static hipStream_t side = nullptr;
+        static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+        if (side_ok && !side) {
+            BS_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            BS_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+            BS_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        }
+        if (!side_ok) {
+            const int rc = launch_tile(main, dtype, conv, tile, st);
+            if (rc != BS_OK) return rc;
+            return launch_tile(p, dtype, conv, 1, st);
+        }
+        BS_CHECK_HIP(hipEventRecord(ev_fork, st));
+        BS_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+        int rc = launch_tile(main, dtype, conv, tile, st);
+        if (rc != BS_OK) return rc;
+        rc = launch_tile(p, dtype, conv, 1, side);
+        if (rc != BS_OK) return rc;
+        BS_CHECK_HIP(hipEventRecord(ev_join, side));
+        BS_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
+        return BS_OK;
     }
     p.m_begin = 0;
     return launch_tile(p, dtype, conv, tile, st);
