@@ -211,6 +211,37 @@ class Plan:
         self.keep = []       # keeps descriptors / tensors alive
         self.marks = {}      # call index -> [(name, tensor)]
         self.gemm_info = {}  # call index -> dict(tile, conv, flops, bytes)
+        self.lane = 0        # lane of the calls being added: 0 = the caller's stream, 1 = the plan's side stream
+        self.lanes = []      # per call
+        self._side = None    # torch side stream + fork / join events, created at the first run
+        self._evf = self._evj = None
+
+    # ---- two-lane plans: a run of calls that only depends on data available at the fork may be issued on a side stream and
+    # overlap the main lane until the join (the bins head's router / seed path beside the fusion stage's convolutions)
+    def fork(self):
+        self.calls.append(("fork", ()))
+        self.names.append("fork")
+        self.lanes.append(0)
+
+    def join(self):
+        self.calls.append(("join", ()))
+        self.names.append("join")
+        self.lanes.append(0)
+
+    def _streams(self):
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+            self._evf, self._evj = torch.cuda.Event(), torch.cuda.Event()
+        return main, self._side
+
+    def _sync_op(self, op, main, side):
+        if op == "fork":
+            self._evf.record(main)
+            side.wait_event(self._evf)
+        else:
+            self._evj.record(side)
+            main.wait_event(self._evj)
 
     def gemm(self, name, A, W, out, **kw):
         passes = kw.pop("precision_passes", 1)
@@ -219,6 +250,7 @@ class Plan:
         self.keep.append((d, A, W, out, kw))
         self.calls.append((load_library().bs_gemm, (C.byref(d),)))
         self.names.append(name)
+        self.lanes.append(self.lane)
         # bookkeeping for the roofline: which kernel instantiation and how many algorithmic FLOPs
         self.gemm_info[len(self.calls) - 1] = dict(
             name=name, tile=load_library().bs_gemm_tile(C.byref(d)), conv=bool(d.conv),
@@ -238,6 +270,7 @@ class Plan:
                 cargs.append(a)
         self.calls.append((getattr(load_library(), fn_name), tuple(cargs)))
         self.names.append(name)
+        self.lanes.append(self.lane)
 
     def mark(self, name, tensor, meta=None):
         self.marks.setdefault(len(self.calls), []).append((name, tensor, meta))
@@ -245,32 +278,45 @@ class Plan:
     def run_timed(self, events: list):
         """Like run(), with a HIP event pair (recorded on the launch stream) around every bs_gemm launch;
         appends (call_index, start_event, end_event) to `events`."""
-        st = stream_ptr()
+        main, side = self._streams()
+        sts = (main, side)
+        ptrs = (main.cuda_stream, side.cuda_stream)
         for i, (fn, args) in enumerate(self.calls):
+            if isinstance(fn, str):
+                self._sync_op(fn, main, side)
+                continue
+            ln = self.lanes[i]
             if i in self.gemm_info:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                rc = fn(*args, st)
-                e1.record()
+                e0.record(sts[ln])
+                rc = fn(*args, ptrs[ln])
+                e1.record(sts[ln])
                 events.append((i, e0, e1))
             else:
-                rc = fn(*args, st)
+                rc = fn(*args, ptrs[ln])
             if rc:
                 check(rc, self.names[i])
 
     def run(self, taps: Optional[dict] = None):
-        st = stream_ptr()
         if taps is None:
+            main, side = self._streams()
+            ptrs = (main.cuda_stream, side.cuda_stream)
             for i, (fn, args) in enumerate(self.calls):
-                rc = fn(*args, st)
+                if isinstance(fn, str):
+                    self._sync_op(fn, main, side)
+                    continue
+                rc = fn(*args, ptrs[self.lanes[i]])
                 if rc:
                     check(rc, self.names[i])
             return
+        st = stream_ptr()       # tap mode (tests): one stream, program order
         for i in range(len(self.calls) + 1):
             for (name, t, meta) in self.marks.get(i, []):
                 taps[name] = (t.clone(), meta)
             if i < len(self.calls):
                 fn, args = self.calls[i]
+                if isinstance(fn, str):
+                    continue
                 check(fn(*args, st), self.names[i])
 
 

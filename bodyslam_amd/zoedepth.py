@@ -490,50 +490,11 @@ class _ZoePlan:
             P.mark(f"neckconv{i}", f16_, ("nhwc", NB, fh, fw, c.fusion, (2 if nf8 else 1) if acc else 0))
             feats.append(f16_)
             fshape.append((fh, fw))
-        # ---- Z5: fusion stage (pre-activation residual units, x2 bilinear, 1x1 projection)
-        Fc = c.fusion
-
-        def res_unit(name, xin, hh, ww, other=None):
-            """y = conv2(relu(conv1(relu(x)))) + x (+ other)."""
-            t = e16(NB, hh, ww, Fc * m2)
-            y = e16(NB, hh, ww, Fc * m2)
-            if acc:
-                xr = e16(NB, hh, ww, Fc * m2)
-                P.add(name + ".relu", "bs_relu_split", xin, xr, NB * hh * ww, Fc, L.dt(xr) | (32 if nf8 else 0))
-                nconv(name + ".c1", xr, name + ".c1.w", t, hh, ww, Fc, Fc, bias=w[name + ".c1.b"], act=L.ACT_RELU)
-            else:
-                nconv(name + ".c1", xin, name + ".c1.w", t, hh, ww, Fc, Fc, relu_a=True, bias=w[name + ".c1.b"], act=L.ACT_RELU)
-            nconv(name + ".c2", t, name + ".c2.w", y, hh, ww, Fc, Fc, bias=w[name + ".c2.b"], res=xin, res2=other)
-            return y
-
-        fused_list = []
-        fused = None
-        for li in range(4):
-            feat = feats[3 - li]
-            fh, fw = fshape[3 - li]
-            if fused is None:
-                cur = feat
-            else:
-                cur = res_unit(f"fu{li}.r1", feat, fh, fw, other=fused)     # fused + residual_layer1(feat)
-            cur = res_unit(f"fu{li}.r2", cur, fh, fw)
-            up = e16(NB, 2 * fh, 2 * fw, Fc * m2)
-            P.add(f"fu{li}.up", "bs_resize_bilinear_nhwc", cur, up, NB, fh, fw, Fc, 2 * fh, 2 * fw, RZ, L.dt(up))
-            fused = e16(NB, 2 * fh, 2 * fw, Fc * m2)
-            nplain(f"fu{li}.proj", up, f"fu{li}.proj.w", fused, NB * 4 * fh * fw, Fc, Fc, bias=w[f"fu{li}.proj.b"])
-            P.mark(f"fused{li}", fused, ("nhwc", NB, 2 * fh, 2 * fw, Fc, (2 if nf8 else 1) if acc else 0))
-            fused_list.append((fused, 2 * fh, 2 * fw))
         bott, (bh_, bw_) = feats[3], fshape[3]
-        # ---- Z6: relative head (conv3 + ReLU -> relative depth is dead code for the NK output and not launched)
-        f3, h3, w3 = fused_list[3]
-        rp = e16(NB, h3, w3, Fc * m2)
-        nconv("rh.projection", f3, "rh.projection.w", rp, h3, w3, Fc, Fc, bias=w["rh.projection.b"], act=L.ACT_RELU)
-        r1 = e16(NB, h3, w3, (Fc // 2) * m2)
-        nconv("rh.conv1", rp, "rh.conv1.w", r1, h3, w3, Fc, Fc // 2, bias=w["rh.conv1.b"])
-        r1u = e16(NB, 2 * h3, 2 * w3, (Fc // 2) * m2)
-        P.add("rh.up", "bs_resize_bilinear_nhwc", r1, r1u, NB, h3, w3, Fc // 2, 2 * h3, 2 * w3, RZ, L.dt(r1))
-        last = e16(NB, 2 * h3, 2 * w3, c.rel_features * m2)
-        nconv("rh.conv2", r1u, "rh.conv2.w", last, 2 * h3, 2 * w3, Fc // 2, c.rel_features, bias=w["rh.conv2.b"], act=L.ACT_RELU)
-        P.mark("rel_features", last, ("nhwc", NB, 2 * h3, 2 * w3, c.rel_features, (2 if nf8 else 1) if acc else 0))
+        # The router and the seed regressors depend only on the bottleneck map: they are issued on the plan's side stream and run
+        # beside the fusion stage / relative head (small, latency-bound kernels that would otherwise serialise behind them).
+        P.fork()
+        P.lane = 1
         # ---- Z7: metric-bins head
         Mb = NB * bh_ * bw_
         xb = e16(Mb, c.bottleneck)
@@ -581,6 +542,52 @@ class _ZoePlan:
         emb_prev = e16(Mb, E * m2)
         P.gemm("seedproj.c2", sh, w["seedproj.c2.w"], emb_prev, M=Mb, N=E, K=E // 2, lda=3 * (E // 2), a_offset=E, bias=w["seedproj.c2.b"],
                ldo=E * m2, out_split_off=E if acc else 0)
+        P.lane = 0
+        # ---- Z5: fusion stage (pre-activation residual units, x2 bilinear, 1x1 projection)
+        Fc = c.fusion
+
+        def res_unit(name, xin, hh, ww, other=None):
+            """y = conv2(relu(conv1(relu(x)))) + x (+ other)."""
+            t = e16(NB, hh, ww, Fc * m2)
+            y = e16(NB, hh, ww, Fc * m2)
+            if acc:
+                xr = e16(NB, hh, ww, Fc * m2)
+                P.add(name + ".relu", "bs_relu_split", xin, xr, NB * hh * ww, Fc, L.dt(xr) | (32 if nf8 else 0))
+                nconv(name + ".c1", xr, name + ".c1.w", t, hh, ww, Fc, Fc, bias=w[name + ".c1.b"], act=L.ACT_RELU)
+            else:
+                nconv(name + ".c1", xin, name + ".c1.w", t, hh, ww, Fc, Fc, relu_a=True, bias=w[name + ".c1.b"], act=L.ACT_RELU)
+            nconv(name + ".c2", t, name + ".c2.w", y, hh, ww, Fc, Fc, bias=w[name + ".c2.b"], res=xin, res2=other)
+            return y
+
+        fused_list = []
+        fused = None
+        for li in range(4):
+            feat = feats[3 - li]
+            fh, fw = fshape[3 - li]
+            if fused is None:
+                cur = feat
+            else:
+                cur = res_unit(f"fu{li}.r1", feat, fh, fw, other=fused)     # fused + residual_layer1(feat)
+            cur = res_unit(f"fu{li}.r2", cur, fh, fw)
+            up = e16(NB, 2 * fh, 2 * fw, Fc * m2)
+            P.add(f"fu{li}.up", "bs_resize_bilinear_nhwc", cur, up, NB, fh, fw, Fc, 2 * fh, 2 * fw, RZ, L.dt(up))
+            fused = e16(NB, 2 * fh, 2 * fw, Fc * m2)
+            nplain(f"fu{li}.proj", up, f"fu{li}.proj.w", fused, NB * 4 * fh * fw, Fc, Fc, bias=w[f"fu{li}.proj.b"])
+            P.mark(f"fused{li}", fused, ("nhwc", NB, 2 * fh, 2 * fw, Fc, (2 if nf8 else 1) if acc else 0))
+            fused_list.append((fused, 2 * fh, 2 * fw))
+        # ---- Z6: relative head (conv3 + ReLU -> relative depth is dead code for the NK output and not launched)
+        f3, h3, w3 = fused_list[3]
+        rp = e16(NB, h3, w3, Fc * m2)
+        nconv("rh.projection", f3, "rh.projection.w", rp, h3, w3, Fc, Fc, bias=w["rh.projection.b"], act=L.ACT_RELU)
+        r1 = e16(NB, h3, w3, (Fc // 2) * m2)
+        nconv("rh.conv1", rp, "rh.conv1.w", r1, h3, w3, Fc, Fc // 2, bias=w["rh.conv1.b"])
+        r1u = e16(NB, 2 * h3, 2 * w3, (Fc // 2) * m2)
+        P.add("rh.up", "bs_resize_bilinear_nhwc", r1, r1u, NB, h3, w3, Fc // 2, 2 * h3, 2 * w3, RZ, L.dt(r1))
+        last = e16(NB, 2 * h3, 2 * w3, c.rel_features * m2)
+        nconv("rh.conv2", r1u, "rh.conv2.w", last, 2 * h3, 2 * w3, Fc // 2, c.rel_features, bias=w["rh.conv2.b"], act=L.ACT_RELU)
+        P.mark("rel_features", last, ("nhwc", NB, 2 * h3, 2 * w3, c.rel_features, (2 if nf8 else 1) if acc else 0))
+        # ---- Z7 (continued): projector / attractor levels on the fusion outputs, joined with the side lane's router + seeds
+        P.join()
         ph_, pw_ = bh_, bw_
         for i in range(4):
             feat, fh, fw = fused_list[i]
