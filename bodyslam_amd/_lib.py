@@ -214,34 +214,39 @@ class Plan:
         self.lane = 0        # lane of the calls being added: 0 = the caller's stream, 1 = the plan's side stream
         self.lanes = []      # per call
         self._side = None    # torch side stream + fork / join events, created at the first run
-        self._evf = self._evj = None
+        self._events = {}
 
-    # ---- two-lane plans: a run of calls that only depends on data available at the fork may be issued on a side stream and
-    # overlap the main lane until the join (the bins head's router / seed path beside the fusion stage's convolutions)
-    def fork(self):
-        self.calls.append(("fork", ()))
-        self.names.append("fork")
-        self.lanes.append(0)
+    # ---- two-lane plans: calls added while `lane` is 1 are issued on the plan's side stream.  `signal(k)` records event k on
+    # the current lane's stream, `wait(k)` makes the current lane's stream wait for it: a run of small, latency-bound kernels
+    # that only depends on data available at some point of the main lane overlaps the main lane's big kernels from there on
+    # (the bins head's router / seeds / attractor chain beside the fusion stage and the relative head).
+    def signal(self, k: int):
+        self.calls.append(("signal", (k, self.lane)))
+        self.names.append(f"signal{k}")
+        self.lanes.append(self.lane)
 
-    def join(self):
-        self.calls.append(("join", ()))
-        self.names.append("join")
-        self.lanes.append(0)
+    def wait(self, k: int):
+        self.calls.append(("wait", (k, self.lane)))
+        self.names.append(f"wait{k}")
+        self.lanes.append(self.lane)
 
     def _streams(self):
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream()
-            self._evf, self._evj = torch.cuda.Event(), torch.cuda.Event()
+            self._events = {}
         return main, self._side
 
-    def _sync_op(self, op, main, side):
-        if op == "fork":
-            self._evf.record(main)
-            side.wait_event(self._evf)
+    def _sync_op(self, op, args, main, side):
+        k, lane = args
+        ev = self._events.get(k)
+        if ev is None:
+            ev = self._events[k] = torch.cuda.Event()
+        st = side if lane else main
+        if op == "signal":
+            ev.record(st)
         else:
-            self._evj.record(side)
-            main.wait_event(self._evj)
+            st.wait_event(ev)
 
     def gemm(self, name, A, W, out, **kw):
         passes = kw.pop("precision_passes", 1)
@@ -283,7 +288,7 @@ class Plan:
         ptrs = (main.cuda_stream, side.cuda_stream)
         for i, (fn, args) in enumerate(self.calls):
             if isinstance(fn, str):
-                self._sync_op(fn, main, side)
+                self._sync_op(fn, args, main, side)
                 continue
             ln = self.lanes[i]
             if i in self.gemm_info:
@@ -303,7 +308,7 @@ class Plan:
             ptrs = (main.cuda_stream, side.cuda_stream)
             for i, (fn, args) in enumerate(self.calls):
                 if isinstance(fn, str):
-                    self._sync_op(fn, main, side)
+                    self._sync_op(fn, args, main, side)
                     continue
                 rc = fn(*args, ptrs[self.lanes[i]])
                 if rc:

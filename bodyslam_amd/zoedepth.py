@@ -493,8 +493,9 @@ class _ZoePlan:
         bott, (bh_, bw_) = feats[3], fshape[3]
         # The router and the seed regressors depend only on the bottleneck map: they are issued on the plan's side stream and run
         # beside the fusion stage / relative head (small, latency-bound kernels that would otherwise serialise behind them).
-        P.fork()
+        P.signal(0)
         P.lane = 1
+        P.wait(0)
         # ---- Z7: metric-bins head
         Mb = NB * bh_ * bw_
         xb = e16(Mb, c.bottleneck)
@@ -542,6 +543,7 @@ class _ZoePlan:
         emb_prev = e16(Mb, E * m2)
         P.gemm("seedproj.c2", sh, w["seedproj.c2.w"], emb_prev, M=Mb, N=E, K=E // 2, lda=3 * (E // 2), a_offset=E, bias=w["seedproj.c2.b"],
                ldo=E * m2, out_split_off=E if acc else 0)
+        P.signal(1)
         P.lane = 0
         # ---- Z5: fusion stage (pre-activation residual units, x2 bilinear, 1x1 projection)
         Fc = c.fusion
@@ -586,8 +588,9 @@ class _ZoePlan:
         last = e16(NB, 2 * h3, 2 * w3, c.rel_features * m2)
         nconv("rh.conv2", r1u, "rh.conv2.w", last, 2 * h3, 2 * w3, Fc // 2, c.rel_features, bias=w["rh.conv2.b"], act=L.ACT_RELU)
         P.mark("rel_features", last, ("nhwc", NB, 2 * h3, 2 * w3, c.rel_features, (2 if nf8 else 1) if acc else 0))
-        # ---- Z7 (continued): projector / attractor levels on the fusion outputs, joined with the side lane's router + seeds
-        P.join()
+        # ---- Z7 (continued): projector / attractor levels on the fusion outputs, after the side lane's router + seeds
+        # (putting this chain on the side lane as well, beside the relative head, measured neutral)
+        P.wait(1)
         ph_, pw_ = bh_, bw_
         for i in range(4):
             feat, fh, fw = fused_list[i]
