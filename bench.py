@@ -15,9 +15,13 @@ Inputs are resident in HBM before the timed region.  K steps are timed between b
 torch.cuda.synchronize() pairs; the value is (ranks x K x B frames) / max-over-ranks time.
 Weights are random-init (no checkpoint is reachable offline); data is synthetic.
 
+The primary line is precision="accurate" (split-precision products, depth L1 vs the fp32 oracle <= 1e-4 m -- the north
+star's tolerance); the single-pass "fast" mode is measured in the same run and reported under "other_mode".
+
 roofline: per-kernel HIP-event timing of every bs_gemm launch inside the timed steps, aggregated per
 kernel instantiation (tile variant x conv/plain); the dominant one by time is reported against the dense
-fp16/bf16 MFMA peak (2.5 PFLOP/s), next to the conv-stack aggregate the north star names.
+fp16/bf16 MFMA peak (2.5 PFLOP/s), next to the conv-stack aggregate the north star names.  `achieved` counts algorithmic
+FLOPs (2*M*N*K of the product computed), `executed` the MFMA work issued in 16-bit-equivalents (2x in accurate mode).
 cpu_baseline: the CPU oracle (torch fp32, all host cores) on ONE frame of the same workload, rank 0 only.
 """
 import argparse

@@ -15,6 +15,9 @@ Data layout in HBM (B frames, flip-aug doubles the image batch: NB = 2B):
   rel-pos bias         fp32 [layers][heads, Sp, Sp], -1e30 in padded key columns (built once per window)
   conv activations     NHWC 16-bit
   bins / attractors    fp32 NHWC, both heads side by side ([nyu 64 | kitti 64], [16 | 16])
+  precision="accurate" every GEMM / conv operand is a pair: activations [rows, 2C] = (hi16 | hi8 | lo8) (or (hi | lo) 16-bit
+                       pairs where a K is not a multiple of 128), weights [W_hi16 | W_lo8 | W_hi8]; one launch evaluates
+                       A_hi W_hi + A_hi W_lo + A_lo W_hi, the corrections on the FP8 MFMA (Numerics)
 PyTorch is used for allocation, views and one-off weight re-layout only.
 """
 from __future__ import annotations
