@@ -6,12 +6,18 @@
 
 namespace bs {
 
-int igemm_launch_tile1(const IgemmParams&, int, bool, hipStream_t);
-int igemm_launch_tile2(const IgemmParams&, int, bool, hipStream_t);
-int igemm_launch_tile3(const IgemmParams&, int, bool, hipStream_t);
-int igemm_launch_tile9(const IgemmParams&, int, bool, hipStream_t);
-int igemm_launch_tile10(const IgemmParams&, int, bool, hipStream_t);
-int igemm_launch_tile11(const IgemmParams&, int, bool, hipStream_t);
+int igemm_launch_tile1_f16(const IgemmParams&, bool, hipStream_t);
+int igemm_launch_tile1_bf16(const IgemmParams&, bool, hipStream_t);
+int igemm_launch_tile2_f16(const IgemmParams&, bool, hipStream_t);
+int igemm_launch_tile2_bf16(const IgemmParams&, bool, hipStream_t);
+int igemm_launch_tile3_f16(const IgemmParams&, bool, hipStream_t);
+int igemm_launch_tile3_bf16(const IgemmParams&, bool, hipStream_t);
+int igemm_launch_tile9_f16(const IgemmParams&, bool, hipStream_t);
+int igemm_launch_tile9_bf16(const IgemmParams&, bool, hipStream_t);
+int igemm_launch_tile10_f16(const IgemmParams&, bool, hipStream_t);
+int igemm_launch_tile10_bf16(const IgemmParams&, bool, hipStream_t);
+int igemm_launch_tile11_f16(const IgemmParams&, bool, hipStream_t);
+int igemm_launch_tile11_bf16(const IgemmParams&, bool, hipStream_t);
 
 // tile ids (BMxBNxBK, LDS stages): 1 128x128x64 s2 (2 blocks/CU) | 2 128x64x64 s2 | 3 128x32x64 s2 | 9 256x256x64 s2 (128 KiB)
 //   10 256x256x32 s4 ping-pong (two wave groups alternate MFMA / load phases) | 11 256x128x32 s3, 4 waves (2 blocks/CU)
@@ -42,12 +48,12 @@ static int launch_tile(IgemmParams& p, int dtype, bool conv, int tile, hipStream
     p.ntm = cdiv(p.M - p.m_begin, BM);
     p.ntn = cdiv(p.N, BN);
     switch (tile) {
-        case 1: return igemm_launch_tile1(p, dtype, conv, st);
-        case 2: return igemm_launch_tile2(p, dtype, conv, st);
-        case 3: return igemm_launch_tile3(p, dtype, conv, st);
-        case 9: return igemm_launch_tile9(p, dtype, conv, st);
-        case 10: return igemm_launch_tile10(p, dtype, conv, st);
-        case 11: return igemm_launch_tile11(p, dtype, conv, st);
+        case 1: return dtype == BS_F16 ? igemm_launch_tile1_f16(p, conv, st) : igemm_launch_tile1_bf16(p, conv, st);
+        case 2: return dtype == BS_F16 ? igemm_launch_tile2_f16(p, conv, st) : igemm_launch_tile2_bf16(p, conv, st);
+        case 3: return dtype == BS_F16 ? igemm_launch_tile3_f16(p, conv, st) : igemm_launch_tile3_bf16(p, conv, st);
+        case 9: return dtype == BS_F16 ? igemm_launch_tile9_f16(p, conv, st) : igemm_launch_tile9_bf16(p, conv, st);
+        case 10: return dtype == BS_F16 ? igemm_launch_tile10_f16(p, conv, st) : igemm_launch_tile10_bf16(p, conv, st);
+        case 11: return dtype == BS_F16 ? igemm_launch_tile11_f16(p, conv, st) : igemm_launch_tile11_bf16(p, conv, st);
         default: set_error("bs_gemm: tile %d is not built (1, 2, 3, 9, 10, 11)", tile); return BS_ERR_INVALID;
     }
 }

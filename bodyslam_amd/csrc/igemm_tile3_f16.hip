@@ -1,0 +1,6 @@
+// One (tile variant, operand type) of the implicit-GEMM kernel per translation unit: they build in parallel (see igemm_kernel.h).
+#include "igemm_kernel.h"
+
+namespace bs {
+int igemm_launch_tile3_f16(const IgemmParams& p, bool conv, hipStream_t st) { return launch_variant<f16, 128, 32, 4, 1, 64, 2>(p, conv, st); }
+}  // namespace bs
