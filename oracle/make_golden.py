@@ -103,6 +103,10 @@ def gen_geom3d(ref: str, out: str):
     np.savez_compressed(os.path.join(out, "geom3d_backproject.npz"), depth=d, K=np.array(K),
                         idx=np.array(idx, dtype=np.int32), xyz=np.array(xyz, dtype=np.float64))
 
+    # KITTI pose text written by the reference's own writer (UTILS/io_utils.py:264-278) for the first 24 absolute poses
+    from UTILS import io_utils   # reference
+    io_utils.TXTIO().save_poses_as_kitti(g_abs[:24], os.path.join(out, "kitti_poses_24.txt"))
+
 
 def gen_cyclepose(ref: str, out: str):
     sys.modules["cv2"] = types.ModuleType("cv2")

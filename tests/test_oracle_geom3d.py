@@ -113,3 +113,14 @@ def test_backproject_c_with_pose_and_empty(bp, clib, chain):
 def test_pixel_to_3d_formula():
     p = G.pixel_to_3d(300, 200, 1.5, *G.REF_INTRINSICS)
     assert np.allclose(p, [(300 - 276.4727783203125) * 1.5 / 383.1901395, (200 - 124.3335933685303) * 1.5 / 383.1901395, 1.5])
+
+
+def test_kitti_pose_writer_matches_reference_file(golden_dir, tmp_path):
+    """save_poses_as_kitti (drop-in for UTILS/io_utils.py:264-278): byte-identical to the file the reference's own writer
+    produced for the same poses (tests/golden/kitti_poses_24.txt, made by oracle/make_golden.py)."""
+    import os
+    from bodyslam_amd.slam_utils import save_poses_as_kitti
+    g = np.load(os.path.join(golden_dir, "geom3d_chain.npz"))
+    out = tmp_path / "poses.txt"
+    save_poses_as_kitti(list(g["g_abs"][:24]), str(out))
+    assert out.read_text() == open(os.path.join(golden_dir, "kitti_poses_24.txt")).read()
