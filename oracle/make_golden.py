@@ -148,8 +148,8 @@ def hf_config(c: Z.ZoeConfig):
         num_relative_features=c.rel_features, bottleneck_features=c.bottleneck, bin_embedding_dim=c.bin_dim,
         num_attractors=[16, 8, 4, 1], attractor_alpha=1000, attractor_gamma=2, attractor_kind="mean",
         min_temp=c.min_temp, max_temp=c.max_temp, bin_centers_type="softplus",
-        bin_configurations=[{"name": "nyu", "n_bins": 64, "min_depth": 1e-3, "max_depth": 10.0},
-                            {"name": "kitti", "n_bins": 64, "min_depth": 1e-3, "max_depth": 80.0}],
+        bin_configurations=[{"name": n_, "n_bins": 64, "min_depth": 1e-3, "max_depth": {"nyu": 10.0, "kitti": 80.0}[n_]}
+                            for n_ in c.head_names],
         num_patch_transformer_layers=c.pt_layers, patch_transformer_hidden_size=c.pt_hidden,
         patch_transformer_intermediate_size=c.pt_inter, patch_transformer_num_attention_heads=c.pt_heads)
 

@@ -57,6 +57,9 @@ class ZoeConfig:
     bottleneck: int = 256
     bin_dim: int = 128
     n_attractors: int = 16           # NK head: every attractor layer emits 16 (modeling_zoedepth.py:1026-1031,:670)
+    # single-head models (ZoeD_N, ZoeD_K = HF ZoeDepthMetricDepthEstimationHead, modeling_zoedepth.py:1106-1200): one bin
+    # configuration, no router, per-level attractor counts, and the relative depth as a 33rd input of the log-binomial MLP
+    level_attractors: Tuple[int, ...] = (16, 8, 4, 1)
     n_bins: int = 64
     min_temp: float = 0.0212
     max_temp: float = 50.0
@@ -70,8 +73,27 @@ class ZoeConfig:
     def head_dim(self) -> int:
         return self.hidden // self.heads
 
+    @property
+    def single_head(self) -> bool:
+        return len(self.head_names) == 1
+
+    @property
+    def seed_mlp(self) -> int:
+        """hidden width of the seed bin regressor: HF's default 256 in the single head, bin_dim // 2 in the NK head (:1000)"""
+        return 256 if self.single_head else self.bin_dim // 2
+
+    @property
+    def proj_mlp(self) -> int:
+        """hidden width of the (seed) projectors: HF's default 128 in the single head, bin_dim // 2 in the NK head (:1003-1011)"""
+        return 128 if self.single_head else self.bin_dim // 2
+
+    def attractors_at(self, level: int) -> int:
+        return self.level_attractors[level] if self.single_head else self.n_attractors
+
 
 ZOED_NK = ZoeConfig()
+ZOED_N = ZoeConfig(head_names=("nyu",))       # Intel/zoedepth-nyu   (max_depth 10; the softplus bin centres ignore it)
+ZOED_K = ZoeConfig(head_names=("kitti",))     # Intel/zoedepth-kitti (max_depth 80)
 
 
 def tiny_config() -> ZoeConfig:
@@ -144,52 +166,62 @@ def param_shapes(cfg: ZoeConfig) -> Dict[str, Tuple[int, ...]]:
     B, E = cfg.bottleneck, cfg.bin_dim
     s["metric_head.conv2.weight"] = (B, B, 1, 1)
     s["metric_head.conv2.bias"] = (B,)
-    for l in range(cfg.pt_layers):
-        p = f"metric_head.patch_transformer.transformer_encoder.{l}."
-        for n in ("query", "key", "value", "out_proj"):
-            s[p + f"self_attn.{n}.weight"] = (cfg.pt_hidden, cfg.pt_hidden)
-            s[p + f"self_attn.{n}.bias"] = (cfg.pt_hidden,)
-        s[p + "linear1.weight"] = (cfg.pt_inter, cfg.pt_hidden)
-        s[p + "linear1.bias"] = (cfg.pt_inter,)
-        s[p + "linear2.weight"] = (cfg.pt_hidden, cfg.pt_inter)
-        s[p + "linear2.bias"] = (cfg.pt_hidden,)
-        for n in ("norm1", "norm2"):
-            s[p + f"{n}.weight"] = (cfg.pt_hidden,)
-            s[p + f"{n}.bias"] = (cfg.pt_hidden,)
-    s["metric_head.patch_transformer.embedding_convPxP.weight"] = (cfg.pt_hidden, B, 1, 1)
-    s["metric_head.patch_transformer.embedding_convPxP.bias"] = (cfg.pt_hidden,)
-    s["metric_head.mlp_classifier.linear1.weight"] = (128, 128)
-    s["metric_head.mlp_classifier.linear1.bias"] = (128,)
-    s["metric_head.mlp_classifier.linear2.weight"] = (2, 128)
-    s["metric_head.mlp_classifier.linear2.bias"] = (2,)
-    for name in cfg.head_names:
-        p = f"metric_head.seed_bin_regressors.{name}."
-        s[p + "conv1.weight"] = (E // 2, B, 1, 1)
-        s[p + "conv1.bias"] = (E // 2,)
-        s[p + "conv2.weight"] = (cfg.n_bins, E // 2, 1, 1)
+    if cfg.single_head:
+        p = "metric_head.seed_bin_regressor."
+        s[p + "conv1.weight"] = (cfg.seed_mlp, B, 1, 1)
+        s[p + "conv1.bias"] = (cfg.seed_mlp,)
+        s[p + "conv2.weight"] = (cfg.n_bins, cfg.seed_mlp, 1, 1)
         s[p + "conv2.bias"] = (cfg.n_bins,)
-    s["metric_head.seed_projector.conv1.weight"] = (E // 2, B, 1, 1)
-    s["metric_head.seed_projector.conv1.bias"] = (E // 2,)
-    s["metric_head.seed_projector.conv2.weight"] = (E, E // 2, 1, 1)
+    else:
+        for l in range(cfg.pt_layers):
+            p = f"metric_head.patch_transformer.transformer_encoder.{l}."
+            for n in ("query", "key", "value", "out_proj"):
+                s[p + f"self_attn.{n}.weight"] = (cfg.pt_hidden, cfg.pt_hidden)
+                s[p + f"self_attn.{n}.bias"] = (cfg.pt_hidden,)
+            s[p + "linear1.weight"] = (cfg.pt_inter, cfg.pt_hidden)
+            s[p + "linear1.bias"] = (cfg.pt_inter,)
+            s[p + "linear2.weight"] = (cfg.pt_hidden, cfg.pt_inter)
+            s[p + "linear2.bias"] = (cfg.pt_hidden,)
+            for n in ("norm1", "norm2"):
+                s[p + f"{n}.weight"] = (cfg.pt_hidden,)
+                s[p + f"{n}.bias"] = (cfg.pt_hidden,)
+        s["metric_head.patch_transformer.embedding_convPxP.weight"] = (cfg.pt_hidden, B, 1, 1)
+        s["metric_head.patch_transformer.embedding_convPxP.bias"] = (cfg.pt_hidden,)
+        s["metric_head.mlp_classifier.linear1.weight"] = (128, 128)
+        s["metric_head.mlp_classifier.linear1.bias"] = (128,)
+        s["metric_head.mlp_classifier.linear2.weight"] = (2, 128)
+        s["metric_head.mlp_classifier.linear2.bias"] = (2,)
+        for name in cfg.head_names:
+            p = f"metric_head.seed_bin_regressors.{name}."
+            s[p + "conv1.weight"] = (E // 2, B, 1, 1)
+            s[p + "conv1.bias"] = (E // 2,)
+            s[p + "conv2.weight"] = (cfg.n_bins, E // 2, 1, 1)
+            s[p + "conv2.bias"] = (cfg.n_bins,)
+    PM = cfg.proj_mlp
+    s["metric_head.seed_projector.conv1.weight"] = (PM, B, 1, 1)
+    s["metric_head.seed_projector.conv1.bias"] = (PM,)
+    s["metric_head.seed_projector.conv2.weight"] = (E, PM, 1, 1)
     s["metric_head.seed_projector.conv2.bias"] = (E,)
     for i in range(4):
         p = f"metric_head.projectors.{i}."
-        s[p + "conv1.weight"] = (E // 2, Fh, 1, 1)
-        s[p + "conv1.bias"] = (E // 2,)
-        s[p + "conv2.weight"] = (E, E // 2, 1, 1)
+        s[p + "conv1.weight"] = (PM, Fh, 1, 1)
+        s[p + "conv1.bias"] = (PM,)
+        s[p + "conv2.weight"] = (E, PM, 1, 1)
         s[p + "conv2.bias"] = (E,)
     for name in cfg.head_names:
+        mid = "" if cfg.single_head else f"{name}."
         for i in range(4):
-            p = f"metric_head.attractors.{name}.{i}."
+            p = f"metric_head.attractors.{mid}{i}."
             s[p + "conv1.weight"] = (E, E, 1, 1)
             s[p + "conv1.bias"] = (E,)
-            s[p + "conv2.weight"] = (cfg.n_attractors, E, 1, 1)
-            s[p + "conv2.bias"] = (cfg.n_attractors,)
-        p = f"metric_head.conditional_log_binomial.{name}.mlp."
-        cin = cfg.rel_features + E
-        s[p + "0.weight"] = (cin // 4, cin, 1, 1)
-        s[p + "0.bias"] = (cin // 4,)
-        s[p + "2.weight"] = (4, cin // 4, 1, 1)
+            s[p + "conv2.weight"] = (cfg.attractors_at(i), E, 1, 1)
+            s[p + "conv2.bias"] = (cfg.attractors_at(i),)
+        p = f"metric_head.conditional_log_binomial.{mid}mlp."
+        cin = cfg.rel_features + (1 if cfg.single_head else 0) + E      # single head: + the relative depth (:1156)
+        hid = cin // (2 if cfg.single_head else 4)                       # bottleneck_factor: default 2 (:1159) vs 4 in the NK head
+        s[p + "0.weight"] = (hid, cin, 1, 1)
+        s[p + "0.bias"] = (hid,)
+        s[p + "2.weight"] = (4, hid, 1, 1)
         s[p + "2.bias"] = (4,)
     return s
 
@@ -479,9 +511,11 @@ def router_logits(w, cfg: ZoeConfig, x: torch.Tensor) -> torch.Tensor:
 
 
 def metric_head_single(w, cfg: ZoeConfig, name: str, x: torch.Tensor, blocks: Sequence[torch.Tensor],
-                       last: torch.Tensor, taps_out=None) -> torch.Tensor:
-    """One named head on a batch that was routed to it.  x = conv2(bottleneck)."""
-    p = f"metric_head.seed_bin_regressors.{name}."
+                       last: torch.Tensor, taps_out=None, rel: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One named head on a batch that was routed to it.  x = conv2(bottleneck).  Single-head models (ZoeD_N / ZoeD_K,
+    modeling_zoedepth.py:1166-1200) use un-named parameters and feed the relative depth ``rel`` [B,h,w] to the last MLP."""
+    mid = "" if cfg.single_head else f"{name}."
+    p = "metric_head.seed_bin_regressor." if cfg.single_head else f"metric_head.seed_bin_regressors.{name}."
     seed = F.softplus(_c1(w, p + "conv2", F.relu(_c1(w, p + "conv1", x))))
     prev_bin = seed
     prev_emb = _c1(w, "metric_head.seed_projector.conv2", F.relu(_c1(w, "metric_head.seed_projector.conv1", x)))
@@ -490,14 +524,14 @@ def metric_head_single(w, cfg: ZoeConfig, name: str, x: torch.Tensor, blocks: Se
     for i, feat in enumerate(blocks):
         pp = f"metric_head.projectors.{i}."
         emb = _c1(w, pp + "conv2", F.relu(_c1(w, pp + "conv1", feat)))
-        pa = f"metric_head.attractors.{name}.{i}."
+        pa = f"metric_head.attractors.{mid}{i}."
         y = emb + F.interpolate(prev_emb, emb.shape[-2:], mode="bilinear", align_corners=True)
         A = F.softplus(_c1(w, pa + "conv2", F.relu(_c1(w, pa + "conv1", y))))
         c = F.interpolate(prev_bin, A.shape[-2:], mode="bilinear", align_corners=True)
         delta = torch.zeros_like(c)
-        for a in range(cfg.n_attractors):
+        for a in range(cfg.attractors_at(i)):
             delta += _inv_attractor(A[:, a, ...].unsqueeze(1) - c)
-        delta = delta / cfg.n_attractors
+        delta = delta / cfg.attractors_at(i)
         bin_centers = c + delta
         prev_bin = bin_centers
         prev_emb = emb
@@ -505,7 +539,9 @@ def metric_head_single(w, cfg: ZoeConfig, name: str, x: torch.Tensor, blocks: Se
             taps_out[f"bins{i}"] = bin_centers
     bc = F.interpolate(bin_centers, last.shape[-2:], mode="bilinear", align_corners=True)
     em = F.interpolate(emb, last.shape[-2:], mode="bilinear", align_corners=True)
-    pm = f"metric_head.conditional_log_binomial.{name}.mlp."
+    pm = f"metric_head.conditional_log_binomial.{mid}mlp."
+    if cfg.single_head:      # :1186-1191: the relative depth (already at `last`'s size here) is concatenated to the features
+        last = torch.cat([last, F.interpolate(rel.unsqueeze(1), size=last.shape[2:], mode="bilinear", align_corners=True)], dim=1)
     pt = F.softplus(_c1(w, pm + "2", F.gelu(_c1(w, pm + "0", torch.cat([last, em], dim=1)))))
     prob = pt[:, :2] + 1e-4
     prob = prob[:, 0] / (prob[:, 0] + prob[:, 1])
@@ -544,6 +580,15 @@ def zoedepth_forward(w: Dict[str, torch.Tensor], cfg: ZoeConfig, x: torch.Tensor
     fused, bottleneck = neck_forward(w, cfg, hiddens, hp, wp, taps_out)
     rel, last = relative_head_forward(w, fused[-1], taps_out)
     xb = _c1(w, "metric_head.conv2", bottleneck)
+    if cfg.single_head:
+        t = {} if taps_out is not None else None
+        out = metric_head_single(w, cfg, cfg.head_names[0], xb, fused, last, t, rel=rel)
+        if taps_out is not None:
+            for k_, v_ in t.items():
+                taps_out[f"{cfg.head_names[0]}.{k_}"] = (torch.arange(B), v_)
+            taps_out["rel_depth"] = rel
+            taps_out["depth_net"] = out
+        return out, torch.zeros(B, 2, dtype=x.dtype)
     logits = router_logits(w, cfg, xb)
     if per_image_route:
         route = torch.argmax(logits, dim=-1)

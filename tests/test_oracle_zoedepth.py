@@ -60,6 +60,25 @@ def test_live_against_hf_tiny():
     assert np.abs(o.domain_logits.numpy() - lg.numpy()).max() < 1e-5
 
 
+@pytest.mark.parametrize("name", ["nyu", "kitti"])
+def test_live_against_hf_tiny_single_head(name):
+    """ZoeD_N / ZoeD_K: one bin configuration -> HF builds ZoeDepthMetricDepthEstimationHead (no router, per-level attractor
+    counts 16/8/4/1, the relative depth as a 33rd input of the log-binomial MLP).  strict=True pins the parameter names."""
+    import dataclasses
+    tr = pytest.importorskip("transformers")
+    from oracle.make_golden import hf_config
+    cfg = dataclasses.replace(Z.tiny_config(), head_names=(name,))
+    w = Z.synth_weights(cfg, seed=11)
+    m = tr.ZoeDepthForDepthEstimation(hf_config(cfg)).eval()
+    m.load_state_dict(w, strict=True)
+    x = torch.randn(2, 3, 96, 64, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        o = m(pixel_values=x)
+        d, _ = Z.zoedepth_forward(w, cfg, x)
+    assert o.domain_logits is None
+    assert np.abs(o.predicted_depth.numpy() - d.numpy()).max() < 2e-5
+
+
 def test_pre_post_geometry():
     assert Z.pad_sizes(480, 640) == (46, 53)
     assert Z.net_size(480 + 92, 640 + 106) == (384, 512)
