@@ -67,6 +67,7 @@ _SIGS = {
     "bs_attractor_step": [C.c_void_p] * 4 + [C.c_int32] * 8 + [C.c_void_p],
     "bs_add_resized": [C.c_void_p] * 3 + [C.c_int32] * 7 + [C.c_void_p],
     "bs_logbinom_depth": [C.c_void_p] * 8 + [C.c_int32] * 5 + [C.c_float, C.c_float, C.c_int32, C.c_void_p],
+    "bs_logbinom_depth_ex": [C.c_void_p] * 7 + [C.c_int32] + [C.c_void_p] * 2 + [C.c_int32] * 5 + [C.c_float, C.c_float, C.c_int32, C.c_void_p],
     "bs_small_attention": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
     "bs_route_argmax": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p],
     "bs_postprocess_depth": [C.c_void_p] * 3 + [C.c_int32] * 6 + [C.c_void_p],

@@ -82,14 +82,15 @@ __global__ __launch_bounds__(256) void attractor_kernel(const float* A, const fl
 //   pt = softplus(W2[4x40] . hidden + b2); p = (pt0+eps)/(pt0+pt1+2eps); T = (max-min)*t + min
 //   y_k = logC(n-1,k) + k log p + (n-1-k) log(1-p); depth = sum_k softmax(y/T)_k * interp(bins)_k
 // ---------------------------------------------------------------------------------------------
-constexpr int LB_HID = 40, LB_IN = 32, LB_BINS = 64;
+constexpr int LB_IN = 32, LB_BINS = 64;      // hidden width LB_HID is a template parameter: 40 (NK head) or 80 (single head)
 constexpr int LB_T = 16;                 // output tile edge (256 threads = 16 x 16 pixels)
 constexpr int LB_MAXSRC = 12;            // low-res rows / columns a 16-pixel span can touch at >= 1.5x upsampling (+1 neighbour, +slack)
 
-template <typename T, int LSPLIT>
+template <typename T, int LSPLIT, int LB_HID>
 __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const float* Eh, const float* bins, const float* w0_last,
-                                                        const float* w2, const float* b2, const int32_t* route, float* depth, int B, int H,
-                                                        int W, int He, int We, float sy, float sx, float min_temp, float max_temp) {
+                                                        const float* w2, const float* b2, const float* rel_w, const int32_t* route,
+                                                        float* depth, int B, int H, int W, int He, int We, float sy, float sx,
+                                                        float min_temp, float max_temp) {
     // LDS: the block's low-res patch of bin centres [rows][cols][64] and of Eh [rows][cols][40] for the routed head only,
     // loaded once (coalesced) instead of 4 x (256 + 160) bytes per output pixel; plus the small MLP weights.
     __shared__ float s_bins[LB_MAXSRC * LB_MAXSRC * LB_BINS];
@@ -163,6 +164,16 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
     const float* __restrict__ gw0 = w0_last + g * LB_HID * LB_IN;
     const float* __restrict__ gw2 = w2 + g * 4 * LB_HID;
     float pt[4] = {b2[g * 4 + 0], b2[g * 4 + 1], b2[g * 4 + 2], b2[g * 4 + 3]};
+    // single-head models feed the relative depth relu(conv3(last)) as a 33rd input (HF modeling_zoedepth.py:1186-1191, :367-371):
+    // rel_w[g] = [W0 column of that input (LB_HID) | conv3 weight (32) | conv3 bias]
+    const float* __restrict__ grel = rel_w ? rel_w + g * (LB_HID + LB_IN + 1) : nullptr;
+    float rd = 0.0f;
+    if (grel) {
+        rd = grel[LB_HID + LB_IN];
+#pragma unroll
+        for (int c = 0; c < LB_IN; ++c) rd += grel[LB_HID + c] * xin[c];
+        rd = fmaxf(rd, 0.0f);
+    }
 #pragma unroll 4
     for (int h = 0; h < LB_HID; ++h) {
         // same bilinear operation order as torch: hy*(hx*p00 + lx*p01) + ly*(hx*p10 + lx*p11)
@@ -170,6 +181,7 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
                   l.ly * (l.hx * s_eh[c10 * LB_HID + h] + l.lx * s_eh[c11 * LB_HID + h]);
 #pragma unroll
         for (int c = 0; c < LB_IN; ++c) a += gw0[h * LB_IN + c] * xin[c];
+        if (grel) a += grel[h] * rd;
         a = gelu_erf_as(a);
 #pragma unroll
         for (int o = 0; o < 4; ++o) pt[o] += gw2[o * LB_HID + h] * a;
@@ -288,13 +300,15 @@ extern "C" int bs_attractor_step(const float* A, const float* bins_prev, float* 
     return BS_OK;
 }
 
-extern "C" int bs_logbinom_depth(const void* last, const float* Eh, const float* bins, const float* w0_last, const float* w2,
-                                 const float* b2, const int32_t* route, float* depth, int32_t B, int32_t H, int32_t W, int32_t He,
-                                 int32_t We, float min_temp, float max_temp, int32_t dtype, void* stream) {
+extern "C" int bs_logbinom_depth_ex(const void* last, const float* Eh, const float* bins, const float* w0_last, const float* w2,
+                                    const float* b2, const float* rel_w, int32_t hid, const int32_t* route, float* depth, int32_t B,
+                                    int32_t H, int32_t W, int32_t He, int32_t We, float min_temp, float max_temp, int32_t dtype,
+                                    void* stream) {
     BS_ENTRY("bs_logbinom_depth");
     BS_REQUIRE(last && Eh && bins && w0_last && w2 && b2 && route && depth && B >= 0 && H > 0 && W > 0 && He > 0 && We > 0,
                "bs_logbinom_depth: bad argument");
     BS_REQUIRE((dtype & 15) == BS_F16 || (dtype & 15) == BS_BF16, "bs_logbinom_depth: dtype");
+    BS_REQUIRE(hid == 40 || hid == 80, "bs_logbinom_depth: hidden width %d (built: 40, 80)", hid);
     if (B == 0) return BS_OK;
     const float sy = H > 1 ? (float)(He - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(We - 1) / (float)(W - 1) : 0.f;
     // a 16-pixel output span must fit the LDS patch: span * scale + 2 <= LB_MAXSRC
@@ -304,21 +318,33 @@ extern "C" int bs_logbinom_depth(const void* last, const float* Eh, const float*
     dim3 grid(cdiv(W, LB_T), cdiv(H, LB_T), B);
     const int lsplit = (dtype & 32) ? 2 : ((dtype & 16) ? 1 : 0);   // bit 4: `last` holds (hi | lo) 16-bit pairs; bit 5: (hi16 | hi8 | lo8)
     dtype &= 15;
-#define BS_LB_LAUNCH(TT, LS)                                                                                                          \
-    hipLaunchKernelGGL((logbinom_kernel<TT, LS>), grid, dim3(256), 0, st, (const TT*)last, Eh, bins, w0_last, w2, b2, route, depth, B, H, W, \
-                       He, We, sy, sx, min_temp, max_temp)
+#define BS_LB_LAUNCH(TT, LS, HD)                                                                                                       \
+    hipLaunchKernelGGL((logbinom_kernel<TT, LS, HD>), grid, dim3(256), 0, st, (const TT*)last, Eh, bins, w0_last, w2, b2, rel_w, route, \
+                       depth, B, H, W, He, We, sy, sx, min_temp, max_temp)
+#define BS_LB_HID(TT, LS)             \
+    do {                              \
+        if (hid == 40) BS_LB_LAUNCH(TT, LS, 40); \
+        else BS_LB_LAUNCH(TT, LS, 80);           \
+    } while (0)
     if (dtype == BS_F16) {
-        if (lsplit == 2) BS_LB_LAUNCH(f16, 2);
-        else if (lsplit == 1) BS_LB_LAUNCH(f16, 1);
-        else BS_LB_LAUNCH(f16, 0);
+        if (lsplit == 2) BS_LB_HID(f16, 2);
+        else if (lsplit == 1) BS_LB_HID(f16, 1);
+        else BS_LB_HID(f16, 0);
     } else {
-        if (lsplit == 2) BS_LB_LAUNCH(bf16, 2);
-        else if (lsplit == 1) BS_LB_LAUNCH(bf16, 1);
-        else BS_LB_LAUNCH(bf16, 0);
+        if (lsplit == 2) BS_LB_HID(bf16, 2);
+        else if (lsplit == 1) BS_LB_HID(bf16, 1);
+        else BS_LB_HID(bf16, 0);
     }
+#undef BS_LB_HID
 #undef BS_LB_LAUNCH
     BS_CHECK_LAUNCH();
     return BS_OK;
+}
+
+extern "C" int bs_logbinom_depth(const void* last, const float* Eh, const float* bins, const float* w0_last, const float* w2,
+                                 const float* b2, const int32_t* route, float* depth, int32_t B, int32_t H, int32_t W, int32_t He,
+                                 int32_t We, float min_temp, float max_temp, int32_t dtype, void* stream) {
+    return bs_logbinom_depth_ex(last, Eh, bins, w0_last, w2, b2, nullptr, 40, route, depth, B, H, W, He, We, min_temp, max_temp, dtype, stream);
 }
 
 extern "C" int bs_small_attention(const float* qkv, void* out, int32_t B, int32_t S, int32_t nheads, int32_t dtype, void* stream) {

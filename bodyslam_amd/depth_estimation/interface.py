@@ -11,7 +11,7 @@ import torch
 from PIL import Image
 
 from ..weights import load_zoedepth_weights
-from ..zoedepth import ZoeDepthEngine
+from ..zoedepth import ZOED_K, ZOED_N, ZOED_NK, ZoeDepthEngine
 
 
 class DepthEstimator:
@@ -31,11 +31,10 @@ class DepthEstimator:
             warnings.warn(
                 f"The model type '{model_type}' is not supported. Using default model '{self.DEFAULT_MODEL}'.")
             model_type = self.DEFAULT_MODEL
-        if model_type != 'ZoeD_NK':
-            raise NotImplementedError("only the two-head ZoeD_NK variant (the reference's default) is built so far")
         sd = weights if isinstance(weights, dict) else load_zoedepth_weights(weights)
         print("[INFO] Model loaded on cuda (MI355X, HIP)")
-        return ZoeDepthEngine(sd, dtype=dtype, precision=precision)
+        cfg = {"ZoeD_NK": ZOED_NK, "ZoeD_N": ZOED_N, "ZoeD_K": ZOED_K}[model_type]      # one / two metric heads
+        return ZoeDepthEngine(sd, cfg, dtype=dtype, precision=precision)
 
     def infer_depth_map(self, path_to_frame: str) -> Image.Image:
         """path -> PIL 'I;16' depth map (metres x 256, as upstream infer_pil(output_type="pil"))."""

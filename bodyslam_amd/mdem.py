@@ -7,7 +7,7 @@ import torch
 from PIL import Image
 
 from .weights import load_zoedepth_weights
-from .zoedepth import ZoeDepthEngine
+from .zoedepth import ZOED_K, ZOED_N, ZOED_NK, ZoeDepthEngine
 
 
 class MDEMInterface:
@@ -19,11 +19,10 @@ class MDEMInterface:
             # mdem_interface.py:42-44 warns (and then still asks the hub for the bad name); here: warn + default
             warnings.warn(f"The model type selected [{model_type}], does not exist! Using default model [ZoeD_NK]")
             model_type = "ZoeD_NK"
-        if model_type != "ZoeD_NK":
-            raise NotImplementedError("only ZoeD_NK is built so far")
         sd = weights if isinstance(weights, dict) else load_zoedepth_weights(weights)
         print("[INFO] model loaded on cuda (MI355X, HIP)")
-        return ZoeDepthEngine(sd, dtype=dtype, precision=precision)
+        cfg = {"ZoeD_NK": ZOED_NK, "ZoeD_N": ZOED_N, "ZoeD_K": ZOED_K}[model_type]      # one / two metric heads
+        return ZoeDepthEngine(sd, cfg, dtype=dtype, precision=precision)
 
     def infer_monocular_depth_map(self, path_to_frame: str) -> Image.Image:
         image = Image.open(path_to_frame).convert("RGB")

@@ -68,37 +68,41 @@ def zoedepth_param_shapes(cfg) -> dict:
     s["relative_head.conv3.weight"], s["relative_head.conv3.bias"] = (1, cfg.rel_features, 1, 1), (1,)
     B, E, D = cfg.bottleneck, cfg.bin_dim, cfg.pt_hidden
     s["metric_head.conv2.weight"], s["metric_head.conv2.bias"] = (B, B, 1, 1), (B,)
-    for l in range(cfg.pt_layers):
-        p = f"metric_head.patch_transformer.transformer_encoder.{l}."
-        for n in ("query", "key", "value", "out_proj"):
-            s[p + f"self_attn.{n}.weight"], s[p + f"self_attn.{n}.bias"] = (D, D), (D,)
-        s[p + "linear1.weight"], s[p + "linear1.bias"] = (cfg.pt_inter, D), (cfg.pt_inter,)
-        s[p + "linear2.weight"], s[p + "linear2.bias"] = (D, cfg.pt_inter), (D,)
-        for n in ("norm1", "norm2"):
-            s[p + f"{n}.weight"], s[p + f"{n}.bias"] = (D,), (D,)
-    s["metric_head.patch_transformer.embedding_convPxP.weight"] = (D, B, 1, 1)
-    s["metric_head.patch_transformer.embedding_convPxP.bias"] = (D,)
-    s["metric_head.mlp_classifier.linear1.weight"], s["metric_head.mlp_classifier.linear1.bias"] = (128, 128), (128,)
-    s["metric_head.mlp_classifier.linear2.weight"], s["metric_head.mlp_classifier.linear2.bias"] = (2, 128), (2,)
+    single = len(cfg.head_names) == 1            # ZoeD_N / ZoeD_K: HF ZoeDepthMetricDepthEstimationHead (modeling_zoedepth.py:1106-1200)
+    SM, PM, HID = cfg.seed_mlp, cfg.proj_mlp, cfg.clb_hidden
+    if not single:
+        for l in range(cfg.pt_layers):
+            p = f"metric_head.patch_transformer.transformer_encoder.{l}."
+            for n in ("query", "key", "value", "out_proj"):
+                s[p + f"self_attn.{n}.weight"], s[p + f"self_attn.{n}.bias"] = (D, D), (D,)
+            s[p + "linear1.weight"], s[p + "linear1.bias"] = (cfg.pt_inter, D), (cfg.pt_inter,)
+            s[p + "linear2.weight"], s[p + "linear2.bias"] = (D, cfg.pt_inter), (D,)
+            for n in ("norm1", "norm2"):
+                s[p + f"{n}.weight"], s[p + f"{n}.bias"] = (D,), (D,)
+        s["metric_head.patch_transformer.embedding_convPxP.weight"] = (D, B, 1, 1)
+        s["metric_head.patch_transformer.embedding_convPxP.bias"] = (D,)
+        s["metric_head.mlp_classifier.linear1.weight"], s["metric_head.mlp_classifier.linear1.bias"] = (128, 128), (128,)
+        s["metric_head.mlp_classifier.linear2.weight"], s["metric_head.mlp_classifier.linear2.bias"] = (2, 128), (2,)
     for name in cfg.head_names:
-        p = f"metric_head.seed_bin_regressors.{name}."
-        s[p + "conv1.weight"], s[p + "conv1.bias"] = (E // 2, B, 1, 1), (E // 2,)
-        s[p + "conv2.weight"], s[p + "conv2.bias"] = (cfg.n_bins, E // 2, 1, 1), (cfg.n_bins,)
-    s["metric_head.seed_projector.conv1.weight"], s["metric_head.seed_projector.conv1.bias"] = (E // 2, B, 1, 1), (E // 2,)
-    s["metric_head.seed_projector.conv2.weight"], s["metric_head.seed_projector.conv2.bias"] = (E, E // 2, 1, 1), (E,)
+        p = "metric_head.seed_bin_regressor." if single else f"metric_head.seed_bin_regressors.{name}."
+        s[p + "conv1.weight"], s[p + "conv1.bias"] = (SM, B, 1, 1), (SM,)
+        s[p + "conv2.weight"], s[p + "conv2.bias"] = (cfg.n_bins, SM, 1, 1), (cfg.n_bins,)
+    s["metric_head.seed_projector.conv1.weight"], s["metric_head.seed_projector.conv1.bias"] = (PM, B, 1, 1), (PM,)
+    s["metric_head.seed_projector.conv2.weight"], s["metric_head.seed_projector.conv2.bias"] = (E, PM, 1, 1), (E,)
     for i in range(4):
         p = f"metric_head.projectors.{i}."
-        s[p + "conv1.weight"], s[p + "conv1.bias"] = (E // 2, F_, 1, 1), (E // 2,)
-        s[p + "conv2.weight"], s[p + "conv2.bias"] = (E, E // 2, 1, 1), (E,)
-    cin = cfg.rel_features + E
+        s[p + "conv1.weight"], s[p + "conv1.bias"] = (PM, F_, 1, 1), (PM,)
+        s[p + "conv2.weight"], s[p + "conv2.bias"] = (E, PM, 1, 1), (E,)
+    cin = cfg.rel_features + (1 if single else 0) + E
     for name in cfg.head_names:
+        mid = "" if single else f"{name}."
         for i in range(4):
-            p = f"metric_head.attractors.{name}.{i}."
+            p = f"metric_head.attractors.{mid}{i}."
             s[p + "conv1.weight"], s[p + "conv1.bias"] = (E, E, 1, 1), (E,)
-            s[p + "conv2.weight"], s[p + "conv2.bias"] = (cfg.n_attractors, E, 1, 1), (cfg.n_attractors,)
-        p = f"metric_head.conditional_log_binomial.{name}.mlp."
-        s[p + "0.weight"], s[p + "0.bias"] = (cin // 4, cin, 1, 1), (cin // 4,)
-        s[p + "2.weight"], s[p + "2.bias"] = (4, cin // 4, 1, 1), (4,)
+            s[p + "conv2.weight"], s[p + "conv2.bias"] = (cfg.attractors_at(i), E, 1, 1), (cfg.attractors_at(i),)
+        p = f"metric_head.conditional_log_binomial.{mid}mlp."
+        s[p + "0.weight"], s[p + "0.bias"] = (HID, cin, 1, 1), (HID,)
+        s[p + "2.weight"], s[p + "2.bias"] = (4, HID, 1, 1), (4,)
     return s
 
 

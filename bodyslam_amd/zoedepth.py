@@ -59,7 +59,32 @@ class ZoeConfig:
     pt_hidden: int = 128
     pt_inter: int = 1024
     pt_heads: int = 4
-    head_names: Tuple[str, ...] = ("nyu", "kitti")
+    head_names: Tuple[str, ...] = ("nyu", "kitti")     # one name = a single-head model (ZoeD_N: ("nyu",), ZoeD_K: ("kitti",))
+    level_attractors: Tuple[int, ...] = (16, 8, 4, 1)  # single-head models only (HF num_attractors); the NK head uses n_attractors
+
+    @property
+    def single_head(self) -> bool:
+        return len(self.head_names) == 1
+
+    @property
+    def seed_mlp(self) -> int:      # HF defaults in the single head (modeling_zoedepth.py:1132-1142) vs bin_dim // 2 in the NK head
+        return 256 if self.single_head else self.bin_dim // 2
+
+    @property
+    def proj_mlp(self) -> int:
+        return 128 if self.single_head else self.bin_dim // 2
+
+    @property
+    def clb_hidden(self) -> int:    # (in + condition) // bottleneck_factor: factor 2 (single, with the relative depth) or 4 (NK)
+        return (self.rel_features + 1 + self.bin_dim) // 2 if self.single_head else (self.rel_features + self.bin_dim) // 4
+
+    def attractors_at(self, level: int) -> int:
+        return self.level_attractors[level] if self.single_head else self.n_attractors
+
+
+ZOED_NK = ZoeConfig()
+ZOED_N = ZoeConfig(head_names=("nyu",))
+ZOED_K = ZoeConfig(head_names=("kitti",))
 
 
 def pad_sizes(h: int, w: int) -> Tuple[int, int]:
@@ -243,34 +268,67 @@ class ZoeDepthEngine:
         B_, E = c.bottleneck, c.bin_dim
         w["mh.conv2.w"] = self._h(g(mh + "conv2.weight").reshape(B_, B_))
         w["mh.conv2.b"] = self._f(g(mh + "conv2.bias"))
-        n0, n1 = c.head_names
+        # Two head slots are carried side by side (buffers, block-diagonal weights) and an image is routed to one of them.  A
+        # single-head model (ZoeD_N / ZoeD_K) fills slot 0 and leaves slot 1 as zeros with every image routed to slot 0.
+        single = c.single_head
         sq = lambda k: g(k).reshape(g(k).shape[0], -1)
-        w["seed.c1.w"] = self._h(torch.cat([sq(mh + f"seed_bin_regressors.{n0}.conv1.weight"), sq(mh + f"seed_bin_regressors.{n1}.conv1.weight"),
-                                            sq(mh + "seed_projector.conv1.weight")], 0))                      # [192, 256]
-        w["seed.c1.b"] = self._f(torch.cat([g(mh + f"seed_bin_regressors.{n0}.conv1.bias"), g(mh + f"seed_bin_regressors.{n1}.conv1.bias"),
-                                            g(mh + "seed_projector.conv1.bias")], 0))
-        w["seed.c2.w"] = self._h(torch.block_diag(sq(mh + f"seed_bin_regressors.{n0}.conv2.weight"),
-                                                  sq(mh + f"seed_bin_regressors.{n1}.conv2.weight")))        # [128, 128]
-        w["seed.c2.b"] = self._f(torch.cat([g(mh + f"seed_bin_regressors.{n0}.conv2.bias"), g(mh + f"seed_bin_regressors.{n1}.conv2.bias")]))
-        w["seedproj.c2.w"] = self._h(sq(mh + "seed_projector.conv2.weight"))                                 # [128, 64]
+        SM, PM, HID = c.seed_mlp, c.proj_mlp, c.clb_hidden
+
+        def pref(kind, slot, i=None):
+            if single:
+                if slot:
+                    return None
+                return {"seed": mh + "seed_bin_regressor.", "att": mh + f"attractors.{i}.", "clb": mh + "conditional_log_binomial.mlp."}[kind]
+            n = c.head_names[slot]
+            return {"seed": mh + f"seed_bin_regressors.{n}.", "att": mh + f"attractors.{n}.{i}.", "clb": mh + f"conditional_log_binomial.{n}.mlp."}[kind]
+
+        def two(kind, suffix, i=None, flat=True, rep=1):
+            """the tensor of both slots (slot 1 = zeros for a single head); rep replicates rows (attractor counts below 4)"""
+            t0 = g(pref(kind, 0, i) + suffix)
+            t0 = t0.reshape(t0.shape[0], -1) if (flat and t0.dim() > 1) else t0
+            if rep > 1:
+                t0 = t0.repeat_interleave(rep, 0)
+            p1 = pref(kind, 1, i)
+            if p1 is None:
+                return t0, torch.zeros_like(t0)
+            t1 = g(p1 + suffix)
+            t1 = t1.reshape(t1.shape[0], -1) if (flat and t1.dim() > 1) else t1
+            return t0, (t1.repeat_interleave(rep, 0) if rep > 1 else t1)
+
+        s0, s1 = two("seed", "conv1.weight")
+        w["seed.c1.w"] = self._h(torch.cat([s0, s1, sq(mh + "seed_projector.conv1.weight")], 0))            # [2*SM + PM, 256]
+        b0, b1 = two("seed", "conv1.bias")
+        w["seed.c1.b"] = self._f(torch.cat([b0, b1, g(mh + "seed_projector.conv1.bias")], 0))
+        s0, s1 = two("seed", "conv2.weight")
+        w["seed.c2.w"] = self._h(torch.block_diag(s0, s1))                                                    # [2*nb, 2*SM]
+        w["seed.c2.b"] = self._f(torch.cat(two("seed", "conv2.bias")))
+        w["seedproj.c2.w"] = self._h(sq(mh + "seed_projector.conv2.weight"))                                 # [E, PM]
         w["seedproj.c2.b"] = self._f(g(mh + "seed_projector.conv2.bias"))
+        self.na_eff = []
         for i in range(4):
             p = mh + f"projectors.{i}."
             w[f"pj{i}.c1.w"], w[f"pj{i}.c1.b"] = self._wp(f"pj{i}.c1.w", sq(p + "conv1.weight")), self._f(g(p + "conv1.bias"))
             w[f"pj{i}.c2.w"], w[f"pj{i}.c2.b"] = self._wn(sq(p + "conv2.weight")), self._f(g(p + "conv2.bias"))
-            a0, a1 = mh + f"attractors.{n0}.{i}.", mh + f"attractors.{n1}.{i}."
-            w[f"at{i}.c1.w"] = self._h(torch.cat([sq(a0 + "conv1.weight"), sq(a1 + "conv1.weight")], 0))      # [256, 128]
-            w[f"at{i}.c1.b"] = self._f(torch.cat([g(a0 + "conv1.bias"), g(a1 + "conv1.bias")]))
-            w[f"at{i}.c2.w"] = self._h(torch.block_diag(sq(a0 + "conv2.weight"), sq(a1 + "conv2.weight")))    # [32, 256]
-            w[f"at{i}.c2.b"] = self._f(torch.cat([g(a0 + "conv2.bias"), g(a1 + "conv2.bias")]))
-        clb = [mh + f"conditional_log_binomial.{n}.mlp." for n in (n0, n1)]
+            w[f"at{i}.c1.w"] = self._h(torch.cat(two("att", "conv1.weight", i), 0))                           # [2E, E]
+            w[f"at{i}.c1.b"] = self._f(torch.cat(two("att", "conv1.bias", i)))
+            # kind "mean": an attractor replicated r times leaves the mean unchanged -> counts below 4 are padded by replication
+            na = c.attractors_at(i)
+            rep = 1 if na % 4 == 0 else 4 // math.gcd(na, 4)
+            self.na_eff.append(na * rep)
+            w[f"at{i}.c2.w"] = self._h(torch.block_diag(*two("att", "conv2.weight", i, rep=rep)))              # [2*na, 2E]
+            w[f"at{i}.c2.b"] = self._f(torch.cat(two("att", "conv2.bias", i, rep=rep)))
         R = c.rel_features
-        w0 = [sq(p + "0.weight") for p in clb]                                                                # [40, 160] = [last 32 | emb 128]
-        w["clb.emb.w"] = self._wn(torch.cat([w0[0][:, R:], w0[1][:, R:]], 0))                                   # [80, 128]
-        w["clb.emb.b"] = self._f(torch.cat([g(clb[0] + "0.bias"), g(clb[1] + "0.bias")]))
-        w["clb.w0_last"] = self._f(torch.stack([w0[0][:, :R], w0[1][:, :R]]))                                  # [2, 40, 32]
-        w["clb.w2"] = self._f(torch.stack([sq(p + "2.weight") for p in clb]))                                  # [2, 4, 40]
-        w["clb.b2"] = self._f(torch.stack([g(p + "2.bias") for p in clb]))                                     # [2, 4]
+        X = 1 if single else 0                                     # the single head's extra input: the relative depth
+        w00, w01 = two("clb", "0.weight")                          # [HID, R + X + E] = [last R | (rel depth) | emb E]
+        w["clb.emb.w"] = self._wn(torch.cat([w00[:, R + X:], w01[:, R + X:]], 0))                               # [2*HID, E]
+        w["clb.emb.b"] = self._f(torch.cat(two("clb", "0.bias")))
+        w["clb.w0_last"] = self._f(torch.stack([w00[:, :R], w01[:, :R]]))                                      # [2, HID, R]
+        w["clb.w2"] = self._f(torch.stack(two("clb", "2.weight")))                                             # [2, 4, HID]
+        w["clb.b2"] = self._f(torch.stack(two("clb", "2.bias")))                                               # [2, 4]
+        if single:
+            r0 = torch.cat([w00[:, R], sq("relative_head.conv3.weight").flatten(), g("relative_head.conv3.bias").flatten()])
+            w["clb.rel"] = self._f(torch.stack([r0, torch.zeros_like(r0)]))                                    # [2, HID + R + 1]
+            return
         # ---- router (HF modeling_zoedepth.py:775-962)
         pt = mh + "patch_transformer."
         w["rt.emb.w"] = self._h(sq(pt + "embedding_convPxP.weight"))
@@ -503,48 +561,50 @@ class _ZoePlan:
         Mb = NB * bh_ * bw_
         xb = e16(Mb, c.bottleneck)
         P.gemm("mh.conv2", bott, w["mh.conv2.w"], xb, M=Mb, N=c.bottleneck, K=c.bottleneck, lda=c.bottleneck * m2, bias=w["mh.conv2.b"])   # hi half of a split map
-        # router: 4-layer post-norm transformer over (1 + bh*bw) tokens, classifier on token 0
-        D, St = c.pt_hidden, bh_ * bw_ + 1
-        pos = torch.arange(0, St, dtype=torch.float32).unsqueeze(1)
-        div = torch.exp(torch.arange(0, D, 2, dtype=torch.float32).unsqueeze(0) * (-torch.log(torch.full((), 10000.0)) / D))
-        pe_tab = torch.cat([torch.sin(pos * div), torch.cos(pos * div)], dim=1).to(dev)          # [St, D]
-        self._pe_src = pe_tab.unsqueeze(0).expand(NB, St, D).contiguous().view(NB * St, D)
-        e32b = e32(NB * St, D)
-        e16b = e16(NB * St, D)
-        self._router_init = (e32b, self._pe_src)
-        # e = pos_enc (token 0 is the zero "cls" pad) ; tokens 1.. += embedding conv
-        P.add("rt.init", "bs_copy_f32", self._pe_src, e32b, e32b.numel())
-        P.gemm("rt.emb", xb, w["rt.emb.w"], e32b, M=Mb, N=D, K=c.bottleneck, lda=c.bottleneck, bias=w["rt.emb.b"], res=e32b, ldr=D,
-               out_group=(bh_ * bw_, St, 1))
-        P.add("rt.cast", "bs_cast", e32b, e16b, e32b.numel(), L.dt(e16b))
-        qkv32 = e32(NB * St, 3 * D)
-        at16 = e16(NB * St, D)
-        tmp32 = e32(NB * St, D)
-        h16 = e16(NB * St, c.pt_inter)
-        for l in range(c.pt_layers):
-            P.gemm(f"rt{l}.qkv", e16b, w[f"rt{l}.qkv.w"], qkv32, M=NB * St, N=3 * D, K=D, lda=D, bias=w[f"rt{l}.qkv.b"])
-            P.add(f"rt{l}.attn", "bs_small_attention", qkv32, at16, NB, St, c.pt_heads, L.dt(at16))
-            P.gemm(f"rt{l}.o", at16, w[f"rt{l}.o.w"], tmp32, M=NB * St, N=D, K=D, lda=D, bias=w[f"rt{l}.o.b"], res=e32b, ldr=D)
-            P.add(f"rt{l}.n1", "bs_layernorm", tmp32, w[f"rt{l}.n1.g"], w[f"rt{l}.n1.b"], e16b, e32b, NB * St, D, 1e-5, L.dt(e16b))
-            P.gemm(f"rt{l}.l1", e16b, w[f"rt{l}.l1.w"], h16, M=NB * St, N=c.pt_inter, K=D, lda=D, bias=w[f"rt{l}.l1.b"], act=L.ACT_RELU)
-            P.gemm(f"rt{l}.l2", h16, w[f"rt{l}.l2.w"], tmp32, M=NB * St, N=D, K=c.pt_inter, lda=c.pt_inter, bias=w[f"rt{l}.l2.b"], res=e32b, ldr=D)
-            P.add(f"rt{l}.n2", "bs_layernorm", tmp32, w[f"rt{l}.n2.g"], w[f"rt{l}.n2.b"], e16b, e32b, NB * St, D, 1e-5, L.dt(e16b))
-        c1 = e16(NB, D)
         self.logits = e32(NB, 4)
-        self.route = torch.zeros(NB, dtype=torch.int32, device=dev)
-        P.gemm("cl.l1", e16b, w["cl.l1.w"], c1, M=NB, N=D, K=D, lda=St * D, bias=w["cl.l1.b"], act=L.ACT_RELU)
-        P.gemm("cl.l2", c1, w["cl.l2.w"], self.logits, M=NB, N=4, K=D, lda=D, bias=w["cl.l2.b"])
-        P.add("route", "bs_route_argmax", self.logits, 4, self.route, NB)
-        P.mark("logits", self.logits, ("raw",))
+        self.route = torch.zeros(NB, dtype=torch.int32, device=dev)       # single-head models: every image stays on slot 0
+        if not c.single_head:
+            # router: 4-layer post-norm transformer over (1 + bh*bw) tokens, classifier on token 0
+            D, St = c.pt_hidden, bh_ * bw_ + 1
+            pos = torch.arange(0, St, dtype=torch.float32).unsqueeze(1)
+            div = torch.exp(torch.arange(0, D, 2, dtype=torch.float32).unsqueeze(0) * (-torch.log(torch.full((), 10000.0)) / D))
+            pe_tab = torch.cat([torch.sin(pos * div), torch.cos(pos * div)], dim=1).to(dev)          # [St, D]
+            self._pe_src = pe_tab.unsqueeze(0).expand(NB, St, D).contiguous().view(NB * St, D)
+            e32b = e32(NB * St, D)
+            e16b = e16(NB * St, D)
+            self._router_init = (e32b, self._pe_src)
+            # e = pos_enc (token 0 is the zero "cls" pad) ; tokens 1.. += embedding conv
+            P.add("rt.init", "bs_copy_f32", self._pe_src, e32b, e32b.numel())
+            P.gemm("rt.emb", xb, w["rt.emb.w"], e32b, M=Mb, N=D, K=c.bottleneck, lda=c.bottleneck, bias=w["rt.emb.b"], res=e32b, ldr=D,
+                   out_group=(bh_ * bw_, St, 1))
+            P.add("rt.cast", "bs_cast", e32b, e16b, e32b.numel(), L.dt(e16b))
+            qkv32 = e32(NB * St, 3 * D)
+            at16 = e16(NB * St, D)
+            tmp32 = e32(NB * St, D)
+            h16 = e16(NB * St, c.pt_inter)
+            for l in range(c.pt_layers):
+                P.gemm(f"rt{l}.qkv", e16b, w[f"rt{l}.qkv.w"], qkv32, M=NB * St, N=3 * D, K=D, lda=D, bias=w[f"rt{l}.qkv.b"])
+                P.add(f"rt{l}.attn", "bs_small_attention", qkv32, at16, NB, St, c.pt_heads, L.dt(at16))
+                P.gemm(f"rt{l}.o", at16, w[f"rt{l}.o.w"], tmp32, M=NB * St, N=D, K=D, lda=D, bias=w[f"rt{l}.o.b"], res=e32b, ldr=D)
+                P.add(f"rt{l}.n1", "bs_layernorm", tmp32, w[f"rt{l}.n1.g"], w[f"rt{l}.n1.b"], e16b, e32b, NB * St, D, 1e-5, L.dt(e16b))
+                P.gemm(f"rt{l}.l1", e16b, w[f"rt{l}.l1.w"], h16, M=NB * St, N=c.pt_inter, K=D, lda=D, bias=w[f"rt{l}.l1.b"], act=L.ACT_RELU)
+                P.gemm(f"rt{l}.l2", h16, w[f"rt{l}.l2.w"], tmp32, M=NB * St, N=D, K=c.pt_inter, lda=c.pt_inter, bias=w[f"rt{l}.l2.b"], res=e32b, ldr=D)
+                P.add(f"rt{l}.n2", "bs_layernorm", tmp32, w[f"rt{l}.n2.g"], w[f"rt{l}.n2.b"], e16b, e32b, NB * St, D, 1e-5, L.dt(e16b))
+            c1 = e16(NB, D)
+            P.gemm("cl.l1", e16b, w["cl.l1.w"], c1, M=NB, N=D, K=D, lda=St * D, bias=w["cl.l1.b"], act=L.ACT_RELU)
+            P.gemm("cl.l2", c1, w["cl.l2.w"], self.logits, M=NB, N=4, K=D, lda=D, bias=w["cl.l2.b"])
+            P.add("route", "bs_route_argmax", self.logits, 4, self.route, NB)
+            P.mark("logits", self.logits, ("raw",))
         # seeds + seed projector
-        E, nb, na = c.bin_dim, c.n_bins, c.n_attractors
-        sh = e16(Mb, 3 * (E // 2))
-        P.gemm("seed.c1", xb, w["seed.c1.w"], sh, M=Mb, N=3 * (E // 2), K=c.bottleneck, lda=c.bottleneck, bias=w["seed.c1.b"], act=L.ACT_RELU)
+        E, nb = c.bin_dim, c.n_bins
+        SM, PM, HID = c.seed_mlp, c.proj_mlp, c.clb_hidden          # hidden widths: 64 / 64 / 40 (NK head), 256 / 128 / 80 (single head)
+        sh = e16(Mb, 2 * SM + PM)                                  # [seed regressor slot 0 | slot 1 | seed projector] hidden units
+        P.gemm("seed.c1", xb, w["seed.c1.w"], sh, M=Mb, N=2 * SM + PM, K=c.bottleneck, lda=c.bottleneck, bias=w["seed.c1.b"], act=L.ACT_RELU)
         bins_prev = e32(NB, bh_, bw_, 2 * nb)
-        P.gemm("seed.c2", sh, w["seed.c2.w"], bins_prev, M=Mb, N=2 * nb, K=E, lda=3 * (E // 2), bias=w["seed.c2.b"], act=L.ACT_SOFTPLUS)
+        P.gemm("seed.c2", sh, w["seed.c2.w"], bins_prev, M=Mb, N=2 * nb, K=2 * SM, lda=2 * SM + PM, bias=w["seed.c2.b"], act=L.ACT_SOFTPLUS)
         # projector embeddings feed the last 1x1 convs of the head almost directly, so accurate mode keeps them as (hi | lo) pairs too
         emb_prev = e16(Mb, E * m2)
-        P.gemm("seedproj.c2", sh, w["seedproj.c2.w"], emb_prev, M=Mb, N=E, K=E // 2, lda=3 * (E // 2), a_offset=E, bias=w["seedproj.c2.b"],
+        P.gemm("seedproj.c2", sh, w["seedproj.c2.w"], emb_prev, M=Mb, N=E, K=PM, lda=2 * SM + PM, a_offset=2 * SM, bias=w["seedproj.c2.b"],
                ldo=E * m2, out_split_off=E if acc else 0)
         P.signal(1)
         P.lane = 0
@@ -598,28 +658,29 @@ class _ZoePlan:
         for i in range(4):
             feat, fh, fw = fused_list[i]
             Mi = NB * fh * fw
-            e1 = e16(Mi, (E // 2) * m2)
-            nplain(f"pj{i}.c1", feat, f"pj{i}.c1.w", e1, Mi, E // 2, Fc, bias=w[f"pj{i}.c1.b"], act=L.ACT_RELU, out8=False)
+            e1 = e16(Mi, PM * m2)
+            nplain(f"pj{i}.c1", feat, f"pj{i}.c1.w", e1, Mi, PM, Fc, bias=w[f"pj{i}.c1.b"], act=L.ACT_RELU, out8=False)
             emb = e16(Mi, E * m2)
-            P.gemm(f"pj{i}.c2", e1, w[f"pj{i}.c2.w"], emb, M=Mi, N=E, K=(E // 2) * np3, lda=(E // 2) * m2, seg1=(E // 2) if acc else 0,
+            P.gemm(f"pj{i}.c2", e1, w[f"pj{i}.c2.w"], emb, M=Mi, N=E, K=PM * np3, lda=PM * m2, seg1=PM if acc else 0,
                    ldo=E * m2, out_split_off=E if acc else 0, bias=w[f"pj{i}.c2.b"], precision_passes=np3)
             y = e16(Mi, E * m2)
             P.add(f"at{i}.add", "bs_add_resized", emb, emb_prev, y, NB, ph_, pw_, fh, fw, E, L.dt(y) | (16 if acc else 0))
             a1 = e16(Mi, 2 * E)
             P.gemm(f"at{i}.c1", y, w[f"at{i}.c1.w"], a1, M=Mi, N=2 * E, K=E, lda=E * m2, bias=w[f"at{i}.c1.b"], act=L.ACT_RELU)
+            na = eng.na_eff[i]                                     # attractors of this level (replicated up to a multiple of 4)
             A = e32(Mi, 2 * na)
             P.gemm(f"at{i}.c2", a1, w[f"at{i}.c2.w"], A, M=Mi, N=2 * na, K=2 * E, lda=2 * E, bias=w[f"at{i}.c2.b"], act=L.ACT_SOFTPLUS)
             bins = e32(NB, fh, fw, 2 * nb)
             P.add(f"at{i}.step", "bs_attractor_step", A, bins_prev, bins, self.route, NB, ph_, pw_, fh, fw, 2, nb, na)
             P.mark(f"bins{i}", bins, ("nhwc_route", NB, fh, fw, 2 * nb))
             bins_prev, emb_prev, ph_, pw_ = bins, emb, fh, fw
-        Eh = e32(NB * ph_ * pw_, 2 * 40)
-        P.gemm("clb.emb", emb_prev, w["clb.emb.w"], Eh, M=NB * ph_ * pw_, N=80, K=E * np3, lda=E * m2, seg1=E if acc else 0, bias=w["clb.emb.b"],
+        Eh = e32(NB * ph_ * pw_, 2 * HID)
+        P.gemm("clb.emb", emb_prev, w["clb.emb.w"], Eh, M=NB * ph_ * pw_, N=2 * HID, K=E * np3, lda=E * m2, seg1=E if acc else 0, bias=w["clb.emb.b"],
                precision_passes=np3)
         self.depth_net = e32(NB, nh_, nw_)
         assert (nh_, nw_) == (2 * h3, 2 * w3)
-        P.add("logbinom", "bs_logbinom_depth", last, Eh, bins_prev, w["clb.w0_last"], w["clb.w2"], w["clb.b2"], self.route, self.depth_net,
-              NB, nh_, nw_, ph_, pw_, c.min_temp, c.max_temp, L.dt(last) | NSP)
+        P.add("logbinom", "bs_logbinom_depth_ex", last, Eh, bins_prev, w["clb.w0_last"], w["clb.w2"], w["clb.b2"], w.get("clb.rel"), HID,
+              self.route, self.depth_net, NB, nh_, nw_, ph_, pw_, c.min_temp, c.max_temp, L.dt(last) | NSP)
         P.mark("depth_net", self.depth_net, ("raw",))
         # ---- Z8: flip average + bicubic + crop + x256 -> uint16
         self.depth_m = e32(B, H, W)

@@ -195,6 +195,14 @@ int bs_add_resized(const void* x, const void* prev, void* out, int32_t B, int32_
 int bs_logbinom_depth(const void* last, const float* Eh, const float* bins, const float* w0_last, const float* w2,
                       const float* b2, const int32_t* route, float* depth, int32_t B, int32_t H, int32_t W,
                       int32_t He, int32_t We, float min_temp, float max_temp, int32_t dtype, void* stream);
+/* The same with the hidden width as an argument (40: NK head, 80: the single-head ZoeD_N / ZoeD_K models, whose Eh is
+ * [B,He,We,2*80] and w0_last / w2 are [2,hid,32] / [2,4,hid]) and the single head's 33rd MLP input, the relative depth
+ * relu(conv3(last)) (HF modeling_zoedepth.py:367-371,1186-1191): rel_w (nullable) = per group
+ * [W0 column of that input x hid | conv3 weight x 32 | conv3 bias]. */
+int bs_logbinom_depth_ex(const void* last, const float* Eh, const float* bins, const float* w0_last, const float* w2,
+                         const float* b2, const float* rel_w, int32_t hid, const int32_t* route, float* depth, int32_t B,
+                         int32_t H, int32_t W, int32_t He, int32_t We, float min_temp, float max_temp, int32_t dtype,
+                         void* stream);
 /* domain router pieces, HF modeling_zoedepth.py:775-962: multi-head attention of the 4-layer patch
  * transformer (head_dim 32, S = 1 + h*w tokens, no mask) on fused fp32 qkv [B*S, 3*D] -> out 16-bit
  * [B*S, D]; the linear layers run on bs_gemm and the post-norms on bs_layernorm. */

@@ -124,3 +124,20 @@ def test_full_loop_smoke():
     """the driver's smoke hook: depth, pose, chain and points of a 3-frame sequence against the oracle"""
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_depth_estimator_single_head_model_type(tmp_path):
+    """DepthEstimator("ZoeD_K") (interface.py:33-51 accepts ZoeD_N / ZoeD_K / ZoeD_NK): the one-head configuration is selected
+    from the model type, full-size weights load by their HF names, and the call surface returns the same kind of image."""
+    from PIL import Image
+    from bodyslam_amd.depth_estimation import DepthEstimator
+    from bodyslam_amd.synthetic import make_sequence, random_zoedepth_weights
+    from bodyslam_amd.zoedepth import ZOED_K
+    est = DepthEstimator("ZoeD_K", weights=random_zoedepth_weights(ZOED_K, seed=1), precision="fast")
+    assert est.model.cfg.single_head and est.model.cfg.head_names == ("kitti",)
+    p1 = str(tmp_path / "f.png")
+    Image.fromarray(make_sequence(1, 480, 640, seed=2)[0]).save(p1)
+    depth = est.infer_depth_map(p1)
+    assert isinstance(depth, Image.Image) and depth.mode == "I;16" and depth.size == (640, 480)
+    a = np.asarray(depth)
+    assert a.min() > 0 and a.max() < 65535

@@ -58,7 +58,7 @@ def to_nchw(t, meta):
     return t
 
 
-def compare_taps(taps_p, taps_o, route_o, tag):
+def compare_taps(taps_p, taps_o, route_o, tag, heads=("nyu", "kitti")):
     worst = {}
     for name, (t, meta) in taps_p.items():
         if name in ("logits",):
@@ -67,7 +67,7 @@ def compare_taps(taps_p, taps_o, route_o, tag):
         if meta[0] == "nhwc_route":
             # both heads' bins are carried side by side; only the routed head is defined per image
             errs = []
-            for hn, hname in enumerate(("nyu", "kitti")):
+            for hn, hname in enumerate(heads):      # slot order = the configuration's head order
                 key = f"{hname}.{name}"
                 if key not in taps_o:
                     continue
@@ -122,8 +122,9 @@ def run_case(cfg_o, dtype, B, H, W, target_hw, seed, route_bias=0.0, flip=True, 
     taps_p = {}
     dm, du = eng.infer(frames.cuda(), flip_aug=flip, taps=taps_p)
     torch.cuda.synchronize()
+    lp = taps_p["logits"][0].cpu()[:, :2] if "logits" in taps_p else None        # single-head models have no router
     return dict(dm=dm.cpu(), du=du.cpu().numpy().view(np.uint16), ref=ref, taps_p=taps_p, taps_o=taps_o, logits_o=logits,
-                logits_p=taps_p["logits"][0].cpu()[:, :2], route_p=eng.plan_for(B, H, W, flip).route.cpu(), t_oracle=t_or, Z=Z)
+                logits_p=lp, route_p=eng.plan_for(B, H, W, flip).route.cpu(), t_oracle=t_or, Z=Z)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -237,3 +238,26 @@ def test_other_frame_geometries(H, W):
     lsb = np.abs(r["du"].astype(np.int32) - Z.to_uint16(r["ref"]).astype(np.int32))
     assert torch.equal(torch.argmax(r["logits_o"], -1).int(), r["route_p"])
     assert l1 <= 1e-4 and lsb.max() <= 1
+
+
+@pytest.mark.parametrize("name", ["nyu", "kitti"])
+@pytest.mark.parametrize("precision", ["accurate", "fast"])
+def test_single_head_models_small(name, precision):
+    """ZoeD_N / ZoeD_K (one metric head, HF ZoeDepthMetricDepthEstimationHead): no router, attractor counts 16/8/4/1, hidden widths
+    256 / 128 / 80, the relative depth as a 33rd input of the log-binomial MLP -- small backbone, full-size neck and head."""
+    cfg_o = dataclasses.replace(small_oracle_cfg(), head_names=(name,))
+    r = run_case(cfg_o, torch.float16, B=2, H=120, W=160, target_hw=(96, 128), seed=5, precision=precision)
+    compare_taps(r["taps_p"], r["taps_o"], None, f"small {name} {precision}", heads=(name,))
+    l1 = (r["dm"] - r["ref"]).abs().mean().item()
+    report(f"[small single-head {name} {precision}] depth L1={l1:.3e} (range {r['ref'].min():.3f}..{r['ref'].max():.3f})")
+    assert (r["route_p"] == 0).all()
+    assert l1 < (1e-4 if precision == "accurate" else 2e-3)
+
+
+def test_full_size_zoed_n_accurate():
+    """ZoeD_N at the real size (BEiT-L, 640x480), accurate mode: the north star's 1e-4 m."""
+    from oracle import zoedepth_ref as Z
+    r = run_case(Z.ZOED_N, torch.float16, B=1, H=480, W=640, target_hw=(384, 512), seed=3, precision="accurate")
+    l1 = (r["dm"] - r["ref"]).abs().mean().item()
+    report(f"[ZoeD_N f16 accurate] 640x480 depth L1={l1:.3e} m, max={(r['dm'] - r['ref']).abs().max().item():.3e} m")
+    assert l1 <= 1e-4
