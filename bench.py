@@ -195,7 +195,7 @@ def main():
     # ---- CPU baseline (rank 0): the oracle on one frame of the same sequence, all host cores
     cpu = None
     l1 = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:       # the contract: rank 0 at N = 1 only
         from oracle import cyclepose_ref as CP
         from oracle import geom3d_ref as G
         from oracle import zoedepth_ref as Z
