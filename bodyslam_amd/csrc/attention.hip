@@ -229,7 +229,10 @@ template <typename T>
 static int dispatch_attn(const void* q, const void* k, const void* vt, const float* bias, void* out, int split, int B, int nh, int S, int Sp,
                          hipStream_t st) {
     const int nqt = cdiv(S, 32);
-    if (nqt % 5 == 0) return launch_attn<T, 5>(q, k, vt, bias, out, split, B, nh, S, Sp, st);
+    // waves (32-query tiles) per block: 5 shares a staged K / V^T tile among the most queries and measured fastest (769 tokens:
+    // 498 us vs 572 / 584 us for 4 / 3 waves), so it is used whenever there are at least 5 query tiles even if the last block
+    // is partly idle (833 tokens = 27 tiles: 6 blocks); tiny sequences take the size that fits
+    if (nqt >= 5) return launch_attn<T, 5>(q, k, vt, bias, out, split, B, nh, S, Sp, st);
     if (nqt % 3 == 0) return launch_attn<T, 3>(q, k, vt, bias, out, split, B, nh, S, Sp, st);
     return launch_attn<T, 4>(q, k, vt, bias, out, split, B, nh, S, Sp, st);
 }
