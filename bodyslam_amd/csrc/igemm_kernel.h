@@ -2,17 +2,21 @@
 //
 // One kernel family serves every Linear / Conv2d / ConvTranspose2d(k == stride) on the hot path
 // (include/bodyslam_hip.h: bs_gemm lists the reference call sites).  Design:
-//   * NHWC activations, weights [N][KH][KW][Cin]: a BK = 64 slice of K is ONE filter tap and 64
-//     contiguous channels, i.e. one 128-byte line per output pixel.  The A tile is therefore a row
-//     gather: each lane of a `global_load_lds_dwordx4` supplies the address of 16 bytes of its pixel
-//     (or of a zero page when the tap falls into the padding) and the data lands in LDS without
-//     touching VGPRs.  No im2col buffer exists anywhere.
+//   * NHWC activations, weights [N][Cin/64][KH][KW][64] (chunk > tap > channel, see the K walk below): a
+//     BK = 64 slice of K is ONE filter tap and 64 contiguous channels, i.e. one 128-byte line per output
+//     pixel.  The A tile is therefore a row gather: each lane of a `buffer_load_dwordx4 ... lds` supplies
+//     the 32-bit offset of 16 bytes of its pixel (an out-of-range offset when the tap falls into the
+//     padding: the DMA then writes zeros) and the data lands in LDS without touching VGPRs.  No im2col
+//     buffer exists anywhere.
 //   * LDS image per operand: [rows][64] 16-bit, 128-byte rows, 16-byte chunk c of row r stored at
 //     chunk position c ^ (r & 7).  The DMA destination is lane-linear, so the XOR is applied to the
 //     SOURCE chunk each lane fetches and again on the ds_read_b128 address (conflict-free for the
 //     16x16x32 operand pattern: 16 distinct rows x one chunk per lane group).
 //   * v_mfma_f32_16x16x32_{f16,bf16}; operands swapped (W fragment as "A", activation fragment as
-//     "B") so a lane ends with 4 consecutive n for one m: 8/16-byte epilogue stores.
+//     "B") so a lane ends with 4 consecutive n for one m, and the W rows of a tile are permuted on load so
+//     that a fragment pair gives a lane 8 consecutive n: 16-byte epilogue stores.
+//   * accurate mode: K segments / FP8 correction stages evaluate a split-precision product in one launch
+//     (IgemmParams::cin1, f8_stages; the F8 template flag keeps that code out of the fast-mode kernels).
 //   * double-buffered LDS, one barrier per K tile: the DMA of tile t+1 is in flight while tile t
 //     is multiplied.
 //   * 1-D grid with the bijective XCD remap: the N-tiles of one M-tile (which share the gathered
