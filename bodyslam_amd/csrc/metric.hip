@@ -196,14 +196,14 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
     omp = fminf(fmaxf(omp, eps), 1.0f);
     p = fminf(fmaxf(p, eps), 1.0f);
     const float lp_ = logf(p), lomp = logf(omp);
-    // y_k / T for all 64 bins, kept in registers (one evaluation; the softmax max needs them all first)
-    float y[LB_BINS];
-    float mx = -3.0e38f;
+    // y_k / T = (lb_k + k log p + (63 - k) log(1 - p)) / T.  The 64 logits are not kept in registers (that cost 64 VGPRs and
+    // halved the occupancy): they are three FMAs each and are evaluated twice, once for the max and once for the exponentials;
+    // the division by T is one reciprocal (T > 0), applied after the max.
+    const float rt = 1.0f / t;
+    auto logit = [&](int k) { return s_lb[k] + (float)k * lp_ + (float)(LB_BINS - 1 - k) * lomp; };
+    float vmx = -3.0e38f;
 #pragma unroll
-    for (int k = 0; k < LB_BINS; ++k) {
-        y[k] = (s_lb[k] + (float)k * lp_ + (float)(LB_BINS - 1 - k) * lomp) / t;
-        mx = fmaxf(mx, y[k]);
-    }
+    for (int k = 0; k < LB_BINS; ++k) vmx = fmaxf(vmx, logit(k));
     float den = 0.f, num = 0.f;
 #pragma unroll
     for (int k4 = 0; k4 < LB_BINS / 4; ++k4) {
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
         const f32x4 b11 = *reinterpret_cast<const f32x4*>(s_bins + c11 * LB_BINS + k4 * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float w = __expf(y[k4 * 4 + e] - mx);
+            const float w = __expf((logit(k4 * 4 + e) - vmx) * rt);
             const float c = l.hy * (l.hx * b00[e] + l.lx * b01[e]) + l.ly * (l.hx * b10[e] + l.lx * b11[e]);
             den += w;
             num += w * c;
