@@ -262,11 +262,11 @@ extern "C" int bs_backproject(const uint16_t* depth, int32_t B, int32_t H, int32
                               int32_t* scratch, void* stream) {
     using namespace bs;
     if (!initialized()) { set_error("bs_backproject: call bs_init first"); return BS_ERR_NOT_INIT; }
-    BS_REQUIRE(depth && K && xyz && idx && count && scratch, "bs_backproject: null argument");
     BS_REQUIRE(B >= 0 && H >= 0 && W >= 0, "bs_backproject: negative size");
+    if (B == 0) return BS_OK;                       // an empty batch has no buffers to check (their pointers may be null)
+    BS_REQUIRE(depth && K && xyz && idx && count && scratch, "bs_backproject: null argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int64_t npix = (int64_t)H * W;
-    if (B == 0) return BS_OK;
     if (npix == 0) {
         BS_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int32_t) * B, st));
         return BS_OK;
