@@ -67,6 +67,8 @@ class CyclePoseEngine:
         assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and pairs.dtype == torch.int32
         N, H, W, _ = frames_u8.shape
         P = pairs.shape[0]
+        if P == 0:      # no pair: nothing to launch
+            return torch.empty(0, 4, 4, device=self.dev)
         plan = self.plan_for(N, P, H, W)
         plan.frames.copy_(frames_u8)
         plan.pairs.copy_(pairs)

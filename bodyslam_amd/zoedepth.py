@@ -384,6 +384,8 @@ class ZoeDepthEngine:
         Outputs are the plan's static buffers (valid until the next call with the same shape)."""
         assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and frames_u8.dim() == 4 and frames_u8.shape[-1] == 3
         B, H, W, _ = frames_u8.shape
+        if B == 0:      # an empty batch: nothing to launch
+            return (torch.empty(0, H, W, device=self.dev), torch.empty(0, H, W, device=self.dev, dtype=torch.int16))
         plan = self.plan_for(B, H, W, flip_aug)
         plan.frames.copy_(frames_u8)
         plan.run(taps)

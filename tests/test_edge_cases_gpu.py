@@ -74,3 +74,15 @@ def test_empty_batch_calls_are_noops():
     from bodyslam_amd import geom3d
     xyz, idx, cnt = geom3d.backproject(z[:0])
     assert xyz.shape[0] == 0 and cnt.numel() == 0
+    # the engines: an empty frame batch / an empty pair list return empty results
+    from bodyslam_amd.cyclepose import CyclePoseEngine
+    from bodyslam_amd.zoedepth import ZoeDepthEngine
+    from oracle import cyclepose_ref as CP
+    from oracle import zoedepth_ref as Z
+    cfg_o, cfg_p = small_cfgs()
+    eng = ZoeDepthEngine(Z.synth_weights(cfg_o, seed=1), cfg_p, target_hw=(64, 96), precision="fast")
+    dm, du = eng.infer(torch.zeros(0, 160, 192, 3, dtype=torch.uint8, device="cuda"))
+    assert dm.shape == (0, 160, 192) and du.shape == (0, 160, 192)
+    pose = CyclePoseEngine(CP.synth_weights(seed=1))
+    T = pose.infer_pairs(torch.zeros(2, 160, 192, 3, dtype=torch.uint8, device="cuda"), torch.zeros(0, 2, dtype=torch.int32, device="cuda"))
+    assert T.shape == (0, 4, 4)
