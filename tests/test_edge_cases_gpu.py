@@ -86,3 +86,21 @@ def test_empty_batch_calls_are_noops():
     pose = CyclePoseEngine(CP.synth_weights(seed=1))
     T = pose.infer_pairs(torch.zeros(2, 160, 192, 3, dtype=torch.uint8, device="cuda"), torch.zeros(0, 2, dtype=torch.int32, device="cuda"))
     assert T.shape == (0, 4, 4)
+
+
+@pytest.mark.parametrize("H,W", [(123, 157), (97, 211), (200, 120)])
+def test_odd_frame_sizes_match_oracle(H, W):
+    """frame sizes that are not multiples of anything (odd reflect pads, non-square resize ratios, portrait): depth vs the oracle"""
+    from bodyslam_amd.synthetic import make_sequence
+    from bodyslam_amd.zoedepth import ZoeDepthEngine
+    from oracle import zoedepth_ref as Z
+    cfg_o, cfg_p = small_cfgs()
+    w = Z.synth_weights(cfg_o, seed=8)
+    frames = torch.from_numpy(make_sequence(2, H, W, seed=8))
+    eng = ZoeDepthEngine(w, cfg_p, target_hw=(96, 128), precision="accurate")
+    dm, du = eng.infer(frames.cuda())
+    with torch.no_grad():
+        ref = Z.infer_depth(w, cfg_o, frames, out_hw=(96, 128))
+    l1 = (dm.cpu() - ref).abs().mean().item()
+    lsb = np.abs(du.cpu().numpy().view(np.uint16).astype(np.int32) - Z.to_uint16(ref).astype(np.int32))
+    assert dm.shape == (2, H, W) and l1 < 1e-4 and lsb.max() <= 1, (l1, lsb.max())
