@@ -84,18 +84,20 @@ __global__ __launch_bounds__(256) void attractor_kernel(const float* A, const fl
 // ---------------------------------------------------------------------------------------------
 constexpr int LB_IN = 32, LB_BINS = 64;      // hidden width LB_HID is a template parameter: 40 (NK head) or 80 (single head)
 constexpr int LB_T = 16;                 // output tile edge (256 threads = 16 x 16 pixels)
-constexpr int LB_MAXSRC = 12;            // low-res rows / columns a 16-pixel span can touch at >= 1.5x upsampling (+1 neighbour, +slack)
+constexpr int LB_MAXSRC = 12;            // most low-res rows / columns a 16-pixel span may touch (>= 1.7x upsampling); the launch sizes LDS for the actual ratio
 
 template <typename T, int LSPLIT, int LB_HID>
 __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const float* Eh, const float* bins, const float* w0_last,
                                                         const float* w2, const float* b2, const float* rel_w, const int32_t* route,
                                                         float* depth, int B, int H, int W, int He, int We, float sy, float sx,
-                                                        float min_temp, float max_temp) {
+                                                        float min_temp, float max_temp, int ncell_max) {
     // LDS: the block's low-res patch of bin centres [rows][cols][64] and of Eh [rows][cols][40] for the routed head only,
     // loaded once (coalesced) instead of 4 x (256 + 160) bytes per output pixel; plus the small MLP weights.
-    __shared__ float s_bins[LB_MAXSRC * LB_MAXSRC * LB_BINS];
-    __shared__ float s_eh[LB_MAXSRC * LB_MAXSRC * LB_HID];
-    __shared__ float s_lb[LB_BINS];
+    // dynamic LDS sized by the launcher for the window the upsampling ratio really needs (2x: 10 x 10 cells = 41.6 KB, 3 blocks/CU)
+    extern __shared__ __attribute__((aligned(16))) float lb_smem[];
+    float* s_lb = lb_smem;                                   // [64]
+    float* s_bins = lb_smem + LB_BINS;                       // [cells][64]
+    float* s_eh = s_bins + ncell_max * LB_BINS;              // [cells][LB_HID]
     const int b = blockIdx.z;
     const int g = route[b];
     const int ty0 = blockIdx.y * LB_T, tx0 = blockIdx.x * LB_T;
@@ -316,11 +318,23 @@ extern "C" int bs_logbinom_depth_ex(const void* last, const float* Eh, const flo
                "bs_logbinom_depth: the bins map must be upsampled by at least ~1.7x (He,We=%d,%d -> H,W=%d,%d)", He, We, H, W);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(cdiv(W, LB_T), cdiv(H, LB_T), B);
+    // rows / columns of the low-res window of a 16-pixel span: floor(scale * 15 + frac) + 2 <= floor(scale * 15) + 3
+    const int nr_max = (int)(sy * (LB_T - 1)) + 3, nc_max = (int)(sx * (LB_T - 1)) + 3;
+    const int ncell_max = nr_max * nc_max;
+    const size_t lds = sizeof(float) * (size_t)(LB_BINS + ncell_max * (LB_BINS + hid));
     const int lsplit = (dtype & 32) ? 2 : ((dtype & 16) ? 1 : 0);   // bit 4: `last` holds (hi | lo) 16-bit pairs; bit 5: (hi16 | hi8 | lo8)
     dtype &= 15;
-#define BS_LB_LAUNCH(TT, LS, HD)                                                                                                       \
-    hipLaunchKernelGGL((logbinom_kernel<TT, LS, HD>), grid, dim3(256), 0, st, (const TT*)last, Eh, bins, w0_last, w2, b2, rel_w, route, \
-                       depth, B, H, W, He, We, sy, sx, min_temp, max_temp)
+#define BS_LB_LAUNCH(TT, LS, HD)                                                                                                 \
+    do {                                                                                                                         \
+        static bool attr_set = false;                                                                                            \
+        if (!attr_set) {                                                                                                         \
+            BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&logbinom_kernel<TT, LS, HD>),                        \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));                            \
+            attr_set = true;                                                                                                     \
+        }                                                                                                                        \
+        hipLaunchKernelGGL((logbinom_kernel<TT, LS, HD>), grid, dim3(256), lds, st, (const TT*)last, Eh, bins, w0_last, w2, b2,   \
+                           rel_w, route, depth, B, H, W, He, We, sy, sx, min_temp, max_temp, ncell_max);                         \
+    } while (0)
 #define BS_LB_HID(TT, LS)             \
     do {                              \
         if (hid == 40) BS_LB_LAUNCH(TT, LS, 40); \
