@@ -37,6 +37,7 @@ def test_flip_symmetry_full_size(engine):
     d = engine.infer(frames)[0].clone()
     df = engine.infer(torch.flip(frames, dims=[2]).contiguous())[0].clone()
     err = (torch.flip(df, dims=[2]) - d).abs()
+    print(f"flip symmetry: mean {err.mean().item():.3e} max {err.max().item():.3e}")
     assert err.mean().item() < 5e-5 and err.max().item() < 1e-3, (err.mean().item(), err.max().item())
 
 
