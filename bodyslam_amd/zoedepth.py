@@ -636,10 +636,13 @@ class _ZoePlan:
             else:
                 cur = res_unit(f"fu{li}.r1", feat, fh, fw, other=fused)     # fused + residual_layer1(feat)
             cur = res_unit(f"fu{li}.r2", cur, fh, fw)
-            up = e16(NB, 2 * fh, 2 * fw, Fc * m2)
-            P.add(f"fu{li}.up", "bs_resize_bilinear_nhwc", cur, up, NB, fh, fw, Fc, 2 * fh, 2 * fw, RZ, L.dt(up))
+            # HF upsamples, then applies the 1x1 projection (modeling_zoedepth.py:316-322).  Both are linear and the bilinear weights
+            # sum to 1, so projection(interpolate(x)) = interpolate(projection(x)) exactly in real arithmetic: the projection runs at
+            # the LOW resolution (a quarter of the FLOPs and of the bytes), the resize writes the fused map directly.
+            lowp = e16(NB, fh, fw, Fc * m2)
+            nplain(f"fu{li}.proj", cur, f"fu{li}.proj.w", lowp, NB * fh * fw, Fc, Fc, bias=w[f"fu{li}.proj.b"])
             fused = e16(NB, 2 * fh, 2 * fw, Fc * m2)
-            nplain(f"fu{li}.proj", up, f"fu{li}.proj.w", fused, NB * 4 * fh * fw, Fc, Fc, bias=w[f"fu{li}.proj.b"])
+            P.add(f"fu{li}.up", "bs_resize_bilinear_nhwc", lowp, fused, NB, fh, fw, Fc, 2 * fh, 2 * fw, RZ, L.dt(fused))
             P.mark(f"fused{li}", fused, ("nhwc", NB, 2 * fh, 2 * fw, Fc, (2 if nf8 else 1) if acc else 0))
             fused_list.append((fused, 2 * fh, 2 * fw))
         # ---- Z6: relative head (conv3 + ReLU -> relative depth is dead code for the NK output and not launched)
