@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the implicit-GEMM kernel on the shapes the ZoeD_NK forward launches
-(NB = 32 images = 16 frames with flip-aug).  Interleaved rounds in ONE process; prints TFLOP/s per
+(--nb images; the bench's 32-frame batch is --nb 64).  Interleaved rounds in ONE process; prints TFLOP/s per
 (shape, tile variant).  Usage on the GPU box:  python tools/bench_kernels.py [--nb 32] [--reps 20]"""
 import argparse
 import math
@@ -17,7 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nb", type=int, default=32)
     ap.add_argument("--reps", type=int, default=20)
-    ap.add_argument("--tiles", default="1,4,5,6,7,8")
+    ap.add_argument("--tiles", default="1,9,10", help="tile ids (igemm.hip); + 100 x ablation bits for diagnostics, e.g. 409 = tile 9 without epilogue")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     L.init(0)
