@@ -1,0 +1,10 @@
+"""Probe: accurate-mode depth L1 vs the oracle over several weight / frame seeds (full-size ZoeD_NK, 640x480)."""
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_zoedepth_gpu as T
+from oracle import zoedepth_ref as Z
+for seed in (2, 3, 4):
+    r = T.run_case(Z.ZOED_NK, torch.float16, B=1, H=480, W=640, target_hw=(384, 512), seed=seed, precision="accurate")
+    e = (r["dm"] - r["ref"]).abs()
+    print(f"seed {seed}: L1 {e.mean().item():.3e} max {e.max().item():.3e} route {r['route_p'].tolist()}")
