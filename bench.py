@@ -229,6 +229,7 @@ def main():
                        "sharding": "contiguous frame blocks per rank, one RCCL all-gather of relative poses per step" if world > 1 else "single GPU"},
             "roofline": roof, "roofline_conv_stack": roof_conv, "cpu_baseline": cpu,
             "precision": args.precision, "depth_l1_vs_oracle_m": l1, "kernels": kern_table,
+            "hbm_allocated_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
         }
         if other:
             out["other_mode"] = {"precision": other_name, "value": round(other["fps"], 2), "unit": "frames/s",
