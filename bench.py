@@ -13,7 +13,13 @@ A step = one pass of the full loop over one batch of B consecutive frames per ra
   3DM   back-projection + compaction of the rank's B depth maps with their absolute poses
 Inputs are resident in HBM before the timed region.  K steps are timed between barrier +
 torch.cuda.synchronize() pairs; the value is (ranks x K x B frames) / max-over-ranks time.
-Weights are random-init (no checkpoint is reachable offline); data is synthetic.
+Weights are random-init (no checkpoint is reachable offline); data is synthetic.  The chain of a rank's sequence continues
+from step to step (bs_pose_chain_from: the last absolute pose of a step is the next step's g0, on the device).
+
+--scaling strong: ONE sequence of --frames frames (default 1000: BASELINE config 4) is cut into contiguous blocks by
+shard_bounds (ragged: 125 frames per rank at 8 GPUs); a step = BodySlamPipeline.run_sequence over the whole sequence
+(every rank: depth + pose on its block with the one-frame halo, ONE all-gather of the relatives, the replicated fp64
+chain, back-projection of its block); value = K x frames / max-over-ranks time; "scaling": "strong".
 
 The primary line is precision="accurate" (split-precision products, depth L1 vs the fp32 oracle <= 1e-4 m -- the north
 star's tolerance); the single-pass "fast" mode is measured in the same run and reported under "other_mode".
@@ -36,6 +42,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PMC_TRAFFIC_FILE = "r02_pmc_hbm_traffic.json"   # HBM bytes per launch by PMC counters, collected offline (profiles/README.md)
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 TILE_NAMES = {1: "128x128x64s2", 2: "128x64x64s2", 3: "128x32x64s2", 4: "256x128x64s2", 5: "256x128x64s3", 6: "256x256x32s4",
               7: "128x128x64s3", 8: "256x128x32s4", 9: "256x256x64s2", 10: "256x256x32s4pp", 11: "256x128x32s3"}
@@ -56,6 +63,9 @@ def main():
     ap.add_argument("--single-mode", action="store_true", help="measure only --precision")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (pure throughput run)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank runs its own sequence, --batch frames per step; strong: one --frames sequence cut across the ranks")
+    ap.add_argument("--frames", type=int, default=1000, help="sequence length of --scaling strong (BASELINE config 4: 1000)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -86,8 +96,21 @@ def main():
     cfg = ZoeConfig()
     wz = random_zoedepth_weights(cfg, seed=0)
     wp = random_cyclepose_weights(seed=0)
-    n_frames = (K + Wm) * B + 1
-    frames = torch.from_numpy(make_sequence(n_frames, H, W, seed=rank)).to(dev)     # resident in HBM
+    strong = args.scaling == "strong"
+    if strong:
+        from bodyslam_amd.pipeline import shard_bounds
+        Nseq = args.frames
+        bounds = [shard_bounds(Nseq, world, r) for r in range(world)]
+        s0, e0 = bounds[rank]
+        # batch: the largest block cut into equal batches of at most --batch frames (125 -> 63 + 62; the last one runs padded)
+        nmax = max(e - s for s, e in bounds)
+        B = -(-nmax // (-(-nmax // B)))
+        foff = max(s0 - 1, 0)
+        frames = torch.from_numpy(make_sequence(Nseq, H, W, seed=0)[foff:e0]).to(dev)    # the rank's block + halo, resident in HBM
+        n_frames = Nseq
+    else:
+        n_frames = (K + Wm) * B + 1
+        frames = torch.from_numpy(make_sequence(n_frames, H, W, seed=rank)).to(dev)     # resident in HBM
     pairs = torch.tensor([[i, i + 1] for i in range(B)], dtype=torch.int32, device=dev)
     counts = [B] * world
 
@@ -100,21 +123,27 @@ def main():
         """W warm-up + K timed steps of the whole loop in one precision mode -> (pipeline, plan, fps, elapsed, rooflines, table)."""
         pipe = BodySlamPipeline(wz, wp, cfg, dtype=dtype, device=local_rank, batch=B, precision=precision)
         zplan = pipe.zoe.plan_for(B, H, W, True)
-        pplan = pipe.pose.plan_for(B + 1, B, H, W)
+        pplan = None if strong else pipe.pose.plan_for(B + 1, B, H, W)
         events = []
 
+        state = {"g_last": None}
+
         def step(k, timed_kernels):
+            zplan.plan.events = events if timed_kernels else None
+            if strong:      # the whole sequence: this rank's block through run_sequence (all-gather + chain + back-projection inside)
+                res = pipe.run_sequence(frames, rank, world, frame_offset=foff, n_frames=Nseq)
+                return res.point_counts
             chunk = frames[k * B: (k + 1) * B + 1]                                       # halo frame + B frames
             zplan.frames.copy_(chunk[1:])
-            if timed_kernels:
-                zplan.plan.run_timed(events)
-            else:
-                zplan.plan.run()
+            zplan.plan.run()
             pplan.frames.copy_(chunk)
             pplan.pairs.copy_(pairs)
             pplan.plan.run()
             t_all = gather_relative_poses(pplan.T, counts) if use_dist else pplan.T
-            g_abs = geom3d.pose_chain(t_all, device=local_rank)
+            # the chain continues from the previous step's last pose (device-resident g0); at N > 1 every rank chains the
+            # gathered block of world x B relatives and keeps its own B poses
+            g_abs = geom3d.pose_chain(t_all, g0=state["g_last"], device=local_rank)
+            state["g_last"] = g_abs[-1]
             xyz, idx, cnt = geom3d.backproject(zplan.depth_u16, pipe.K, pipe.depth_scale, pipe.depth_trunc,
                                                poses=g_abs[rank * B + 1: (rank + 1) * B + 1])
             return cnt
@@ -127,11 +156,14 @@ def main():
             step(k, not args.no_kernel_timing)
         barrier()
         elapsed = time.perf_counter() - t0
+        zplan.plan.events = None
         if use_dist:
             te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             elapsed = te.item()
-        fps = world * K * B / elapsed
+        fps = (K * Nseq if strong else world * K * B) / elapsed
+        # frame 0 of the LAST TIMED step's batch, as the timed plan left it (compared with the oracle below)
+        d_timed = zplan.depth_m[0].detach().cpu().clone()
 
         # ---- per-kernel roofline from the HIP events of the timed steps (rank 0's view).  "achieved" counts ALGORITHMIC FLOPs
         # (2*M*N*K of the convolution / GEMM being computed); "executed" counts the MFMA work actually issued, which in
@@ -158,20 +190,22 @@ def main():
             exe = a["flops"] / (a["ms"] * 1e-3) / 1e12
             # HBM bytes per launch of that kernel from the committed PMC collection (separate --pmc passes, FETCH_SIZE doubled as
             # the microarch guide prescribes for gfx950); only valid for the batch / mode it was collected at
-            traffic = None
+            traffic, traffic_source = None, None
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+                pmc_file = PMC_TRAFFIC_FILE
+                pm = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
                 mode = {"gemm": "ELi0E", "conv": "ELi1E"}[kind]
                 dims = TILE_NAMES[tile].split("s")[0].split("x")
                 cands = [v for name, v in pm["modes"][precision]["kernels"].items()
                          if ("igemm_kernel" in name and f"Li{dims[0]}ELi{dims[1]}E" in name and f"Li{dims[2]}E" in name and mode in name
-                             and ("DF16_" in name) == (args.dtype == "f16") and B == 64)]
+                             and ("DF16_" in name) == (args.dtype == "f16") and B == pm.get("batch", 64) and not strong)]
                 if cands:       # the F8 / plain instantiation with the most launches is the one the events timed
                     traffic = round(max(cands, key=lambda v: v["launches"])["hbm_bytes_per_launch_corrected"])
+                    traffic_source = f"profiles/{pmc_file}: offline rocprofv3 PMC passes of this command (2*FETCH_SIZE + WRITE_SIZE), not measured in this run"
             except Exception:
                 traffic = None
             roof = dict(bound="mfma", kernel=f"igemm_kernel<{args.dtype},{TILE_NAMES[tile]},{kind}>", achieved=round(ach, 1),
-                        peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=traffic,
+                        peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source,
                         executed=round(exe, 1), executed_frac=round(exe / MFMA_PEAK_TFLOPS, 4),
                         avg_launch_us=round(1e3 * a["ms"] / a["n"], 2), gflop_per_launch=round(a["alg"] / a["n"] / 1e9, 3))
             cms = sum(a["ms"] for (kd, _), a in agg.items() if kd == "conv")
@@ -182,7 +216,7 @@ def main():
                                  achieved=round(cfl / (cms * 1e-3) / 1e12, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                                  frac=round(cfl / (cms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                                  executed=round(cex / (cms * 1e-3) / 1e12, 1), executed_frac=round(cex / (cms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4))
-        return dict(pipe=pipe, zplan=zplan, fps=fps, elapsed=elapsed, roof=roof, roof_conv=roof_conv, kern=kern_table)
+        return dict(pipe=pipe, zplan=zplan, fps=fps, elapsed=elapsed, roof=roof, roof_conv=roof_conv, kern=kern_table, d_timed=d_timed)
 
     main_run = measure(args.precision)
     pipe, zplan, fps, elapsed = main_run["pipe"], main_run["zplan"], main_run["fps"], main_run["elapsed"]
@@ -202,10 +236,16 @@ def main():
         # torch CPU ops stop scaling (and then collapse) far below a 256-thread host: use at most 32 threads
         ncores = min(os.cpu_count() or 1, 32)
         torch.set_num_threads(ncores)
-        f2 = frames[:2].cpu()
-        gd, _ = pipe.zoe.infer(frames[1:2])
-        gd = gd.cpu().clone()
-        gd_other = other["pipe"].zoe.infer(frames[1:2])[0].cpu().clone() if other else None
+        # the frame the timed plan processed last as its frame 0 (and its predecessor, for the pose pair)
+        if strong:      # the last batch of the rank's block: frame 0 of that batch
+            i0 = (s0 - foff) + ((e0 - s0 - 1) // B) * B
+        else:
+            i0 = (Wm + K - 1) * B + 1
+        f2 = frames[max(i0 - 1, 0): i0 + 1].cpu()
+        if f2.shape[0] < 2:
+            f2 = torch.cat([f2, f2], 0)
+        gd = main_run["d_timed"]
+        gd_other = other["d_timed"] if other else None
         tc = time.perf_counter()
         with torch.no_grad():
             d_ref = Z.infer_depth(wz, Z.ZOED_NK, f2[1:2], flip_aug=True)
@@ -223,12 +263,19 @@ def main():
         out = {
             "metric": "frames/sec depth+pose+back-proj, 640x480 seq", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic frames, random-init weights",
-            "config": {"workload": f"full MDEM(ZoeD_NK, flip-aug)+MPEM(CyclePose)+3DM loop, {K * B} synthetic {W}x{H} frames per GPU, "
-                                   f"batch {B} frames/step", "frames_per_step_per_gpu": B, "net_input": list(zplan.geom[k] for k in ("nh", "nw")),
-                       "sharding": "contiguous frame blocks per rank, one RCCL all-gather of relative poses per step" if world > 1 else "single GPU"},
+            "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic frames, random-init weights",
+            "config": ({"workload": f"full MDEM(ZoeD_NK, flip-aug)+MPEM(CyclePose)+3DM loop, ONE {Nseq}-frame synthetic {W}x{H} sequence cut "
+                                    f"into {world} contiguous block(s), batch {B} frames (ragged last batch padded)",
+                        "sequence_frames": Nseq, "frames_per_step": Nseq, "batch": B, "net_input": list(zplan.geom[k] for k in ("nh", "nw")),
+                        "sharding": {"blocks": [e - s for s, e in bounds], "halo_frames": 1,
+                                     "exchange": "one RCCL all-gather of the [N_r,16] relative poses per sequence" if world > 1 else "none (single GPU)"}}
+                       if strong else
+                       {"workload": f"full MDEM(ZoeD_NK, flip-aug)+MPEM(CyclePose)+3DM loop, {K * B} synthetic {W}x{H} frames per GPU, "
+                                    f"batch {B} frames/step", "frames_per_step_per_gpu": B, "net_input": list(zplan.geom[k] for k in ("nh", "nw")),
+                        "sharding": "contiguous frame blocks per rank, one RCCL all-gather of relative poses per step" if world > 1 else "single GPU"}),
             "roofline": roof, "roofline_conv_stack": roof_conv, "cpu_baseline": cpu,
-            "precision": args.precision, "depth_l1_vs_oracle_m": l1, "kernels": kern_table,
+            "precision": args.precision, "depth_l1_vs_oracle_m": l1, "depth_l1_frame": "frame 0 of the last timed step's batch, from the timed plan's output",
+            "kernels": kern_table,
             "hbm_allocated_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
         }
         if other:

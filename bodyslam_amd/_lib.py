@@ -44,6 +44,7 @@ class GemmDesc(C.Structure):
         ("qkv_hidden", C.c_int32), ("qkv_tokens", C.c_int32), ("qkv_sp", C.c_int32), ("q_scale", C.c_float),
         ("tile", C.c_int32), ("seg1", C.c_int32), ("out_split_off", C.c_int32), ("res_split_off", C.c_int32),
         ("f8_seg", C.c_int32), ("f8_scales", C.c_uint32), ("out_f8", C.c_int32), ("res_f8", C.c_int32),
+        ("qkv_cls_last", C.c_int32),
     ]
 
 
@@ -55,6 +56,7 @@ _SIGS = {
     "bs_gemm": [C.POINTER(GemmDesc), C.c_void_p],
     "bs_gemm_tile": [C.POINTER(GemmDesc)],
     "bs_attention": [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p],
+    "bs_attention_table": [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p],
     "bs_layernorm": [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p],
     "bs_cast": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p],
     "bs_copy_f32": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
@@ -77,6 +79,7 @@ _SIGS = {
     "bs_cyclepose_head": [C.c_void_p] * 12 + [C.c_int32] * 3 + [C.c_void_p],
     "bs_backproject": [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_double, C.c_double] + [C.c_void_p] * 6,
     "bs_pose_chain": [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+    "bs_pose_chain_from": [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
     "bs_pixel_to_3d": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p],
 }
 EXPORTS = sorted(list(_SIGS) + ["bs_last_error"])
@@ -147,7 +150,7 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
                    res_split_off: int = 0, f8_seg: int = 0, f8_scales=(127, 127, 127, 127), out_f8=None, res_f8: bool = False) -> GemmDesc:
     """Fill a bs_gemm_desc.  conv = (Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_h, pad_w) or None;
     out_group = (rows, stride, offset); shuffle = (s, Cout, Hgrid, Wgrid);
-    qkv = (hidden, tokens, Sp, q_scale, out_k, out_vt); a_offset in elements."""
+    qkv = (hidden, tokens, Sp, q_scale, out_k, out_vt[, cls_last]); a_offset in elements."""
     d = GemmDesc()
     d.A = A.data_ptr() + a_offset * A.element_size()
     d.W = W.data_ptr()
@@ -183,7 +186,8 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
         d.shuffle_s, d.shuffle_cout, d.Hout, d.Wout = shuffle
     if qkv is not None:
         d.out_mode = OUT_QKV
-        hidden, tokens, sp, q_scale, out_k, out_vt = qkv
+        hidden, tokens, sp, q_scale, out_k, out_vt = qkv[:6]
+        d.qkv_cls_last = int(bool(qkv[6])) if len(qkv) > 6 else 0
         d.qkv_hidden, d.qkv_tokens, d.qkv_sp, d.q_scale = hidden, tokens, sp, q_scale
         d.out2 = out_k.data_ptr()
         d.out3 = out_vt.data_ptr()
@@ -206,7 +210,9 @@ class Plan:
     marshalled once, so replaying a forward costs one ctypes call per kernel (and the whole sequence
     can be captured into a HIP graph).  `mark(name, tensor)` records a named intermediate for tests."""
 
-    def __init__(self):
+    def __init__(self, device=None):
+        # the device whose streams the plan is issued on (an engine passes its own; None = torch's current device at run time)
+        self.device = None if device is None else torch.device(device)
         self.calls = []      # (cfunc, args) ; args exclude the trailing stream
         self.names = []
         self.keep = []       # keeps descriptors / tensors alive
@@ -214,6 +220,7 @@ class Plan:
         self.gemm_info = {}  # call index -> dict(tile, conv, flops, bytes)
         self.lane = 0        # lane of the calls being added: 0 = the caller's stream, 1 = the plan's side stream
         self.lanes = []      # per call
+        self.events = None   # a list: run() records a HIP event pair around every bs_gemm launch into it (see run_timed)
         self._side = None    # torch side stream + fork / join events, created at the first run
         self._events = {}
 
@@ -232,9 +239,9 @@ class Plan:
         self.lanes.append(self.lane)
 
     def _streams(self):
-        main = torch.cuda.current_stream()
+        main = torch.cuda.current_stream(self.device)
         if self._side is None:
-            self._side = torch.cuda.Stream()
+            self._side = torch.cuda.Stream(device=self.device)
             self._events = {}
         return main, self._side
 
@@ -304,6 +311,8 @@ class Plan:
                 check(rc, self.names[i])
 
     def run(self, taps: Optional[dict] = None):
+        if taps is None and self.events is not None:      # a caller (bench.py) asked for per-launch HIP events
+            return self.run_timed(self.events)
         if taps is None:
             main, side = self._streams()
             ptrs = (main.cuda_stream, side.cuda_stream)
@@ -315,7 +324,7 @@ class Plan:
                 if rc:
                     check(rc, self.names[i])
             return
-        st = stream_ptr()       # tap mode (tests): one stream, program order
+        st = torch.cuda.current_stream(self.device).cuda_stream       # tap mode (tests): one stream, program order
         for i in range(len(self.calls) + 1):
             for (name, t, meta) in self.marks.get(i, []):
                 taps[name] = (t.clone(), meta)
@@ -388,6 +397,11 @@ def conv_geom(Hin, Win, Cin, KH, KW, stride, pad):
 
 def attention(q, k, vt, bias, out, B, nh, S, Sp):
     check(load_library().bs_attention(p(q), p(k), p(vt), p(bias), p(out), B, nh, S, Sp, dt(q), stream_ptr()), "bs_attention")
+
+
+def attention_table(q, k, vt, table, out, B, nh, hp, wp, Sp, split=0):
+    check(load_library().bs_attention_table(p(q), p(k), p(vt), p(table), p(out), B, nh, hp, wp, Sp, dt(q) | split, stream_ptr()),
+          "bs_attention_table")
 
 
 def layernorm(x, gamma, beta, out16, out32, rows, cols, eps, dtype=F16):
@@ -485,6 +499,11 @@ def pose_chain(t_rel, N, g0, g_abs):
     if g0 is not None:
         g0arr = C.cast((C.c_double * 16)(*[float(v) for v in g0]), C.c_void_p)
     check(load_library().bs_pose_chain(p(t_rel), N, g0arr, p(g_abs), stream_ptr()), "bs_pose_chain")
+
+
+def pose_chain_from(t_rel, N, g0_dev, g_abs):
+    """g0_dev: fp64 [16] device tensor (e.g. the last pose of the previous call's output)"""
+    check(load_library().bs_pose_chain_from(p(t_rel), N, p(g0_dev), p(g_abs), stream_ptr()), "bs_pose_chain_from")
 
 
 def pixel_to_3d(uvd, K4, out, n):

@@ -215,6 +215,232 @@ __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Table variant (the full-size networks: window hp x 32 patches).  The additive bias of (query, key) depends only on the
+// offset (qy - ky, qx - kx) of the two patches -- HF gathers a [S, S] matrix per head from a ((2hp-1)(2wp-1) + 3)-entry
+// table (modeling_beit.py:194-265).  Here the per-head table (12 KiB fp32, pre-multiplied by log2 e) sits in LDS and a lane
+// reads its 16 values of a sub-tile straight from it: no [nh, Sp, Sp] tensor exists and nothing but the K / V^T tiles is
+// fetched inside the loop (the materialised-bias kernel above streamed 4 KiB of bias per wave and 32-key sub-tile -- 2.5x the
+// K / V^T bytes -- through VGPR-destination loads whose waits also drained the tile prefetch).
+// Token order inside Q / K / V^T is patches first, cls LAST (written so by the QKV epilogue, bs_gemm_desc.qkv_cls_last):
+// a 32-query tile is then one patch row (qy = tile index, qx = lane) and a 32-key sub-tile one key row (ky, kx = 0..31), and
+//   bias = tab[(qy - ky + hp - 1) * 63 + (qx - kx + 31)]
+// is a wave-uniform row base plus a per-lane offset plus an immediate: conflict-free ds_read_b32 (32 consecutive words per
+// lane half).  The cls key is the single valid key of the last sub-tile (tab[nrd-2]; tab[nrd-1] for the cls query), the cls
+// query tile takes tab[nrd-3] for every patch key.  Output rows are written back in the residual stream's order (cls first).
+template <typename T, int QW>
+__global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ Vt,
+                                                                 const float* __restrict__ table, T* __restrict__ out, int split, int B, int nh,
+                                                                 int hp, int Sp, int nqb, int ntab) {
+    typedef typename T16<T>::v8 v8;
+    constexpr int STAGE = 16 * 1024;  // K tile 8 KiB + V^T tile 8 KiB
+    constexpr int WP = 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tab = reinterpret_cast<float*>(smem + 2 * STAGE);
+    const int S = hp * WP + 1, nqt = hp + 1;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + loc;
+    const int b = wg % B;
+    const int qblk = (wg / B) % nqb;
+    const int head = wg / (B * nqb);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h2 = lane >> 5;
+    int qt = qblk * QW + wave;
+    const bool active = qt < nqt;
+    qt = active ? qt : nqt - 1;
+    const int q0 = qt * 32;
+    const bool cls_tile = qt == hp;           // wave-uniform: the tile whose only valid query is the cls token
+    const int64_t bh = (int64_t)b * nh + head;
+
+    const T* Qg = Q + bh * Sp * 64;
+    const T* Kg = K + bh * Sp * 64;
+    const T* Vg = Vt + bh * 64 * Sp;
+
+    // the head's table -> LDS (visible after the first barrier of the loop)
+    for (int i = tid; i < ntab; i += QW * 64) tab[i] = table[(int64_t)head * ntab + i];
+
+    v8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const v8*>(Qg + (int64_t)(q0 + r) * 64 + ks * 16 + h2 * 8);
+
+    const int srow = lane >> 3;
+    auto stage = [&](int kt, int buf) {
+        char* sb = smem + buf * STAGE;
+        for (int i = wave; i < 16; i += QW) {
+            const int row = (i & 7) * 8 + srow;
+            const int cs8 = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+            const T* src;
+            if (i < 8) {
+                src = Kg + (int64_t)(kt * 64 + row) * 64 + cs8;
+            } else {
+                src = Vg + (int64_t)row * Sp + kt * 64 + cs8;
+            }
+            glds16(src, sb + i * 1024);
+        }
+    };
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        oacc[0][i] = 0.f;
+        oacc[1][i] = 0.f;
+    }
+    float m_run = 0.f, l_run = 0.f;
+    const int kap = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+    const int nkt = (S + 63) >> 6;
+    constexpr float THR = 6.0f;
+
+    // registers 8s..8s+7 of lane half h2 are keys key0 + 16s + 8*h2 + e -> kx = 16s + 8*h2 + e:
+    //   word = (qt - ky + hp - 1) * 63 + lane_w + (23 - 16s - e),   lane_w = r + 8 - 8*h2   (>= 0)
+    const float* lane_tab = tab + r + 8 - 8 * h2;
+    const float c_cls_key = 0.f, NEG = -1.0e30f;
+    (void)c_cls_key;
+    float bnext[16];
+    auto load_bias = [&](int ky) {      // the 16 bias values of the sub-tile holding key row ky (ky == hp: the cls key + padding)
+        if (ky < hp) {
+            if (cls_tile) {
+                const float c3 = tab[ntab - 3];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) bnext[i] = c3;
+            } else {
+                const float* rowp = lane_tab + (qt - ky + hp - 1) * (2 * WP - 1);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bnext[8 * s2 + e] = rowp[23 - 16 * s2 - e];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bnext[i] = NEG;
+            if (h2 == 0) bnext[0] = cls_tile ? tab[ntab - 1] : tab[ntab - 2];
+        }
+    };
+
+    bool first = true;
+    stage(0, 0);
+    __syncthreads();                    // tile 0 and the table have landed
+    if (1 < nkt) stage(1, 1);
+    load_bias(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt > 0) {
+            __syncthreads();
+            if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
+        }
+        const char* sk = smem + (kt & 1) * STAGE;
+        const char* sv = sk + 8 * 1024;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int ky = kt * 2 + sub;
+            if (ky > hp) break;
+            f32x16 sacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[i] = bnext[i] - m_run;
+            if (ky + 1 <= hp) load_bias(ky + 1);
+            const int krow = sub * 32 + kap;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int chunk = 2 * ks + h2;
+                const v8 kf = *reinterpret_cast<const v8*>(sk + krow * 128 + ((chunk ^ ((krow >> 1) & 7)) << 4));
+                sacc = T16<T>::mfma32(kf, qf[ks], sacc);
+            }
+            float mloc = fmaxf(fmaxf(sacc[0], sacc[1]), sacc[2]);
+#pragma unroll
+            for (int i = 3; i < 15; i += 2) mloc = fmaxf(fmaxf(mloc, sacc[i]), sacc[i + 1]);
+            mloc = fmaxf(mloc, sacc[15]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            if (first || __any(mloc > THR)) {
+                const float alpha = __builtin_amdgcn_exp2f(-mloc);
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    oacc[0][i] *= alpha;
+                    oacc[1][i] *= alpha;
+                    sacc[i] -= mloc;
+                }
+                m_run += mloc;
+                first = false;
+            }
+            float p[16];
+            float psum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                p[i] = __builtin_amdgcn_exp2f(sacc[i]);
+                psum += p[i];
+            }
+            l_run += psum;
+            v8 pf[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[s2][e] = T16<T>::from_f32(p[8 * s2 + e]);
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh) {
+                const int drow = dh * 32 + r;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int chunk = sub * 4 + 2 * s2 + h2;
+                    const v8 vf = *reinterpret_cast<const v8*>(sv + drow * 128 + ((chunk ^ ((drow >> 1) & 7)) << 4));
+                    oacc[dh] = T16<T>::mfma32(vf, pf[s2], oacc[dh]);
+                }
+            }
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qpos = q0 + r;
+    if (active && qpos < S) {
+        const int tok = qpos == S - 1 ? 0 : qpos + 1;        // back to the residual stream's order: cls first
+        T* orow = out + ((int64_t)b * S + tok) * (nh * 64) * (split ? 2 : 1) + head * 64;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                typename T16<T>::v4 o, ol;
+                float yv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    yv[e] = oacc[dh][gg * 4 + e] * inv;
+                    o[e] = T16<T>::from_f32(yv[e]);
+                    ol[e] = T16<T>::from_f32(yv[e] - T16<T>::to_f32(o[e]));
+                }
+                *reinterpret_cast<typename T16<T>::v4*>(orow + dh * 32 + 8 * gg + 4 * h2) = o;
+                if (split == 2) {
+                    const int col = head * 64 + dh * 32 + 8 * gg + 4 * h2;
+                    char* planes = reinterpret_cast<char*>(orow - head * 64 + nh * 64);
+                    const float sh = __builtin_ldexpf(1.0f, F8_ACT_HI_EXP), sl = __builtin_ldexpf(1.0f, F8_ACT_LO_EXP);
+                    *reinterpret_cast<int*>(planes + col) = f8_pack4(yv[0] * sh, yv[1] * sh, yv[2] * sh, yv[3] * sh);
+                    *reinterpret_cast<int*>(planes + nh * 64 + col) =
+                        f8_pack4((yv[0] - T16<T>::to_f32(o[0])) * sl, (yv[1] - T16<T>::to_f32(o[1])) * sl, (yv[2] - T16<T>::to_f32(o[2])) * sl,
+                                 (yv[3] - T16<T>::to_f32(o[3])) * sl);
+                } else if (split) {
+                    *reinterpret_cast<typename T16<T>::v4*>(orow + nh * 64 + dh * 32 + 8 * gg + 4 * h2) = ol;
+                }
+            }
+    }
+}
+
+template <typename T>
+static int launch_attn_tab(const void* q, const void* k, const void* vt, const float* table, void* out, int split, int B, int nh, int hp, int Sp,
+                           hipStream_t st) {
+    constexpr int QW = 5;
+    const int nqt = hp + 1, nqb = cdiv(nqt, QW), ntab = (2 * hp - 1) * 63 + 3;
+    const int smem = 32 * 1024 + ((ntab * 4 + 15) & ~15);
+    auto kern = attention_tab_kernel<T, QW>;
+    static bool attr = false;
+    if (!attr) {
+        BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(B * nh * nqb), dim3(QW * 64), smem, st, (const T*)q, (const T*)k, (const T*)vt, table, (T*)out, split, B,
+                       nh, hp, Sp, nqb, ntab);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
 template <typename T, int QW>
 static int launch_attn(const void* q, const void* k, const void* vt, const float* bias, void* out, int split, int B, int nh, int S, int Sp,
                        hipStream_t st) {
@@ -252,4 +478,22 @@ extern "C" int bs_attention(const void* q, const void* k, const void* vt, const 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return dtype == BS_F16 ? dispatch_attn<f16>(q, k, vt, bias, out, split, B, nh, S, Sp, st)
                            : dispatch_attn<bf16>(q, k, vt, bias, out, split, B, nh, S, Sp, st);
+}
+
+extern "C" int bs_attention_table(const void* q, const void* k, const void* vt, const float* table, void* out, int32_t B, int32_t nh,
+                                  int32_t hp, int32_t wp, int32_t Sp, int32_t dtype, void* stream) {
+    using namespace bs;
+    if (!initialized()) { set_error("bs_attention_table: call bs_init first"); return BS_ERR_NOT_INIT; }
+    BS_REQUIRE(q && k && vt && table && out && B >= 0 && nh > 0 && hp > 0, "bs_attention_table: bad argument");
+    BS_REQUIRE(wp == 32, "bs_attention_table: built for windows of 32 patches per row (wp=%d): use bs_attention", wp);
+    BS_REQUIRE(hp <= 40, "bs_attention_table: hp=%d: the table must fit 32 KiB of LDS", hp);
+    const int S = hp * wp + 1;
+    BS_REQUIRE(Sp % 64 == 0 && Sp >= S, "bs_attention_table: Sp=%d must be a multiple of 64 and >= S=%d", Sp, S);
+    const int split = (dtype & 32) ? 2 : ((dtype & 16) ? 1 : 0);
+    dtype &= 15;
+    BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_attention_table: dtype");
+    if (B == 0) return BS_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return dtype == BS_F16 ? launch_attn_tab<f16>(q, k, vt, table, out, split, B, nh, hp, Sp, st)
+                           : launch_attn_tab<bf16>(q, k, vt, table, out, split, B, nh, hp, Sp, st);
 }

@@ -206,12 +206,11 @@ __device__ void svd3_project_so3(double (&M)[3][3]) {
         }
 }
 
-__global__ void pose_chain_kernel(const float* t_rel, int N, const double* g0, double* g_abs) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// The strict recurrence, one lane (kept for inputs whose 4x4 matrices are not affine: a bottom row other than [0 0 0 1]).
+__device__ void pose_chain_sequential(const float* t_rel, int N, const double* g0, double* g_abs) {
     double G[4][4];
     for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) G[i][j] = g0 ? g0[i * 4 + j] : (i == j ? 1.0 : 0.0);
-    for (int i = 0; i < 16; ++i) g_abs[i] = G[i / 4][i % 4];
+        for (int j = 0; j < 4; ++j) G[i][j] = g0[i * 4 + j];
     for (int n = 0; n < N; ++n) {
         double T[4][4], C[4][4];
         for (int i = 0; i < 16; ++i) T[i / 4][i % 4] = (double)t_rel[(int64_t)n * 16 + i];
@@ -232,6 +231,125 @@ __global__ void pose_chain_kernel(const float* t_rel, int N, const double* g0, d
                 G[i][j] = C[i][j];
                 g_abs[(int64_t)(n + 1) * 16 + i * 4 + j] = C[i][j];
             }
+    }
+}
+
+// Wavefront formulation of the chain.  With G_{i-1} a rotation, the SO(3) projection commutes with the product:
+//   proj(G_{i-1}.R * R_i) = G_{i-1}.R * proj(R_i)      (SVD of G R = (G U) S V^T; same singular values, same determinant sign)
+// so the recurrence  G_i = proj(G_{i-1} T_i)  is the prefix product of the independently projected elements
+// E_i = (proj(R_i), t_i) under (Ra, ta) o (Rb, tb) = (Ra Rb, Ra tb + ta).  Phase 1 projects every relative pose in parallel
+// (one lane per pose, fp64 one-sided Jacobi); phase 2 is a wave-shuffle prefix product (Kogge-Stone over 64 lanes, wave
+// totals combined through LDS, 256-pose chunks carried by the block).  Pose 1 is formed from g0 exactly as the reference does
+// (g0 need not be a rotation: ensure_so3_v2 goes through here); reassociation moves results by ~1e-15 (tolerance 1e-9).
+struct Se3 {
+    double r[9], t[3];
+};
+__device__ __forceinline__ Se3 se3_compose(const Se3& a, const Se3& b) {
+    Se3 c;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c.r[i * 3 + j] = a.r[i * 3] * b.r[j] + a.r[i * 3 + 1] * b.r[3 + j] + a.r[i * 3 + 2] * b.r[6 + j];
+        c.t[i] = a.r[i * 3] * b.t[0] + a.r[i * 3 + 1] * b.t[1] + a.r[i * 3 + 2] * b.t[2] + a.t[i];
+    }
+    return c;
+}
+__device__ __forceinline__ Se3 se3_shfl_up(const Se3& a, int d) {
+    Se3 o;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o.r[i] = __shfl_up(a.r[i], d, 64);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o.t[i] = __shfl_up(a.t[i], d, 64);
+    return o;
+}
+
+// phase 1: element n (pose n + 1) -> g_abs[(n + 1) * 16 ..]: rows 0-2 = [proj(R) | t], slot 12 = 1.0 when the input is not affine
+__global__ __launch_bounds__(64) void pose_project_kernel(const float* t_rel, int N, const double* g0, double* g_abs) {
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    if (n >= N) return;
+    double T[4][4];
+    for (int i = 0; i < 16; ++i) T[i / 4][i % 4] = (double)t_rel[(int64_t)n * 16 + i];
+    bool bad = !(T[3][0] == 0.0 && T[3][1] == 0.0 && T[3][2] == 0.0 && T[3][3] == 1.0);
+    double C[3][4];
+    if (n == 0) {   // the first step multiplies by g0 in full, as the reference does
+        double G[4][4];
+        for (int i = 0; i < 16; ++i) G[i / 4][i % 4] = g0[i];
+        bad = bad || !(G[3][0] == 0.0 && G[3][1] == 0.0 && G[3][2] == 0.0 && G[3][3] == 1.0);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 4; ++j) C[i][j] = G[i][0] * T[0][j] + G[i][1] * T[1][j] + G[i][2] * T[2][j] + G[i][3] * T[3][j];
+    } else {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 4; ++j) C[i][j] = T[i][j];
+    }
+    double R[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R[i][j] = C[i][j];
+    svd3_project_so3(R);
+    double* o = g_abs + (int64_t)(n + 1) * 16;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) o[i * 4 + j] = R[i][j];
+        o[i * 4 + 3] = C[i][3];
+    }
+    o[12] = bad ? 1.0 : 0.0;
+}
+
+// phase 2: in-place prefix product over the projected elements (one block; 256 poses per round)
+constexpr int CHAIN_THREADS = 256;
+__global__ __launch_bounds__(CHAIN_THREADS) void pose_scan_kernel(const float* t_rel, int N, double* g_abs) {
+    __shared__ Se3 wave_tot[CHAIN_THREADS / 64];
+    __shared__ Se3 carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // any non-affine input: the strict recurrence on one lane (g_abs[0:16] holds g0)
+    int bad = 0;
+    for (int n = tid; n < N; n += CHAIN_THREADS) bad |= g_abs[(int64_t)(n + 1) * 16 + 12] != 0.0;
+    if (__syncthreads_or(bad)) {
+        if (tid == 0) pose_chain_sequential(t_rel, N, g_abs, g_abs);
+        return;
+    }
+    for (int base = 0; base < N; base += CHAIN_THREADS) {
+        const int n = base + tid;
+        Se3 e;
+        if (n < N) {
+            const double* s = g_abs + (int64_t)(n + 1) * 16;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) e.r[i * 3 + j] = s[i * 4 + j];
+                e.t[i] = s[i * 4 + 3];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) e.r[i] = (i % 4 == 0) ? 1.0 : 0.0;
+            e.t[0] = e.t[1] = e.t[2] = 0.0;
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const Se3 o = se3_shfl_up(e, d);
+            if (lane >= d) e = se3_compose(o, e);
+        }
+        if (lane == 63) wave_tot[wave] = e;
+        __syncthreads();
+        Se3 pre;
+        bool has_pre = false;
+        if (base > 0) { pre = carry; has_pre = true; }
+        for (int w = 0; w < wave; ++w) {
+            pre = has_pre ? se3_compose(pre, wave_tot[w]) : wave_tot[w];
+            has_pre = true;
+        }
+        if (has_pre) e = se3_compose(pre, e);
+        __syncthreads();                       // everyone has read carry / wave_tot
+        if (tid == CHAIN_THREADS - 1) carry = e;
+        if (n < N) {
+            double* o = g_abs + (int64_t)(n + 1) * 16;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) o[i * 4 + j] = e.r[i * 3 + j];
+                o[i * 4 + 3] = e.t[i];
+            }
+            o[12] = 0.0; o[13] = 0.0; o[14] = 0.0; o[15] = 1.0;
+        }
+        __syncthreads();
     }
 }
 
@@ -285,18 +403,33 @@ extern "C" int bs_backproject(const uint16_t* depth, int32_t B, int32_t H, int32
     return BS_OK;
 }
 
+static int pose_chain_launch(const float* t_rel, int32_t N, double* g_abs, hipStream_t st) {
+    using namespace bs;
+    if (N > 0) {   // g_abs[0:16] already holds g0
+        hipLaunchKernelGGL(pose_project_kernel, dim3(cdiv(N, 64)), dim3(64), 0, st, t_rel, N, (const double*)g_abs, g_abs);
+        BS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(pose_scan_kernel, dim3(1), dim3(CHAIN_THREADS), 0, st, t_rel, N, g_abs);
+        BS_CHECK_LAUNCH();
+    }
+    return BS_OK;
+}
+
 extern "C" int bs_pose_chain(const float* t_rel, int32_t N, const double* g0_host, double* g_abs, void* stream) {
     using namespace bs;
     if (!initialized()) { set_error("bs_pose_chain: call bs_init first"); return BS_ERR_NOT_INIT; }
     BS_REQUIRE(g_abs && (t_rel || N == 0) && N >= 0, "bs_pose_chain: bad argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const double* g0 = nullptr;
-    if (g0_host) {
-        // g_abs[0:16] doubles as the device staging slot for g0 (the kernel rewrites it with the same values)
-        BS_CHECK_HIP(hipMemcpyAsync(g_abs, g0_host, 16 * sizeof(double), hipMemcpyHostToDevice, st));
-        g0 = g_abs;
-    }
-    hipLaunchKernelGGL(pose_chain_kernel, dim3(1), dim3(64), 0, st, t_rel, N, g0, g_abs);
-    BS_CHECK_LAUNCH();
-    return BS_OK;
+    static const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    // g_abs[0:16] is the device slot of g0 (pose 0 of the output)
+    BS_CHECK_HIP(hipMemcpyAsync(g_abs, g0_host ? g0_host : eye, 16 * sizeof(double), hipMemcpyHostToDevice, st));
+    return pose_chain_launch(t_rel, N, g_abs, st);
+}
+
+extern "C" int bs_pose_chain_from(const float* t_rel, int32_t N, const double* g0_dev, double* g_abs, void* stream) {
+    using namespace bs;
+    if (!initialized()) { set_error("bs_pose_chain_from: call bs_init first"); return BS_ERR_NOT_INIT; }
+    BS_REQUIRE(g_abs && g0_dev && (t_rel || N == 0) && N >= 0, "bs_pose_chain_from: bad argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (g0_dev != g_abs) BS_CHECK_HIP(hipMemcpyAsync(g_abs, g0_dev, 16 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return pose_chain_launch(t_rel, N, g_abs, st);
 }

@@ -2,6 +2,10 @@
 // igemm_tile*.hip).
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "igemm_kernel.h"
 
 namespace bs {
@@ -58,6 +62,31 @@ static int launch_tile(IgemmParams& p, int dtype, bool conv, int tile, hipStream
     }
 }
 
+// Side stream + fork / join events of the tail split, one set per (device, caller stream): two plan lanes (or two host
+// threads) issuing split GEMMs on different streams never share events, and a set created on one device is never used on
+// another.  Created on first use under a mutex; they live for the life of the process.
+struct TailLane {
+    hipStream_t side;
+    hipEvent_t fork, join;
+};
+static int tail_lane(hipStream_t caller, hipStream_t& side, hipEvent_t& ev_fork, hipEvent_t& ev_join) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, TailLane> lanes;
+    int dev = 0;
+    BS_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = lanes.find({dev, caller});
+    if (it == lanes.end()) {
+        TailLane l{};
+        BS_CHECK_HIP(hipStreamCreateWithFlags(&l.side, hipStreamNonBlocking));
+        BS_CHECK_HIP(hipEventCreateWithFlags(&l.fork, hipEventDisableTiming));
+        BS_CHECK_HIP(hipEventCreateWithFlags(&l.join, hipEventDisableTiming));
+        it = lanes.emplace(std::make_pair(dev, caller), l).first;
+    }
+    side = it->second.side; ev_fork = it->second.fork; ev_join = it->second.join;
+    return BS_OK;
+}
+
 // Tail split.  A 256-row tile grid over M = 64 x 769 token rows is 192.25 tiles tall: the quarter-full last tile row costs a
 // whole extra round of the chip (772 blocks on 256 CUs = 4 rounds for 3.02 rounds of work in o_proj / fc2).  When dropping the
 // ragged rows saves a round, the full tiles go out as one launch and the <= 128 ragged rows as a second, small-tile launch
@@ -80,12 +109,11 @@ static int dispatch(IgemmParams& p, int dtype, bool conv, int tile, hipStream_t 
         // The two launches touch disjoint rows, so the short, latency-bound tail (8-32 small blocks, ~60 us on its own) runs on
         // a side stream beside the main launch and fills CUs the main grid leaves idle in its last round: fork / join by events.
         static const bool side_ok = getenv("BS_NO_TAIL_STREAM") == nullptr;
-        static hipStream_t side = nullptr;
-        static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-        if (side_ok && !side) {
-            BS_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-            BS_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-            BS_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        hipStream_t side = nullptr;
+        hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+        if (side_ok) {
+            const int rc = tail_lane(st, side, ev_fork, ev_join);
+            if (rc != BS_OK) return rc;
         }
         if (!side_ok) {
             const int rc = launch_tile(main, dtype, conv, tile, st);
@@ -179,6 +207,7 @@ extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
     p.out_group_rows = d->out_group_rows; p.out_group_stride = d->out_group_stride; p.out_row_offset = d->out_row_offset;
     p.shuffle_s = d->shuffle_s; p.shuffle_cout = d->shuffle_cout;
     p.qkv_hidden = d->qkv_hidden; p.qkv_tokens = d->qkv_tokens; p.qkv_sp = d->qkv_sp; p.q_scale = d->q_scale;
+    p.qkv_cls_last = d->qkv_cls_last;
     if (d->out_mode == BS_OUT_SHUFFLE) {
         BS_REQUIRE(!d->conv && d->shuffle_s > 0 && d->shuffle_cout % 4 == 0 && d->N == d->shuffle_s * d->shuffle_s * d->shuffle_cout,
                    "bs_gemm: bad shuffle geometry");

@@ -57,6 +57,7 @@ struct IgemmParams {
     int out_group_rows, out_group_stride, out_row_offset;
     int shuffle_s, shuffle_cout;
     int qkv_hidden, qkv_tokens, qkv_sp;
+    int qkv_cls_last;    // Q / K / V^T hold an image's tokens patches first, cls (token 0) last
     float q_scale;
     int ntm, ntn;
     int m_begin;        // first output row this launch covers (a GEMM may be issued as a main launch + a tail launch)
@@ -575,7 +576,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                     const int s = p.shuffle_s;
                     roff = (((int64_t)(ob * p.Hout + oy) * s) * (p.Wout * s) + ox * s) * p.ldo;
                 } else {
-                    const int ob = m / p.qkv_tokens, otok = m - ob * p.qkv_tokens;
+                    const int ob = m / p.qkv_tokens;
+                    int otok = m - ob * p.qkv_tokens;
+                    if (p.qkv_cls_last) otok = otok == 0 ? p.qkv_tokens - 1 : otok - 1;
                     roff = ((int64_t)ob * (p.qkv_hidden >> 6) * p.qkv_sp + otok) * 64;
                 }
 #pragma unroll
@@ -688,7 +691,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
             constexpr int CPS = 64 / PASS_R >= 1 ? 64 / PASS_R : 1;     // columns per 64-lane sweep
             const int r = lane % PASS_R, csub = lane / PASS_R;
             const int m = m_base + r;
-            const int ob = m / p.qkv_tokens, otok = m - ob * p.qkv_tokens;
+            const int ob = m / p.qkv_tokens;
+            int otok = m - ob * p.qkv_tokens;
+            if (p.qkv_cls_last) otok = otok == 0 ? p.qkv_tokens - 1 : otok - 1;
             if (m < p.M) {
                 for (int c0 = 0; c0 < TN; c0 += CPS) {
                     const int c = c0 + csub;

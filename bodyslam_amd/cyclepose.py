@@ -83,7 +83,7 @@ class _PosePlan:
         e32 = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         self.frames = torch.empty(N, H, W, 3, device=dev, dtype=torch.uint8)
         self.pairs = torch.zeros(P, 2, device=dev, dtype=torch.int32)
-        Pl = self.plan = L.Plan()
+        Pl = self.plan = L.Plan(dev)
         in_scratch = e32(P * (CROP * CROP // 256) * 2 * 256)
         cols = e16(P * CROP * CROP, K0)
         Pl.add("im2col", "bs_cyclepose_im2col", self.frames, self.pairs, cols, P, H, W, L.dt(cols))

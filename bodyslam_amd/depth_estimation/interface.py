@@ -54,17 +54,3 @@ class DepthEstimator:
         if extension:
             saving_path = os.path.splitext(saving_path)[0] + '.' + extension.lstrip('.')
         image.save(saving_path)
-
-    def debug(self, path_to_frame: str, saving_path: str):
-        tests = [
-            ("load image", lambda: self.load_image(path_to_frame)),
-            ("infer method", lambda: self.infer_depth_map(path_to_frame)),
-            ("saving method", lambda: self.save_depth_map(Image.new('RGB', (100, 100)), saving_path)),
-        ]
-        for test_name, test_func in tests:
-            print(f"[DEBUG]: Testing {test_name}...")
-            try:
-                test_func()
-                print(f"[DEBUG]: {test_name} status -> ok")
-            except Exception as e:
-                print(f"[DEBUG]: OPS :/ -> {e}")

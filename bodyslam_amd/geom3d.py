@@ -28,14 +28,18 @@ def _dev(device: int = 0) -> torch.device:
     return torch.device("cuda", device)
 
 
-def pose_chain(t_rel, g0: Optional[np.ndarray] = None, device: int = 0) -> torch.Tensor:
+def pose_chain(t_rel, g0=None, device: int = 0) -> torch.Tensor:
     """relative poses float32 [N,4,4] (torch GPU tensor or numpy) -> absolute poses float64 [N+1,4,4]
-    on the GPU; element 0 is g0 (identity).  G_i = ensure_so3(G_{i-1} @ T_i) (slam_utils.py:110-122)."""
+    on the GPU; element 0 is g0 (identity; a numpy (4,4) or a GPU tensor).  G_i = ensure_so3(G_{i-1} @ T_i)
+    (slam_utils.py:110-122)."""
     dev = _dev(device)
     t = torch.as_tensor(t_rel, dtype=torch.float32).to(dev).reshape(-1, 16).contiguous()
     N = t.shape[0]
     out = torch.empty(N + 1, 16, dtype=torch.float64, device=dev)
-    L.pose_chain(t, N, None if g0 is None else np.asarray(g0, dtype=np.float64).reshape(16), out)
+    if isinstance(g0, torch.Tensor) and g0.is_cuda:      # continue a chain from a pose already on the device
+        L.pose_chain_from(t, N, g0.to(torch.float64).reshape(16).contiguous(), out)
+    else:
+        L.pose_chain(t, N, None if g0 is None else np.asarray(g0, dtype=np.float64).reshape(16), out)
     return out.view(N + 1, 4, 4)
 
 

@@ -45,8 +45,13 @@ def gather_relative_poses(t_local: torch.Tensor, counts: Sequence[int], group=No
     Ranks own different pair counts (rank 0 has one fewer), so blocks are padded to the maximum."""
     import torch.distributed as dist
     if not dist.is_initialized():
+        if len(counts) > 1:
+            raise RuntimeError(f"gather_relative_poses: {len(counts)} ranks but torch.distributed is not initialised "
+                               "(a sharded sequence cannot chain only its local poses)")
         return t_local
     world = dist.get_world_size(group)
+    if len(counts) != world or t_local.shape[0] != counts[dist.get_rank(group)]:
+        raise ValueError(f"gather_relative_poses: counts {list(counts)} do not match world {world} / local pairs {t_local.shape[0]}")
     pmax = max(counts)
     buf = torch.zeros(pmax, 16, dtype=torch.float32, device=t_local.device)
     buf[: t_local.shape[0]] = t_local
@@ -72,21 +77,25 @@ class BodySlamPipeline:
                  zoe_cfg: Optional[ZoeConfig] = None, dtype=torch.float16, device: int = 0, batch: int = 8,
                  K: Sequence[float] = geom3d.REF_INTRINSICS, depth_scale: float = geom3d.REF_DEPTH_SCALE,
                  depth_trunc: float = geom3d.REF_DEPTH_TRUNC, flip_aug: bool = True,
-                 target_hw: Tuple[int, int] = (384, 512), precision: str = "accurate"):
+                 target_hw: Tuple[int, int] = (384, 512), precision: str = "accurate", pad_ragged: bool = True):
         """precision: ZoeDepthEngine's -- "accurate" keeps depth within 1e-4 m (L1) of the fp32 reference, "fast" is one
-        16-bit MFMA pass per product (L1 ~3e-4 m at fp16)."""
+        16-bit MFMA pass per product (L1 ~3e-4 m at fp16).  pad_ragged: run a ragged last batch of a block through the
+        full-size plan instead of building a second plan for its size."""
         L.init(device)
         self.dev = torch.device("cuda", device)
         self.batch = batch
+        self.pad_ragged = pad_ragged
         self.K, self.depth_scale, self.depth_trunc, self.flip = tuple(K), depth_scale, depth_trunc, flip_aug
         self.zoe = ZoeDepthEngine(zoe_weights, zoe_cfg, dtype=dtype, device=device, target_hw=target_hw, precision=precision)
         self.precision = precision
         self.pose = CyclePoseEngine(pose_weights, dtype=dtype, device=device)
 
     # -- stage 1+2 for one block of frames ----------------------------------------------------------
-    def depth_and_pose_block(self, frames: torch.Tensor, start: int, end: int, keep_depth_m: bool = False):
-        """frames: the FULL sequence as a uint8 tensor [N,H,W,3] (CPU pinned or GPU); processes [start,end)."""
-        N, H, W, _ = frames.shape
+    def depth_and_pose_block(self, frames: torch.Tensor, start: int, end: int, keep_depth_m: bool = False, frame_offset: int = 0):
+        """frames: the sequence as a uint8 tensor [N,H,W,3] (CPU pinned or GPU); processes the frames [start,end) (global
+        indices).  frame_offset: global index of frames[0] -- a rank may hold only its block and the one-frame halo."""
+        _, H, W, _ = frames.shape
+        assert frame_offset <= max(start - 1, 0) and end - frame_offset <= frames.shape[0], (frame_offset, start, end, frames.shape[0])
         n_local = end - start
         depth = torch.empty(n_local, H, W, dtype=torch.int16, device=self.dev)
         depth_m = torch.empty(n_local, H, W, dtype=torch.float32, device=self.dev) if keep_depth_m else None
@@ -96,8 +105,18 @@ class BodySlamPipeline:
         for b0 in range(start, end, self.batch):
             b1 = min(b0 + self.batch, end)
             h0 = max(b0 - 1, 0)                                     # one-frame halo for the first pair of the batch
-            chunk = frames[h0:b1].to(self.dev, non_blocking=True)
-            dm, du = self.zoe.infer(chunk[b0 - h0:], flip_aug=self.flip)
+            chunk = frames[h0 - frame_offset: b1 - frame_offset].to(self.dev, non_blocking=True)
+            nb = b1 - b0
+            if self.pad_ragged and nb < self.batch and end - start > self.batch:
+                # a ragged last batch runs through the full-size plan (its buffers exist already; a second plan of nearly the
+                # same size would cost its own tens of GB): the missing frames repeat the last one and their outputs are
+                # dropped.  Results do not depend on the batch (per-image routing; tests/test_fullsize_properties_gpu.py).
+                fr = chunk[b0 - h0:]
+                fr = torch.cat([fr, fr[-1:].expand(self.batch - nb, -1, -1, -1)], 0)
+                dm, du = self.zoe.infer(fr, flip_aug=self.flip)
+                dm, du = dm[:nb], du[:nb]
+            else:
+                dm, du = self.zoe.infer(chunk[b0 - h0:], flip_aug=self.flip)
             depth[b0 - start: b1 - start].copy_(du)
             if keep_depth_m:
                 depth_m[b0 - start: b1 - start].copy_(dm)
@@ -110,14 +129,28 @@ class BodySlamPipeline:
         return depth, depth_m, t_rel
 
     def run_sequence(self, frames, rank: int = 0, world: int = 1, group=None, keep_points: bool = False,
-                     keep_depth_m: bool = False, on_points: Optional[Callable] = None) -> SequenceResult:
+                     keep_depth_m: bool = False, on_points: Optional[Callable] = None,
+                     gather: Optional[Callable] = None, frame_offset: int = 0, n_frames: Optional[int] = None) -> SequenceResult:
+        """``gather(t_local, counts) -> t_all`` replaces the RCCL all-gather (tests emulate several ranks on one GPU with
+        it); by default the relatives go through ``gather_relative_poses`` on ``group``.  A rank that holds only its block
+        (+ the halo frame) passes it with ``frame_offset`` = global index of frames[0] and ``n_frames`` = sequence length."""
         frames = torch.as_tensor(frames)
         assert frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[-1] == 3
-        N = frames.shape[0]
+        N = frames.shape[0] if n_frames is None else n_frames
         start, end = shard_bounds(N, world, rank)
-        depth, depth_m, t_local = self.depth_and_pose_block(frames, start, end, keep_depth_m)
+        depth, depth_m, t_local = self.depth_and_pose_block(frames, start, end, keep_depth_m, frame_offset)
         counts = [local_pairs(*shard_bounds(N, world, r)).shape[0] for r in range(world)]
-        t_all = gather_relative_poses(t_local, counts, group) if world > 1 else t_local
+        if gather is not None:
+            t_all = gather(t_local, counts)
+        else:
+            t_all = gather_relative_poses(t_local, counts, group) if world > 1 else t_local
+        return self.chain_and_backproject(N, start, end, depth, depth_m, t_all, keep_points, on_points)
+
+    def chain_and_backproject(self, N: int, start: int, end: int, depth: torch.Tensor, depth_m: Optional[torch.Tensor],
+                              t_all: torch.Tensor, keep_points: bool = False, on_points: Optional[Callable] = None) -> SequenceResult:
+        """Stage 3 of a rank: the replicated fp64 chain over the gathered relatives, then the rank's own back-projection."""
+        if t_all.shape[0] != max(N - 1, 0):
+            raise ValueError(f"chain needs the {max(N - 1, 0)} relatives of the whole sequence, got {t_all.shape[0]}")
         g_abs = geom3d.pose_chain(t_all, device=self.dev.index or 0)          # [N,4,4] fp64, replicated
         n_local = end - start
         cnt_all = torch.empty(n_local, dtype=torch.int32, device=self.dev)

@@ -12,7 +12,8 @@ Data layout in HBM (B frames, flip-aug doubles the image batch: NB = 2B):
   residual stream      fp32 [NB*S, hidden]            S = 1 + hp*wp tokens (cls first)
   GEMM operands        fp16/bf16, K-major weights [N, K]; conv weights [O][I/64][kh][kw][64]
   Q, K / V^T           [NB, heads, Sp, 64] / [NB, heads, 64, Sp], Sp = S rounded up to 64, zero padded
-  rel-pos bias         fp32 [layers][heads, Sp, Sp], -1e30 in padded key columns (built once per window)
+  rel-pos bias         fp32 [layers][heads, (2hp-1)(2wp-1)+3] table per window (wp = 32: gathered in LDS by bs_attention_table;
+                       other windows: materialised [heads, Sp, Sp] with -1e30 in padded key columns)
   conv activations     NHWC 16-bit
   bins / attractors    fp32 NHWC, both heads side by side ([nyu 64 | kitti 64], [16 | 16])
   precision="accurate" every GEMM / conv operand is a pair: activations [rows, 2C] = (hi16 | hi8 | lo8) (or (hi | lo) 16-bit
@@ -82,6 +83,11 @@ class ZoeConfig:
         return self.level_attractors[level] if self.single_head else self.n_attractors
 
 
+# Backbone GEMM classes that stay single-pass in accurate mode.  The fused QKV projection feeds only Q, K and V, which are
+# 16-bit operands of the attention anyway: rounding its input (the LayerNorm output) perturbs them by no more than their own
+# storage rounding does (measured: tools/probes/precision_classes.py, DESIGN.md Numerics).
+ACCURATE_SINGLE_PASS: Tuple[str, ...] = ()
+
 ZOED_NK = ZoeConfig()
 ZOED_N = ZoeConfig(head_names=("nyu",))
 ZOED_K = ZoeConfig(head_names=("kitti",))
@@ -130,11 +136,14 @@ class ZoeDepthEngine:
     """
 
     def __init__(self, weights: Dict[str, torch.Tensor], cfg: Optional[ZoeConfig] = None, dtype=torch.float16,
-                 device: int = 0, target_hw: Tuple[int, int] = (384, 512), precision: str = "fast"):
+                 device: int = 0, target_hw: Tuple[int, int] = (384, 512), precision: str = "fast",
+                 single_pass: Optional[Tuple[str, ...]] = None):
         """precision: "fast" = one MFMA pass per product (16-bit operands, fp32 accumulate);
         "accurate" = split-precision products (Numerics): every GEMM / conv operand of the backbone, the DPT neck,
         the relative head and the projector path of the bins head is a (hi, lo) pair of 16-bit values; one launch evaluates
-        A_hi W_hi + A_lo W_hi + A_hi W_lo (3 MFMA passes).  Attention (Q, K, V, P) and the small bins-head MLPs stay single."""
+        A_hi W_hi + A_lo W_hi + A_hi W_lo (3 MFMA passes).  Attention (Q, K, V, P) and the small bins-head MLPs stay single.
+        single_pass: backbone GEMM classes ("qkv", "o", "fc1", "fc2") that run as ONE 16-bit pass even in accurate mode
+        (default: ACCURATE_SINGLE_PASS -- the classes whose rounding noise the depth map does not see, DESIGN.md Numerics)."""
         L.init(device)
         assert precision in ("fast", "accurate")
         self.acc = precision == "accurate"
@@ -148,6 +157,8 @@ class ZoeDepthEngine:
         self._plans: Dict[Tuple, "_ZoePlan"] = {}
         self._raw_tables = []
         self.f8s: Dict[str, Tuple[int, int]] = {}
+        self.single_pass = tuple(ACCURATE_SINGLE_PASS if single_pass is None else single_pass) if self.acc else ()
+        self.single_keys = set()
         c_ = self.cfg
         # the neck switches to the (hi16 | hi8 | lo8) operand format as a whole: every K / Cin on it must be whole 128-byte FP8 stages
         self.neck_f8 = self.acc and all(v % 128 == 0 for v in (c_.hidden, c_.fusion, c_.fusion // 2, *c_.neck_hidden))
@@ -176,6 +187,9 @@ class ZoeDepthEngine:
         """backbone GEMM weight [N, K]; accurate: rows of [W_hi16 | W_lo8 | W_hi8] bytes (bs_gemm's FP8 correction segment);
         the two plane scales go to self.f8s[key]."""
         if not self.acc:
+            return self._h(t)
+        if key.split(".")[-2] in self.single_pass and key[0] == "l":      # "l7.qkv.w" -> class "qkv"
+            self.single_keys.add(key)
             return self._h(t)
         if t.shape[1] % 128 != 0:        # the FP8 segment walks whole 128-byte stages per plane: fall back to three 16-bit passes
             return self._wn(t)
@@ -372,6 +386,24 @@ class ZoeDepthEngine:
         self._bias_cache[key] = out
         return out
 
+    def _rel_table(self, hp: int, wp: int):
+        """[layers] x fp32 [heads, (2hp-1)(2wp-1)+3]: the bias table re-interpolated for an (hp, wp) window (HF modeling_beit.py:
+        220-245), times log2(e) -- the operand of bs_attention_table (no [heads, Sp, Sp] tensor is materialised)."""
+        key = ("tab", hp, wp)
+        if key in self._bias_cache:
+            return self._bias_cache[key]
+        c = self.cfg
+        old = 2 * (c.image_size // c.patch) - 1
+        nh_, nw_ = 2 * hp - 1, 2 * wp - 1
+        out = []
+        for tab in self._raw_tables:
+            sub = tab[: old * old].reshape(1, old, old, -1).permute(0, 3, 1, 2)
+            new = F.interpolate(sub, size=(nh_, nw_), mode="bilinear").permute(0, 2, 3, 1).reshape(nh_ * nw_, -1)
+            full = torch.cat([new, tab[old * old:]])                    # [ntab, heads]
+            out.append((full.t() * LOG2E).contiguous().to(self.dev))
+        self._bias_cache[key] = out
+        return out
+
     def plan_for(self, B: int, H: int, W: int, flip: bool = True) -> "_ZoePlan":
         key = (B, H, W, flip)
         if key not in self._plans:
@@ -406,12 +438,13 @@ class _ZoePlan:
         Sp = (S + 63) // 64 * 64
         Hd = c.hidden
         self.geom = dict(B=B, NB=NB, H=H, W=W, nh=nh_, nw=nw_, hp=hp, wp=wp, S=S, Sp=Sp)
-        P = L.Plan()
+        P = L.Plan(dev)
         self.plan = P
         e16 = lambda *s: torch.empty(*s, device=dev, dtype=dt_)
         z16 = lambda *s: torch.zeros(*s, device=dev, dtype=dt_)
         e32 = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
-        bias = eng._rel_bias(hp, wp, Sp)
+        use_tab = wp == 32 and hp <= 40         # every 512-wide network input: bias from the per-head table held in LDS
+        bias = eng._rel_table(hp, wp) if use_tab else eng._rel_bias(hp, wp, Sp)
 
         acc = eng.acc
         m2 = 2 if acc else 1          # channel multiplier of (hi | lo) activations
@@ -428,18 +461,27 @@ class _ZoePlan:
 
         f8s = eng.f8s
 
+        single = eng.single_keys
+
         def fmt(*wkeys):
             """producer format flag of an activation: 32 = (hi16 | hi8 | lo8) when every consumer GEMM runs its corrections on
-            the FP8 MFMA, 16 = (hi | lo) 16-bit pairs otherwise (accurate mode), 0 = single (fast mode)."""
-            if not acc:
+            the FP8 MFMA, 16 = (hi | lo) 16-bit pairs otherwise (accurate mode), 0 = single (fast mode, or every consumer is a
+            single-pass GEMM)."""
+            if not acc or all(k_ in single for k_ in wkeys):
                 return 0
             return 32 if all(k_ in f8s for k_ in wkeys) else 16
+
+        def am(wkey):
+            """row multiplier of the activation a backbone GEMM reads: 1 = single rows, 2 = pair rows"""
+            return 2 if fmt(wkey) else 1
 
         def bgemm(name, A, wkey, out, M, N, K, **kw):
             """backbone GEMM.  Accurate mode: A_hi W_hi + A_hi W_lo + A_lo W_hi in one launch -- the two corrections on the
             block-scaled FP8 MFMA where the weight was packed for it (A = [hi16 | hi8 | lo8], 2 pass-equivalents), else as
             K segments of 16-bit (hi | lo) pairs (3 passes)."""
-            if acc and wkey in f8s:
+            if acc and wkey in single:
+                P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=K, precision_passes=1, **kw)
+            elif acc and wkey in f8s:
                 sb0, sb1 = f8s[wkey]
                 P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=2 * K, f8_seg=2 * K,
                        f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1), precision_passes=1, **kw)
@@ -457,15 +499,19 @@ class _ZoePlan:
         for l in range(c.layers):
             P.add(f"l{l}.ln1", "bs_layernorm", x, w[f"l{l}.ln1.g"], w[f"l{l}.ln1.b"], xn, None, NB * S, Hd, c.ln_eps,
                   L.dt(xn) | fmt(f"l{l}.qkv.w"))
-            bgemm(f"l{l}.qkv", xn, f"l{l}.qkv.w", q, NB * S, 3 * Hd, Hd, bias=w[f"l{l}.qkv.b"], qkv=(Hd, S, Sp, LOG2E / math.sqrt(64.0), k, vt))
-            P.add(f"l{l}.attn", "bs_attention", q, k, vt, bias[l], ao, NB, c.heads, S, Sp, L.dt(q) | fmt(f"l{l}.o.w"))
+            bgemm(f"l{l}.qkv", xn, f"l{l}.qkv.w", q, NB * S, 3 * Hd, Hd, bias=w[f"l{l}.qkv.b"],
+                  qkv=(Hd, S, Sp, LOG2E / math.sqrt(64.0), k, vt, use_tab))
+            if use_tab:
+                P.add(f"l{l}.attn", "bs_attention_table", q, k, vt, bias[l], ao, NB, c.heads, hp, wp, Sp, L.dt(q) | fmt(f"l{l}.o.w"))
+            else:
+                P.add(f"l{l}.attn", "bs_attention", q, k, vt, bias[l], ao, NB, c.heads, S, Sp, L.dt(q) | fmt(f"l{l}.o.w"))
             bgemm(f"l{l}.o", ao, f"l{l}.o.w", x, NB * S, Hd, Hd, bias=w[f"l{l}.o.b"], scale=w[f"l{l}.lam1"], res=x, ldr=Hd)
             P.add(f"l{l}.ln2", "bs_layernorm", x, w[f"l{l}.ln2.g"], w[f"l{l}.ln2.b"], xn, None, NB * S, Hd, c.ln_eps,
                   L.dt(xn) | fmt(f"l{l}.fc1.w"))
-            hid8 = fmt(f"l{l}.fc2.w") == 32
+            hfmt = fmt(f"l{l}.fc2.w")
             bgemm(f"l{l}.fc1", xn, f"l{l}.fc1.w", hid, NB * S, c.intermediate, Hd, bias=w[f"l{l}.fc1.b"], act=L.ACT_GELU,
-                  ldo=c.intermediate * m2, out_split_off=c.intermediate if acc else 0,
-                  out_f8=(L.F8_ACT_HI_EXP, L.F8_ACT_LO_EXP) if hid8 else None)
+                  ldo=c.intermediate * am(f"l{l}.fc2.w"), out_split_off=c.intermediate if hfmt else 0,
+                  out_f8=(L.F8_ACT_HI_EXP, L.F8_ACT_LO_EXP) if hfmt == 32 else None)
             bgemm(f"l{l}.fc2", hid, f"l{l}.fc2.w", x, NB * S, Hd, c.intermediate, bias=w[f"l{l}.fc2.b"], scale=w[f"l{l}.lam2"], res=x, ldr=Hd)
             P.mark(f"layer{l + 1}", x, ("tokens", NB, S, Hd))
             if (l + 1) in c.taps:

@@ -114,6 +114,8 @@ typedef struct bs_gemm_desc {
     uint32_t f8_scales;
     int32_t out_f8;
     int32_t res_f8;                /* != 0: res / res2 are rows in that format too (N channels, ldr >= 2N) */
+    int32_t qkv_cls_last;          /* BS_OUT_QKV: token 0 of an image (cls) is stored at position tokens-1 of Q / K / V^T and token t
+                                    * at position t-1 (patches first: the layout bs_attention_table reads) */
 } bs_gemm_desc;
 int bs_gemm(const bs_gemm_desc* d, void* stream);
 /* the tile variant bs_gemm will pick for this descriptor (1: 128x128, 2: 128x64, 3: 128x32, 4: 256x128) */
@@ -128,6 +130,13 @@ int bs_gemm_tile(const bs_gemm_desc* d);
  * dtype | 16: out holds (hi | lo) pairs, [B*S, 2*nh*64]; dtype | 32: (hi16 | hi8 | lo8) rows of the same size. */
 int bs_attention(const void* q, const void* k, const void* vt, const float* bias, void* out,
                  int32_t B, int32_t nh, int32_t S, int32_t Sp, int32_t dtype, void* stream);
+/* The same attention for a window of hp x wp patches + cls with the bias taken from the per-head TABLE instead of a
+ * materialised [nh,Sp,Sp] tensor: table fp32 [nh, (2hp-1)(2wp-1)+3] in HF's layout (modeling_beit.py:194-218: entry
+ * (dy+hp-1)*(2wp-1) + (dx+wp-1) for patch pairs, then cls->patch, patch->cls, cls->cls), pre-multiplied by log2(e).
+ * q / k / vt hold the tokens of an image patches first, cls LAST (S = hp*wp + 1; bs_gemm_desc.qkv_cls_last); out rows are in
+ * the usual order (cls first).  Built for wp == 32 (every 512-wide network input). */
+int bs_attention_table(const void* q, const void* k, const void* vt, const float* table, void* out,
+                       int32_t B, int32_t nh, int32_t hp, int32_t wp, int32_t Sp, int32_t dtype, void* stream);
 
 /* LayerNorm over the last dim, fp32 in; out16 (fp16/bf16, nullable) and out32 (fp32, nullable, may
  * alias x) -- HF modeling_beit.py:418,432; post-norm of the router HF modeling_zoedepth.py:876-881
@@ -247,8 +256,13 @@ int bs_backproject(const uint16_t* depth, int32_t B, int32_t H, int32_t W, const
 int bs_pixel_to_3d(const double* uvd, int64_t n, const double* K_host, double* out, void* stream);
 /* 3DM/slam_utils.py:110-122 compute_curr_estimate_global_pose chained over N relatives (fp32 [N,16]) from
  * g0 (fp64 [16], host, nullable = identity) -> g_abs fp64 [N+1,16]; per-step SO(3) projection
- * (slam_utils.py:93-108).  Sequential by construction: one wavefront. */
+ * (slam_utils.py:93-108).  With G_{i-1} a rotation, proj(G_{i-1}.R R_i) = G_{i-1}.R proj(R_i): every relative pose is
+ * projected independently (one lane per pose), then the chain is a wave-shuffle prefix product over SE(3); matrices whose
+ * bottom row is not [0 0 0 1] take the strict one-lane recurrence. */
 int bs_pose_chain(const float* t_rel, int32_t N, const double* g0_host, double* g_abs, void* stream);
+/* the same with g0 on the DEVICE (fp64 [16]; it may be the last pose of a previous call's g_abs: a sequence processed in
+ * steps continues its chain without a host round trip -- 3DM/slam.py:148-153 keeps current_global_extrinsic_matrix) */
+int bs_pose_chain_from(const float* t_rel, int32_t N, const double* g0_dev, double* g_abs, void* stream);
 
 #ifdef __cplusplus
 }

@@ -155,6 +155,44 @@ def test_gemm_tail_split(L, dtype, M, N, K):
     assert err < 1e-4 * math.sqrt(K)
 
 
+@pytest.mark.parametrize("f8", [False, True])
+@pytest.mark.parametrize("M,N,K", [(256 * 128 + 128, 1024, 4096), (256 * 64 + 1, 2048, 2048)])
+def test_gemm_tail_split_taken(L, f8, M, N, K):
+    """The two-launch tail split as the bench batch runs it (o_proj / fc2 at NB = 128: K >= 2048 on the 256x256 tile, the ragged
+    rows on a side stream with an event fork / join), plain and with the FP8 correction segment, residual updated in place.
+    Proof that the split was taken: the same descriptor with the split switched off (ablate bit 8, one launch) must give the
+    same bits, and both must match the fp32 reference."""
+    dtype = torch.float16
+    A = rnd(M, K, seed=1)
+    W = rnd(N, K, seed=2, scale=1 / math.sqrt(K))
+    bias = rnd(N, seed=3)
+    res = rnd(M, N, seed=4)
+    ref = (A.double() @ W.double().t() + bias.double() + res.double())
+    if f8:
+        w8, (sb0, sb1) = L.f8_weight(W, dtype)
+        w8 = w8.to(dev())
+        A8 = torch.empty(M, 2 * K, device=dev(), dtype=dtype)
+        L.cast_split(A, A8, M, K, f8=True)
+        kw = dict(M=M, N=N, K=K, lda=2 * K, f8_seg=2 * K, f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1))
+        a_, w_ = A8, w8
+    else:
+        kw = dict(M=M, N=N, K=K, lda=K)
+        a_, w_ = A.to(dtype), W.to(dtype)
+        ref = a_.double() @ w_.double().t() + bias.double() + res.double()
+    assert L.load_library().bs_gemm_tile(L.C.byref(L.make_gemm_desc(a_, w_, res, **kw))) == 9
+    out = res.clone()
+    L.gemm(a_, w_, out, bias=bias, res=out, ldr=N, **kw)
+    out1 = res.clone()
+    L.gemm(a_, w_, out1, bias=bias, res=out1, ldr=N, tile=809, **kw)       # tile 9, ablate bit 8: no tail split
+    torch.cuda.synchronize()
+    err = (out.double() - ref).abs().max().item()
+    report(f"gemm tail split taken f8={f8} M{M} N{N} K{K}: max|err|={err:.3e}, split vs single launch identical: {torch.equal(out, out1)}")
+    # the ragged rows run on the 128x128 tile in the split and on the 256x256 tile otherwise: same K order, same products -> same bits
+    assert torch.equal(out[: M // 256 * 256], out1[: M // 256 * 256])
+    assert (out[M // 256 * 256:] - out1[M // 256 * 256:]).abs().max().item() < 1e-4
+    assert err < (2e-4 if f8 else 1e-4 * math.sqrt(K))      # split-precision: ~16 bits per operand; single-pass fp16 would be ~1e-3
+
+
 @pytest.mark.parametrize("tile", [1, 9, 10, 2])
 def test_split_precision_plain(L, tile):
     """A = [hi | lo], W' = [W_hi | W_hi | W_lo]: one launch evaluates A_hi W_hi + A_lo W_hi + A_hi W_lo (segments),
@@ -363,6 +401,60 @@ def test_qkv_scatter_and_attention(L, dtype, B, S, nh):
     ref = (a @ vf).permute(0, 2, 1, 3).reshape(B * S, hidden)
     err = (out.float() - ref).abs().max().item()
     report(f"attention {dtype} B{B} S{S} nh{nh}: max|err|={err:.3e} (ref max {ref.abs().max().item():.2f})")
+    assert err < (4e-3 if dtype == torch.float16 else 3e-2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,hp,nh,split", [(2, 24, 16, 0), (1, 26, 4, 0), (3, 3, 2, 0), (2, 24, 2, 16), (2, 24, 2, 32)])
+def test_attention_table(L, dtype, B, hp, nh, split):
+    """bs_attention_table (bias gathered from the per-head table in LDS; Q / K / V^T patches first, cls last) against torch
+    softmax attention with HF's gathered [S, S] bias (modeling_beit.py:194-265), for the 24x32 and 26x32 windows of the
+    full-size networks and a 3-row toy window; also the pair output formats of accurate mode."""
+    from bodyslam_amd.zoedepth import _relative_position_index
+    wp = 32
+    S = hp * wp + 1
+    Sp = (S + 63) // 64 * 64
+    hidden = nh * 64
+    ntab = (2 * hp - 1) * (2 * wp - 1) + 3
+    LOG2E = 1.4426950408889634
+    x = rnd(B * S, hidden, seed=1, dtype=dtype)
+    wqkv = rnd(3 * hidden, hidden, seed=2, scale=1 / math.sqrt(hidden), dtype=dtype)
+    bqkv = rnd(3 * hidden, seed=3, scale=0.1)
+    q = torch.zeros(B, nh, Sp, 64, device=dev(), dtype=dtype)
+    k = torch.zeros(B, nh, Sp, 64, device=dev(), dtype=dtype)
+    vt = torch.zeros(B, nh, 64, Sp, device=dev(), dtype=dtype)
+    L.gemm(x, wqkv, q, M=B * S, N=3 * hidden, K=hidden, lda=hidden, bias=bqkv, qkv=(hidden, S, Sp, 0.125 * LOG2E, k, vt, True))
+    # the scatter put token t at position t-1 and the cls token last
+    y = (x.float() @ wqkv.float().t() + bqkv).view(B, S, 3, nh, 64)
+    perm = torch.cat([torch.arange(1, S), torch.zeros(1, dtype=torch.long)]).to(dev())
+    kr = y[:, :, 1].permute(0, 2, 1, 3)[:, :, perm]
+    assert (k[:, :, :S].float() - kr).abs().max().item() < tol(dtype, hidden) * 4
+    vr = y[:, :, 2].permute(0, 2, 1, 3)[:, :, perm]
+    assert (vt[:, :, :, :S].float() - vr.transpose(2, 3)).abs().max().item() < tol(dtype, hidden) * 4
+    table = rnd(nh, ntab, seed=4)                                   # natural-log domain
+    tab2 = (table * LOG2E).contiguous()
+    mult = 2 if split else 1
+    out = torch.zeros(B * S, hidden * mult, device=dev(), dtype=dtype)
+    L.attention_table(q, k, vt, tab2, out, B, nh, hp, wp, Sp, split=split)
+    idx = _relative_position_index(hp, wp).to(dev())
+    bias = table[:, idx.view(-1)].view(nh, S, S)                    # [nh, q, k] in token order (cls first)
+    inv = torch.empty(S, dtype=torch.long, device=dev())
+    inv[perm] = torch.arange(S, device=dev())                       # token -> position
+    qf = q[:, :, :S].float()[:, :, inv] / LOG2E
+    kf, vf = k[:, :, :S].float()[:, :, inv], vt[:, :, :, :S].float().transpose(2, 3)[:, :, inv]
+    a = torch.softmax(qf @ kf.transpose(2, 3) + bias[None], dim=-1)
+    ref = (a @ vf).permute(0, 2, 1, 3).reshape(B * S, hidden)
+    if split == 16:
+        got = out[:, :hidden].float() + out[:, hidden:].float()
+    elif split == 32:
+        planes = out[:, hidden:].contiguous().view(torch.uint8).view(B * S, 2 * hidden)
+        got = out[:, :hidden].float() + planes[:, hidden:].contiguous().view(torch.float8_e4m3fn).float() * 2.0 ** -L.F8_ACT_LO_EXP
+        hi8 = planes[:, :hidden].contiguous().view(torch.float8_e4m3fn).float() * 2.0 ** -L.F8_ACT_HI_EXP
+        assert (hi8 - ref).abs().max().item() < 0.07 * ref.abs().max().item() + 1e-2
+    else:
+        got = out.float()
+    err = (got - ref).abs().max().item()
+    report(f"attention_table {dtype} B{B} hp{hp} nh{nh} split{split}: max|err|={err:.3e} (ref max {ref.abs().max().item():.2f})")
     assert err < (4e-3 if dtype == torch.float16 else 3e-2)
 
 
