@@ -44,7 +44,7 @@ class GemmDesc(C.Structure):
         ("qkv_hidden", C.c_int32), ("qkv_tokens", C.c_int32), ("qkv_sp", C.c_int32), ("q_scale", C.c_float),
         ("tile", C.c_int32), ("seg1", C.c_int32), ("out_split_off", C.c_int32), ("res_split_off", C.c_int32),
         ("f8_seg", C.c_int32), ("f8_scales", C.c_uint32), ("out_f8", C.c_int32), ("res_f8", C.c_int32),
-        ("qkv_cls_last", C.c_int32),
+        ("qkv_cls_last", C.c_int32), ("qkv_cls_rows", C.c_int32), ("f8_wonly_from", C.c_int32),
     ]
 
 
@@ -56,7 +56,7 @@ _SIGS = {
     "bs_gemm": [C.POINTER(GemmDesc), C.c_void_p],
     "bs_gemm_tile": [C.POINTER(GemmDesc)],
     "bs_attention": [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p],
-    "bs_attention_table": [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p],
+    "bs_attention_table": [C.c_void_p] * 5 + [C.c_int32] * 7 + [C.c_void_p],
     "bs_layernorm": [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p],
     "bs_cast": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p],
     "bs_copy_f32": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
@@ -147,10 +147,11 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
                    act: int = ACT_NONE, scale: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
                    res2: Optional[torch.Tensor] = None, ldr: int = 0, ldo: Optional[int] = None, out_group=None,
                    shuffle=None, qkv=None, a_offset: int = 0, tile: int = 0, seg1: int = 0, out_split_off: int = 0,
-                   res_split_off: int = 0, f8_seg: int = 0, f8_scales=(127, 127, 127, 127), out_f8=None, res_f8: bool = False) -> GemmDesc:
+                   res_split_off: int = 0, f8_seg: int = 0, f8_scales=(127, 127, 127, 127), out_f8=None, res_f8: bool = False,
+                   f8_wonly_from: int = 0) -> GemmDesc:
     """Fill a bs_gemm_desc.  conv = (Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_h, pad_w) or None;
     out_group = (rows, stride, offset); shuffle = (s, Cout, Hgrid, Wgrid);
-    qkv = (hidden, tokens, Sp, q_scale, out_k, out_vt[, cls_last]); a_offset in elements."""
+    qkv = (hidden, tokens, Sp, q_scale, out_k, out_vt[, cls_last[, cls_rows]]); a_offset in elements."""
     d = GemmDesc()
     d.A = A.data_ptr() + a_offset * A.element_size()
     d.W = W.data_ptr()
@@ -188,6 +189,7 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
         d.out_mode = OUT_QKV
         hidden, tokens, sp, q_scale, out_k, out_vt = qkv[:6]
         d.qkv_cls_last = int(bool(qkv[6])) if len(qkv) > 6 else 0
+        d.qkv_cls_rows = int(qkv[7]) if len(qkv) > 7 else 0
         d.qkv_hidden, d.qkv_tokens, d.qkv_sp, d.q_scale = hidden, tokens, sp, q_scale
         d.out2 = out_k.data_ptr()
         d.out3 = out_vt.data_ptr()
@@ -197,6 +199,7 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
     d.f8_scales = f8_scales[0] | (f8_scales[1] << 8) | (f8_scales[2] << 16) | (f8_scales[3] << 24)
     d.out_f8 = 0 if out_f8 is None else ((out_f8[0] & 0xff) | ((out_f8[1] & 0xff) << 8))
     d.res_f8 = int(res_f8)
+    d.f8_wonly_from = f8_wonly_from
     return d
 
 
@@ -268,7 +271,8 @@ class Plan:
         self.gemm_info[len(self.calls) - 1] = dict(
             name=name, tile=load_library().bs_gemm_tile(C.byref(d)), conv=bool(d.conv),
             # executed work in 16-bit-MFMA-equivalents: an FP8 correction stage covers 128 k in the time of 64
-            flops=2.0 * d.M * d.N * (d.K + (d.KH * d.KW if d.conv else 1) * d.f8_seg / 2),
+            # (tiles past f8_wonly_from run only the first FP8 half)
+            flops=2.0 * d.M * d.N * (d.K + (d.KH * d.KW if d.conv else 1) * d.f8_seg / (4 if d.f8_wonly_from else 2)),
             # algorithmic FLOPs exclude the extra passes of a split-precision product
             alg_flops=2.0 * d.M * d.N * (d.K / kw.get("precision_passes", 1)),
             bytes=float(d.M) * (d.Cin if d.conv else d.K) * 2 + float(d.N) * d.K * 2 + float(d.M) * d.N * (4 if d.out_dtype == F32 else 2))
@@ -335,11 +339,11 @@ class Plan:
                 check(fn(*args, st), self.names[i])
 
 
-def f8_weight(w: torch.Tensor, dtype) -> tuple:
+def f8_weight(w: torch.Tensor, dtype, planes: str = "both") -> tuple:
     """fp32 [N, K] -> ([N, 2K] `dtype`-typed rows of [W_hi16 | W_lo8 | W_hi8] bytes, (sb0, sb1)): the weight side of bs_gemm's
     FP8 correction segment.  W_hi8 = e4m3(W_hi * 2^e_hi), W_lo8 = e4m3((W - W_hi) * 2^e_lo) with per-matrix power-of-two
     scales that put the largest magnitude just under e4m3's 448; sb0 / sb1 are the E8M0 exponents bs_gemm applies to the
-    lo / hi plane (127 - e)."""
+    lo / hi plane (127 - e).  planes: "both" (default), "lo" = [W_hi16 | W_lo8] only, "hi_only" = the W_lo8 plane zeroed."""
     import math
     w = w.detach().float().cpu()
     hi = w.to(dtype)
@@ -352,7 +356,13 @@ def f8_weight(w: torch.Tensor, dtype) -> tuple:
 
     hi8, e_hi = plane(hi.float())
     lo8, e_lo = plane(lo)
-    row = torch.cat([hi.contiguous().view(torch.uint8).view(w.shape[0], -1), lo8, hi8], 1).contiguous()
+    hi16 = hi.contiguous().view(torch.uint8).view(w.shape[0], -1)
+    if planes == "lo":            # [W_hi16 | W_lo8]: the weight-rounding correction only (bs_gemm f8_seg = K)
+        row = torch.cat([hi16, lo8], 1).contiguous()
+    elif planes == "hi_only":     # probe: no weight-rounding correction (the W_lo8 plane is zero)
+        row = torch.cat([hi16, torch.zeros_like(lo8), hi8], 1).contiguous()
+    else:
+        row = torch.cat([hi16, lo8, hi8], 1).contiguous()
     return row.view(dtype), (127 - e_lo, 127 - e_hi)
 
 
@@ -399,8 +409,8 @@ def attention(q, k, vt, bias, out, B, nh, S, Sp):
     check(load_library().bs_attention(p(q), p(k), p(vt), p(bias), p(out), B, nh, S, Sp, dt(q), stream_ptr()), "bs_attention")
 
 
-def attention_table(q, k, vt, table, out, B, nh, hp, wp, Sp, split=0):
-    check(load_library().bs_attention_table(p(q), p(k), p(vt), p(table), p(out), B, nh, hp, wp, Sp, dt(q) | split, stream_ptr()),
+def attention_table(q, k, vt, table, out, B, nh, hp, wp, Sp, split=0, grouped=False):
+    check(load_library().bs_attention_table(p(q), p(k), p(vt), p(table), p(out), B, nh, hp, wp, Sp, int(grouped), dt(q) | split, stream_ptr()),
           "bs_attention_table")
 
 

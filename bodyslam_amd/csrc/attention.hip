@@ -231,7 +231,7 @@ __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict_
 template <typename T, int QW>
 __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ Vt,
                                                                  const float* __restrict__ table, T* __restrict__ out, int split, int B, int nh,
-                                                                 int hp, int Sp, int nqb, int ntab) {
+                                                                 int hp, int Sp, int nqb, int ntab, int grouped) {
     typedef typename T16<T>::v8 v8;
     constexpr int STAGE = 16 * 1024;  // K tile 8 KiB + V^T tile 8 KiB
     constexpr int WP = 32;
@@ -393,8 +393,10 @@ __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restr
     const float inv = 1.0f / l_tot;
     const int qpos = q0 + r;
     if (active && qpos < S) {
-        const int tok = qpos == S - 1 ? 0 : qpos + 1;        // back to the residual stream's order: cls first
-        T* orow = out + ((int64_t)b * S + tok) * (nh * 64) * (split ? 2 : 1) + head * 64;
+        // back to the residual stream's row order: cls first per image, or (grouped) the B cls rows first, then the patches
+        const int64_t row = grouped ? (qpos == S - 1 ? (int64_t)b : (int64_t)B + (int64_t)b * (S - 1) + qpos)
+                                    : (int64_t)b * S + (qpos == S - 1 ? 0 : qpos + 1);
+        T* orow = out + row * (nh * 64) * (split ? 2 : 1) + head * 64;
 #pragma unroll
         for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restr
 
 template <typename T>
 static int launch_attn_tab(const void* q, const void* k, const void* vt, const float* table, void* out, int split, int B, int nh, int hp, int Sp,
-                           hipStream_t st) {
+                           int grouped, hipStream_t st) {
     constexpr int QW = 5;
     const int nqt = hp + 1, nqb = cdiv(nqt, QW), ntab = (2 * hp - 1) * 63 + 3;
     const int smem = 32 * 1024 + ((ntab * 4 + 15) & ~15);
@@ -436,7 +438,7 @@ static int launch_attn_tab(const void* q, const void* k, const void* vt, const f
         attr = true;
     }
     hipLaunchKernelGGL(kern, dim3(B * nh * nqb), dim3(QW * 64), smem, st, (const T*)q, (const T*)k, (const T*)vt, table, (T*)out, split, B,
-                       nh, hp, Sp, nqb, ntab);
+                       nh, hp, Sp, nqb, ntab, grouped);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }
@@ -481,7 +483,7 @@ extern "C" int bs_attention(const void* q, const void* k, const void* vt, const 
 }
 
 extern "C" int bs_attention_table(const void* q, const void* k, const void* vt, const float* table, void* out, int32_t B, int32_t nh,
-                                  int32_t hp, int32_t wp, int32_t Sp, int32_t dtype, void* stream) {
+                                  int32_t hp, int32_t wp, int32_t Sp, int32_t grouped, int32_t dtype, void* stream) {
     using namespace bs;
     if (!initialized()) { set_error("bs_attention_table: call bs_init first"); return BS_ERR_NOT_INIT; }
     BS_REQUIRE(q && k && vt && table && out && B >= 0 && nh > 0 && hp > 0, "bs_attention_table: bad argument");
@@ -494,6 +496,6 @@ extern "C" int bs_attention_table(const void* q, const void* k, const void* vt, 
     BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_attention_table: dtype");
     if (B == 0) return BS_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    return dtype == BS_F16 ? launch_attn_tab<f16>(q, k, vt, table, out, split, B, nh, hp, Sp, st)
-                           : launch_attn_tab<bf16>(q, k, vt, table, out, split, B, nh, hp, Sp, st);
+    return dtype == BS_F16 ? launch_attn_tab<f16>(q, k, vt, table, out, split, B, nh, hp, Sp, grouped, st)
+                           : launch_attn_tab<bf16>(q, k, vt, table, out, split, B, nh, hp, Sp, grouped, st);
 }

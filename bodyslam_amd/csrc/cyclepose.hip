@@ -14,7 +14,8 @@ constexpr int CP_K = 320;  // 7*7*6 = 294 padded to a multiple of 64
 
 // one thread per (row m, tap): writes the 6 channels of that tap (12 bytes) -- consecutive threads
 // cover consecutive taps of one row, so a row's 640 bytes are written by 54 neighbouring lanes
-template <typename T>
+// SPLIT: a row is [hi x 320 | lo x 320], value = hi + lo to ~22 bits (the A operand of a split-precision GEMM, bs_gemm seg1)
+template <typename T, bool SPLIT>
 __global__ __launch_bounds__(256) void cp_im2col_kernel(const uint8_t* frames, const int32_t* pairs, T* out, int P, int H, int W,
                                                          int top, int left) {
     const int64_t total = (int64_t)P * CP_CROP * CP_CROP * 54;  // 49 taps + 5 pad slots (6 elems each -> 324 >= 320)
@@ -22,11 +23,14 @@ __global__ __launch_bounds__(256) void cp_im2col_kernel(const uint8_t* frames, c
     if (gid >= total) return;
     const int slot = (int)(gid % 54);
     const int64_t m = gid / 54;
-    T* row = out + m * CP_K;
+    T* row = out + m * (SPLIT ? 2 * CP_K : CP_K);
     if (slot >= 49) {
         // zero padding 294..319 (26 elements): slots 49..53 write 6,6,6,6,2
         const int k0 = 294 + (slot - 49) * 6;
-        for (int i = 0; i < 6 && k0 + i < CP_K; ++i) row[k0 + i] = T16<T>::from_f32(0.0f);
+        for (int i = 0; i < 6 && k0 + i < CP_K; ++i) {
+            row[k0 + i] = T16<T>::from_f32(0.0f);
+            if (SPLIT) row[CP_K + k0 + i] = T16<T>::from_f32(0.0f);
+        }
         return;
     }
     const int x = (int)(m % CP_CROP);
@@ -43,8 +47,13 @@ __global__ __launch_bounds__(256) void cp_im2col_kernel(const uint8_t* frames, c
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         // ToTensor (/255) then Normalize(0.5, 0.5), both in fp32 as torchvision does
-        o[c] = T16<T>::from_f32((__fdiv_rn((float)p0[c], 255.0f) - 0.5f) / 0.5f);
-        o[3 + c] = T16<T>::from_f32((__fdiv_rn((float)p1[c], 255.0f) - 0.5f) / 0.5f);
+        const float v0 = (__fdiv_rn((float)p0[c], 255.0f) - 0.5f) / 0.5f, v1 = (__fdiv_rn((float)p1[c], 255.0f) - 0.5f) / 0.5f;
+        o[c] = T16<T>::from_f32(v0);
+        o[3 + c] = T16<T>::from_f32(v1);
+        if (SPLIT) {
+            o[CP_K + c] = T16<T>::from_f32(v0 - T16<T>::to_f32(o[c]));
+            o[CP_K + 3 + c] = T16<T>::from_f32(v1 - T16<T>::to_f32(o[3 + c]));
+        }
     }
 }
 
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(256) void instnorm_stats_kernel(const float* x, flo
     }
 }
 
-template <typename T>
+template <typename T, bool SPLIT>
 __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* x, const float* part, T* out, float* out_f32, int HW, int C,
                                                               int nchunk, float eps) {
     const int p = blockIdx.y, ch = blockIdx.x;
@@ -125,13 +134,20 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* x, con
     for (int r = r0 + rg; r < r1; r += rps) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + base + (int64_t)r * C);
         f32x4 y;
-        typename T16<T>::v4 o;
+        typename T16<T>::v4 o, ol;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             y[e] = fmaxf((v[e] - mu[e]) * rs[e], 0.0f);
             o[e] = T16<T>::from_f32(y[e]);
+            ol[e] = T16<T>::from_f32(y[e] - T16<T>::to_f32(o[e]));
         }
-        *reinterpret_cast<typename T16<T>::v4*>(out + base + (int64_t)r * C) = o;
+        if (SPLIT) {     // pixel vector [hi x C | lo x C]
+            T* op = out + (((int64_t)p * HW + r) * 2) * C + c4;
+            *reinterpret_cast<typename T16<T>::v4*>(op) = o;
+            *reinterpret_cast<typename T16<T>::v4*>(op + C) = ol;
+        } else {
+            *reinterpret_cast<typename T16<T>::v4*>(out + base + (int64_t)r * C) = o;
+        }
         if (out_f32) *reinterpret_cast<f32x4*>(out_f32 + base + (int64_t)r * C) = y;
     }
 }
@@ -231,6 +247,8 @@ extern "C" int bs_cyclepose_im2col(const uint8_t* frames, const int32_t* pairs, 
     if (!initialized()) { set_error("bs_cyclepose_im2col: call bs_init first"); return BS_ERR_NOT_INIT; }
     BS_REQUIRE(frames && pairs && out && P >= 0, "bs_cyclepose_im2col: bad argument");
     BS_REQUIRE(H >= CP_CROP && W >= CP_CROP, "bs_cyclepose_im2col: frame %dx%d smaller than the 128 crop", W, H);
+    const bool split = (dtype & 16) != 0;      // bit 4: rows of (hi | lo) pairs, [P*128*128, 640]
+    dtype &= 15;
     BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_cyclepose_im2col: dtype");
     if (P == 0) return BS_OK;
     // torchvision CenterCrop: top = int(round((H - 128) / 2.0)) (Python banker's rounding of x.5)
@@ -239,10 +257,14 @@ extern "C" int bs_cyclepose_im2col(const uint8_t* frames, const int32_t* pairs, 
     const int64_t total = (int64_t)P * CP_CROP * CP_CROP * 54;
     const unsigned blocks = (unsigned)cdiv64(total, 256);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == BS_F16)
-        hipLaunchKernelGGL(cp_im2col_kernel<f16>, dim3(blocks), dim3(256), 0, st, frames, pairs, (f16*)out, P, H, W, top, left);
+    if (dtype == BS_F16 && split)
+        hipLaunchKernelGGL((cp_im2col_kernel<f16, true>), dim3(blocks), dim3(256), 0, st, frames, pairs, (f16*)out, P, H, W, top, left);
+    else if (dtype == BS_F16)
+        hipLaunchKernelGGL((cp_im2col_kernel<f16, false>), dim3(blocks), dim3(256), 0, st, frames, pairs, (f16*)out, P, H, W, top, left);
+    else if (split)
+        hipLaunchKernelGGL((cp_im2col_kernel<bf16, true>), dim3(blocks), dim3(256), 0, st, frames, pairs, (bf16*)out, P, H, W, top, left);
     else
-        hipLaunchKernelGGL(cp_im2col_kernel<bf16>, dim3(blocks), dim3(256), 0, st, frames, pairs, (bf16*)out, P, H, W, top, left);
+        hipLaunchKernelGGL((cp_im2col_kernel<bf16, false>), dim3(blocks), dim3(256), 0, st, frames, pairs, (bf16*)out, P, H, W, top, left);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }
@@ -253,6 +275,8 @@ extern "C" int bs_instnorm_relu_nhwc(const float* x, void* out, float* out_f32, 
     if (!initialized()) { set_error("bs_instnorm_relu_nhwc: call bs_init first"); return BS_ERR_NOT_INIT; }
     BS_REQUIRE(x && out && scratch && P >= 0 && HW > 0 && C % 4 == 0 && C >= 4 && C <= 256 && 256 % (C / 4) == 0,
                "bs_instnorm_relu_nhwc: bad argument (C must be 4..256 with C/4 dividing 256)");
+    const bool split = (dtype & 16) != 0;      // bit 4: pixel vectors of (hi | lo) pairs, [P, HW, 2C]
+    dtype &= 15;
     BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_instnorm_relu_nhwc: dtype");
     if (P == 0) return BS_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -260,10 +284,14 @@ extern "C" int bs_instnorm_relu_nhwc(const float* x, void* out, float* out_f32, 
     dim3 grid(nchunk, P);
     hipLaunchKernelGGL(instnorm_stats_kernel, grid, dim3(256), 0, st, x, scratch, HW, C, nchunk);
     BS_CHECK_LAUNCH();
-    if (dtype == BS_F16)
-        hipLaunchKernelGGL(instnorm_apply_kernel<f16>, grid, dim3(256), 0, st, x, (const float*)scratch, (f16*)out, out_f32, HW, C, nchunk, eps);
+    if (dtype == BS_F16 && split)
+        hipLaunchKernelGGL((instnorm_apply_kernel<f16, true>), grid, dim3(256), 0, st, x, (const float*)scratch, (f16*)out, out_f32, HW, C, nchunk, eps);
+    else if (dtype == BS_F16)
+        hipLaunchKernelGGL((instnorm_apply_kernel<f16, false>), grid, dim3(256), 0, st, x, (const float*)scratch, (f16*)out, out_f32, HW, C, nchunk, eps);
+    else if (split)
+        hipLaunchKernelGGL((instnorm_apply_kernel<bf16, true>), grid, dim3(256), 0, st, x, (const float*)scratch, (bf16*)out, out_f32, HW, C, nchunk, eps);
     else
-        hipLaunchKernelGGL(instnorm_apply_kernel<bf16>, grid, dim3(256), 0, st, x, (const float*)scratch, (bf16*)out, out_f32, HW, C, nchunk, eps);
+        hipLaunchKernelGGL((instnorm_apply_kernel<bf16, false>), grid, dim3(256), 0, st, x, (const float*)scratch, (bf16*)out, out_f32, HW, C, nchunk, eps);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }

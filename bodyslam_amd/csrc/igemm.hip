@@ -208,6 +208,12 @@ extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
     p.shuffle_s = d->shuffle_s; p.shuffle_cout = d->shuffle_cout;
     p.qkv_hidden = d->qkv_hidden; p.qkv_tokens = d->qkv_tokens; p.qkv_sp = d->qkv_sp; p.q_scale = d->q_scale;
     p.qkv_cls_last = d->qkv_cls_last;
+    p.qkv_cls_rows = d->qkv_cls_rows;
+    p.f8_wonly_from = d->f8_wonly_from;
+    BS_REQUIRE(d->f8_wonly_from == 0 || d->f8_seg > 0, "bs_gemm: f8_wonly_from needs the FP8 correction segment");
+    BS_REQUIRE(d->qkv_cls_rows == 0 || (d->out_mode == BS_OUT_QKV && d->qkv_cls_last && d->qkv_tokens > 1 &&
+                                        d->M == d->qkv_cls_rows * d->qkv_tokens),
+               "bs_gemm: qkv_cls_rows needs BS_OUT_QKV, qkv_cls_last and M = qkv_cls_rows * tokens");
     if (d->out_mode == BS_OUT_SHUFFLE) {
         BS_REQUIRE(!d->conv && d->shuffle_s > 0 && d->shuffle_cout % 4 == 0 && d->N == d->shuffle_s * d->shuffle_s * d->shuffle_cout,
                    "bs_gemm: bad shuffle geometry");

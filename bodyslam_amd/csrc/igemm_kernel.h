@@ -58,6 +58,8 @@ struct IgemmParams {
     int shuffle_s, shuffle_cout;
     int qkv_hidden, qkv_tokens, qkv_sp;
     int qkv_cls_last;    // Q / K / V^T hold an image's tokens patches first, cls (token 0) last
+    int qkv_cls_rows;    // > 0: grouped rows -- the first qkv_cls_rows rows are the images' cls tokens, then tokens-1 patches per image
+    int f8_wonly_from;   // tiles starting at a row >= this (> 0; -1: every tile) skip the second FP8 half (activation-rounding correction)
     float q_scale;
     int ntm, ntn;
     int m_begin;        // first output row this launch covers (a GEMM may be issued as a main launch + a tail launch)
@@ -358,8 +360,11 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
     const int koff0 = ((0 + fq) ^ fswz) << 4, koff1 = (BK == 64) ? (((4 + fq) ^ fswz) << 4) : 0;
     const int a_base = (wm * TM + frow) * ROWB, b_base = (wn * TN + frow) * ROWB;
 
-    const int nt = p.K / BK;
-    const int nt16 = F8 ? nt - p.f8_stages : nt;   // stages multiplied as 16-bit data; the rest are FP8 correction stages (BK = 64 tiles)
+    const int nt_all = p.K / BK;
+    const int nt16 = F8 ? nt_all - p.f8_stages : nt_all;   // stages multiplied as 16-bit data; the rest are FP8 correction stages (BK = 64 tiles)
+    // the second half of the FP8 stages (A_lo8 W_hi8) is dropped for tiles past f8_wonly_from: they stop after the first half
+    const bool wonly = F8 && p.f8_wonly_from != 0 && (p.f8_wonly_from < 0 || m0 >= p.f8_wonly_from);
+    const int nt = wonly ? nt_all - (p.f8_stages >> 1) : nt_all;
     if constexpr (!PP) {
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s)
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                 // permutation of k, so the product is unchanged -- as one 8-register operand of the 16x16x128 MFMA.
                 typedef int i32x4 __attribute__((ext_vector_type(4)));
                 typedef int i32x8 __attribute__((ext_vector_type(8)));
-                const bool second = t >= nt16 + ((nt - nt16) >> 1);
+                const bool second = t >= nt16 + ((nt_all - nt16) >> 1);
                 const int sca = (second ? p.f8_sa1 : p.f8_sa0) * 0x01010101, scb = (second ? p.f8_sb1 : p.f8_sb0) * 0x01010101;
                 auto ld8 = [&](const char* base) {
                     const i32x4 lo = *reinterpret_cast<const i32x4*>(base + koff0);
@@ -576,9 +581,16 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                     const int s = p.shuffle_s;
                     roff = (((int64_t)(ob * p.Hout + oy) * s) * (p.Wout * s) + ox * s) * p.ldo;
                 } else {
-                    const int ob = m / p.qkv_tokens;
-                    int otok = m - ob * p.qkv_tokens;
-                    if (p.qkv_cls_last) otok = otok == 0 ? p.qkv_tokens - 1 : otok - 1;
+                    int ob, otok;
+                    if (p.qkv_cls_rows > 0) {      // grouped rows: cls tokens first, then the patches image by image (positions: cls last)
+                        const int mp = m - p.qkv_cls_rows;
+                        ob = mp < 0 ? m : mp / (p.qkv_tokens - 1);
+                        otok = mp < 0 ? p.qkv_tokens - 1 : mp - ob * (p.qkv_tokens - 1);
+                    } else {
+                        ob = m / p.qkv_tokens;
+                        otok = m - ob * p.qkv_tokens;
+                        if (p.qkv_cls_last) otok = otok == 0 ? p.qkv_tokens - 1 : otok - 1;
+                    }
                     roff = ((int64_t)ob * (p.qkv_hidden >> 6) * p.qkv_sp + otok) * 64;
                 }
 #pragma unroll
@@ -691,9 +703,16 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
             constexpr int CPS = 64 / PASS_R >= 1 ? 64 / PASS_R : 1;     // columns per 64-lane sweep
             const int r = lane % PASS_R, csub = lane / PASS_R;
             const int m = m_base + r;
-            const int ob = m / p.qkv_tokens;
-            int otok = m - ob * p.qkv_tokens;
-            if (p.qkv_cls_last) otok = otok == 0 ? p.qkv_tokens - 1 : otok - 1;
+            int ob, otok;
+            if (p.qkv_cls_rows > 0) {
+                const int mp = m - p.qkv_cls_rows;
+                ob = mp < 0 ? m : mp / (p.qkv_tokens - 1);
+                otok = mp < 0 ? p.qkv_tokens - 1 : mp - ob * (p.qkv_tokens - 1);
+            } else {
+                ob = m / p.qkv_tokens;
+                otok = m - ob * p.qkv_tokens;
+                if (p.qkv_cls_last) otok = otok == 0 ? p.qkv_tokens - 1 : otok - 1;
+            }
             if (m < p.M) {
                 for (int c0 = 0; c0 < TN; c0 += CPS) {
                     const int c = c0 + csub;

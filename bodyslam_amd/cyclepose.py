@@ -11,7 +11,8 @@ Here ``skip_linear.weight/bias`` are explicit weights (taken from the checkpoint
 
 Layout: 7x7 conv as a GEMM over a reflect-padded patch matrix [P*128*128, 320] (K = 294 padded);
 the three stride-2 3x3 convs as implicit GEMM over NHWC; conv outputs fp32 (InstanceNorm statistics
-are taken in fp32), normalised activations 16-bit; the 262 656-long skip dot products in fp32.
+are taken in fp32), normalised activations 16-bit -- (hi | lo) pairs in the default accurate mode, where
+every convolution is a split-precision product; the 262 656-long skip dot products in fp32.
 """
 from __future__ import annotations
 
@@ -27,22 +28,42 @@ SKIP_FEATURES = 512 + 256 * 32 * 32
 
 
 class CyclePoseEngine:
-    def __init__(self, weights: Dict[str, torch.Tensor], dtype=torch.float16, device: int = 0):
+    def __init__(self, weights: Dict[str, torch.Tensor], dtype=torch.float16, device: int = 0, precision: str = "accurate"):
+        """precision: "accurate" (default) -- the four convolutions as split-precision products: activations and weights are
+        (hi, lo) pairs of 16-bit values (x = hi + lo to ~22 bits) and one bs_gemm launch evaluates A_hi W_hi + A_lo W_hi +
+        A_hi W_lo (K segments; 2.43 GFLOP per pair, 0.16 % of the loop's work, so the three passes are free); relative pose
+        within 1e-5 of the fp32 reference.  "fast": one 16-bit pass per product (~1e-3 at fp16)."""
         L.init(device)
-        assert dtype in (torch.float16, torch.bfloat16)
+        assert dtype in (torch.float16, torch.bfloat16) and precision in ("accurate", "fast")
         self.dtype = dtype
+        self.acc = precision == "accurate"
         self.dev = torch.device("cuda", device)
         self._plans = {}
         g = lambda k: weights[k].detach().float()
         h = lambda t: t.to(self.dev, dtype=dtype).contiguous()
         f = lambda t: t.to(self.dev, dtype=torch.float32).contiguous()
         cw = lambda t: t.permute(0, 2, 3, 1).reshape(t.shape[0], -1)          # [O,I,kh,kw] -> [O][(ky,kx,ci)]
+
+        def split(t):
+            hi = t.to(dtype)
+            return hi, (t - hi.float()).to(dtype)
+
         w = self.w = {}
         w0 = cw(g("initial_model.1.weight"))                                   # [64, 294]
-        w["c0.w"] = h(torch.cat([w0, torch.zeros(w0.shape[0], K0 - w0.shape[1])], 1))
+        w0 = torch.cat([w0, torch.zeros(w0.shape[0], K0 - w0.shape[1])], 1)
+        if self.acc:                                                           # [W_hi | W_hi | W_lo] against A = [hi | lo], then hi again
+            hi, lo = split(w0)
+            w["c0.w"] = torch.cat([hi, hi, lo], 1).to(self.dev).contiguous()
+        else:
+            w["c0.w"] = h(w0)
         w["c0.b"] = f(g("initial_model.1.bias"))
         for name, key in (("c1", "downsampling.0"), ("c2", "downsampling.3"), ("c3", "pose_conv.0")):
-            w[name + ".w"] = h(L.conv_weight(g(key + ".weight").permute(0, 2, 3, 1)))   # conv mode K order: chunk, tap, channel
+            k = g(key + ".weight").permute(0, 2, 3, 1)                         # [O, kh, kw, I]
+            if self.acc:    # segment 0 = [W_hi | W_hi] against the 2I (hi | lo) channels, segment 1 = W_lo against the hi channels
+                hi, lo = split(k)
+                w[name + ".w"] = torch.cat([L.conv_weight(torch.cat([hi, hi], -1)), L.conv_weight(lo)], 1).to(self.dev).contiguous()
+            else:
+                w[name + ".w"] = h(L.conv_weight(k))                           # conv mode K order: chunk, tap, channel
             w[name + ".b"] = f(g(key + ".bias"))
         if "skip_linear.weight" not in weights:
             raise KeyError("skip_linear.weight missing: the reference would silently use a random layer here "
@@ -85,26 +106,37 @@ class _PosePlan:
         self.pairs = torch.zeros(P, 2, device=dev, dtype=torch.int32)
         Pl = self.plan = L.Plan(dev)
         in_scratch = e32(P * (CROP * CROP // 256) * 2 * 256)
-        cols = e16(P * CROP * CROP, K0)
-        Pl.add("im2col", "bs_cyclepose_im2col", self.frames, self.pairs, cols, P, H, W, L.dt(cols))
+        acc = eng.acc
+        m2, SP = (2, 16) if acc else (1, 0)           # pair multiplier / the producers' "split" flag
+
+        def conv(name, A, out, hin, ci, co, **kw):
+            if acc:
+                Pl.gemm(name, A, w[name + ".w"], out, M=P * (hin // 2) ** 2, N=co, K=9 * ci * 3, lda=2 * ci, seg1=ci,
+                        conv=L.conv_geom(hin, hin, 2 * ci, 3, 3, 2, 1), bias=w[name + ".b"], precision_passes=3, **kw)
+            else:
+                Pl.gemm(name, A, w[name + ".w"], out, M=P * (hin // 2) ** 2, N=co, K=9 * ci, lda=ci,
+                        conv=L.conv_geom(hin, hin, ci, 3, 3, 2, 1), bias=w[name + ".b"], **kw)
+
+        cols = e16(P * CROP * CROP, K0 * m2)
+        Pl.add("im2col", "bs_cyclepose_im2col", self.frames, self.pairs, cols, P, H, W, L.dt(cols) | SP)
         c0 = e32(P, CROP, CROP, 64)
-        Pl.gemm("c0", cols, w["c0.w"], c0, M=P * CROP * CROP, N=64, K=K0, lda=K0, bias=w["c0.b"])
-        a0 = e16(P, CROP, CROP, 64)
-        Pl.add("in0", "bs_instnorm_relu_nhwc", c0, a0, None, in_scratch, P, CROP * CROP, 64, 1e-5, L.dt(a0))
-        Pl.mark("c0", a0, ("nhwc", P, CROP, CROP, 64))
+        Pl.gemm("c0", cols, w["c0.w"], c0, M=P * CROP * CROP, N=64, K=K0 * (3 if acc else 1), lda=K0 * m2, seg1=K0 if acc else 0,
+                bias=w["c0.b"], precision_passes=3 if acc else 1)
+        a0 = e16(P, CROP, CROP, 64 * m2)
+        Pl.add("in0", "bs_instnorm_relu_nhwc", c0, a0, None, in_scratch, P, CROP * CROP, 64, 1e-5, L.dt(a0) | SP)
+        Pl.mark("c0", a0, ("nhwc", P, CROP, CROP, 64, 1 if acc else 0))
         c1 = e32(P, 64, 64, 128)
-        Pl.gemm("c1", a0, w["c1.w"], c1, M=P * 64 * 64, N=128, K=9 * 64, lda=64, conv=L.conv_geom(128, 128, 64, 3, 3, 2, 1), bias=w["c1.b"])
-        a1 = e16(P, 64, 64, 128)
-        Pl.add("in1", "bs_instnorm_relu_nhwc", c1, a1, None, in_scratch, P, 64 * 64, 128, 1e-5, L.dt(a1))
+        conv("c1", a0, c1, 128, 64, 128)
+        a1 = e16(P, 64, 64, 128 * m2)
+        Pl.add("in1", "bs_instnorm_relu_nhwc", c1, a1, None, in_scratch, P, 64 * 64, 128, 1e-5, L.dt(a1) | SP)
         c2 = e32(P, 32, 32, 256)
-        Pl.gemm("c2", a1, w["c2.w"], c2, M=P * 32 * 32, N=256, K=9 * 128, lda=128, conv=L.conv_geom(64, 64, 128, 3, 3, 2, 1), bias=w["c2.b"])
-        a2 = e16(P, 32, 32, 256)
+        conv("c2", a1, c2, 64, 128, 256)
+        a2 = e16(P, 32, 32, 256 * m2)
         x2 = e32(P, 32, 32, 256)
-        Pl.add("in2", "bs_instnorm_relu_nhwc", c2, a2, x2, in_scratch, P, 32 * 32, 256, 1e-5, L.dt(a2))
+        Pl.add("in2", "bs_instnorm_relu_nhwc", c2, a2, x2, in_scratch, P, 32 * 32, 256, 1e-5, L.dt(a2) | SP)
         Pl.mark("c2", x2, ("nhwc", P, 32, 32, 256))
         c3 = e32(P, 16, 16, 512)
-        Pl.gemm("c3", a2, w["c3.w"], c3, M=P * 16 * 16, N=512, K=9 * 256, lda=256, conv=L.conv_geom(32, 32, 256, 3, 3, 2, 1), bias=w["c3.b"],
-                act=L.ACT_RELU)
+        conv("c3", a2, c3, 32, 256, 512, act=L.ACT_RELU)
         pooled = e32(P, 512)
         Pl.add("pool", "bs_avgpool_nhwc", c3, pooled, P, 16 * 16, 512)
         Pl.mark("pooled", pooled, ("raw",))

@@ -8,16 +8,16 @@ from .weights import load_cyclepose_checkpoint
 
 
 class MPEMInterface:
-    def __init__(self, path_to_model, dtype=torch.float16):
+    def __init__(self, path_to_model, dtype=torch.float16, precision: str = "accurate"):
         """``path_to_model``: the reference's checkpoint file (ModelIO container) or a loaded state dict."""
         self.input_shape = (6, 256, 256)
         self.device = "cuda"
-        self.pose_model = self._initialize_pose_model(path_to_model, dtype)
+        self.pose_model = self._initialize_pose_model(path_to_model, dtype, precision)
 
-    def _initialize_pose_model(self, path_to_model, dtype=torch.float16):
+    def _initialize_pose_model(self, path_to_model, dtype=torch.float16, precision: str = "accurate"):
         print(f"[INFO] model loaded on {self.device}")
         sd = path_to_model if isinstance(path_to_model, dict) else load_cyclepose_checkpoint(path_to_model)
-        return CyclePoseEngine(sd, dtype=dtype)
+        return CyclePoseEngine(sd, dtype=dtype, precision=precision)
 
     def infer_relative_pose_between(self, path_frame1, path_frame2, type_of_trans='crop'):
         """two frame paths -> (4,4) float32 SE(3) relative pose (prev -> curr)."""

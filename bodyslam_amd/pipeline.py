@@ -88,7 +88,7 @@ class BodySlamPipeline:
         self.K, self.depth_scale, self.depth_trunc, self.flip = tuple(K), depth_scale, depth_trunc, flip_aug
         self.zoe = ZoeDepthEngine(zoe_weights, zoe_cfg, dtype=dtype, device=device, target_hw=target_hw, precision=precision)
         self.precision = precision
-        self.pose = CyclePoseEngine(pose_weights, dtype=dtype, device=device)
+        self.pose = CyclePoseEngine(pose_weights, dtype=dtype, device=device, precision=precision)
 
     # -- stage 1+2 for one block of frames ----------------------------------------------------------
     def depth_and_pose_block(self, frames: torch.Tensor, start: int, end: int, keep_depth_m: bool = False, frame_offset: int = 0):

@@ -83,10 +83,9 @@ class ZoeConfig:
         return self.level_attractors[level] if self.single_head else self.n_attractors
 
 
-# Backbone GEMM classes that stay single-pass in accurate mode.  The fused QKV projection feeds only Q, K and V, which are
-# 16-bit operands of the attention anyway: rounding its input (the LayerNorm output) perturbs them by no more than their own
-# storage rounding does (measured: tools/probes/precision_classes.py, DESIGN.md Numerics).
-ACCURATE_SINGLE_PASS: Tuple[str, ...] = ()
+# Which correction products accurate mode evaluates per backbone GEMM class (tools/probes/precision_classes.py, DESIGN.md Numerics)
+ACCURATE_CLASS_MODES: Dict[str, str] = {"qkv": "full", "o": "full", "fc1": "full", "fc2": "full"}
+ACCURATE_NECK_MODE = "full"
 
 ZOED_NK = ZoeConfig()
 ZOED_N = ZoeConfig(head_names=("nyu",))
@@ -137,13 +136,17 @@ class ZoeDepthEngine:
 
     def __init__(self, weights: Dict[str, torch.Tensor], cfg: Optional[ZoeConfig] = None, dtype=torch.float16,
                  device: int = 0, target_hw: Tuple[int, int] = (384, 512), precision: str = "fast",
-                 single_pass: Optional[Tuple[str, ...]] = None):
+                 class_modes: Optional[Dict[str, str]] = None, neck_mode: Optional[str] = None):
         """precision: "fast" = one MFMA pass per product (16-bit operands, fp32 accumulate);
         "accurate" = split-precision products (Numerics): every GEMM / conv operand of the backbone, the DPT neck,
         the relative head and the projector path of the bins head is a (hi, lo) pair of 16-bit values; one launch evaluates
         A_hi W_hi + A_lo W_hi + A_hi W_lo (3 MFMA passes).  Attention (Q, K, V, P) and the small bins-head MLPs stay single.
-        single_pass: backbone GEMM classes ("qkv", "o", "fc1", "fc2") that run as ONE 16-bit pass even in accurate mode
-        (default: ACCURATE_SINGLE_PASS -- the classes whose rounding noise the depth map does not see, DESIGN.md Numerics)."""
+        class_modes: per backbone GEMM class ("qkv", "o", "fc1", "fc2") which correction products accurate mode evaluates --
+        "full" A_hi W_hi + A_hi W_lo + A_lo W_hi (2 pass-equivalents); "wcls" the same on the cls-token rows and A_hi W_hi +
+        A_hi W_lo (the weight-rounding correction only, 1.5 pass-equivalents) on the patch rows -- activation rounding is per-row
+        noise that stays incoherent in the depth map except on the cls rows, whose error shifts the whole map; probes: "w" (no
+        activation correction anywhere), "a" A_hi W_hi + A_lo W_hi, "single" one 16-bit pass.  Default ACCURATE_CLASS_MODES
+        (DESIGN.md Numerics: which rounding errors the depth map sees)."""
         L.init(device)
         assert precision in ("fast", "accurate")
         self.acc = precision == "accurate"
@@ -157,8 +160,14 @@ class ZoeDepthEngine:
         self._plans: Dict[Tuple, "_ZoePlan"] = {}
         self._raw_tables = []
         self.f8s: Dict[str, Tuple[int, int]] = {}
-        self.single_pass = tuple(ACCURATE_SINGLE_PASS if single_pass is None else single_pass) if self.acc else ()
+        self.class_modes = dict(ACCURATE_CLASS_MODES)
+        self.class_modes.update(class_modes or {})
+        assert all(v in ("full", "w", "wcls", "a", "single") for v in self.class_modes.values()), self.class_modes
         self.single_keys = set()
+        self.wmode: Dict[str, str] = {}
+        # DPT neck / heads (no cls rows there): "full" = both correction products, "w" = the weight-rounding correction only
+        self.neck_mode = neck_mode or ACCURATE_NECK_MODE
+        assert self.neck_mode in ("full", "w")
         c_ = self.cfg
         # the neck switches to the (hi16 | hi8 | lo8) operand format as a whole: every K / Cin on it must be whole 128-byte FP8 stages
         self.neck_f8 = self.acc and all(v % 128 == 0 for v in (c_.hidden, c_.fusion, c_.fusion // 2, *c_.neck_hidden))
@@ -188,13 +197,17 @@ class ZoeDepthEngine:
         the two plane scales go to self.f8s[key]."""
         if not self.acc:
             return self._h(t)
-        if key.split(".")[-2] in self.single_pass and key[0] == "l":      # "l7.qkv.w" -> class "qkv"
+        mode = self.class_modes.get(key.split(".")[-2], "full") if key[0] == "l" else "full"      # "l7.qkv.w" -> class "qkv"
+        if mode == "single":
             self.single_keys.add(key)
             return self._h(t)
         if t.shape[1] % 128 != 0:        # the FP8 segment walks whole 128-byte stages per plane: fall back to three 16-bit passes
             return self._wn(t)
-        w8, sb = L.f8_weight(t, self.dtype)
+        if mode == "w" and t.shape[1] % 256 != 0:
+            mode = "full"
+        w8, sb = L.f8_weight(t, self.dtype, planes={"full": "both", "wcls": "both", "w": "lo", "a": "hi_only"}[mode])
         self.f8s[key] = sb
+        self.wmode[key] = mode
         return w8.to(self.dev)
 
     def _w8conv(self, key: str, t: torch.Tensor) -> torch.Tensor:
@@ -445,6 +458,12 @@ class _ZoePlan:
         e32 = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         use_tab = wp == 32 and hp <= 40         # every 512-wide network input: bias from the per-head table held in LDS
         bias = eng._rel_table(hp, wp) if use_tab else eng._rel_bias(hp, wp, Sp)
+        # Row order of the token tensors (residual stream, LN / attention outputs, MLP hidden).  Grouped (with the table
+        # attention): rows [0, NB) are the cls tokens of the NB images, row NB + b*T0 + t is patch t of image b -- the cls rows
+        # sit in the first GEMM tile, which alone evaluates the activation-rounding correction ("wcls", bs_gemm f8_wonly_from).
+        # Otherwise image-major, cls first ([NB, S, hidden]).
+        grouped = use_tab
+        self.grouped = grouped
 
         acc = eng.acc
         m2 = 2 if acc else 1          # channel multiplier of (hi | lo) activations
@@ -481,9 +500,15 @@ class _ZoePlan:
             K segments of 16-bit (hi | lo) pairs (3 passes)."""
             if acc and wkey in single:
                 P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=K, precision_passes=1, **kw)
+            elif acc and wkey in f8s and eng.wmode.get(wkey) == "w":
+                # weight-rounding correction only: the FP8 segment is A_hi8 x W_lo8 (K bytes per row, both halves on the same scales)
+                sb0, _ = f8s[wkey]
+                P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=2 * K, f8_seg=K,
+                       f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_HI_EXP, sb0), precision_passes=1, **kw)
             elif acc and wkey in f8s:
                 sb0, sb1 = f8s[wkey]
-                P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=2 * K, f8_seg=2 * K,
+                wonly = NB if (eng.wmode.get(wkey) == "wcls" and grouped) else 0      # rows past the cls rows: weight correction only
+                P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=2 * K, f8_seg=2 * K, f8_wonly_from=wonly,
                        f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1), precision_passes=1, **kw)
             else:
                 P.gemm(name, A, w[wkey], out, M=M, N=N, K=K * np3, lda=K * m2, seg1=K if acc else 0, precision_passes=np3, **kw)
@@ -491,18 +516,24 @@ class _ZoePlan:
         # ---- Z1 + Z2: pre-processing fused with the patch gather, patch embedding, cls token
         PK = 3 * c.patch * c.patch
         P.add("preprocess", "bs_preprocess_patches", self.frames, patches, B, H, W, nh_, nw_, int(flip), L.dt(patches) | fmt("pe.w"))
-        P.add("cls", "bs_fill_rows", x, w["cls"], NB, S, Hd)
-        bgemm("patch_embed", patches, "pe.w", x, NB * T0, Hd, PK, bias=w["pe.b"], out_group=(T0, S, 1))
-        P.mark("embed", x, ("tokens", NB, S, Hd))
+        TOK = ("tokens_grouped" if grouped else "tokens", NB, S, Hd)
+        if grouped:
+            P.add("cls", "bs_fill_rows", x, w["cls"], NB, 1, Hd)                 # rows 0 .. NB-1
+            bgemm("patch_embed", patches, "pe.w", x, NB * T0, Hd, PK, bias=w["pe.b"], out_group=(NB * T0, 0, NB))   # rows NB ..
+        else:
+            P.add("cls", "bs_fill_rows", x, w["cls"], NB, S, Hd)
+            bgemm("patch_embed", patches, "pe.w", x, NB * T0, Hd, PK, bias=w["pe.b"], out_group=(T0, S, 1))
+        P.mark("embed", x, TOK)
         # ---- Z3: BEiT layers
         ti = 0
         for l in range(c.layers):
             P.add(f"l{l}.ln1", "bs_layernorm", x, w[f"l{l}.ln1.g"], w[f"l{l}.ln1.b"], xn, None, NB * S, Hd, c.ln_eps,
                   L.dt(xn) | fmt(f"l{l}.qkv.w"))
             bgemm(f"l{l}.qkv", xn, f"l{l}.qkv.w", q, NB * S, 3 * Hd, Hd, bias=w[f"l{l}.qkv.b"],
-                  qkv=(Hd, S, Sp, LOG2E / math.sqrt(64.0), k, vt, use_tab))
+                  qkv=(Hd, S, Sp, LOG2E / math.sqrt(64.0), k, vt, use_tab, NB if grouped else 0))
             if use_tab:
-                P.add(f"l{l}.attn", "bs_attention_table", q, k, vt, bias[l], ao, NB, c.heads, hp, wp, Sp, L.dt(q) | fmt(f"l{l}.o.w"))
+                P.add(f"l{l}.attn", "bs_attention_table", q, k, vt, bias[l], ao, NB, c.heads, hp, wp, Sp, int(grouped),
+                      L.dt(q) | fmt(f"l{l}.o.w"))
             else:
                 P.add(f"l{l}.attn", "bs_attention", q, k, vt, bias[l], ao, NB, c.heads, S, Sp, L.dt(q) | fmt(f"l{l}.o.w"))
             bgemm(f"l{l}.o", ao, f"l{l}.o.w", x, NB * S, Hd, Hd, bias=w[f"l{l}.o.b"], scale=w[f"l{l}.lam1"], res=x, ldr=Hd)
@@ -513,7 +544,7 @@ class _ZoePlan:
                   ldo=c.intermediate * am(f"l{l}.fc2.w"), out_split_off=c.intermediate if hfmt else 0,
                   out_f8=(L.F8_ACT_HI_EXP, L.F8_ACT_LO_EXP) if hfmt == 32 else None)
             bgemm(f"l{l}.fc2", hid, f"l{l}.fc2.w", x, NB * S, Hd, c.intermediate, bias=w[f"l{l}.fc2.b"], scale=w[f"l{l}.lam2"], res=x, ldr=Hd)
-            P.mark(f"layer{l + 1}", x, ("tokens", NB, S, Hd))
+            P.mark(f"layer{l + 1}", x, TOK)
             if (l + 1) in c.taps:
                 if acc:
                     P.add(f"tap{ti}", "bs_cast_split", x, taps16[ti], NB * S, Hd, L.dt(xn) | (32 if eng.neck_f8 else 0))
@@ -531,7 +562,7 @@ class _ZoePlan:
 
         def f8kw(wkey):
             sb0, sb1 = f8s[wkey]
-            return dict(f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1))
+            return dict(f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1), f8_wonly_from=-1 if eng.neck_mode == "w" else 0)
 
         def nplain(name, A, wkey, out, M, N, K, shuffle=None, out_pairs=True, **kw):
             """plain GEMM on pair operands; out_pairs=False leaves the output alone (fp32 or caller-specified)"""
@@ -569,9 +600,13 @@ class _ZoePlan:
         for i, ch in enumerate(c.neck_hidden):
             t16 = taps16[i]
             # cls half of the readout: per-image bias vector  c_b = cls_b @ W_cls^T + b   (A rows = the cls row of every image)
-            nplain(f"ro{i}.cls", t16, f"ro{i}.w_cls", cb, NB, Hd, Hd, out_pairs=False, lda=S * Hd * m2, bias=w[f"ro{i}.b"])
-            # token half: rows 1..S-1 of every image (a 1-row "conv" with a -1 column crop), + c_b, GELU
-            if acc and f"ro{i}.w_tok" in f8s:
+            nplain(f"ro{i}.cls", t16, f"ro{i}.w_cls", cb, NB, Hd, Hd, out_pairs=False, lda=(1 if grouped else S) * Hd * m2, bias=w[f"ro{i}.b"])
+            # token half: the patch rows of every image, + c_b, GELU.  Grouped rows: a plain GEMM over rows NB..; image-major rows:
+            # rows 1..S-1 of every image (a 1-row "conv" with a -1 column crop)
+            if grouped:
+                nplain(f"ro{i}.tok", t16, f"ro{i}.w_tok", r16, NB * T0, Hd, Hd, a_offset=NB * Hd * m2, bias=cb, bias_group_rows=T0,
+                       act=L.ACT_GELU)
+            elif acc and f"ro{i}.w_tok" in f8s:
                 P.gemm(f"ro{i}.tok", t16, w[f"ro{i}.w_tok"], r16, M=NB * T0, N=Hd, K=Hd, lda=2 * Hd, conv=(1, S, Hd, 1, T0, 1, 1, 1, 0, -1),
                        f8_seg=2 * Hd, bias=cb, bias_group_rows=T0, act=L.ACT_GELU, ldo=2 * Hd, out_split_off=Hd, out_f8=F8O if nf8 else None,
                        precision_passes=1, **f8kw(f"ro{i}.w_tok"))

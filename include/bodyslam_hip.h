@@ -116,6 +116,14 @@ typedef struct bs_gemm_desc {
     int32_t res_f8;                /* != 0: res / res2 are rows in that format too (N channels, ldr >= 2N) */
     int32_t qkv_cls_last;          /* BS_OUT_QKV: token 0 of an image (cls) is stored at position tokens-1 of Q / K / V^T and token t
                                     * at position t-1 (patches first: the layout bs_attention_table reads) */
+    int32_t qkv_cls_rows;          /* BS_OUT_QKV, > 0: the rows are GROUPED -- rows [0, qkv_cls_rows) are the cls tokens of the images,
+                                    * row qkv_cls_rows + b*(tokens-1) + t is patch t of image b (needs qkv_cls_last) */
+    int32_t f8_wonly_from;         /* with f8_seg: 0 = every row gets both correction products; k > 0 = the 256-row tiles that start at
+                                    * a row >= k evaluate only the first FP8 half (A_hi8 W_lo8, the weight-rounding correction) and
+                                    * stop before the second (A_lo8 W_hi8, the activation-rounding correction); -1 = all rows.
+                                    * Activation rounding is per-row noise that stays incoherent in the depth map except on the
+                                    * cls-token rows, whose error shifts the whole map (Numerics): grouped cls rows + this
+                                    * switch run the backbone at 1.5 instead of 2 pass-equivalents. */
 } bs_gemm_desc;
 int bs_gemm(const bs_gemm_desc* d, void* stream);
 /* the tile variant bs_gemm will pick for this descriptor (1: 128x128, 2: 128x64, 3: 128x32, 4: 256x128) */
@@ -134,9 +142,10 @@ int bs_attention(const void* q, const void* k, const void* vt, const float* bias
  * materialised [nh,Sp,Sp] tensor: table fp32 [nh, (2hp-1)(2wp-1)+3] in HF's layout (modeling_beit.py:194-218: entry
  * (dy+hp-1)*(2wp-1) + (dx+wp-1) for patch pairs, then cls->patch, patch->cls, cls->cls), pre-multiplied by log2(e).
  * q / k / vt hold the tokens of an image patches first, cls LAST (S = hp*wp + 1; bs_gemm_desc.qkv_cls_last); out rows are in
- * the usual order (cls first).  Built for wp == 32 (every 512-wide network input). */
+ * the usual order (cls first per image), or with grouped != 0 the B cls rows first and then the hp*wp patch rows of every
+ * image (bs_gemm_desc.qkv_cls_rows).  Built for wp == 32 (every 512-wide network input). */
 int bs_attention_table(const void* q, const void* k, const void* vt, const float* table, void* out,
-                       int32_t B, int32_t nh, int32_t hp, int32_t wp, int32_t Sp, int32_t dtype, void* stream);
+                       int32_t B, int32_t nh, int32_t hp, int32_t wp, int32_t Sp, int32_t grouped, int32_t dtype, void* stream);
 
 /* LayerNorm over the last dim, fp32 in; out16 (fp16/bf16, nullable) and out32 (fp32, nullable, may
  * alias x) -- HF modeling_beit.py:418,432; post-norm of the router HF modeling_zoedepth.py:876-881

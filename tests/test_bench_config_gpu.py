@@ -167,4 +167,4 @@ def test_cyclepose_256_pairs(weights, dtype):
     assert torch.equal(one, T[129])
 
 
-POSE_TOL = 5e-3      # tightened to 1e-5 with the accurate MPEM path (Numerics)
+POSE_TOL = 1e-5      # the accurate MPEM path (split-precision convolutions; DESIGN.md, Numerics)

@@ -18,8 +18,14 @@ def report(line):
     print(line)
 
 
+# stated tolerances of the relative pose |T - T_oracle| (Numerics): the accurate mode's split-precision convolutions
+# leave fp32-level differences; fast mode is one 16-bit pass per product
+POSE_TOL = {("accurate", torch.float16): 1e-5, ("accurate", torch.bfloat16): 2e-4, ("fast", torch.float16): 5e-3, ("fast", torch.bfloat16): 4e-2}
+
+
+@pytest.mark.parametrize("precision", ["accurate", "fast"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_cyclepose_matches_reference_golden(golden_dir, dtype):
+def test_cyclepose_matches_reference_golden(golden_dir, dtype, precision):
     """Same seeded weights + inputs as oracle/make_golden.py fed to the reference's ConditionalGenerator."""
     from bodyslam_amd.cyclepose import CyclePoseEngine
     from oracle import cyclepose_ref as CP
@@ -30,9 +36,12 @@ def test_cyclepose_matches_reference_golden(golden_dir, dtype):
     rng = np.random.default_rng(0)
     frames = torch.from_numpy(rng.integers(0, 256, size=(4, 480, 640, 3), dtype=np.uint8))
     pairs = torch.tensor([[0, 1], [1, 2], [2, 3], [0, 3]], dtype=torch.int32)
-    eng = CyclePoseEngine(w, dtype=dtype)
+    eng = CyclePoseEngine(w, dtype=dtype, precision=precision)
     taps = {}
     T = eng.infer_pairs(frames.cuda(), pairs.cuda(), taps).cpu()
+    if precision == "accurate":      # normalised activations are (hi | lo) pairs per pixel
+        t0, m0 = taps["c0"]
+        taps["c0"] = (t0.float()[..., :64] + t0.float()[..., 64:], m0)
     x = CP.center_crop_pair(frames, pairs.long())
     ot = {}
     with torch.no_grad():
@@ -43,8 +52,8 @@ def test_cyclepose_matches_reference_golden(golden_dir, dtype):
     eT = (T - Tref).abs().max().item()
     ec0 = (taps["c0"][0].float().cpu().permute(0, 3, 1, 2) - ot["c0"]).abs().max().item()
     ec2 = (taps["c2"][0].float().cpu().permute(0, 3, 1, 2) - ot["c2"]).abs().max().item()
-    report(f"cyclepose {dtype}: |pose7 err|={e7:.3e} |T err|={eT:.3e} c0 {ec0:.3e} c2 {ec2:.3e} (pose7 max {p7.abs().max():.2f})")
-    assert eT < (5e-3 if dtype == torch.float16 else 4e-2)
+    report(f"cyclepose {dtype} {precision}: |pose7 err|={e7:.3e} |T err|={eT:.3e} c0 {ec0:.3e} c2 {ec2:.3e} (pose7 max {p7.abs().max():.2f})")
+    assert eT < POSE_TOL[(precision, dtype)]
     R = T[:, :3, :3]
     assert (R @ R.transpose(1, 2) - torch.eye(3)).abs().max().item() < 1e-5
     assert torch.equal(T[:, 3], torch.tensor([[0., 0., 0., 1.]]).expand(4, 4))
@@ -97,7 +106,7 @@ def test_interfaces_roundtrip(tmp_path):
     T = mp_.infer_relative_pose_between(p1, p2)
     assert T.shape == (4, 4) and T.dtype == np.float32
     Tref = CP.forward_pose(wp, CP.center_crop_pair(torch.from_numpy(frames), torch.tensor([[0, 1]]))).numpy()[0]
-    assert np.abs(T - Tref).max() < 5e-3
+    assert np.abs(T - Tref).max() < 1e-5
     with pytest.raises(AssertionError):
         mp_.infer_relative_pose_between(p1, p2, type_of_trans="zoom")
 

@@ -76,6 +76,12 @@ def main():
         pl = L.Plan()
         pl.add("attn", "bs_attention", q, k, vt, bias, ao, NB, 16, S, Sp, L.dt(q))
         results.append(("attn  769 tokens x16 heads", 0, 4.0 * NB * 16 * S * S * 64, pl.run))
+        tab = torch.randn(16, 47 * 63 + 3, device=dev)
+        for split in (0, 32):
+            ao2 = torch.empty(NB * S, 1024 * (2 if split else 1), device=dev, dtype=dt)
+            pl = L.Plan()
+            pl.add("attn_tab", "bs_attention_table", q, k, vt, tab, ao2, NB, 16, 24, 32, Sp, 0, L.dt(q) | split)
+            results.append((f"attn_table 24x32 window split{split}", 0, 4.0 * NB * 16 * S * S * 64, pl.run))
     # warm up, then interleaved rounds
     for _, _, _, fn in results:
         fn()

@@ -1,5 +1,6 @@
 """Probe: which backbone GEMM classes need the split-precision corrections?  Full-size ZoeD_NK, 640x480, accurate mode with
-one or more classes ("qkv", "o", "fc1", "fc2") switched to a single 16-bit pass; depth L1 against the fp32 oracle.
+the correction products of one or more classes ("qkv", "o", "fc1", "fc2") reduced ("w": weight correction only, "a": activation
+correction only, "single": none); depth L1 against the fp32 oracle.
     python tools/probes/precision_classes.py [seeds...]        (on the GPU box; ~1 min per configuration)"""
 import gc
 import os
@@ -14,16 +15,19 @@ import test_zoedepth_gpu as T                      # noqa: E402
 from bodyslam_amd.zoedepth import ZoeDepthEngine   # noqa: E402
 from oracle import zoedepth_ref as Z               # noqa: E402
 
-CONFIGS = [(), ("qkv",), ("o",), ("fc1",), ("fc2",), ("qkv", "o"), ("qkv", "fc1"), ("qkv", "o", "fc1", "fc2")]
+ALL = ("qkv", "o", "fc1", "fc2")
+WC = {c: "wcls" for c in ALL}
+CONFIGS = [({}, "full"), (WC, "full"), ({c: "w" for c in ALL}, "full"), (dict(WC, o="full"), "full"), (dict(WC, qkv="full"), "full"),
+           (dict(WC, fc1="full"), "full"), (dict(WC, fc2="full"), "full"), ({}, "w"), (WC, "w"), (dict(WC, o="full"), "w")]
 seeds = [int(a) for a in sys.argv[1:]] or [1, 2]
 out = open(os.path.join(ROOT, "gpurun_out", "precision_classes.txt"), "a")
 for seed in seeds:
     w, frames, taps_o, logits, ref, t_or = T.oracle_case(Z.ZOED_NK, 1, 480, 640, (384, 512), seed, 0.0, True)
-    for single in CONFIGS:
-        eng = ZoeDepthEngine(w, T.product_cfg(Z.ZOED_NK), dtype=torch.float16, precision="accurate", single_pass=single)
+    for single, neck in CONFIGS:
+        eng = ZoeDepthEngine(w, T.product_cfg(Z.ZOED_NK), dtype=torch.float16, precision="accurate", class_modes=single, neck_mode=neck)
         dm, _ = eng.infer(frames.cuda())
         e = (dm.cpu() - ref).abs()
-        line = f"seed {seed} single_pass={single}: L1 {e.mean().item():.3e} max {e.max().item():.3e} signed {(dm.cpu() - ref).mean().item():+.3e}"
+        line = f"seed {seed} class_modes={single} neck={neck}: L1 {e.mean().item():.3e} max {e.max().item():.3e} signed {(dm.cpu() - ref).mean().item():+.3e}"
         print(line, flush=True)
         out.write(line + "\n")
         out.flush()
