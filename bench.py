@@ -184,6 +184,17 @@ def main():
                     launches=a["n"], avg_us=1e3 * a["ms"] / a["n"], tflops=a["alg"] / (a["ms"] * 1e-3) / 1e12,
                     executed_tflops=a["flops"] / (a["ms"] * 1e-3) / 1e12,
                     gflop_per_launch=a["alg"] / a["n"] / 1e9, share_of_step=a["ms"] / (elapsed * 1e3))
+            # the same launches by call site (layer index stripped): which GEMM of the network is how far from the roofline
+            import re
+            by = {}
+            for (ci, e0, e1) in events:
+                gi = zplan.plan.gemm_info[ci]
+                nm = re.sub(r"^(l|rt|ro|ra|nc|fu|pj|at)\d+", r"\1*", gi["name"])
+                a = by.setdefault(nm, dict(ms=0.0, alg=0.0, ex=0.0, n=0))
+                a["ms"] += e0.elapsed_time(e1); a["alg"] += gi["alg_flops"]; a["ex"] += gi["flops"]; a["n"] += 1
+            for nm, a in sorted(by.items(), key=lambda kv: -kv[1]["ms"])[:14]:
+                kern_table["site:" + nm] = dict(launches=a["n"], avg_us=round(1e3 * a["ms"] / a["n"], 1), tflops=round(a["alg"] / a["ms"] / 1e9, 1),
+                                                executed_tflops=round(a["ex"] / a["ms"] / 1e9, 1), share_of_step=round(a["ms"] / (elapsed * 1e3), 4))
             dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
             (kind, tile), a = dom
             ach = a["alg"] / (a["ms"] * 1e-3) / 1e12
