@@ -16,6 +16,8 @@
 // images shared by the QW waves of a block.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace bs {
@@ -215,6 +217,100 @@ __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict_
     }
 }
 
+// Epilogue shared by the table kernels: a wave's 32 x 64 output tile (lane = query r + 32*h2, 8 groups of 4 consecutive d) goes
+// through an 8 KiB region of LDS so that every global store instruction covers whole rows -- the row-per-lane stores it
+// replaces touched 64 different 128-byte lines per instruction (8 + 4 + 4 bytes per lane and line) and cost the accurate
+// mode's (hi16 | hi8 | lo8) output 200 us per launch at NB = 128, all of it address-coalescer time.
+//   LDS image per wave: hi16 [32][64] 16-bit (128-byte rows, 16-byte chunk c of row r at c ^ (r & 7)), then the two FP8
+//   planes [32][64] bytes (64-byte rows, chunk c at c ^ ((r >> 1) & 3)).
+template <typename T>
+__device__ __forceinline__ void store_out_tile(char* wlds, const f32x16 (&oacc)[2], float inv, T* __restrict__ out, int split, int nh, int head,
+                                               int64_t row0, int64_t row_cls, int S, int q0, bool active, int lane) {
+    typedef typename T16<T>::v8 v8;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const int r = lane & 31, h2 = lane >> 5;
+    char* l16 = wlds;
+    char* lh8 = wlds + 4096;
+    char* ll8 = wlds + 6144;
+    char* llo = wlds + 4096;     // split == 1: the 16-bit lo plane, same image as hi16
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            typename T16<T>::v4 o, ol;
+            float yv[4], rl[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                yv[e] = oacc[dh][gg * 4 + e] * inv;
+                o[e] = T16<T>::from_f32(yv[e]);
+                rl[e] = yv[e] - T16<T>::to_f32(o[e]);
+                ol[e] = T16<T>::from_f32(rl[e]);
+            }
+            const int d0 = dh * 32 + 8 * gg + 4 * h2;                 // first of this lane's 4 consecutive d
+            const int c16 = d0 >> 3, w16 = (d0 & 7) * 2;              // 16-byte chunk of the 128-byte hi16 row, byte inside it
+            *reinterpret_cast<typename T16<T>::v4*>(l16 + r * 128 + ((c16 ^ (r & 7)) << 4) + w16) = o;
+            if (split == 2) {
+                const float sh = __builtin_ldexpf(1.0f, F8_ACT_HI_EXP), sl = __builtin_ldexpf(1.0f, F8_ACT_LO_EXP);
+                const int c8 = d0 >> 4, w8 = d0 & 15;                  // 16-byte chunk of the 64-byte plane row
+                const int pos = r * 64 + ((c8 ^ ((r >> 1) & 3)) << 4) + w8;
+                *reinterpret_cast<int*>(lh8 + pos) = f8_pack4(yv[0] * sh, yv[1] * sh, yv[2] * sh, yv[3] * sh);
+                *reinterpret_cast<int*>(ll8 + pos) = f8_pack4(rl[0] * sl, rl[1] * sl, rl[2] * sl, rl[3] * sl);
+            } else if (split == 1) {
+                *reinterpret_cast<typename T16<T>::v4*>(llo + r * 128 + ((c16 ^ (r & 7)) << 4) + w16) = ol;
+            }
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (!active) return;
+    const int W = nh * 64 * (split ? 2 : 1);                          // row pitch of `out` in 16-bit elements
+    auto out_row = [&](int rr) -> T* {                                // query position -> row of `out` (nullptr: padding query)
+        const int qpos = q0 + rr;
+        if (qpos >= S) return nullptr;
+        const int64_t row = qpos == S - 1 ? row_cls : row0 + qpos;
+        return out + row * W;
+    };
+    // hi16 (and the 16-bit lo plane): 8 lanes cover one 128-byte row, a wave-instruction 8 rows
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int rr = ps * 8 + (lane >> 3), c = lane & 7;
+        T* orow = out_row(rr);
+        if (orow) {
+            *reinterpret_cast<v8*>(orow + head * 64 + c * 8) = *reinterpret_cast<const v8*>(l16 + rr * 128 + ((c ^ (rr & 7)) << 4));
+            if (split == 1) *reinterpret_cast<v8*>(orow + nh * 64 + head * 64 + c * 8) = *reinterpret_cast<const v8*>(llo + rr * 128 + ((c ^ (rr & 7)) << 4));
+        }
+    }
+    if (split == 2) {   // FP8 planes: 4 lanes cover one 64-byte row, a wave-instruction 16 rows
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int rr = ps * 16 + (lane >> 2), c = lane & 3;
+            T* orow = out_row(rr);
+            if (orow) {
+                char* planes = reinterpret_cast<char*>(orow + nh * 64);
+                const int pos = rr * 64 + ((c ^ ((rr >> 1) & 3)) << 4);
+                *reinterpret_cast<i32x4*>(planes + head * 64 + c * 16) = *reinterpret_cast<const i32x4*>(lh8 + pos);
+                *reinterpret_cast<i32x4*>(planes + nh * 64 + head * 64 + c * 16) = *reinterpret_cast<const i32x4*>(ll8 + pos);
+            }
+        }
+    }
+}
+
+// the head's bias table -> LDS: by LDS-DMA when its byte size and offset keep 16-byte alignment (even hp), else through registers.
+// The last 1-KiB piece may run past the table: its lanes re-read the table's last 16 bytes (the words they write lie past ntab).
+template <int NT_>
+__device__ __forceinline__ void load_table(float* tab, const float* __restrict__ table, int head, int ntab, int tid, int wave, int lane) {
+    const float* src = table + (int64_t)head * ntab;
+    if ((ntab & 3) == 0) {
+        const int bytes = ntab * 4, pieces = (bytes + 1023) >> 10;
+        for (int pc = wave; pc < pieces; pc += NT_ / 64) {
+            int off = pc * 1024 + lane * 16;
+            off = off > bytes - 16 ? bytes - 16 : off;
+            glds16(reinterpret_cast<const char*>(src) + off, reinterpret_cast<char*>(tab) + pc * 1024);
+        }
+    } else {
+        for (int i = tid; i < ntab; i += NT_) tab[i] = src[i];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Table variant (the full-size networks: window hp x 32 patches).  The additive bias of (query, key) depends only on the
 // offset (qy - ky, qx - kx) of the two patches -- HF gathers a [S, S] matrix per head from a ((2hp-1)(2wp-1) + 3)-entry
@@ -224,14 +320,14 @@ __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict_
 // K / V^T bytes -- through VGPR-destination loads whose waits also drained the tile prefetch).
 // Token order inside Q / K / V^T is patches first, cls LAST (written so by the QKV epilogue, bs_gemm_desc.qkv_cls_last):
 // a 32-query tile is then one patch row (qy = tile index, qx = lane) and a 32-key sub-tile one key row (ky, kx = 0..31), and
-//   bias = tab[(qy - ky + hp - 1) * 63 + (qx - kx + 31)]
+//   bias = body[(qy - ky + hp - 1) * 63 + (qx - kx + 31)]
 // is a wave-uniform row base plus a per-lane offset plus an immediate: conflict-free ds_read_b32 (32 consecutive words per
-// lane half).  The cls key is the single valid key of the last sub-tile (tab[nrd-2]; tab[nrd-1] for the cls query), the cls
+// lane half).  The table operand holds the body REVERSED (see bs_attention_table), so consecutive keys are ascending words.  The cls key is the single valid key of the last sub-tile (tab[nrd-2]; tab[nrd-1] for the cls query), the cls
 // query tile takes tab[nrd-3] for every patch key.  Output rows are written back in the residual stream's order (cls first).
 template <typename T, int QW>
 __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ Vt,
                                                                  const float* __restrict__ table, T* __restrict__ out, int split, int B, int nh,
-                                                                 int hp, int Sp, int nqb, int ntab, int grouped) {
+                                                                 int hp, int Sp, int nqb, int ntab, int grouped, int ablate) {
     typedef typename T16<T>::v8 v8;
     constexpr int STAGE = 16 * 1024;  // K tile 8 KiB + V^T tile 8 KiB
     constexpr int WP = 32;
@@ -242,8 +338,10 @@ __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restr
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + loc;
-    const int b = wg % B;
-    const int qblk = (wg / B) % nqb;
+    // the q-blocks of one (image, head) are consecutive work ids: they stream the same K / V^T tiles at about the same time,
+    // from the same XCD's L2
+    const int qblk = wg % nqb;
+    const int b = (wg / nqb) % B;
     const int head = wg / (B * nqb);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -261,7 +359,7 @@ __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restr
     const T* Vg = Vt + bh * 64 * Sp;
 
     // the head's table -> LDS (visible after the first barrier of the loop)
-    for (int i = tid; i < ntab; i += QW * 64) tab[i] = table[(int64_t)head * ntab + i];
+    if (!(ablate & 64)) load_table<QW * 64>(tab, table, head, ntab, tid, wave, lane);
 
     v8 qf[4];
 #pragma unroll
@@ -294,11 +392,12 @@ __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restr
     const int nkt = (S + 63) >> 6;
     constexpr float THR = 6.0f;
 
-    // registers 8s..8s+7 of lane half h2 are keys key0 + 16s + 8*h2 + e -> kx = 16s + 8*h2 + e:
-    //   word = (qt - ky + hp - 1) * 63 + lane_w + (23 - 16s - e),   lane_w = r + 8 - 8*h2   (>= 0)
-    const float* lane_tab = tab + r + 8 - 8 * h2;
-    const float c_cls_key = 0.f, NEG = -1.0e30f;
-    (void)c_cls_key;
+    // registers 8s..8s+7 of lane half h2 are keys key0 + 16s + 8*h2 + e -> kx = 16s + 8*h2 + e.  The table body arrives REVERSED
+    // (entry i at word nbody - 1 - i), so the 8 keys of a register group are 8 ascending words:
+    //   word = [nbody - 63 - (qt + hp - 1) * 63] + ky * 63 + (31 - r + 8*h2) + 16s + e
+    const int nbody = ntab - 3;
+    const float* lane_tab = tab + (nbody - (2 * WP - 1) - (qt + hp - 1) * (2 * WP - 1)) + (31 - r + 8 * h2);
+    const float NEG = -1.0e30f;
     float bnext[16];
     auto load_bias = [&](int ky) {      // the 16 bias values of the sub-tile holding key row ky (ky == hp: the cls key + padding)
         if (ky < hp) {
@@ -307,11 +406,11 @@ __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restr
 #pragma unroll
                 for (int i = 0; i < 16; ++i) bnext[i] = c3;
             } else {
-                const float* rowp = lane_tab + (qt - ky + hp - 1) * (2 * WP - 1);
+                const float* rowp = lane_tab + ky * (2 * WP - 1);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) bnext[8 * s2 + e] = rowp[23 - 16 * s2 - e];
+                    for (int e = 0; e < 8; ++e) bnext[8 * s2 + e] = rowp[16 * s2 + e];
             }
         } else {
 #pragma unroll
@@ -326,9 +425,10 @@ __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restr
     if (1 < nkt) stage(1, 1);
     load_bias(0);
     for (int kt = 0; kt < nkt; ++kt) {
+        if (ablate & 32) break;
         if (kt > 0) {
             __syncthreads();
-            if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
+            if (kt + 1 < nkt && !(ablate & 16)) stage(kt + 1, (kt + 1) & 1);
         }
         const char* sk = smem + (kt & 1) * STAGE;
         const char* sv = sk + 8 * 1024;
@@ -339,10 +439,11 @@ __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restr
             f32x16 sacc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) sacc[i] = bnext[i] - m_run;
-            if (ky + 1 <= hp) load_bias(ky + 1);
+            if (ky + 1 <= hp && !(ablate & 8)) load_bias(ky + 1);
             const int krow = sub * 32 + kap;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
+                if (ablate & 4) break;
                 const int chunk = 2 * ks + h2;
                 const v8 kf = *reinterpret_cast<const v8*>(sk + krow * 128 + ((chunk ^ ((krow >> 1) & 7)) << 4));
                 sacc = T16<T>::mfma32(kf, qf[ks], sacc);
@@ -351,7 +452,10 @@ __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restr
 #pragma unroll
             for (int i = 3; i < 15; i += 2) mloc = fmaxf(fmaxf(mloc, sacc[i]), sacc[i + 1]);
             mloc = fmaxf(mloc, sacc[15]);
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            {   // the other lane half holds the other 16 keys of this query: one v_permlane32_swap instead of a trip through LDS
+                const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mloc), __builtin_bit_cast(unsigned, mloc), false, false);
+                mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+            }
             if (first || __any(mloc > THR)) {
                 const float alpha = __builtin_amdgcn_exp2f(-mloc);
                 l_run *= alpha;
@@ -366,10 +470,15 @@ __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restr
             }
             float p[16];
             float psum = 0.f;
+            if (ablate & 1) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                p[i] = __builtin_amdgcn_exp2f(sacc[i]);
-                psum += p[i];
+                for (int i = 0; i < 16; ++i) p[i] = sacc[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    p[i] = __builtin_amdgcn_exp2f(sacc[i]);
+                    psum += p[i];
+                }
             }
             l_run += psum;
             v8 pf[2];
@@ -379,6 +488,7 @@ __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restr
                 for (int e = 0; e < 8; ++e) pf[s2][e] = T16<T>::from_f32(p[8 * s2 + e]);
 #pragma unroll
             for (int dh = 0; dh < 2; ++dh) {
+                if (ablate & 2) break;
                 const int drow = dh * 32 + r;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -391,38 +501,204 @@ __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restr
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    const int qpos = q0 + r;
-    if (active && qpos < S) {
-        // back to the residual stream's row order: cls first per image, or (grouped) the B cls rows first, then the patches
-        const int64_t row = grouped ? (qpos == S - 1 ? (int64_t)b : (int64_t)B + (int64_t)b * (S - 1) + qpos)
-                                    : (int64_t)b * S + (qpos == S - 1 ? 0 : qpos + 1);
-        T* orow = out + row * (nh * 64) * (split ? 2 : 1) + head * 64;
+    __syncthreads();                     // every wave is done with the K / V^T ring and the table: the LDS becomes the store staging
+    store_out_tile<T>(smem + wave * 8192, oacc, inv, out, split, nh, head, grouped ? (int64_t)B + (int64_t)b * (S - 1) : (int64_t)b * S + 1,
+                      grouped ? (int64_t)b : (int64_t)b * S, S, q0, active, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pipelined form of the table variant (hp even: the 384x512 and 416x512 network inputs).  The loop above runs a wave through
+// QK^T -> softmax -> PV strictly in turn and branches on the kind of key row / query tile inside the loop (the merges cost
+// dozens of register copies per sub-tile: 153 VALU + 63 SALU instructions per 32x32 sub-tile by PMC, twice the arithmetic).  Here
+//   * one loop iteration = one 64-key tile = two full key rows, no special cases: the cls key (the single valid key of the
+//     last tile) is a peeled step after the loop, the cls-query tile reads its constant bias through the same addressing
+//     (row stride 0 into a constant region of LDS);
+//   * the bias table sits in LDS REVERSED, so a lane's 8 consecutive keys are 8 ascending words (no re-ordering moves), and it is
+//     read straight into the score accumulator, which the MFMA chain then continues from (bias - running max);
+//   * both sub-tiles' QK^T MFMAs are issued before the first softmax: the matrix pipe works under the exp / convert / sum
+//     VALU stream of the same wave, and PV of the first half overlaps the softmax of the second.  A rescale of the running max
+//     also shifts the accumulator still in flight.
+// Table operand: `table` holds per head [(2hp-1)*63 body entries in REVERSED order | cls->patch, patch->cls, cls->cls].
+template <typename T, int QW, int WPE>
+__global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ Vt,
+                                                                  const float* __restrict__ table, T* __restrict__ out, int split, int B, int nh,
+                                                                  int hp, int Sp, int nqb, int ntab, int grouped) {
+    typedef typename T16<T>::v8 v8;
+    constexpr int STAGE = 16 * 1024;  // K tile 8 KiB + V^T tile 8 KiB
+    constexpr int WP = 32, RW = 2 * WP - 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tab = reinterpret_cast<float*>(smem + 2 * STAGE);
+    const int ntab_pad = (ntab + 255) & ~255; // whole 1-KiB DMA pieces
+    float* creg = tab + ntab_pad;             // 64 words of the cls->patch entry: the cls query's bias towards every patch key
+    const int S = hp * WP + 1, nqt = hp + 1;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + loc;
+    // the q-blocks of one (image, head) are consecutive work ids: they stream the same K / V^T tiles at about the same time,
+    // from the same XCD's L2
+    const int qblk = wg % nqb;
+    const int b = (wg / nqb) % B;
+    const int head = wg / (B * nqb);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h2 = lane >> 5;
+    int qt = qblk * QW + wave;
+    const bool active = qt < nqt;
+    qt = active ? qt : nqt - 1;
+    const int q0 = qt * 32;
+    const bool cls_tile = qt == hp;
+    const int64_t bh = (int64_t)b * nh + head;
+
+    const T* Qg = Q + bh * Sp * 64;
+    const T* Kg = K + bh * Sp * 64;
+    const T* Vg = Vt + bh * 64 * Sp;
+
+    load_table<QW * 64>(tab, table, head, ntab, tid, wave, lane);
+    if (tid < 64) creg[tid] = table[(int64_t)head * ntab + ntab - 3];
+
+    v8 qf[4];
 #pragma unroll
-        for (int dh = 0; dh < 2; ++dh)
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const v8*>(Qg + (int64_t)(q0 + r) * 64 + ks * 16 + h2 * 8);
+
+    const int srow = lane >> 3;
+    auto stage = [&](int kt, int buf) {
+        char* sb = smem + buf * STAGE;
+        for (int i = wave; i < 16; i += QW) {
+            const int row = (i & 7) * 8 + srow;
+            const int cs8 = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+            const T* src = i < 8 ? Kg + (int64_t)(kt * 64 + row) * 64 + cs8 : Vg + (int64_t)row * Sp + kt * 64 + cs8;
+            glds16(src, sb + i * 1024);
+        }
+    };
+
+    f32x16 oacc[2];
 #pragma unroll
-            for (int gg = 0; gg < 4; ++gg) {
-                typename T16<T>::v4 o, ol;
-                float yv[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    yv[e] = oacc[dh][gg * 4 + e] * inv;
-                    o[e] = T16<T>::from_f32(yv[e]);
-                    ol[e] = T16<T>::from_f32(yv[e] - T16<T>::to_f32(o[e]));
-                }
-                *reinterpret_cast<typename T16<T>::v4*>(orow + dh * 32 + 8 * gg + 4 * h2) = o;
-                if (split == 2) {
-                    const int col = head * 64 + dh * 32 + 8 * gg + 4 * h2;
-                    char* planes = reinterpret_cast<char*>(orow - head * 64 + nh * 64);
-                    const float sh = __builtin_ldexpf(1.0f, F8_ACT_HI_EXP), sl = __builtin_ldexpf(1.0f, F8_ACT_LO_EXP);
-                    *reinterpret_cast<int*>(planes + col) = f8_pack4(yv[0] * sh, yv[1] * sh, yv[2] * sh, yv[3] * sh);
-                    *reinterpret_cast<int*>(planes + nh * 64 + col) =
-                        f8_pack4((yv[0] - T16<T>::to_f32(o[0])) * sl, (yv[1] - T16<T>::to_f32(o[1])) * sl, (yv[2] - T16<T>::to_f32(o[2])) * sl,
-                                 (yv[3] - T16<T>::to_f32(o[3])) * sl);
-                } else if (split) {
-                    *reinterpret_cast<typename T16<T>::v4*>(orow + nh * 64 + dh * 32 + 8 * gg + 4 * h2) = ol;
-                }
-            }
+    for (int i = 0; i < 16; ++i) {
+        oacc[0][i] = 0.f;
+        oacc[1][i] = 0.f;
     }
+    float m_run = 0.f, l_run = 0.f;
+    bool first = true;
+    const int kap = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+    constexpr float THR = 6.0f;
+
+    // Bias of (query (qt, r), key (ky, kx)), kx = 16s + 8*h2 + e for accumulator register 8s + e: body entry
+    // (qt - ky + hp - 1) * 63 + (r - kx + 31), i.e. word (nbody - 1) - that of the reversed table
+    //   = [nbody - 63 - (qt + hp - 1) * 63] + ky * 63 + (31 - r + 8*h2) + 16s + e        (ascending in e).
+    // The cls-query tile reads the constant region with row stride 0.
+    const int nbody = ntab - 3;
+    const float* lt = cls_tile ? creg : tab + (nbody - RW - (qt + hp - 1) * RW) + (31 - r + 8 * h2);
+    const int rstep = cls_tile ? 0 : RW;
+    auto load_bias = [&](f32x16& sacc, int ky) {
+        const float* rowp = lt + ky * rstep;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sacc[8 * s2 + e] = rowp[16 * s2 + e];
+    };
+    // scores of one sub-tile: (bias - running max) + K Q^T, four MFMAs left in flight
+    auto qk = [&](f32x16& sacc, const char* sk, int sub) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[i] -= m_run;
+        const int krow = sub * 32 + kap;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int chunk = 2 * ks + h2;
+            const v8 kf = *reinterpret_cast<const v8*>(sk + krow * 128 + ((chunk ^ ((krow >> 1) & 7)) << 4));
+            sacc = T16<T>::mfma32(kf, qf[ks], sacc);
+        }
+    };
+    // softmax of one sub-tile's scores + O^T += V^T P^T.  OTHER: `other` is the accumulator of the next sub-tile, already shifted
+    // by the current running max and in flight on the matrix pipe: a rescale shifts it too.  NEXT: once the probabilities are
+    // packed the score registers are free and take the bias of key row next_ky (for the tile after this one).
+    auto softmax_pv = [&](f32x16& sacc, f32x16& other, const char* sv, int sub, int next_ky, auto other_tag, auto next_tag) {
+        constexpr bool OTHER = decltype(other_tag)::value;
+        constexpr bool NEXT = decltype(next_tag)::value;
+        float mloc = fmaxf(fmaxf(sacc[0], sacc[1]), sacc[2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) mloc = fmaxf(fmaxf(mloc, sacc[i]), sacc[i + 1]);
+        mloc = fmaxf(mloc, sacc[15]);
+        {   // the other lane half holds the other 16 keys of this query: one v_permlane32_swap instead of a trip through LDS
+            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mloc), __builtin_bit_cast(unsigned, mloc), false, false);
+            mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+        }
+        if (first || __any(mloc > THR)) {
+            const float alpha = __builtin_amdgcn_exp2f(-mloc);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                oacc[0][i] *= alpha;
+                oacc[1][i] *= alpha;
+                sacc[i] -= mloc;
+                if (OTHER) other[i] -= mloc;
+            }
+            m_run += mloc;
+            first = false;
+        }
+        float psum = 0.f;
+        v8 pf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(sacc[8 * s2 + e]);
+                psum += pv;
+                pf[s2][e] = T16<T>::from_f32(pv);
+            }
+        l_run += psum;
+        if (NEXT) load_bias(sacc, next_ky);
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh) {
+            const int drow = dh * 32 + r;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int chunk = sub * 4 + 2 * s2 + h2;
+                const v8 vf = *reinterpret_cast<const v8*>(sv + drow * 128 + ((chunk ^ ((drow >> 1) & 7)) << 4));
+                oacc[dh] = T16<T>::mfma32(vf, pf[s2], oacc[dh]);
+            }
+        }
+    };
+
+    const int NT = hp >> 1;               // full 64-key tiles (two key rows each); tile NT holds the cls key
+    f32x16 sa, sb2;
+    typedef std::true_type Yes;
+    typedef std::false_type No;
+    stage(0, 0);
+    __syncthreads();                      // tile 0 and the table have landed
+    load_bias(sa, 0);
+    load_bias(sb2, 1);
+    for (int kt = 0; kt < NT - 1; ++kt) {
+        if (kt > 0) __syncthreads();      // tile kt has landed; everyone is done with tile kt - 1
+        stage(kt + 1, (kt + 1) & 1);
+        const char* sk = smem + (kt & 1) * STAGE;
+        qk(sa, sk, 0);
+        qk(sb2, sk, 1);
+        softmax_pv(sa, sb2, sk + 8 * 1024, 0, 2 * kt + 2, Yes{}, Yes{});
+        softmax_pv(sb2, sa, sk + 8 * 1024, 1, 2 * kt + 3, No{}, Yes{});
+    }
+    {   // last full tile; then the cls key (sub-tile 0 of tile NT: one valid key, the rest padding)
+        if (NT > 1) __syncthreads();
+        stage(NT, NT & 1);
+        const char* sk = smem + ((NT - 1) & 1) * STAGE;
+        qk(sa, sk, 0);
+        qk(sb2, sk, 1);
+        softmax_pv(sa, sb2, sk + 8 * 1024, 0, 0, Yes{}, No{});
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sa[i] = -1.0e30f;
+        if (h2 == 0) sa[0] = cls_tile ? tab[ntab - 1] : tab[ntab - 2];
+        softmax_pv(sb2, sa, sk + 8 * 1024, 1, 0, No{}, No{});
+        __syncthreads();
+        const char* sk2 = smem + (NT & 1) * STAGE;
+        qk(sa, sk2, 0);
+        softmax_pv(sa, sb2, sk2 + 8 * 1024, 0, 0, No{}, No{});
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    __syncthreads();                     // every wave is done with the K / V^T ring and the table: the LDS becomes the store staging
+    store_out_tile<T>(smem + wave * 8192, oacc, inv, out, split, nh, head, grouped ? (int64_t)B + (int64_t)b * (S - 1) : (int64_t)b * S + 1,
+                      grouped ? (int64_t)b : (int64_t)b * S, S, q0, active, lane);
 }
 
 template <typename T>
@@ -430,15 +706,31 @@ static int launch_attn_tab(const void* q, const void* k, const void* vt, const f
                            int grouped, hipStream_t st) {
     constexpr int QW = 5;
     const int nqt = hp + 1, nqb = cdiv(nqt, QW), ntab = (2 * hp - 1) * 63 + 3;
-    const int smem = 32 * 1024 + ((ntab * 4 + 15) & ~15);
+    int smem = 32 * 1024 + ((ntab * 4 + 1023) & ~1023);
+    smem = smem < QW * 8192 ? QW * 8192 : smem;                    // the epilogue stages 8 KiB per wave
     auto kern = attention_tab_kernel<T, QW>;
     static bool attr = false;
     if (!attr) {
         BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         attr = true;
     }
+    static const bool pipelined_ok = getenv("BS_ATTN_NO_PIPE") == nullptr;       // diagnostics: the unpipelined loop
+    if (hp % 2 == 0 && pipelined_ok) {
+        static const bool wpe3 = getenv("BS_ATTN_WPE3") != nullptr;       // diagnostics: 3 waves / SIMD, no spill
+        auto kern2 = wpe3 ? attention_tab2_kernel<T, QW, 3> : attention_tab2_kernel<T, QW, 4>;
+        static bool attr2 = false;
+        if (!attr2) {
+            BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            attr2 = true;
+        }
+        const int smem2 = 32 * 1024 + (((ntab + 255) & ~255) + 64) * 4;
+        hipLaunchKernelGGL(kern2, dim3(B * nh * nqb), dim3(QW * 64), smem2, st, (const T*)q, (const T*)k, (const T*)vt, table, (T*)out,
+                           split, B, nh, hp, Sp, nqb, ntab, grouped);
+        BS_CHECK_LAUNCH();
+        return BS_OK;
+    }
     hipLaunchKernelGGL(kern, dim3(B * nh * nqb), dim3(QW * 64), smem, st, (const T*)q, (const T*)k, (const T*)vt, table, (T*)out, split, B,
-                       nh, hp, Sp, nqb, ntab, grouped);
+                       nh, hp, Sp, nqb, ntab, grouped, getenv("BS_ATTN_ABLATE") ? atoi(getenv("BS_ATTN_ABLATE")) : 0);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }

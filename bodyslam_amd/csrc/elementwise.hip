@@ -256,6 +256,81 @@ __global__ __launch_bounds__(256) void pre_image_kernel(const uint8_t* frames, f
 }
 
 // ---------------------------------------------------------------------------------------------
+// (hi16 | hi8 | lo8) pixels, 16 channels per thread: every access is 16 bytes wide (two for the hi16 values, one per FP8 plane);
+// the x2 upsampling of the fusion stage / relative head writes 6-13 GB per call at the bench batch
+template <typename T>
+__global__ __launch_bounds__(256) void resize_nhwc_f8_kernel(const T* x, T* out, int B, int Hin, int Win, int C, int Hout, int Wout, float sy,
+                                                              float sx, int align) {
+    const int c16n = C >> 4;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (unsigned)Wout * c16n) return;
+    const int c16 = idx % c16n, ox = idx / c16n;
+    const int b = blockIdx.y / Hout, oy = blockIdx.y - b * Hout;
+    const int64_t pix = ((int64_t)b * Hout + oy) * Wout + ox;
+    float fy, fx;
+    if (align) {
+        fy = sy * (float)oy;
+        fx = sx * (float)ox;
+    } else {
+        fy = fmaxf(__fmaf_rn(sy, (float)oy + 0.5f, -0.5f), 0.0f);
+        fx = fmaxf(__fmaf_rn(sx, (float)ox + 0.5f, -0.5f), 0.0f);
+    }
+    int y0 = (int)fy, x0 = (int)fx;
+    y0 = y0 > Hin - 1 ? Hin - 1 : y0;
+    x0 = x0 > Win - 1 ? Win - 1 : x0;
+    const int y1 = y0 + (y0 < Hin - 1 ? 1 : 0), x1 = x0 + (x0 < Win - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+    typedef typename T16<T>::v8 v8;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const T* xb = x + (int64_t)b * Hin * Win * C * 2;
+    const float sc = __builtin_ldexpf(1.0f, -F8_ACT_LO_EXP);
+    float q00[16], q01[16], q10[16], q11[16];
+    auto ld = [&](int yy, int xx, float (&q)[16]) {
+        const T* pp = xb + ((int64_t)yy * Win + xx) * C * 2;
+        const v8 h0 = *reinterpret_cast<const v8*>(pp + c16 * 16), h1 = *reinterpret_cast<const v8*>(pp + c16 * 16 + 8);
+        const i32x4 l = *reinterpret_cast<const i32x4*>(reinterpret_cast<const char*>(pp + C + (C >> 1)) + c16 * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            q[e] = (float)h0[e];
+            q[8 + e] = (float)h1[e];
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float lo[4];
+            f8_unpack4(l[g], lo);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[4 * g + e] += lo[e] * sc;
+        }
+    };
+    ld(y0, x0, q00);
+    ld(y0, x1, q01);
+    ld(y1, x0, q10);
+    ld(y1, x1, q11);
+    v8 o0, o1;
+    float vv[16], rl[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float v = hy * (hx * q00[e] + lx * q01[e]) + ly * (hx * q10[e] + lx * q11[e]);
+        vv[e] = v;
+        const T h = T16<T>::from_f32(v);
+        if (e < 8) o0[e] = h; else o1[e - 8] = h;
+        rl[e] = v - (float)h;
+    }
+    T* op = out + pix * C * 2;
+    *reinterpret_cast<v8*>(op + c16 * 16) = o0;
+    *reinterpret_cast<v8*>(op + c16 * 16 + 8) = o1;
+    const float sh = __builtin_ldexpf(1.0f, F8_ACT_HI_EXP), sl = __builtin_ldexpf(1.0f, F8_ACT_LO_EXP);
+    char* planes = reinterpret_cast<char*>(op + C);
+    i32x4 ph, pl;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        ph[g] = f8_pack4(vv[4 * g] * sh, vv[4 * g + 1] * sh, vv[4 * g + 2] * sh, vv[4 * g + 3] * sh);
+        pl[g] = f8_pack4(rl[4 * g] * sl, rl[4 * g + 1] * sl, rl[4 * g + 2] * sl, rl[4 * g + 3] * sl);
+    }
+    *reinterpret_cast<i32x4*>(planes + c16 * 16) = ph;
+    *reinterpret_cast<i32x4*>(planes + C + c16 * 16) = pl;
+}
+
 // NHWC bilinear resize (+ optional add): thread = one 8-channel group of one output pixel
 // ---------------------------------------------------------------------------------------------
 template <typename T, bool ADD, int SPLIT>
@@ -500,8 +575,8 @@ static int launch_resize(const void* x, const void* addend, void* out, int B, in
     }
     const dim3 blocks(cdiv(Wout * (C / 8), 256), B * Hout);
     if (split == 2) {      // (hi16 | hi8 | lo8) pixels (no add variant: the bins head's embeddings stay 16-bit pairs)
-        hipLaunchKernelGGL((resize_nhwc_kernel<T, false, 2>), blocks, dim3(256), 0, st, (const T*)x, (const T*)nullptr, (T*)out, B, Hin, Win,
-                           C, Hout, Wout, sy, sx, align);
+        const dim3 blocks16(cdiv(Wout * (C / 16), 256), B * Hout);
+        hipLaunchKernelGGL((resize_nhwc_f8_kernel<T>), blocks16, dim3(256), 0, st, (const T*)x, (T*)out, B, Hin, Win, C, Hout, Wout, sy, sx, align);
         BS_CHECK_LAUNCH();
         return BS_OK;
     }

@@ -171,7 +171,7 @@ class ZoeDepthEngine:
         self.wmode: Dict[str, str] = {}
         # DPT neck / heads (no cls rows there): "full" = both correction products, "w" = the weight-rounding correction only
         self.neck_mode = neck_mode or ACCURATE_NECK_MODE
-        assert self.neck_mode in ("full", "w")
+        # (probes: a comma-separated list of weight-key prefixes that KEEP both products, e.g. "ro,ra,nc": everything else "w")
         c_ = self.cfg
         # the neck switches to the (hi16 | hi8 | lo8) operand format as a whole: every K / Cin on it must be whole 128-byte FP8 stages
         self.neck_f8 = self.acc and all(v % 128 == 0 for v in (c_.hidden, c_.fusion, c_.fusion // 2, *c_.neck_hidden))
@@ -405,7 +405,8 @@ class ZoeDepthEngine:
 
     def _rel_table(self, hp: int, wp: int):
         """[layers] x fp32 [heads, (2hp-1)(2wp-1)+3]: the bias table re-interpolated for an (hp, wp) window (HF modeling_beit.py:
-        220-245), times log2(e) -- the operand of bs_attention_table (no [heads, Sp, Sp] tensor is materialised)."""
+        220-245), times log2(e), patch-pair entries in reversed order -- the operand of bs_attention_table (no [heads, Sp, Sp]
+        tensor is materialised)."""
         key = ("tab", hp, wp)
         if key in self._bias_cache:
             return self._bias_cache[key]
@@ -416,7 +417,7 @@ class ZoeDepthEngine:
         for tab in self._raw_tables:
             sub = tab[: old * old].reshape(1, old, old, -1).permute(0, 3, 1, 2)
             new = F.interpolate(sub, size=(nh_, nw_), mode="bilinear").permute(0, 2, 3, 1).reshape(nh_ * nw_, -1)
-            full = torch.cat([new, tab[old * old:]])                    # [ntab, heads]
+            full = torch.cat([torch.flip(new, dims=[0]), tab[old * old:]])       # [ntab, heads]: patch-pair entries reversed, cls entries last
             out.append((full.t() * LOG2E).contiguous().to(self.dev))
         self._bias_cache[key] = out
         return out
@@ -566,7 +567,12 @@ class _ZoePlan:
 
         def f8kw(wkey):
             sb0, sb1 = f8s[wkey]
-            return dict(f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1), f8_wonly_from=-1 if eng.neck_mode == "w" else 0)
+            # the per-image readout bias (cls row x W_cls, added to every token of the image) always gets both products: an error
+            # there is a coherent offset of the whole map
+            wonly = eng.neck_mode == "w" or (eng.neck_mode != "full" and not any(wkey.startswith(p_) for p_ in eng.neck_mode.split(",")))
+            if wkey.endswith("w_cls"):
+                wonly = False
+            return dict(f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1), f8_wonly_from=-1 if wonly else 0)
 
         def nplain(name, A, wkey, out, M, N, K, shuffle=None, out_pairs=True, **kw):
             """plain GEMM on pair operands; out_pairs=False leaves the output alone (fp32 or caller-specified)"""

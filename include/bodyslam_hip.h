@@ -139,8 +139,10 @@ int bs_gemm_tile(const bs_gemm_desc* d);
 int bs_attention(const void* q, const void* k, const void* vt, const float* bias, void* out,
                  int32_t B, int32_t nh, int32_t S, int32_t Sp, int32_t dtype, void* stream);
 /* The same attention for a window of hp x wp patches + cls with the bias taken from the per-head TABLE instead of a
- * materialised [nh,Sp,Sp] tensor: table fp32 [nh, (2hp-1)(2wp-1)+3] in HF's layout (modeling_beit.py:194-218: entry
- * (dy+hp-1)*(2wp-1) + (dx+wp-1) for patch pairs, then cls->patch, patch->cls, cls->cls), pre-multiplied by log2(e).
+ * materialised [nh,Sp,Sp] tensor: table fp32 [nh, (2hp-1)(2wp-1)+3], pre-multiplied by log2(e): HF's entries
+ * (modeling_beit.py:194-218: (dy+hp-1)*(2wp-1) + (dx+wp-1) for patch pairs, then cls->patch, patch->cls, cls->cls) with the
+ * (2hp-1)(2wp-1) patch-pair entries stored in REVERSED order (entry i at index nbody-1-i: the 8 consecutive keys a lane
+ * handles are then 8 ascending words), the three cls entries last, unchanged.
  * q / k / vt hold the tokens of an image patches first, cls LAST (S = hp*wp + 1; bs_gemm_desc.qkv_cls_last); out rows are in
  * the usual order (cls first per image), or with grouped != 0 the B cls rows first and then the hp*wp patch rows of every
  * image (bs_gemm_desc.qkv_cls_rows).  Built for wp == 32 (every 512-wide network input). */

@@ -432,7 +432,7 @@ def test_attention_table(L, dtype, B, hp, nh, split):
     vr = y[:, :, 2].permute(0, 2, 1, 3)[:, :, perm]
     assert (vt[:, :, :, :S].float() - vr.transpose(2, 3)).abs().max().item() < tol(dtype, hidden) * 4
     table = rnd(nh, ntab, seed=4)                                   # natural-log domain
-    tab2 = (table * LOG2E).contiguous()
+    tab2 = (torch.cat([torch.flip(table[:, :ntab - 3], dims=[1]), table[:, ntab - 3:]], 1) * LOG2E).contiguous()   # the kernel's operand: body reversed
     mult = 2 if split else 1
     out = torch.zeros(B * S, hidden * mult, device=dev(), dtype=dtype)
     L.attention_table(q, k, vt, tab2, out, B, nh, hp, wp, Sp, split=split)

@@ -17,8 +17,8 @@ from oracle import zoedepth_ref as Z               # noqa: E402
 
 ALL = ("qkv", "o", "fc1", "fc2")
 WC = {c: "wcls" for c in ALL}
-CONFIGS = [({}, "full"), (WC, "full"), ({c: "w" for c in ALL}, "full"), (dict(WC, o="full"), "full"), (dict(WC, qkv="full"), "full"),
-           (dict(WC, fc1="full"), "full"), (dict(WC, fc2="full"), "full"), ({}, "w"), (WC, "w"), (dict(WC, o="full"), "w")]
+CONFIGS = [(WC, "full"), (WC, "w"), (WC, "ro"), (WC, "ro,ra"), (WC, "ro,ra,nc"), (WC, "ro,ra,nc,fu"), (WC, "rh"), (WC, "fu"), (WC, "rh,pj"), (WC, "ro,ra,nc,rh,pj"),
+           (WC, "ro,ra,nc,fu,pj")]
 seeds = [int(a) for a in sys.argv[1:]] or [1, 2]
 out = open(os.path.join(ROOT, "gpurun_out", "precision_classes.txt"), "a")
 for seed in seeds:
