@@ -44,7 +44,7 @@ class GemmDesc(C.Structure):
         ("qkv_hidden", C.c_int32), ("qkv_tokens", C.c_int32), ("qkv_sp", C.c_int32), ("q_scale", C.c_float),
         ("tile", C.c_int32), ("seg1", C.c_int32), ("out_split_off", C.c_int32), ("res_split_off", C.c_int32),
         ("f8_seg", C.c_int32), ("f8_scales", C.c_uint32), ("out_f8", C.c_int32), ("res_f8", C.c_int32),
-        ("qkv_cls_last", C.c_int32), ("qkv_cls_rows", C.c_int32), ("f8_wonly_from", C.c_int32),
+        ("qkv_cls_last", C.c_int32), ("qkv_cls_rows", C.c_int32), ("qkv_patch_row0", C.c_int32), ("f8_wonly_from", C.c_int32),
     ]
 
 
@@ -151,7 +151,7 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
                    f8_wonly_from: int = 0) -> GemmDesc:
     """Fill a bs_gemm_desc.  conv = (Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_h, pad_w) or None;
     out_group = (rows, stride, offset); shuffle = (s, Cout, Hgrid, Wgrid);
-    qkv = (hidden, tokens, Sp, q_scale, out_k, out_vt[, cls_last[, cls_rows]]); a_offset in elements."""
+    qkv = (hidden, tokens, Sp, q_scale, out_k, out_vt[, cls_last[, cls_rows[, patch_row0]]]); a_offset in elements."""
     d = GemmDesc()
     d.A = A.data_ptr() + a_offset * A.element_size()
     d.W = W.data_ptr()
@@ -190,6 +190,7 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
         hidden, tokens, sp, q_scale, out_k, out_vt = qkv[:6]
         d.qkv_cls_last = int(bool(qkv[6])) if len(qkv) > 6 else 0
         d.qkv_cls_rows = int(qkv[7]) if len(qkv) > 7 else 0
+        d.qkv_patch_row0 = int(qkv[8]) if len(qkv) > 8 else d.qkv_cls_rows
         d.qkv_hidden, d.qkv_tokens, d.qkv_sp, d.q_scale = hidden, tokens, sp, q_scale
         d.out2 = out_k.data_ptr()
         d.out3 = out_vt.data_ptr()
@@ -409,7 +410,7 @@ def attention(q, k, vt, bias, out, B, nh, S, Sp):
     check(load_library().bs_attention(p(q), p(k), p(vt), p(bias), p(out), B, nh, S, Sp, dt(q), stream_ptr()), "bs_attention")
 
 
-def attention_table(q, k, vt, table, out, B, nh, hp, wp, Sp, split=0, grouped=False):
+def attention_table(q, k, vt, table, out, B, nh, hp, wp, Sp, split=0, grouped=0):
     check(load_library().bs_attention_table(p(q), p(k), p(vt), p(table), p(out), B, nh, hp, wp, Sp, int(grouped), dt(q) | split, stream_ptr()),
           "bs_attention_table")
 

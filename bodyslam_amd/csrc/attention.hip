@@ -502,7 +502,7 @@ __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restr
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     __syncthreads();                     // every wave is done with the K / V^T ring and the table: the LDS becomes the store staging
-    store_out_tile<T>(smem + wave * 8192, oacc, inv, out, split, nh, head, grouped ? (int64_t)B + (int64_t)b * (S - 1) : (int64_t)b * S + 1,
+    store_out_tile<T>(smem + wave * 8192, oacc, inv, out, split, nh, head, grouped ? (int64_t)grouped + (int64_t)b * (S - 1) : (int64_t)b * S + 1,
                       grouped ? (int64_t)b : (int64_t)b * S, S, q0, active, lane);
 }
 
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     __syncthreads();                     // every wave is done with the K / V^T ring and the table: the LDS becomes the store staging
-    store_out_tile<T>(smem + wave * 8192, oacc, inv, out, split, nh, head, grouped ? (int64_t)B + (int64_t)b * (S - 1) : (int64_t)b * S + 1,
+    store_out_tile<T>(smem + wave * 8192, oacc, inv, out, split, nh, head, grouped ? (int64_t)grouped + (int64_t)b * (S - 1) : (int64_t)b * S + 1,
                       grouped ? (int64_t)b : (int64_t)b * S, S, q0, active, lane);
 }
 
@@ -781,6 +781,7 @@ extern "C" int bs_attention_table(const void* q, const void* k, const void* vt, 
     BS_REQUIRE(q && k && vt && table && out && B >= 0 && nh > 0 && hp > 0, "bs_attention_table: bad argument");
     BS_REQUIRE(wp == 32, "bs_attention_table: built for windows of 32 patches per row (wp=%d): use bs_attention", wp);
     BS_REQUIRE(hp <= 40, "bs_attention_table: hp=%d: the table must fit 32 KiB of LDS", hp);
+    BS_REQUIRE(grouped == 0 || grouped >= B, "bs_attention_table: grouped=%d is the first patch row, >= B", grouped);
     const int S = hp * wp + 1;
     BS_REQUIRE(Sp % 64 == 0 && Sp >= S, "bs_attention_table: Sp=%d must be a multiple of 64 and >= S=%d", Sp, S);
     const int split = (dtype & 32) ? 2 : ((dtype & 16) ? 1 : 0);

@@ -209,18 +209,19 @@ extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
     p.qkv_hidden = d->qkv_hidden; p.qkv_tokens = d->qkv_tokens; p.qkv_sp = d->qkv_sp; p.q_scale = d->q_scale;
     p.qkv_cls_last = d->qkv_cls_last;
     p.qkv_cls_rows = d->qkv_cls_rows;
+    p.qkv_patch_row0 = d->qkv_patch_row0;
     p.f8_wonly_from = d->f8_wonly_from;
     BS_REQUIRE(d->f8_wonly_from == 0 || d->f8_seg > 0, "bs_gemm: f8_wonly_from needs the FP8 correction segment");
-    BS_REQUIRE(d->qkv_cls_rows == 0 || (d->out_mode == BS_OUT_QKV && d->qkv_cls_last && d->qkv_tokens > 1 &&
-                                        d->M == d->qkv_cls_rows * d->qkv_tokens),
-               "bs_gemm: qkv_cls_rows needs BS_OUT_QKV, qkv_cls_last and M = qkv_cls_rows * tokens");
+    BS_REQUIRE(d->qkv_cls_rows == 0 || (d->out_mode == BS_OUT_QKV && d->qkv_cls_last && d->qkv_tokens > 1 && d->qkv_patch_row0 >= d->qkv_cls_rows &&
+                                        d->M == d->qkv_patch_row0 + d->qkv_cls_rows * (d->qkv_tokens - 1)),
+               "bs_gemm: qkv_cls_rows needs BS_OUT_QKV, qkv_cls_last and M = qkv_patch_row0 + qkv_cls_rows * (tokens - 1)");
     if (d->out_mode == BS_OUT_SHUFFLE) {
         BS_REQUIRE(!d->conv && d->shuffle_s > 0 && d->shuffle_cout % 4 == 0 && d->N == d->shuffle_s * d->shuffle_s * d->shuffle_cout,
                    "bs_gemm: bad shuffle geometry");
         BS_REQUIRE(d->Hout > 0 && d->Wout > 0 && d->M % (d->Hout * d->Wout) == 0, "bs_gemm: shuffle needs the input grid in Hout/Wout");
     } else if (d->out_mode == BS_OUT_QKV) {
         BS_REQUIRE(d->out2 && d->out3 && d->qkv_hidden % 64 == 0 && d->N == 3 * d->qkv_hidden && d->qkv_tokens > 0 &&
-                       d->M % d->qkv_tokens == 0 && d->qkv_sp >= d->qkv_tokens && d->out_dtype == d->dtype,
+                       (d->qkv_cls_rows > 0 || d->M % d->qkv_tokens == 0) && d->qkv_sp >= d->qkv_tokens && d->out_dtype == d->dtype,
                    "bs_gemm: bad qkv geometry");
     } else {
         BS_REQUIRE(d->out_mode == BS_OUT_PLAIN && d->ldo >= d->N, "bs_gemm: bad out_mode/ldo");

@@ -58,7 +58,8 @@ struct IgemmParams {
     int shuffle_s, shuffle_cout;
     int qkv_hidden, qkv_tokens, qkv_sp;
     int qkv_cls_last;    // Q / K / V^T hold an image's tokens patches first, cls (token 0) last
-    int qkv_cls_rows;    // > 0: grouped rows -- the first qkv_cls_rows rows are the images' cls tokens, then tokens-1 patches per image
+    int qkv_cls_rows;    // > 0: grouped rows -- the first qkv_cls_rows rows are the images' cls tokens, patches from qkv_patch_row0 on
+    int qkv_patch_row0;
     int f8_wonly_from;   // tiles starting at a row >= this (> 0; -1: every tile) skip the second FP8 half (activation-rounding correction)
     float q_scale;
     int ntm, ntn;
@@ -583,7 +584,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                 } else {
                     int ob, otok;
                     if (p.qkv_cls_rows > 0) {      // grouped rows: cls tokens first, then the patches image by image (positions: cls last)
-                        const int mp = m - p.qkv_cls_rows;
+                        if (m >= p.qkv_cls_rows && m < p.qkv_patch_row0) continue;      // padding rows between the two groups
+                        const int mp = m - p.qkv_patch_row0;
                         ob = mp < 0 ? m : mp / (p.qkv_tokens - 1);
                         otok = mp < 0 ? p.qkv_tokens - 1 : mp - ob * (p.qkv_tokens - 1);
                     } else {
@@ -704,8 +706,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
             const int r = lane % PASS_R, csub = lane / PASS_R;
             const int m = m_base + r;
             int ob, otok;
+            bool pad_row = false;
             if (p.qkv_cls_rows > 0) {
-                const int mp = m - p.qkv_cls_rows;
+                pad_row = m >= p.qkv_cls_rows && m < p.qkv_patch_row0;
+                const int mp = m - p.qkv_patch_row0;
                 ob = mp < 0 ? m : mp / (p.qkv_tokens - 1);
                 otok = mp < 0 ? p.qkv_tokens - 1 : mp - ob * (p.qkv_tokens - 1);
             } else {
@@ -713,7 +717,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                 otok = m - ob * p.qkv_tokens;
                 if (p.qkv_cls_last) otok = otok == 0 ? p.qkv_tokens - 1 : otok - 1;
             }
-            if (m < p.M) {
+            if (m < p.M && !pad_row) {
                 for (int c0 = 0; c0 < TN; c0 += CPS) {
                     const int c = c0 + csub;
                     const int n = n_wave + c;

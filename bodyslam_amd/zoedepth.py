@@ -467,8 +467,12 @@ class _ZoePlan:
         # attention): rows [0, NB) are the cls tokens of the NB images, row NB + b*T0 + t is patch t of image b -- the cls rows
         # sit in the first GEMM tile, which alone evaluates the activation-rounding correction ("wcls", bs_gemm f8_wonly_from).
         # Otherwise image-major, cls first ([NB, S, hidden]).
+        # The cls group is padded to whole 256-row GEMM tiles (CP rows, NB of them used): a tile then holds either cls rows or patch
+        # rows, never both, so which rows get the activation-rounding correction does not depend on the batch size.
         grouped = use_tab
         self.grouped = grouped
+        CP = (NB + 255) // 256 * 256 if grouped else 0
+        MT = CP + NB * T0 if grouped else NB * S          # rows of the token tensors
 
         acc = eng.acc
         m2 = 2 if acc else 1          # channel multiplier of (hi | lo) activations
@@ -476,12 +480,12 @@ class _ZoePlan:
         SP = 16 if acc else 0         # "split" flag (bit 4 of the dtype argument) of the pointwise producers
         self.frames = torch.empty(B, H, W, 3, device=dev, dtype=torch.uint8)
         patches = e16(NB * T0, 3 * c.patch * c.patch * m2)
-        x = e32(NB * S, Hd)
-        xn = e16(NB * S, Hd * m2)
+        x = torch.zeros(MT, Hd, device=dev, dtype=torch.float32)           # (padding rows of the grouped layout stay finite)
+        xn = z16(MT, Hd * m2)
         q, k, vt = z16(NB, c.heads, Sp, 64), z16(NB, c.heads, Sp, 64), z16(NB, c.heads, 64, Sp)
-        ao = e16(NB * S, Hd * m2)
-        hid = e16(NB * S, c.intermediate * m2)
-        taps16 = [e16(NB * S, Hd * m2) for _ in c.taps]
+        ao = z16(MT, Hd * m2)
+        hid = z16(MT, c.intermediate * m2)
+        taps16 = [z16(MT, Hd * m2) for _ in c.taps]
 
         f8s = eng.f8s
 
@@ -512,7 +516,7 @@ class _ZoePlan:
                        f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_HI_EXP, sb0), precision_passes=1, **kw)
             elif acc and wkey in f8s:
                 sb0, sb1 = f8s[wkey]
-                wonly = NB if (eng.wmode.get(wkey) == "wcls" and grouped) else 0      # rows past the cls rows: weight correction only
+                wonly = CP if (eng.wmode.get(wkey) == "wcls" and grouped) else 0      # tiles past the cls group: weight correction only
                 P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=2 * K, f8_seg=2 * K, f8_wonly_from=wonly,
                        f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1), precision_passes=1, **kw)
             else:
@@ -521,10 +525,10 @@ class _ZoePlan:
         # ---- Z1 + Z2: pre-processing fused with the patch gather, patch embedding, cls token
         PK = 3 * c.patch * c.patch
         P.add("preprocess", "bs_preprocess_patches", self.frames, patches, B, H, W, nh_, nw_, int(flip), L.dt(patches) | fmt("pe.w"))
-        TOK = ("tokens_grouped" if grouped else "tokens", NB, S, Hd)
+        TOK = ("tokens_grouped" if grouped else "tokens", NB, S, Hd, CP)
         if grouped:
             P.add("cls", "bs_fill_rows", x, w["cls"], NB, 1, Hd)                 # rows 0 .. NB-1
-            bgemm("patch_embed", patches, "pe.w", x, NB * T0, Hd, PK, bias=w["pe.b"], out_group=(NB * T0, 0, NB))   # rows NB ..
+            bgemm("patch_embed", patches, "pe.w", x, NB * T0, Hd, PK, bias=w["pe.b"], out_group=(NB * T0, 0, CP))   # rows CP ..
         else:
             P.add("cls", "bs_fill_rows", x, w["cls"], NB, S, Hd)
             bgemm("patch_embed", patches, "pe.w", x, NB * T0, Hd, PK, bias=w["pe.b"], out_group=(T0, S, 1))
@@ -532,27 +536,27 @@ class _ZoePlan:
         # ---- Z3: BEiT layers
         ti = 0
         for l in range(c.layers):
-            P.add(f"l{l}.ln1", "bs_layernorm", x, w[f"l{l}.ln1.g"], w[f"l{l}.ln1.b"], xn, None, NB * S, Hd, c.ln_eps,
+            P.add(f"l{l}.ln1", "bs_layernorm", x, w[f"l{l}.ln1.g"], w[f"l{l}.ln1.b"], xn, None, MT, Hd, c.ln_eps,
                   L.dt(xn) | fmt(f"l{l}.qkv.w"))
-            bgemm(f"l{l}.qkv", xn, f"l{l}.qkv.w", q, NB * S, 3 * Hd, Hd, bias=w[f"l{l}.qkv.b"],
-                  qkv=(Hd, S, Sp, LOG2E / math.sqrt(64.0), k, vt, use_tab, NB if grouped else 0))
+            bgemm(f"l{l}.qkv", xn, f"l{l}.qkv.w", q, MT, 3 * Hd, Hd, bias=w[f"l{l}.qkv.b"],
+                  qkv=(Hd, S, Sp, LOG2E / math.sqrt(64.0), k, vt, use_tab, NB if grouped else 0, CP))
             if use_tab:
-                P.add(f"l{l}.attn", "bs_attention_table", q, k, vt, bias[l], ao, NB, c.heads, hp, wp, Sp, int(grouped),
+                P.add(f"l{l}.attn", "bs_attention_table", q, k, vt, bias[l], ao, NB, c.heads, hp, wp, Sp, CP,
                       L.dt(q) | fmt(f"l{l}.o.w"))
             else:
                 P.add(f"l{l}.attn", "bs_attention", q, k, vt, bias[l], ao, NB, c.heads, S, Sp, L.dt(q) | fmt(f"l{l}.o.w"))
-            bgemm(f"l{l}.o", ao, f"l{l}.o.w", x, NB * S, Hd, Hd, bias=w[f"l{l}.o.b"], scale=w[f"l{l}.lam1"], res=x, ldr=Hd)
-            P.add(f"l{l}.ln2", "bs_layernorm", x, w[f"l{l}.ln2.g"], w[f"l{l}.ln2.b"], xn, None, NB * S, Hd, c.ln_eps,
+            bgemm(f"l{l}.o", ao, f"l{l}.o.w", x, MT, Hd, Hd, bias=w[f"l{l}.o.b"], scale=w[f"l{l}.lam1"], res=x, ldr=Hd)
+            P.add(f"l{l}.ln2", "bs_layernorm", x, w[f"l{l}.ln2.g"], w[f"l{l}.ln2.b"], xn, None, MT, Hd, c.ln_eps,
                   L.dt(xn) | fmt(f"l{l}.fc1.w"))
             hfmt = fmt(f"l{l}.fc2.w")
-            bgemm(f"l{l}.fc1", xn, f"l{l}.fc1.w", hid, NB * S, c.intermediate, Hd, bias=w[f"l{l}.fc1.b"], act=L.ACT_GELU,
+            bgemm(f"l{l}.fc1", xn, f"l{l}.fc1.w", hid, MT, c.intermediate, Hd, bias=w[f"l{l}.fc1.b"], act=L.ACT_GELU,
                   ldo=c.intermediate * am(f"l{l}.fc2.w"), out_split_off=c.intermediate if hfmt else 0,
                   out_f8=(L.F8_ACT_HI_EXP, L.F8_ACT_LO_EXP) if hfmt == 32 else None)
-            bgemm(f"l{l}.fc2", hid, f"l{l}.fc2.w", x, NB * S, Hd, c.intermediate, bias=w[f"l{l}.fc2.b"], scale=w[f"l{l}.lam2"], res=x, ldr=Hd)
+            bgemm(f"l{l}.fc2", hid, f"l{l}.fc2.w", x, MT, Hd, c.intermediate, bias=w[f"l{l}.fc2.b"], scale=w[f"l{l}.lam2"], res=x, ldr=Hd)
             P.mark(f"layer{l + 1}", x, TOK)
             if (l + 1) in c.taps:
                 if acc:
-                    P.add(f"tap{ti}", "bs_cast_split", x, taps16[ti], NB * S, Hd, L.dt(xn) | (32 if eng.neck_f8 else 0))
+                    P.add(f"tap{ti}", "bs_cast_split", x, taps16[ti], MT, Hd, L.dt(xn) | (32 if eng.neck_f8 else 0))
                 else:
                     P.add(f"tap{ti}", "bs_cast", x, taps16[ti], x.numel(), L.dt(xn))
                 ti += 1
@@ -614,7 +618,7 @@ class _ZoePlan:
             # token half: the patch rows of every image, + c_b, GELU.  Grouped rows: a plain GEMM over rows NB..; image-major rows:
             # rows 1..S-1 of every image (a 1-row "conv" with a -1 column crop)
             if grouped:
-                nplain(f"ro{i}.tok", t16, f"ro{i}.w_tok", r16, NB * T0, Hd, Hd, a_offset=NB * Hd * m2, bias=cb, bias_group_rows=T0,
+                nplain(f"ro{i}.tok", t16, f"ro{i}.w_tok", r16, NB * T0, Hd, Hd, a_offset=CP * Hd * m2, bias=cb, bias_group_rows=T0,
                        act=L.ACT_GELU)
             elif acc and f"ro{i}.w_tok" in f8s:
                 P.gemm(f"ro{i}.tok", t16, w[f"ro{i}.w_tok"], r16, M=NB * T0, N=Hd, K=Hd, lda=2 * Hd, conv=(1, S, Hd, 1, T0, 1, 1, 1, 0, -1),

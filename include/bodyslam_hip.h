@@ -117,7 +117,9 @@ typedef struct bs_gemm_desc {
     int32_t qkv_cls_last;          /* BS_OUT_QKV: token 0 of an image (cls) is stored at position tokens-1 of Q / K / V^T and token t
                                     * at position t-1 (patches first: the layout bs_attention_table reads) */
     int32_t qkv_cls_rows;          /* BS_OUT_QKV, > 0: the rows are GROUPED -- rows [0, qkv_cls_rows) are the cls tokens of the images,
-                                    * row qkv_cls_rows + b*(tokens-1) + t is patch t of image b (needs qkv_cls_last) */
+                                    * row qkv_patch_row0 + b*(tokens-1) + t is patch t of image b (needs qkv_cls_last); the rows
+                                    * in between are padding and are not stored */
+    int32_t qkv_patch_row0;        /* >= qkv_cls_rows; M = qkv_patch_row0 + qkv_cls_rows * (tokens-1) */
     int32_t f8_wonly_from;         /* with f8_seg: 0 = every row gets both correction products; k > 0 = the 256-row tiles that start at
                                     * a row >= k evaluate only the first FP8 half (A_hi8 W_lo8, the weight-rounding correction) and
                                     * stop before the second (A_lo8 W_hi8, the activation-rounding correction); -1 = all rows.
@@ -144,8 +146,8 @@ int bs_attention(const void* q, const void* k, const void* vt, const float* bias
  * (2hp-1)(2wp-1) patch-pair entries stored in REVERSED order (entry i at index nbody-1-i: the 8 consecutive keys a lane
  * handles are then 8 ascending words), the three cls entries last, unchanged.
  * q / k / vt hold the tokens of an image patches first, cls LAST (S = hp*wp + 1; bs_gemm_desc.qkv_cls_last); out rows are in
- * the usual order (cls first per image), or with grouped != 0 the B cls rows first and then the hp*wp patch rows of every
- * image (bs_gemm_desc.qkv_cls_rows).  Built for wp == 32 (every 512-wide network input). */
+ * the usual order (cls first per image), or with grouped > 0 the B cls rows first and the hp*wp patch rows of image b from row
+ * grouped + b*hp*wp on (bs_gemm_desc.qkv_cls_rows / qkv_patch_row0).  Built for wp == 32 (every 512-wide network input). */
 int bs_attention_table(const void* q, const void* k, const void* vt, const float* table, void* out,
                        int32_t B, int32_t nh, int32_t hp, int32_t wp, int32_t Sp, int32_t grouped, int32_t dtype, void* stream);
 

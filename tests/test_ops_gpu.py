@@ -405,8 +405,9 @@ def test_qkv_scatter_and_attention(L, dtype, B, S, nh):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("B,hp,nh,split", [(2, 24, 16, 0), (1, 26, 4, 0), (3, 3, 2, 0), (2, 24, 2, 16), (2, 24, 2, 32)])
-def test_attention_table(L, dtype, B, hp, nh, split):
+@pytest.mark.parametrize("B,hp,nh,split,grouped", [(2, 24, 16, 0, 0), (1, 26, 4, 0, 0), (3, 3, 2, 0, 0), (2, 24, 2, 16, 0), (2, 24, 2, 32, 0),
+                                                   (3, 24, 2, 32, 256), (2, 4, 2, 0, 2)])
+def test_attention_table(L, dtype, B, hp, nh, split, grouped):
     """bs_attention_table (bias gathered from the per-head table in LDS; Q / K / V^T patches first, cls last) against torch
     softmax attention with HF's gathered [S, S] bias (modeling_beit.py:194-265), for the 24x32 and 26x32 windows of the
     full-size networks and a 3-row toy window; also the pair output formats of accurate mode."""
@@ -417,13 +418,21 @@ def test_attention_table(L, dtype, B, hp, nh, split):
     hidden = nh * 64
     ntab = (2 * hp - 1) * (2 * wp - 1) + 3
     LOG2E = 1.4426950408889634
-    x = rnd(B * S, hidden, seed=1, dtype=dtype)
+    x = rnd(B * S, hidden, seed=1, dtype=dtype)                    # image-major rows, cls first
     wqkv = rnd(3 * hidden, hidden, seed=2, scale=1 / math.sqrt(hidden), dtype=dtype)
     bqkv = rnd(3 * hidden, seed=3, scale=0.1)
     q = torch.zeros(B, nh, Sp, 64, device=dev(), dtype=dtype)
     k = torch.zeros(B, nh, Sp, 64, device=dev(), dtype=dtype)
     vt = torch.zeros(B, nh, 64, Sp, device=dev(), dtype=dtype)
-    L.gemm(x, wqkv, q, M=B * S, N=3 * hidden, K=hidden, lda=hidden, bias=bqkv, qkv=(hidden, S, Sp, 0.125 * LOG2E, k, vt, True))
+    if grouped:     # grouped rows: the B cls rows, padding up to row `grouped`, then the patch rows image by image
+        MT = grouped + B * (S - 1)
+        xg = torch.zeros(MT, hidden, device=dev(), dtype=dtype)
+        xv = x.view(B, S, hidden)
+        xg[:B] = xv[:, 0]
+        xg[grouped:] = xv[:, 1:].reshape(-1, hidden)
+        L.gemm(xg, wqkv, q, M=MT, N=3 * hidden, K=hidden, lda=hidden, bias=bqkv, qkv=(hidden, S, Sp, 0.125 * LOG2E, k, vt, True, B, grouped))
+    else:
+        L.gemm(x, wqkv, q, M=B * S, N=3 * hidden, K=hidden, lda=hidden, bias=bqkv, qkv=(hidden, S, Sp, 0.125 * LOG2E, k, vt, True))
     # the scatter put token t at position t-1 and the cls token last
     y = (x.float() @ wqkv.float().t() + bqkv).view(B, S, 3, nh, 64)
     perm = torch.cat([torch.arange(1, S), torch.zeros(1, dtype=torch.long)]).to(dev())
@@ -434,8 +443,11 @@ def test_attention_table(L, dtype, B, hp, nh, split):
     table = rnd(nh, ntab, seed=4)                                   # natural-log domain
     tab2 = (torch.cat([torch.flip(table[:, :ntab - 3], dims=[1]), table[:, ntab - 3:]], 1) * LOG2E).contiguous()   # the kernel's operand: body reversed
     mult = 2 if split else 1
-    out = torch.zeros(B * S, hidden * mult, device=dev(), dtype=dtype)
-    L.attention_table(q, k, vt, tab2, out, B, nh, hp, wp, Sp, split=split)
+    out = torch.zeros((grouped + B * (S - 1)) if grouped else B * S, hidden * mult, device=dev(), dtype=dtype)
+    L.attention_table(q, k, vt, tab2, out, B, nh, hp, wp, Sp, split=split, grouped=grouped)
+    if grouped:     # back to image-major rows for the comparison
+        assert out[B:grouped].abs().max().item() == 0 if grouped > B else True
+        out = torch.cat([out[:B].view(B, 1, -1), out[grouped:].view(B, S - 1, -1)], 1).reshape(B * S, -1)
     idx = _relative_position_index(hp, wp).to(dev())
     bias = table[:, idx.view(-1)].view(nh, S, S)                    # [nh, q, k] in token order (cls first)
     inv = torch.empty(S, dtype=torch.long, device=dev())
