@@ -74,6 +74,7 @@ _SIGS = {
     "bs_route_argmax": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p],
     "bs_postprocess_depth": [C.c_void_p] * 3 + [C.c_int32] * 6 + [C.c_void_p],
     "bs_cyclepose_im2col": [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p],
+    "bs_cyclepose_im2col_window": [C.c_void_p] * 3 + [C.c_int32] * 8 + [C.c_void_p],
     "bs_instnorm_relu_nhwc": [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_float, C.c_int32, C.c_void_p],
     "bs_avgpool_nhwc": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
     "bs_cyclepose_head": [C.c_void_p] * 12 + [C.c_int32] * 3 + [C.c_void_p],

@@ -17,8 +17,10 @@ constexpr int CP_K = 320;  // 7*7*6 = 294 padded to a multiple of 64
 // SPLIT: a row is [hi x 320 | lo x 320], value = hi + lo to ~22 bits (the A operand of a split-precision GEMM, bs_gemm seg1)
 template <typename T, bool SPLIT>
 __global__ __launch_bounds__(256) void cp_im2col_kernel(const uint8_t* frames, const int32_t* pairs, T* out, int P, int H, int W,
-                                                         int top, int left) {
-    const int64_t total = (int64_t)P * CP_CROP * CP_CROP * 54;  // 49 taps + 5 pad slots (6 elems each -> 324 >= 320)
+                                                         int top, int left, int CH, int CW) {
+    // the network sees the CH x CW window of every frame that starts at (top, left): 128 x 128 centre crop, or a whole
+    // (already resized) frame
+    const int64_t total = (int64_t)P * CH * CW * 54;  // 49 taps + 5 pad slots (6 elems each -> 324 >= 320)
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
     const int slot = (int)(gid % 54);
@@ -33,13 +35,13 @@ __global__ __launch_bounds__(256) void cp_im2col_kernel(const uint8_t* frames, c
         }
         return;
     }
-    const int x = (int)(m % CP_CROP);
-    const int y = (int)((m / CP_CROP) % CP_CROP);
-    const int p = (int)(m / (CP_CROP * CP_CROP));
+    const int x = (int)(m % CW);
+    const int y = (int)((m / CW) % CH);
+    const int p = (int)(m / ((int64_t)CW * CH));
     const int ky = slot / 7, kx = slot - ky * 7;
     int yy = y + ky - 3, xx = x + kx - 3;
-    yy = yy < 0 ? -yy : (yy >= CP_CROP ? 2 * CP_CROP - 2 - yy : yy);  // ReflectionPad2d(3)
-    xx = xx < 0 ? -xx : (xx >= CP_CROP ? 2 * CP_CROP - 2 - xx : xx);
+    yy = yy < 0 ? -yy : (yy >= CH ? 2 * CH - 2 - yy : yy);  // ReflectionPad2d(3)
+    xx = xx < 0 ? -xx : (xx >= CW ? 2 * CW - 2 - xx : xx);
     const int f0 = pairs[2 * p], f1 = pairs[2 * p + 1];
     const uint8_t* p0 = frames + (((int64_t)f0 * H + top + yy) * W + left + xx) * 3;
     const uint8_t* p1 = frames + (((int64_t)f1 * H + top + yy) * W + left + xx) * 3;
@@ -241,6 +243,23 @@ __global__ __launch_bounds__(64) void pose_head_kernel(const float* pooled, cons
 
 }  // namespace bs
 
+static int im2col_launch(const uint8_t* frames, const int32_t* pairs, void* out, int P, int H, int W, int top, int left, int CH, int CW,
+                         int dtype, bool split, hipStream_t st) {
+    using namespace bs;
+    const int64_t total = (int64_t)P * CH * CW * 54;
+    const unsigned blocks = (unsigned)cdiv64(total, 256);
+    if (dtype == BS_F16 && split)
+        hipLaunchKernelGGL((cp_im2col_kernel<f16, true>), dim3(blocks), dim3(256), 0, st, frames, pairs, (f16*)out, P, H, W, top, left, CH, CW);
+    else if (dtype == BS_F16)
+        hipLaunchKernelGGL((cp_im2col_kernel<f16, false>), dim3(blocks), dim3(256), 0, st, frames, pairs, (f16*)out, P, H, W, top, left, CH, CW);
+    else if (split)
+        hipLaunchKernelGGL((cp_im2col_kernel<bf16, true>), dim3(blocks), dim3(256), 0, st, frames, pairs, (bf16*)out, P, H, W, top, left, CH, CW);
+    else
+        hipLaunchKernelGGL((cp_im2col_kernel<bf16, false>), dim3(blocks), dim3(256), 0, st, frames, pairs, (bf16*)out, P, H, W, top, left, CH, CW);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
 extern "C" int bs_cyclepose_im2col(const uint8_t* frames, const int32_t* pairs, void* out, int32_t P, int32_t H, int32_t W,
                                    int32_t dtype, void* stream) {
     using namespace bs;
@@ -254,19 +273,21 @@ extern "C" int bs_cyclepose_im2col(const uint8_t* frames, const int32_t* pairs, 
     // torchvision CenterCrop: top = int(round((H - 128) / 2.0)) (Python banker's rounding of x.5)
     auto pyround_half = [](int v) { const int q = v / 2; return (v % 2 == 0) ? q : ((q % 2 == 0) ? q : q + 1); };
     const int top = pyround_half(H - CP_CROP), left = pyround_half(W - CP_CROP);
-    const int64_t total = (int64_t)P * CP_CROP * CP_CROP * 54;
-    const unsigned blocks = (unsigned)cdiv64(total, 256);
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == BS_F16 && split)
-        hipLaunchKernelGGL((cp_im2col_kernel<f16, true>), dim3(blocks), dim3(256), 0, st, frames, pairs, (f16*)out, P, H, W, top, left);
-    else if (dtype == BS_F16)
-        hipLaunchKernelGGL((cp_im2col_kernel<f16, false>), dim3(blocks), dim3(256), 0, st, frames, pairs, (f16*)out, P, H, W, top, left);
-    else if (split)
-        hipLaunchKernelGGL((cp_im2col_kernel<bf16, true>), dim3(blocks), dim3(256), 0, st, frames, pairs, (bf16*)out, P, H, W, top, left);
-    else
-        hipLaunchKernelGGL((cp_im2col_kernel<bf16, false>), dim3(blocks), dim3(256), 0, st, frames, pairs, (bf16*)out, P, H, W, top, left);
-    BS_CHECK_LAUNCH();
-    return BS_OK;
+    return im2col_launch(frames, pairs, out, P, H, W, top, left, CP_CROP, CP_CROP, dtype, split, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int bs_cyclepose_im2col_window(const uint8_t* frames, const int32_t* pairs, void* out, int32_t P, int32_t H, int32_t W,
+                                          int32_t top, int32_t left, int32_t CH, int32_t CW, int32_t dtype, void* stream) {
+    using namespace bs;
+    if (!initialized()) { set_error("bs_cyclepose_im2col_window: call bs_init first"); return BS_ERR_NOT_INIT; }
+    BS_REQUIRE(frames && pairs && out && P >= 0, "bs_cyclepose_im2col_window: bad argument");
+    BS_REQUIRE(CH >= 4 && CW >= 4 && top >= 0 && left >= 0 && top + CH <= H && left + CW <= W,
+               "bs_cyclepose_im2col_window: window %dx%d at (%d,%d) outside the %dx%d frame (or smaller than the reflection pad)", CW, CH, left, top, W, H);
+    const bool split = (dtype & 16) != 0;
+    dtype &= 15;
+    BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_cyclepose_im2col_window: dtype");
+    if (P == 0) return BS_OK;
+    return im2col_launch(frames, pairs, out, P, H, W, top, left, CH, CW, dtype, split, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int bs_instnorm_relu_nhwc(const float* x, void* out, float* out_f32, float* scratch, int32_t P, int32_t HW, int32_t C,

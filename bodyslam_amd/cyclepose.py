@@ -68,29 +68,47 @@ class CyclePoseEngine:
         if "skip_linear.weight" not in weights:
             raise KeyError("skip_linear.weight missing: the reference would silently use a random layer here "
                            "(architecture_v3.py:208-209); pass it explicitly")
-        ws = g("skip_linear.weight")
-        assert ws.shape == (7, SKIP_FEATURES), ws.shape
-        w["skip.pool"] = f(ws[:, :512])
-        w["skip.x2"] = f(ws[:, 512:].view(7, 256, 1024).permute(0, 2, 1))      # NCHW flatten -> [7][HW][C]
-        w["skip.b"] = f(g("skip_linear.bias"))
+        # skip_linear is sized by the network input (architecture_v3.py:205-209): one weight per input window, keyed by the
+        # number of pixels of the stride-4 map (32*32 for the 128x128 crop)
+        self._skip = {}
+        self.add_skip(g("skip_linear.weight"), g("skip_linear.bias"))
         w["d1.w"], w["d1.b"] = f(g("pose_dense.1.weight")), f(g("pose_dense.1.bias"))
         w["d2.w"], w["d2.b"] = f(g("pose_dense.3.weight")), f(g("pose_dense.3.bias"))
 
-    def plan_for(self, N: int, P: int, H: int, W: int) -> "_PosePlan":
-        key = (N, P, H, W)
+    def add_skip(self, weight: torch.Tensor, bias: torch.Tensor) -> int:
+        """Register a skip_linear weight [7, 512 + 256*h*w] (h x w = the stride-4 map of the network input); returns h*w."""
+        ws = weight.detach().float()
+        assert ws.dim() == 2 and ws.shape[0] == 7 and (ws.shape[1] - 512) % 256 == 0 and ws.shape[1] > 512, ws.shape
+        hw = (ws.shape[1] - 512) // 256
+        f = lambda t: t.to(self.dev, dtype=torch.float32).contiguous()
+        self._skip[hw] = (f(ws[:, :512]), f(ws[:, 512:].view(7, 256, hw).permute(0, 2, 1)),      # NCHW flatten -> [7][HW][C]
+                          f(bias.detach().float()))
+        return hw
+
+    @staticmethod
+    def map_hw(ch: int, cw: int):
+        """spatial size after the two stride-2 convolutions (k3 p1): the map skip_linear flattens"""
+        h1, w1 = (ch - 1) // 2 + 1, (cw - 1) // 2 + 1
+        return (h1 - 1) // 2 + 1, (w1 - 1) // 2 + 1
+
+    def plan_for(self, N: int, P: int, H: int, W: int, window=None) -> "_PosePlan":
+        key = (N, P, H, W, window)
         if key not in self._plans:
-            self._plans[key] = _PosePlan(self, N, P, H, W)
+            self._plans[key] = _PosePlan(self, N, P, H, W, window)
         return self._plans[key]
 
-    def infer_pairs(self, frames_u8: torch.Tensor, pairs: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+    def infer_pairs(self, frames_u8: torch.Tensor, pairs: torch.Tensor, taps: Optional[dict] = None, window=None) -> torch.Tensor:
         """frames uint8 [N,H,W,3] (GPU), pairs int32 [P,2] (indices into frames: prev, curr)
-        -> relative poses fp32 [P,4,4] (the plan's static buffer)."""
+        -> relative poses fp32 [P,4,4] (the plan's static buffer).  window: None = the reference's CenterCrop(128); "full" = the
+        whole frame is the network input (type_of_trans='resize': frames already resized to 128 x W'), or (top, left, h, w)."""
         assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and pairs.dtype == torch.int32
         N, H, W, _ = frames_u8.shape
         P = pairs.shape[0]
         if P == 0:      # no pair: nothing to launch
             return torch.empty(0, 4, 4, device=self.dev)
-        plan = self.plan_for(N, P, H, W)
+        if window == "full":
+            window = (0, 0, H, W)
+        plan = self.plan_for(N, P, H, W, window)
         plan.frames.copy_(frames_u8)
         plan.pairs.copy_(pairs)
         plan.plan.run(taps)
@@ -98,50 +116,63 @@ class CyclePoseEngine:
 
 
 class _PosePlan:
-    def __init__(self, eng: CyclePoseEngine, N: int, P: int, H: int, W: int):
+    def __init__(self, eng: CyclePoseEngine, N: int, P: int, H: int, W: int, window=None):
         w, dt_, dev = eng.w, eng.dtype, eng.dev
+        CH, CW = (CROP, CROP) if window is None else (window[2], window[3])
+        h2, w2 = eng.map_hw(CH, CW)
+        if h2 * w2 not in eng._skip:
+            raise KeyError(f"no skip_linear weight for a {CH}x{CW} network input ({512 + 256 * h2 * w2} features): "
+                           "register one with CyclePoseEngine.add_skip (the reference would create a random layer, architecture_v3.py:208-209)")
+        skip_pool, skip_x2, skip_b = eng._skip[h2 * w2]
+        H1, W1 = (CH - 1) // 2 + 1, (CW - 1) // 2 + 1
+        H3, W3 = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
         e16 = lambda *s: torch.empty(*s, device=dev, dtype=dt_)
         e32 = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         self.frames = torch.empty(N, H, W, 3, device=dev, dtype=torch.uint8)
         self.pairs = torch.zeros(P, 2, device=dev, dtype=torch.int32)
         Pl = self.plan = L.Plan(dev)
-        in_scratch = e32(P * (CROP * CROP // 256) * 2 * 256)
+        in_scratch = e32(P * ((CH * CW + 255) // 256) * 2 * 256)
         acc = eng.acc
         m2, SP = (2, 16) if acc else (1, 0)           # pair multiplier / the producers' "split" flag
 
-        def conv(name, A, out, hin, ci, co, **kw):
+        def conv(name, A, out, hin, win, ci, co, **kw):
+            ho, wo = (hin - 1) // 2 + 1, (win - 1) // 2 + 1
             if acc:
-                Pl.gemm(name, A, w[name + ".w"], out, M=P * (hin // 2) ** 2, N=co, K=9 * ci * 3, lda=2 * ci, seg1=ci,
-                        conv=L.conv_geom(hin, hin, 2 * ci, 3, 3, 2, 1), bias=w[name + ".b"], precision_passes=3, **kw)
+                Pl.gemm(name, A, w[name + ".w"], out, M=P * ho * wo, N=co, K=9 * ci * 3, lda=2 * ci, seg1=ci,
+                        conv=(hin, win, 2 * ci, ho, wo, 3, 3, 2, 1, 1), bias=w[name + ".b"],
+                        precision_passes=3, **kw)
             else:
-                Pl.gemm(name, A, w[name + ".w"], out, M=P * (hin // 2) ** 2, N=co, K=9 * ci, lda=ci,
-                        conv=L.conv_geom(hin, hin, ci, 3, 3, 2, 1), bias=w[name + ".b"], **kw)
+                Pl.gemm(name, A, w[name + ".w"], out, M=P * ho * wo, N=co, K=9 * ci, lda=ci,
+                        conv=(hin, win, ci, ho, wo, 3, 3, 2, 1, 1), bias=w[name + ".b"], **kw)
 
-        cols = e16(P * CROP * CROP, K0 * m2)
-        Pl.add("im2col", "bs_cyclepose_im2col", self.frames, self.pairs, cols, P, H, W, L.dt(cols) | SP)
-        c0 = e32(P, CROP, CROP, 64)
-        Pl.gemm("c0", cols, w["c0.w"], c0, M=P * CROP * CROP, N=64, K=K0 * (3 if acc else 1), lda=K0 * m2, seg1=K0 if acc else 0,
+        cols = e16(P * CH * CW, K0 * m2)
+        if window is None:
+            Pl.add("im2col", "bs_cyclepose_im2col", self.frames, self.pairs, cols, P, H, W, L.dt(cols) | SP)
+        else:
+            Pl.add("im2col", "bs_cyclepose_im2col_window", self.frames, self.pairs, cols, P, H, W, window[0], window[1], CH, CW, L.dt(cols) | SP)
+        c0 = e32(P, CH, CW, 64)
+        Pl.gemm("c0", cols, w["c0.w"], c0, M=P * CH * CW, N=64, K=K0 * (3 if acc else 1), lda=K0 * m2, seg1=K0 if acc else 0,
                 bias=w["c0.b"], precision_passes=3 if acc else 1)
-        a0 = e16(P, CROP, CROP, 64 * m2)
-        Pl.add("in0", "bs_instnorm_relu_nhwc", c0, a0, None, in_scratch, P, CROP * CROP, 64, 1e-5, L.dt(a0) | SP)
-        Pl.mark("c0", a0, ("nhwc", P, CROP, CROP, 64, 1 if acc else 0))
-        c1 = e32(P, 64, 64, 128)
-        conv("c1", a0, c1, 128, 64, 128)
-        a1 = e16(P, 64, 64, 128 * m2)
-        Pl.add("in1", "bs_instnorm_relu_nhwc", c1, a1, None, in_scratch, P, 64 * 64, 128, 1e-5, L.dt(a1) | SP)
-        c2 = e32(P, 32, 32, 256)
-        conv("c2", a1, c2, 64, 128, 256)
-        a2 = e16(P, 32, 32, 256 * m2)
-        x2 = e32(P, 32, 32, 256)
-        Pl.add("in2", "bs_instnorm_relu_nhwc", c2, a2, x2, in_scratch, P, 32 * 32, 256, 1e-5, L.dt(a2) | SP)
-        Pl.mark("c2", x2, ("nhwc", P, 32, 32, 256))
-        c3 = e32(P, 16, 16, 512)
-        conv("c3", a2, c3, 32, 256, 512, act=L.ACT_RELU)
+        a0 = e16(P, CH, CW, 64 * m2)
+        Pl.add("in0", "bs_instnorm_relu_nhwc", c0, a0, None, in_scratch, P, CH * CW, 64, 1e-5, L.dt(a0) | SP)
+        Pl.mark("c0", a0, ("nhwc", P, CH, CW, 64, 1 if acc else 0))
+        c1 = e32(P, H1, W1, 128)
+        conv("c1", a0, c1, CH, CW, 64, 128)
+        a1 = e16(P, H1, W1, 128 * m2)
+        Pl.add("in1", "bs_instnorm_relu_nhwc", c1, a1, None, in_scratch, P, H1 * W1, 128, 1e-5, L.dt(a1) | SP)
+        c2 = e32(P, h2, w2, 256)
+        conv("c2", a1, c2, H1, W1, 128, 256)
+        a2 = e16(P, h2, w2, 256 * m2)
+        x2 = e32(P, h2, w2, 256)
+        Pl.add("in2", "bs_instnorm_relu_nhwc", c2, a2, x2, in_scratch, P, h2 * w2, 256, 1e-5, L.dt(a2) | SP)
+        Pl.mark("c2", x2, ("nhwc", P, h2, w2, 256))
+        c3 = e32(P, H3, W3, 512)
+        conv("c3", a2, c3, h2, w2, 256, 512, act=L.ACT_RELU)
         pooled = e32(P, 512)
-        Pl.add("pool", "bs_avgpool_nhwc", c3, pooled, P, 16 * 16, 512)
+        Pl.add("pool", "bs_avgpool_nhwc", c3, pooled, P, H3 * W3, 512)
         Pl.mark("pooled", pooled, ("raw",))
         self.pose7 = e32(P, 7)
         self.T = e32(P, 16)
-        scratch = e32(P * 64 * 8)
-        Pl.add("head", "bs_cyclepose_head", pooled, x2, w["skip.pool"], w["skip.x2"], w["skip.b"], w["d1.w"], w["d1.b"], w["d2.w"], w["d2.b"],
-               self.pose7, self.T, scratch, P, 32 * 32, 256)
+        scratch = e32(P * ((h2 * w2 * 256 + 4095) // 4096) * 8)
+        Pl.add("head", "bs_cyclepose_head", pooled, x2, skip_pool, skip_x2, skip_b, w["d1.w"], w["d1.b"], w["d2.w"], w["d2.b"],
+               self.pose7, self.T, scratch, P, h2 * w2, 256)

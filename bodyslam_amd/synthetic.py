@@ -62,7 +62,8 @@ def zoedepth_param_shapes(cfg) -> dict:
         for r in ("residual_layer1", "residual_layer2"):
             for c in ("convolution1", "convolution2"):
                 s[p + f"{r}.{c}.weight"], s[p + f"{r}.{c}.bias"] = (F_, F_, 3, 3), (F_,)
-    s["relative_head.projection.weight"], s["relative_head.projection.bias"] = (256, 256, 3, 3), (256,)
+    if getattr(cfg, "add_projection", True):
+        s["relative_head.projection.weight"], s["relative_head.projection.bias"] = (256, 256, 3, 3), (256,)
     s["relative_head.conv1.weight"], s["relative_head.conv1.bias"] = (F_ // 2, F_, 3, 3), (F_ // 2,)
     s["relative_head.conv2.weight"], s["relative_head.conv2.bias"] = (cfg.rel_features, F_ // 2, 3, 3), (cfg.rel_features,)
     s["relative_head.conv3.weight"], s["relative_head.conv3.bias"] = (1, cfg.rel_features, 1, 1), (1,)

@@ -61,6 +61,7 @@ class ZoeConfig:
     pt_inter: int = 1024
     pt_heads: int = 4
     head_names: Tuple[str, ...] = ("nyu", "kitti")     # one name = a single-head model (ZoeD_N: ("nyu",), ZoeD_K: ("kitti",))
+    add_projection: bool = True    # HF ZoeDepthConfig.add_projection; the engine follows the WEIGHTS (relative_head.projection.* present or not)
     level_attractors: Tuple[int, ...] = (16, 8, 4, 1)  # single-head models only (HF num_attractors); the NK head uses n_attractors
 
     @property
@@ -291,7 +292,9 @@ class ZoeDepthEngine:
                 for cv in (1, 2):
                     w[f"fu{i}.r{r}.c{cv}.w"] = self._wc(f"fu{i}.r{r}.c{cv}.w", g(p + f"residual_layer{r}.convolution{cv}.weight"))
                     w[f"fu{i}.r{r}.c{cv}.b"] = self._f(g(p + f"residual_layer{r}.convolution{cv}.bias"))
-        for n in ("projection", "conv1", "conv2"):
+        # relative_head.projection exists only in checkpoints converted with config.add_projection (HF modeling_zoedepth.py:344-346)
+        self.add_projection = "relative_head.projection.weight" in sd
+        for n in (("projection",) if self.add_projection else ()) + ("conv1", "conv2"):
             w[f"rh.{n}.w"] = self._wc(f"rh.{n}.w", g(f"relative_head.{n}.weight"))
             w[f"rh.{n}.b"] = self._f(g(f"relative_head.{n}.bias"))
         # ---- metric head
@@ -742,8 +745,11 @@ class _ZoePlan:
             fused_list.append((fused, 2 * fh, 2 * fw))
         # ---- Z6: relative head (conv3 + ReLU -> relative depth is dead code for the NK output and not launched)
         f3, h3, w3 = fused_list[3]
-        rp = e16(NB, h3, w3, Fc * m2)
-        nconv("rh.projection", f3, "rh.projection.w", rp, h3, w3, Fc, Fc, bias=w["rh.projection.b"], act=L.ACT_RELU)
+        if eng.add_projection:
+            rp = e16(NB, h3, w3, Fc * m2)
+            nconv("rh.projection", f3, "rh.projection.w", rp, h3, w3, Fc, Fc, bias=w["rh.projection.b"], act=L.ACT_RELU)
+        else:
+            rp = f3
         r1 = e16(NB, h3, w3, (Fc // 2) * m2)
         nconv("rh.conv1", rp, "rh.conv1.w", r1, h3, w3, Fc, Fc // 2, bias=w["rh.conv1.b"])
         r1u = e16(NB, 2 * h3, 2 * w3, (Fc // 2) * m2)

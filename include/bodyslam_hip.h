@@ -243,6 +243,10 @@ int bs_postprocess_depth(const float* depth_net, float* depth_m, uint16_t* depth
  * concat, ReflectionPad(3) and 7x7 im2col: out [P*128*128, 320] (k = (ky*7+kx)*6 + c, zero padded 294..319) */
 int bs_cyclepose_im2col(const uint8_t* frames, const int32_t* pairs, void* out, int32_t P, int32_t H, int32_t W,
                         int32_t dtype, void* stream);
+/* the same over an arbitrary CH x CW window at (top, left) of every frame (type_of_trans='resize', mpem_interface.py:45-50,88-90:
+ * the frames arrive already resized to 128 x W' by PIL and the window is the whole frame); rows [P*CH*CW, 320 (x2 with | 16)] */
+int bs_cyclepose_im2col_window(const uint8_t* frames, const int32_t* pairs, void* out, int32_t P, int32_t H, int32_t W,
+                               int32_t top, int32_t left, int32_t CH, int32_t CW, int32_t dtype, void* stream);
 /* InstanceNorm2d(eps, no affine) + ReLU on an NHWC map, fp32 in -> fp16/bf16 out (+ optional fp32 copy)
  * architecture_v3.py:123-124,134-137.  scratch: >= P * ceil(HW/256) * 2 * C floats (per-chunk mean / M2). */
 int bs_instnorm_relu_nhwc(const float* x, void* out, float* out_f32, float* scratch, int32_t P, int32_t HW, int32_t C,

@@ -144,7 +144,7 @@ def hf_config(c: Z.ZoeConfig):
                            out_features=[f"stage{t}" for t in c.taps])
     return ZoeDepthConfig(
         backbone_config=backbone_config, neck_hidden_sizes=list(c.neck_hidden), fusion_hidden_size=c.fusion,
-        reassemble_factors=list(c.reassemble_factors), readout_type="project", add_projection=True,
+        reassemble_factors=list(c.reassemble_factors), readout_type="project", add_projection=c.add_projection,
         num_relative_features=c.rel_features, bottleneck_features=c.bottleneck, bin_embedding_dim=c.bin_dim,
         num_attractors=[16, 8, 4, 1], attractor_alpha=1000, attractor_gamma=2, attractor_kind="mean",
         min_temp=c.min_temp, max_temp=c.max_temp, bin_centers_type="softplus",

@@ -68,6 +68,10 @@ class ZoeConfig:
     pt_inter: int = 1024
     pt_heads: int = 4
     head_names: Tuple[str, ...] = ("nyu", "kitti")
+    # HF ZoeDepthConfig.add_projection (modeling_zoedepth.py:344-346,358-360): a 3x3 256->256 conv + ReLU in front of the relative
+    # head.  The survey's configuration ("as recalled") has it; HF's config default is False and upstream
+    # MiDaS has no such layer, so a real checkpoint may lack it: the forward keys on the weight being present.
+    add_projection: bool = True
 
     @property
     def head_dim(self) -> int:
@@ -155,8 +159,9 @@ def param_shapes(cfg: ZoeConfig) -> Dict[str, Tuple[int, ...]]:
             for c in ("convolution1", "convolution2"):
                 s[p + f"{r}.{c}.weight"] = (Fh, Fh, 3, 3)
                 s[p + f"{r}.{c}.bias"] = (Fh,)
-    s["relative_head.projection.weight"] = (256, 256, 3, 3)
-    s["relative_head.projection.bias"] = (256,)
+    if cfg.add_projection:
+        s["relative_head.projection.weight"] = (256, 256, 3, 3)
+        s["relative_head.projection.bias"] = (256,)
     s["relative_head.conv1.weight"] = (Fh // 2, Fh, 3, 3)
     s["relative_head.conv1.bias"] = (Fh // 2,)
     s["relative_head.conv2.weight"] = (cfg.rel_features, Fh // 2, 3, 3)
@@ -458,7 +463,9 @@ def neck_forward(w, cfg: ZoeConfig, hiddens: Sequence[torch.Tensor], hp: int, wp
 
 
 def relative_head_forward(w, fused_last: torch.Tensor, taps_out=None):
-    y = F.relu(F.conv2d(fused_last, w["relative_head.projection.weight"], w["relative_head.projection.bias"], padding=1))
+    y = fused_last
+    if "relative_head.projection.weight" in w:       # config.add_projection (modeling_zoedepth.py:358-360)
+        y = F.relu(F.conv2d(y, w["relative_head.projection.weight"], w["relative_head.projection.bias"], padding=1))
     y = F.conv2d(y, w["relative_head.conv1.weight"], w["relative_head.conv1.bias"], padding=1)
     y = F.interpolate(y, scale_factor=2, mode="bilinear", align_corners=True)
     feat = F.relu(F.conv2d(y, w["relative_head.conv2.weight"], w["relative_head.conv2.bias"], padding=1))

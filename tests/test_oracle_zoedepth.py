@@ -45,13 +45,17 @@ def test_per_image_route_is_batch_invariant():
     assert np.abs(d_all.numpy() - d_one.numpy()).max() < 2e-5
 
 
-def test_live_against_hf_tiny():
+@pytest.mark.parametrize("add_projection", [True, False])
+def test_live_against_hf_tiny(add_projection):
+    """add_projection False = HF's config default (no conv in front of the relative head): the oracle keys on the weight"""
+    import dataclasses
     tr = pytest.importorskip("transformers")
     from oracle.make_golden import hf_config
-    cfg = Z.tiny_config()
+    cfg = dataclasses.replace(Z.tiny_config(), add_projection=add_projection)
     w = Z.synth_weights(cfg, seed=9)
     m = tr.ZoeDepthForDepthEstimation(hf_config(cfg)).eval()
     m.load_state_dict(w, strict=True)
+    assert ("relative_head.projection.weight" in w) == add_projection
     x = torch.randn(2, 3, 96, 64, generator=torch.Generator().manual_seed(0))
     with torch.no_grad():
         o = m(pixel_values=x)

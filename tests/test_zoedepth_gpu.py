@@ -149,6 +149,19 @@ def test_small_backbone_full_head(dtype, route_bias):
     report(f"[{tag}] u16: max |diff| = {lsb.max()} LSB, mean {lsb.mean():.3f}")
 
 
+@pytest.mark.parametrize("precision", ["accurate", "fast"])
+def test_small_without_relative_head_projection(precision):
+    """HF's config default add_projection=False (a checkpoint without relative_head.projection.*): the engine follows the weights
+    and feeds the last fused map straight into relative_head.conv1."""
+    cfg_o = dataclasses.replace(small_oracle_cfg(), add_projection=False)
+    r = run_case(cfg_o, torch.float16, B=2, H=120, W=160, target_hw=(96, 128), seed=6, precision=precision)
+    compare_taps(r["taps_p"], r["taps_o"], None, f"small no-projection {precision}")
+    l1 = (r["dm"] - r["ref"]).abs().mean().item()
+    report(f"[small no-projection {precision}] depth L1={l1:.3e}")
+    assert torch.equal(torch.argmax(r["logits_o"], -1).int(), r["route_p"])
+    assert l1 < (1e-4 if precision == "accurate" else 2e-3)
+
+
 def test_small_accurate_mode():
     """precision="accurate" (split-precision products in the neck / heads, split weights in the backbone) on the small case:
     every split code path (cast_split, relu_split, split resize / add_resized / logbinom, 2- and 3-segment GEMMs) runs and must
