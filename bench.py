@@ -42,10 +42,51 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_TRAFFIC_FILE = "r02_pmc_hbm_traffic.json"   # HBM bytes per launch by PMC counters, collected offline (profiles/README.md)
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 TILE_NAMES = {1: "128x128x64s2", 2: "128x64x64s2", 3: "128x32x64s2", 4: "256x128x64s2", 5: "256x128x64s3", 6: "256x256x32s4",
               7: "128x128x64s3", 8: "256x128x32s4", 9: "256x256x64s2", 10: "256x256x32s4pp", 11: "256x128x32s3"}
+
+
+def measure_pmc_traffic(args):
+    """{kernel name: (launches, mean FETCH_SIZE KB, mean WRITE_SIZE KB)} from two `rocprofv3 --pmc` child runs, or None."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="bs_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", counter, "--",
+                   "python3", os.path.join(ROOT, "bench.py"), "--single-mode", "--precision", args.precision, "--steps", "1", "--warmup", "0",
+                   "--batch", str(args.batch), "--dtype", args.dtype, "--height", str(args.height), "--width", str(args.width),
+                   "--no-cpu-baseline", "--no-kernel-timing", "--no-pmc-traffic"]
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            path = None
+            for dp, _, fns in os.walk(tmp):
+                for fn in fns:
+                    if fn.startswith(counter) and fn.endswith("counter_collection.csv"):
+                        path = os.path.join(dp, fn)
+            if path is None:
+                return None
+            with open(path, newline="") as f:
+                for row in csv.DictReader(f):
+                    if row["Counter_Name"] != counter:
+                        continue
+                    a = out.setdefault(row["Kernel_Name"], {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]})[counter]
+                    a[0] += 1
+                    a[1] += float(row["Counter_Value"])
+        return {k: (max(v["FETCH_SIZE"][0], v["WRITE_SIZE"][0]), v["FETCH_SIZE"][1] / max(v["FETCH_SIZE"][0], 1),
+                    v["WRITE_SIZE"][1] / max(v["WRITE_SIZE"][0], 1)) for k, v in out.items()}
+    except Exception as e:      # no profiler / not permitted here: the line carries traffic = null
+        print(f"[bench] PMC traffic pass skipped: {e!r}", file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -66,11 +107,18 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank runs its own sequence, --batch frames per step; strong: one --frames sequence cut across the ranks")
     ap.add_argument("--frames", type=int, default=1000, help="sequence length of --scaling strong (BASELINE config 4: 1000)")
+    ap.add_argument("--no-pmc-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # HBM traffic of every kernel by PMC counters, BEFORE this process touches the GPU: two child runs of this same command
+    # (one timed step) under rocprofv3, FETCH_SIZE and WRITE_SIZE in separate passes as the microarch guide prescribes
+    pmc = None
+    if world == 1 and "RANK" not in os.environ and not args.no_pmc_traffic and args.scaling == "weak":
+        pmc = measure_pmc_traffic(args)
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
@@ -174,10 +222,11 @@ def main():
             for (ci, e0, e1) in events:
                 gi = zplan.plan.gemm_info[ci]
                 key = ("conv" if gi["conv"] else "gemm", gi["tile"])
-                a = agg.setdefault(key, dict(ms=0.0, flops=0.0, alg=0.0, n=0))
+                a = agg.setdefault(key, dict(ms=0.0, flops=0.0, alg=0.0, n=0, bytes=0.0))
                 a["ms"] += e0.elapsed_time(e1)
                 a["flops"] += gi["flops"]
                 a["alg"] += gi["alg_flops"]
+                a["bytes"] += gi["bytes"]
                 a["n"] += 1
             for (kind, tile), a in agg.items():
                 kern_table[f"igemm_{kind}_{TILE_NAMES[tile]}"] = dict(
@@ -201,24 +250,25 @@ def main():
             exe = a["flops"] / (a["ms"] * 1e-3) / 1e12
             # HBM bytes per launch of that kernel from the committed PMC collection (separate --pmc passes, FETCH_SIZE doubled as
             # the microarch guide prescribes for gfx950); only valid for the batch / mode it was collected at
+            # HBM bytes per launch of that kernel: PMC counters of the child runs above (2 * FETCH_SIZE + WRITE_SIZE: gfx950's
+            # FETCH_SIZE counts 64 of every 128 streamed bytes, /opt/skills/guides/MI355X_MICROARCH.md "HBM"; values are KB)
             traffic, traffic_source = None, None
-            try:
-                pmc_file = PMC_TRAFFIC_FILE
-                pm = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+            if pmc and precision == args.precision:
                 mode = {"gemm": "ELi0E", "conv": "ELi1E"}[kind]
                 dims = TILE_NAMES[tile].split("s")[0].split("x")
-                cands = [v for name, v in pm["modes"][precision]["kernels"].items()
+                cands = [v for name, v in pmc.items()
                          if ("igemm_kernel" in name and f"Li{dims[0]}ELi{dims[1]}E" in name and f"Li{dims[2]}E" in name and mode in name
-                             and ("DF16_" in name) == (args.dtype == "f16") and B == pm.get("batch", 64) and not strong)]
+                             and ("DF16_" in name) == (args.dtype == "f16"))]
                 if cands:       # the F8 / plain instantiation with the most launches is the one the events timed
-                    traffic = round(max(cands, key=lambda v: v["launches"])["hbm_bytes_per_launch_corrected"])
-                    traffic_source = f"profiles/{pmc_file}: offline rocprofv3 PMC passes of this command (2*FETCH_SIZE + WRITE_SIZE), not measured in this run"
-            except Exception:
-                traffic = None
+                    n_l, f_kb, w_kb = max(cands, key=lambda v: v[0])
+                    traffic = round((2.0 * f_kb + w_kb) * 1024.0)
+                    traffic_source = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two child runs of this command (1 step) before the timed "
+                                      "run; (2*FETCH_SIZE + WRITE_SIZE) KB per launch, mean over the kernel's launches")
             roof = dict(bound="mfma", kernel=f"igemm_kernel<{args.dtype},{TILE_NAMES[tile]},{kind}>", achieved=round(ach, 1),
                         peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source,
                         executed=round(exe, 1), executed_frac=round(exe / MFMA_PEAK_TFLOPS, 4),
-                        avg_launch_us=round(1e3 * a["ms"] / a["n"], 2), gflop_per_launch=round(a["alg"] / a["n"] / 1e9, 3))
+                        avg_launch_us=round(1e3 * a["ms"] / a["n"], 2), gflop_per_launch=round(a["alg"] / a["n"] / 1e9, 3),
+                        algorithmic_bytes_per_launch=round(a["bytes"] / a["n"]))
             cms = sum(a["ms"] for (kd, _), a in agg.items() if kd == "conv")
             cfl = sum(a["alg"] for (kd, _), a in agg.items() if kd == "conv")
             cex = sum(a["flops"] for (kd, _), a in agg.items() if kd == "conv")

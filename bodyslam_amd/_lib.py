@@ -277,7 +277,10 @@ class Plan:
             flops=2.0 * d.M * d.N * (d.K + (d.KH * d.KW if d.conv else 1) * d.f8_seg / (4 if d.f8_wonly_from else 2)),
             # algorithmic FLOPs exclude the extra passes of a split-precision product
             alg_flops=2.0 * d.M * d.N * (d.K / kw.get("precision_passes", 1)),
-            bytes=float(d.M) * (d.Cin if d.conv else d.K) * 2 + float(d.N) * d.K * 2 + float(d.M) * d.N * (4 if d.out_dtype == F32 else 2))
+            # algorithmic HBM bytes: A once (16-bit values + the FP8 planes of a pair row), W once, the output (+ the fp32 residual read)
+            bytes=(float(d.M if not d.conv else d.M / max(d.stride * d.stride, 1)) * ((d.Cin if d.conv else d.K) * 2 + d.f8_seg)
+                   + float(d.N) * (d.K * 2 + (d.KH * d.KW if d.conv else 1) * d.f8_seg)
+                   + float(d.M) * d.N * ((4 if d.out_dtype == F32 else 2) * (2 if d.out_split_off else 1) + (4 if (d.res and d.res_dtype == F32) else 0))))
 
     def add(self, name, fn_name, *args):
         cargs = []
