@@ -85,6 +85,11 @@ class BodySlamPipeline:
         self.dev = torch.device("cuda", device)
         self.batch = batch
         self.pad_ragged = pad_ragged
+        # BASELINE config 5 ("with pose-graph re-linearisation"): the reference optimises its pose graph every 500 frames
+        # (3DM/slam.py:54,159-165).  0 = off.  loop_closures: extra (source, target, T[4,4], information[6,6]) edges, uncertain
+        # (the reference never adds any: slam.py:30,80)
+        self.posegraph_every = 0
+        self.loop_closures = []
         self.K, self.depth_scale, self.depth_trunc, self.flip = tuple(K), depth_scale, depth_trunc, flip_aug
         self.zoe = ZoeDepthEngine(zoe_weights, zoe_cfg, dtype=dtype, device=device, target_hw=target_hw, precision=precision)
         self.precision = precision
@@ -128,6 +133,35 @@ class BodySlamPipeline:
                 pi += i.size
         return depth, depth_m, t_rel
 
+    def _posegraph_relinearise(self, g_abs: torch.Tensor, t_all: torch.Tensor) -> torch.Tensor:
+        """3DM/slam.py:156-175 on the finished chain: nodes = absolute poses, one odometry edge per frame, global optimisation
+        every ``posegraph_every`` nodes; replicated on every rank (host side, as in the reference).  With odometry edges only
+        the chain is the optimum and comes back bit for bit."""
+        from .posegraph import PoseGraph, update_global_extrinsic
+        G = g_abs.cpu().numpy()
+        T = t_all.view(-1, 4, 4).cpu().numpy().astype(np.float64)
+        N = G.shape[0]
+        pg = PoseGraph()
+        pg.add_node(G[0])
+        lc = sorted(self.loop_closures, key=lambda e: max(e[0], e[1]))
+        k = 0
+        changed = False
+        for i in range(1, N):
+            # (after an optimisation moved the nodes, the chain continues from the updated last pose, slam.py:148-153,165)
+            pg.add_node(G[i] if not changed else geom3d.compute_curr_estimate_global_pose(update_global_extrinsic(pg.pose_graph)[-1],
+                                                                                          T[i - 1].astype(np.float32)))
+            pg.add_edge(T[i - 1], i, i - 1, False)
+            while k < len(lc) and max(lc[k][0], lc[k][1]) <= i:
+                pg.add_edge(lc[k][2], lc[k][0], lc[k][1], True, lc[k][3])
+                k += 1
+            if i % self.posegraph_every == 0 or i == N - 1:
+                before = [n.pose.copy() for n in pg.pose_graph.nodes]
+                pg.optimize()
+                changed = changed or any(not np.array_equal(a, n.pose) for a, n in zip(before, pg.pose_graph.nodes))
+        if not changed:
+            return g_abs
+        return torch.from_numpy(np.stack(update_global_extrinsic(pg.pose_graph))).to(g_abs.device)
+
     def run_sequence(self, frames, rank: int = 0, world: int = 1, group=None, keep_points: bool = False,
                      keep_depth_m: bool = False, on_points: Optional[Callable] = None,
                      gather: Optional[Callable] = None, frame_offset: int = 0, n_frames: Optional[int] = None) -> SequenceResult:
@@ -152,6 +186,8 @@ class BodySlamPipeline:
         if t_all.shape[0] != max(N - 1, 0):
             raise ValueError(f"chain needs the {max(N - 1, 0)} relatives of the whole sequence, got {t_all.shape[0]}")
         g_abs = geom3d.pose_chain(t_all, device=self.dev.index or 0)          # [N,4,4] fp64, replicated
+        if self.posegraph_every > 0 and N > 1:
+            g_abs = self._posegraph_relinearise(g_abs, t_all)
         n_local = end - start
         cnt_all = torch.empty(n_local, dtype=torch.int32, device=self.dev)
         points = [] if keep_points else None

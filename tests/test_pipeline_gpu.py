@@ -151,6 +151,36 @@ def test_mpem_resize_mode(tmp_path):
     assert np.abs(R @ R.T - np.eye(3)).max() < 1e-5 and np.array_equal(T2[3], [0, 0, 0, 1])
 
 
+def test_sequence_with_posegraph_relinearisation():
+    """BASELINE config 5's extra step on a small configuration: with the reference's odometry-only graph the sequence result is
+    bit-identical; a loop-closure edge moves the absolute poses (and with them the world-frame points), the first pose stays."""
+    import dataclasses
+    from bodyslam_amd.pipeline import BodySlamPipeline
+    from bodyslam_amd.synthetic import make_sequence
+    from bodyslam_amd.zoedepth import ZoeConfig
+    from oracle import cyclepose_ref as CP
+    from oracle import zoedepth_ref as Z
+    cfg_o = Z.ZoeConfig(hidden=128, layers=4, heads=2, intermediate=256, taps=(1, 2, 3, 4), image_size=64)
+    names = {f.name for f in dataclasses.fields(ZoeConfig)}
+    cfg_p = ZoeConfig(**{k: v for k, v in dataclasses.asdict(cfg_o).items() if k in names})
+    pipe = BodySlamPipeline(Z.synth_weights(cfg_o, seed=2), CP.synth_weights(seed=2), cfg_p, batch=4, target_hw=(64, 96))
+    frames = make_sequence(9, 160, 192, seed=5)
+    a = pipe.run_sequence(frames, keep_points=True)
+    pipe.posegraph_every = 4
+    b = pipe.run_sequence(frames, keep_points=True)
+    assert torch.equal(a.g_abs, b.g_abs) and all(torch.equal(x[0], y[0]) for x, y in zip(a.points, b.points))
+    info = np.eye(6) * 100.0
+    info[5, 5] = 5000.0
+    pipe.loop_closures = [(8, 0, np.eye(4), info)]               # "frame 8 is back where frame 0 was"
+    c = pipe.run_sequence(frames, keep_points=True)
+    ga, gc = a.g_abs.cpu().numpy(), c.g_abs.cpu().numpy()
+    assert np.array_equal(gc[0], ga[0])
+    assert np.abs(gc[8][:3, 3]).max() < np.abs(ga[8][:3, 3]).max()          # pulled towards the start
+    R = gc[:, :3, :3]
+    assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-9
+    assert torch.equal(a.points[5][1], c.points[5][1]) and not torch.equal(a.points[5][0], c.points[5][0])   # same pixels, moved points
+
+
 def test_slam_utils_dropins(golden_dir):
     from bodyslam_amd import slam_utils as S
     g = np.load(os.path.join(golden_dir, "geom3d_chain.npz"))
