@@ -169,13 +169,22 @@ def test_sequence_with_posegraph_relinearisation():
     pipe.posegraph_every = 4
     b = pipe.run_sequence(frames, keep_points=True)
     assert torch.equal(a.g_abs, b.g_abs) and all(torch.equal(x[0], y[0]) for x, y in zip(a.points, b.points))
-    info = np.eye(6) * 100.0
+    ga = a.g_abs.cpu().numpy()
+    info = np.eye(6)
     info[5, 5] = 5000.0
-    pipe.loop_closures = [(8, 0, np.eye(4), info)]               # "frame 8 is back where frame 0 was"
+    # a gross outlier ("frame 8 is back where frame 0 was", nothing like the chain) is switched off by its line process: no change
+    pipe.loop_closures = [(8, 0, np.eye(4), info * 100.0)]
+    c0 = pipe.run_sequence(frames)
+    assert torch.equal(c0.g_abs, a.g_abs)
+    # a closure that disagrees with the chain by 2 mm is kept and spreads the correction over the chain
+    T80 = np.linalg.inv(ga[0]) @ ga[8]
+    T80[:3, 3] += 2e-3
+    pipe.loop_closures = [(8, 0, T80, info)]
     c = pipe.run_sequence(frames, keep_points=True)
-    ga, gc = a.g_abs.cpu().numpy(), c.g_abs.cpu().numpy()
+    gc = c.g_abs.cpu().numpy()
     assert np.array_equal(gc[0], ga[0])
-    assert np.abs(gc[8][:3, 3]).max() < np.abs(ga[8][:3, 3]).max()          # pulled towards the start
+    d = np.abs(gc - ga).max(axis=(1, 2))
+    assert 2e-4 < d[8] < 3e-3 and d[4] > 1e-5                              # moved towards the closure, the middle of the chain too
     R = gc[:, :3, :3]
     assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-9
     assert torch.equal(a.points[5][1], c.points[5][1]) and not torch.equal(a.points[5][0], c.points[5][0])   # same pixels, moved points
