@@ -226,6 +226,7 @@ class Plan:
         self.lane = 0        # lane of the calls being added: 0 = the caller's stream, 1 = the plan's side stream
         self.lanes = []      # per call
         self.events = None   # a list: run() records a HIP event pair around every bs_gemm launch into it (see run_timed)
+        self._graph = None   # torch.cuda.CUDAGraph of the captured sequence (capture())
         self._side = None    # torch side stream + fork / join events, created at the first run
         self._events = {}
 
@@ -319,9 +320,32 @@ class Plan:
             if rc:
                 check(rc, self.names[i])
 
+    def capture(self):
+        """Capture the whole launch sequence (both lanes, their fork / join events, the GEMM tail launches) into one HIP graph;
+        run() then replays it with a single hipGraphLaunch instead of ~600 ctypes calls.  The buffers are static, so the
+        captured pointers stay valid; inputs are copied into them before run() as usual.  Worth it for the reference's
+        one-frame-per-call pattern (host time 3.6 ms -> ~0.1 ms per forward; the GPU time does not change)."""
+        if self._graph is not None:
+            return
+        self.run()                              # warm-up: first-use attribute calls, lazy streams and events
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        cap = torch.cuda.Stream(device=self.device)
+        cap.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(cap):
+            with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
+                self._events = {}               # events recorded during capture belong to the capture
+                self.run()
+        self._events = {}
+        torch.cuda.current_stream(self.device).wait_stream(cap)
+        self._graph = g
+
     def run(self, taps: Optional[dict] = None):
         if taps is None and self.events is not None:      # a caller (bench.py) asked for per-launch HIP events
             return self.run_timed(self.events)
+        if taps is None and self._graph is not None and not torch.cuda.is_current_stream_capturing():
+            self._graph.replay()
+            return
         if taps is None:
             main, side = self._streams()
             ptrs = (main.cuda_stream, side.cuda_stream)

@@ -431,16 +431,20 @@ class ZoeDepthEngine:
             self._plans[key] = _ZoePlan(self, B, H, W, flip)
         return self._plans[key]
 
-    def infer(self, frames_u8: torch.Tensor, flip_aug: bool = True, taps: Optional[dict] = None, want_u16: bool = True):
+    def infer(self, frames_u8: torch.Tensor, flip_aug: bool = True, taps: Optional[dict] = None, want_u16: bool = True,
+              graph: bool = False):
         """uint8 [B,H,W,3] on the GPU -> (depth metres fp32 [B,H,W], uint16 metres*256 [B,H,W] as int16 storage).
 
-        Outputs are the plan's static buffers (valid until the next call with the same shape)."""
+        Outputs are the plan's static buffers (valid until the next call with the same shape).  graph=True: the plan of this
+        shape is captured into a HIP graph on first use and replayed afterwards (one launch call per forward)."""
         assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and frames_u8.dim() == 4 and frames_u8.shape[-1] == 3
         B, H, W, _ = frames_u8.shape
         if B == 0:      # an empty batch: nothing to launch
             return (torch.empty(0, H, W, device=self.dev), torch.empty(0, H, W, device=self.dev, dtype=torch.int16))
         plan = self.plan_for(B, H, W, flip_aug)
         plan.frames.copy_(frames_u8)
+        if graph and taps is None:
+            plan.plan.capture()
         plan.run(taps)
         return plan.depth_m, plan.depth_u16
 

@@ -162,6 +162,25 @@ def test_small_without_relative_head_projection(precision):
     assert l1 < (1e-4 if precision == "accurate" else 2e-3)
 
 
+def test_hip_graph_replay_equals_eager():
+    """Plan.capture(): the two-lane launch sequence as one HIP graph; replays give the eager result bit for bit, for new inputs too."""
+    from bodyslam_amd.synthetic import make_sequence
+    from bodyslam_amd.zoedepth import ZoeDepthEngine
+    from oracle import zoedepth_ref as Z
+    cfg_o = small_oracle_cfg()
+    eng = ZoeDepthEngine(Z.synth_weights(cfg_o, seed=4), product_cfg(cfg_o), dtype=torch.float16, target_hw=(96, 128), precision="accurate")
+    frames = torch.from_numpy(make_sequence(4, 120, 160, seed=9)).cuda()
+    eager = [eng.infer(frames[i:i + 2])[0].clone() for i in (0, 2)]
+    g0 = eng.infer(frames[0:2], graph=True)[0].clone()
+    assert eng.plan_for(2, 120, 160, True).plan._graph is not None
+    g1 = eng.infer(frames[2:4], graph=True)[0].clone()
+    g0b = eng.infer(frames[0:2], graph=True)[0].clone()
+    assert torch.equal(g0, eager[0]) and torch.equal(g1, eager[1]) and torch.equal(g0b, eager[0])
+    taps = {}
+    eng.infer(frames[0:2], taps=taps)           # the tap path still runs eagerly on a captured plan
+    assert "depth_net" in taps
+
+
 def test_small_accurate_mode():
     """precision="accurate" (split-precision products in the neck / heads, split weights in the backbone) on the small case:
     every split code path (cast_split, relu_split, split resize / add_resized / logbinom, 2- and 3-segment GEMMs) runs and must

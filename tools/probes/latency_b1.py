@@ -15,4 +15,11 @@ for prec in ("accurate", "fast"):
         t_host = (time.perf_counter() - t0) / n
         torch.cuda.synchronize(); t = (time.perf_counter() - t0) / n
         print(f"{prec} B={B}: {t*1e3:.2f} ms/call ({B/t:.1f} frames/s), host issue {t_host*1e3:.2f} ms/call")
+        if B <= 2:      # the same through a captured HIP graph
+            for _ in range(3): eng.infer(frames, graph=True)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(n): eng.infer(frames, graph=True)
+            t_host = (time.perf_counter() - t0) / n
+            torch.cuda.synchronize(); t = (time.perf_counter() - t0) / n
+            print(f"{prec} B={B} hipGraph: {t*1e3:.2f} ms/call ({B/t:.1f} frames/s), host issue {t_host*1e3:.2f} ms/call")
     del eng
