@@ -449,6 +449,45 @@ class ZoeDepthEngine:
         return plan.depth_m, plan.depth_u16
 
 
+class _Pool:
+    """Plan-time buffer reuse.  The launch sequence of a plan is fixed, so the lifetime of every intermediate is known while the
+    plan is being built: ``free(t)`` -- placed right after the call that reads ``t`` last -- returns its block, and a later
+    ``alloc`` of at most that size takes it over (best fit).  Kernels of the main lane run in program order, so a block handed
+    on at build position p is only ever overwritten by work issued after p.  The side lane never uses pooled blocks
+    (``hold``): it runs beside main-lane kernels that were added later."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.free_blocks = []        # uint8 tensors
+        self.owner = {}              # data_ptr -> block
+        self.hold = False
+        self.bytes_new = 0
+
+    def alloc(self, shape, dtype):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = max(n * torch.empty((), dtype=dtype).element_size(), 16)
+        blk = None
+        if not self.hold:
+            fits = [b for b in self.free_blocks if b.numel() >= nbytes]
+            if fits:
+                blk = min(fits, key=lambda b: b.numel())
+                self.free_blocks = [b for b in self.free_blocks if b is not blk]
+        if blk is None:
+            blk = torch.empty((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=self.dev)
+            self.bytes_new += blk.numel()
+        t = blk[:nbytes].view(dtype).view(*shape)
+        self.owner[t.data_ptr()] = blk
+        return t
+
+    def free(self, *tensors):
+        for t in tensors:
+            blk = self.owner.pop(t.data_ptr(), None) if t is not None else None
+            if blk is not None:
+                self.free_blocks.append(blk)
+
+
 class _ZoePlan:
     """All buffers + the launch sequence for one (frames, H, W, flip) configuration."""
 
@@ -465,9 +504,14 @@ class _ZoePlan:
         self.geom = dict(B=B, NB=NB, H=H, W=W, nh=nh_, nw=nw_, hp=hp, wp=wp, S=S, Sp=Sp)
         P = L.Plan(dev)
         self.plan = P
-        e16 = lambda *s: torch.empty(*s, device=dev, dtype=dt_)
+        # intermediates of the neck / heads come from a pool and are handed on after their last reader (free); the backbone's
+        # buffers (whose padding rows must stay zero) and everything the side lane touches are plain allocations
+        pool = _Pool(dev)
+        self.pool = pool
+        e16 = lambda *s: pool.alloc(s, dt_)
         z16 = lambda *s: torch.zeros(*s, device=dev, dtype=dt_)
-        e32 = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        e32 = lambda *s: pool.alloc(s, torch.float32)
+        free = pool.free
         use_tab = wp == 32 and hp <= 40         # every 512-wide network input: bias from the per-head table held in LDS
         bias = eng._rel_table(hp, wp) if use_tab else eng._rel_bias(hp, wp, Sp)
         # Row order of the token tensors (residual stream, LN / attention outputs, MLP hidden).  Grouped (with the table
@@ -539,6 +583,7 @@ class _ZoePlan:
         else:
             P.add("cls", "bs_fill_rows", x, w["cls"], NB, S, Hd)
             bgemm("patch_embed", patches, "pe.w", x, NB * T0, Hd, PK, bias=w["pe.b"], out_group=(T0, S, 1))
+        free(patches)
         P.mark("embed", x, TOK)
         # ---- Z3: BEiT layers
         ti = 0
@@ -642,6 +687,7 @@ class _ZoePlan:
                 up = e16(NB, hp * s_, wp * s_, ch * m2)
                 nplain(f"ra{i}.up", pr, f"ra{i}.up.w", up, NB * T0, s_ * s_ * ch, ch, shuffle=(s_, ch, hp, wp), bias=w[f"ra{i}.up.b"],
                        ldo=ch * m2, split_off=ch)
+                free(pr)
                 fh, fw, src = hp * s_, wp * s_, up
             elif i == 2:
                 fh, fw, src = hp, wp, pr
@@ -649,18 +695,22 @@ class _ZoePlan:
                 fh, fw = (hp + 2 - 3) // 2 + 1, (wp + 2 - 3) // 2 + 1
                 src = e16(NB, fh, fw, ch * m2)
                 nconv(f"ra{i}.down", pr, f"ra{i}.down.w", src, hp, wp, ch, ch, stride=2, bias=w[f"ra{i}.down.b"])
+                free(pr)
             P.mark(f"reassemble{i}", src, ("nhwc", NB, fh, fw, ch, (2 if nf8 else 1) if acc else 0))
             f16_ = e16(NB, fh, fw, c.fusion * m2)
             nconv(f"nc{i}", src, f"nc{i}.w", f16_, fh, fw, ch, c.fusion)
+            free(src)                                                  # (level 2: src is pr)
             P.mark(f"neckconv{i}", f16_, ("nhwc", NB, fh, fw, c.fusion, (2 if nf8 else 1) if acc else 0))
             feats.append(f16_)
             fshape.append((fh, fw))
+        free(r16, cb)
         bott, (bh_, bw_) = feats[3], fshape[3]
         # The router and the seed regressors depend only on the bottleneck map: they are issued on the plan's side stream and run
         # beside the fusion stage / relative head (small, latency-bound kernels that would otherwise serialise behind them).
         P.signal(0)
         P.lane = 1
         P.wait(0)
+        pool.hold = True
         # ---- Z7: metric-bins head
         Mb = NB * bh_ * bw_
         xb = e16(Mb, c.bottleneck)
@@ -712,6 +762,7 @@ class _ZoePlan:
                ldo=E * m2, out_split_off=E if acc else 0)
         P.signal(1)
         P.lane = 0
+        pool.hold = False
         # ---- Z5: fusion stage (pre-activation residual units, x2 bilinear, 1x1 projection)
         Fc = c.fusion
 
@@ -723,9 +774,11 @@ class _ZoePlan:
                 xr = e16(NB, hh, ww, Fc * m2)
                 P.add(name + ".relu", "bs_relu_split", xin, xr, NB * hh * ww, Fc, L.dt(xr) | (32 if nf8 else 0))
                 nconv(name + ".c1", xr, name + ".c1.w", t, hh, ww, Fc, Fc, bias=w[name + ".c1.b"], act=L.ACT_RELU)
+                free(xr)
             else:
                 nconv(name + ".c1", xin, name + ".c1.w", t, hh, ww, Fc, Fc, relu_a=True, bias=w[name + ".c1.b"], act=L.ACT_RELU)
             nconv(name + ".c2", t, name + ".c2.w", y, hh, ww, Fc, Fc, bias=w[name + ".c2.b"], res=xin, res2=other)
+            free(t)
             return y
 
         fused_list = []
@@ -734,17 +787,25 @@ class _ZoePlan:
             feat = feats[3 - li]
             fh, fw = fshape[3 - li]
             if fused is None:
-                cur = feat
+                cur = feat                                                  # (the bottleneck map: the side lane reads it until wait(1))
+                own = False
             else:
                 cur = res_unit(f"fu{li}.r1", feat, fh, fw, other=fused)     # fused + residual_layer1(feat)
+                free(feat)                                                  # (fused stays: the bins head reads it later)
+                own = True
+            cur_in = cur
             cur = res_unit(f"fu{li}.r2", cur, fh, fw)
+            if own:
+                free(cur_in)
             # HF upsamples, then applies the 1x1 projection (modeling_zoedepth.py:316-322).  Both are linear and the bilinear weights
             # sum to 1, so projection(interpolate(x)) = interpolate(projection(x)) exactly in real arithmetic: the projection runs at
             # the LOW resolution (a quarter of the FLOPs and of the bytes), the resize writes the fused map directly.
             lowp = e16(NB, fh, fw, Fc * m2)
             nplain(f"fu{li}.proj", cur, f"fu{li}.proj.w", lowp, NB * fh * fw, Fc, Fc, bias=w[f"fu{li}.proj.b"])
+            free(cur)
             fused = e16(NB, 2 * fh, 2 * fw, Fc * m2)
             P.add(f"fu{li}.up", "bs_resize_bilinear_nhwc", lowp, fused, NB, fh, fw, Fc, 2 * fh, 2 * fw, RZ, L.dt(fused))
+            free(lowp)
             P.mark(f"fused{li}", fused, ("nhwc", NB, 2 * fh, 2 * fw, Fc, (2 if nf8 else 1) if acc else 0))
             fused_list.append((fused, 2 * fh, 2 * fw))
         # ---- Z6: relative head (conv3 + ReLU -> relative depth is dead code for the NK output and not launched)
@@ -756,10 +817,14 @@ class _ZoePlan:
             rp = f3
         r1 = e16(NB, h3, w3, (Fc // 2) * m2)
         nconv("rh.conv1", rp, "rh.conv1.w", r1, h3, w3, Fc, Fc // 2, bias=w["rh.conv1.b"])
+        if eng.add_projection:
+            free(rp)
         r1u = e16(NB, 2 * h3, 2 * w3, (Fc // 2) * m2)
         P.add("rh.up", "bs_resize_bilinear_nhwc", r1, r1u, NB, h3, w3, Fc // 2, 2 * h3, 2 * w3, RZ, L.dt(r1))
+        free(r1)
         last = e16(NB, 2 * h3, 2 * w3, c.rel_features * m2)
         nconv("rh.conv2", r1u, "rh.conv2.w", last, 2 * h3, 2 * w3, Fc // 2, c.rel_features, bias=w["rh.conv2.b"], act=L.ACT_RELU)
+        free(r1u)
         P.mark("rel_features", last, ("nhwc", NB, 2 * h3, 2 * w3, c.rel_features, (2 if nf8 else 1) if acc else 0))
         # ---- Z7 (continued): projector / attractor levels on the fusion outputs, after the side lane's router + seeds
         # (putting this chain on the side lane as well, beside the relative head, measured neutral)
@@ -770,30 +835,38 @@ class _ZoePlan:
             Mi = NB * fh * fw
             e1 = e16(Mi, PM * m2)
             nplain(f"pj{i}.c1", feat, f"pj{i}.c1.w", e1, Mi, PM, Fc, bias=w[f"pj{i}.c1.b"], act=L.ACT_RELU, out8=False)
+            free(feat)                                             # the fused map's last reader (fused 3 fed the relative head earlier)
             emb = e16(Mi, E * m2)
             P.gemm(f"pj{i}.c2", e1, w[f"pj{i}.c2.w"], emb, M=Mi, N=E, K=PM * np3, lda=PM * m2, seg1=PM if acc else 0,
                    ldo=E * m2, out_split_off=E if acc else 0, bias=w[f"pj{i}.c2.b"], precision_passes=np3)
+            free(e1)
             y = e16(Mi, E * m2)
             P.add(f"at{i}.add", "bs_add_resized", emb, emb_prev, y, NB, ph_, pw_, fh, fw, E, L.dt(y) | (16 if acc else 0))
+            free(emb_prev)
             a1 = e16(Mi, 2 * E)
             P.gemm(f"at{i}.c1", y, w[f"at{i}.c1.w"], a1, M=Mi, N=2 * E, K=E, lda=E * m2, bias=w[f"at{i}.c1.b"], act=L.ACT_RELU)
+            free(y)
             na = eng.na_eff[i]                                     # attractors of this level (replicated up to a multiple of 4)
             A = e32(Mi, 2 * na)
             P.gemm(f"at{i}.c2", a1, w[f"at{i}.c2.w"], A, M=Mi, N=2 * na, K=2 * E, lda=2 * E, bias=w[f"at{i}.c2.b"], act=L.ACT_SOFTPLUS)
+            free(a1)
             bins = e32(NB, fh, fw, 2 * nb)
             P.add(f"at{i}.step", "bs_attractor_step", A, bins_prev, bins, self.route, NB, ph_, pw_, fh, fw, 2, nb, na)
+            free(A, bins_prev)
             P.mark(f"bins{i}", bins, ("nhwc_route", NB, fh, fw, 2 * nb))
             bins_prev, emb_prev, ph_, pw_ = bins, emb, fh, fw
         Eh = e32(NB * ph_ * pw_, 2 * HID)
         P.gemm("clb.emb", emb_prev, w["clb.emb.w"], Eh, M=NB * ph_ * pw_, N=2 * HID, K=E * np3, lda=E * m2, seg1=E if acc else 0, bias=w["clb.emb.b"],
                precision_passes=np3)
-        self.depth_net = e32(NB, nh_, nw_)
+        free(emb_prev)
+        self.depth_net = torch.empty(NB, nh_, nw_, device=dev, dtype=torch.float32)        # plan outputs are not pooled
         assert (nh_, nw_) == (2 * h3, 2 * w3)
         P.add("logbinom", "bs_logbinom_depth_ex", last, Eh, bins_prev, w["clb.w0_last"], w["clb.w2"], w["clb.b2"], w.get("clb.rel"), HID,
               self.route, self.depth_net, NB, nh_, nw_, ph_, pw_, c.min_temp, c.max_temp, L.dt(last) | NSP)
         P.mark("depth_net", self.depth_net, ("raw",))
         # ---- Z8: flip average + bicubic + crop + x256 -> uint16
-        self.depth_m = e32(B, H, W)
+        free(last, Eh, bins_prev)
+        self.depth_m = torch.empty(B, H, W, device=dev, dtype=torch.float32)
         self.depth_u16 = torch.empty(B, H, W, device=dev, dtype=torch.int16)   # uint16 payload
         P.add("postprocess", "bs_postprocess_depth", self.depth_net, self.depth_m, self.depth_u16, B, H, W, nh_, nw_, int(flip))
 
