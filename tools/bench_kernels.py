@@ -37,6 +37,8 @@ def main():
     for name, g, epi in shapes:
         if a.only and a.only not in name:
             continue
+        if a.only == "f8":
+            continue
         A = torch.randn(g["M"], g["K"], device=dev).to(dt)
         Wt = (torch.randn(g["N"], g["K"], device=dev) / math.sqrt(g["K"])).to(dt)
         bias = torch.randn(g["N"], device=dev)
@@ -53,6 +55,38 @@ def main():
             pl = L.Plan()
             pl.gemm(name, A, Wt, out, M=g["M"], N=g["N"], K=g["K"], lda=g["K"], tile=t, **kw)
             results.append((name, t, 2.0 * g["M"] * g["N"] * g["K"], pl.run))
+    # accurate mode's backbone GEMMs: A = (hi16 | hi8 | lo8) rows, W = [W_hi16 | W_lo8 | W_hi8], activation-rounding correction on
+    # the first (cls) tile only -- the shapes of the grouped token layout (256 cls / padding rows + NB x 768 patch rows)
+    if not a.only or "f8" in a.only:
+        MT = 256 + NB * 768
+        for name, N_, K_, epi in (("f8 qkv  K1024 N3072", 3072, 1024, "qkv"), ("f8 o    K1024 N1024 f32res", 1024, 1024, "res"),
+                                  ("f8 fc1  K1024 N4096 gelu pair-out", 4096, 1024, "gelu8"), ("f8 fc2  K4096 N1024 f32res", 1024, 4096, "res")):
+            A32 = torch.randn(MT, K_, device=dev)
+            A8 = torch.empty(MT, 2 * K_, device=dev, dtype=dt)
+            L.cast_split(A32, A8, MT, K_, f8=True)
+            del A32
+            w8, (sb0, sb1) = L.f8_weight(torch.randn(N_, K_) / math.sqrt(K_), dt)
+            w8 = w8.to(dev)
+            bias = torch.randn(N_, device=dev)
+            kw = dict(M=MT, N=N_, K=K_, lda=2 * K_, f8_seg=2 * K_, f8_wonly_from=256, bias=bias,
+                      f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1))
+            if epi == "res":
+                out = torch.randn(MT, N_, device=dev)
+                kw.update(scale=bias, res=out, ldr=N_)
+            elif epi == "gelu8":
+                out = torch.empty(MT, 2 * N_, device=dev, dtype=dt)
+                kw.update(act=L.ACT_GELU, ldo=2 * N_, out_split_off=N_, out_f8=(L.F8_ACT_HI_EXP, L.F8_ACT_LO_EXP))
+            else:
+                Sp = 832
+                out = torch.zeros(NB, 16, Sp, 64, device=dev, dtype=dt)
+                k2, vt2 = torch.zeros_like(out), torch.zeros(NB, 16, 64, Sp, device=dev, dtype=dt)
+                kw.update(qkv=(1024, 769, Sp, 0.18, k2, vt2, True, NB, 256))
+            for t in tiles:
+                if t % 100 not in (0, 9, 1):
+                    continue
+                pl = L.Plan()
+                pl.gemm(name, A8, w8, out, tile=t, **kw)
+                results.append((name, t, 2.0 * MT * N_ * K_, pl.run))
     for name, H, W_, Ci, Co in convs:
         if a.only and a.only not in name:
             continue
