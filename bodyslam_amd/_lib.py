@@ -44,7 +44,7 @@ class GemmDesc(C.Structure):
         ("qkv_hidden", C.c_int32), ("qkv_tokens", C.c_int32), ("qkv_sp", C.c_int32), ("q_scale", C.c_float),
         ("tile", C.c_int32), ("seg1", C.c_int32), ("out_split_off", C.c_int32), ("res_split_off", C.c_int32),
         ("f8_seg", C.c_int32), ("f8_scales", C.c_uint32), ("out_f8", C.c_int32), ("res_f8", C.c_int32),
-        ("qkv_cls_last", C.c_int32), ("qkv_cls_rows", C.c_int32), ("qkv_patch_row0", C.c_int32), ("f8_wonly_from", C.c_int32),
+        ("qkv_cls_last", C.c_int32), ("qkv_cls_rows", C.c_int32), ("qkv_patch_row0", C.c_int32), ("f8_wonly_from", C.c_int32), ("out_lo8_rows", C.c_int32),
     ]
 
 
@@ -149,7 +149,7 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
                    res2: Optional[torch.Tensor] = None, ldr: int = 0, ldo: Optional[int] = None, out_group=None,
                    shuffle=None, qkv=None, a_offset: int = 0, tile: int = 0, seg1: int = 0, out_split_off: int = 0,
                    res_split_off: int = 0, f8_seg: int = 0, f8_scales=(127, 127, 127, 127), out_f8=None, res_f8: bool = False,
-                   f8_wonly_from: int = 0) -> GemmDesc:
+                   f8_wonly_from: int = 0, out_lo8_rows: int = 0) -> GemmDesc:
     """Fill a bs_gemm_desc.  conv = (Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_h, pad_w) or None;
     out_group = (rows, stride, offset); shuffle = (s, Cout, Hgrid, Wgrid);
     qkv = (hidden, tokens, Sp, q_scale, out_k, out_vt[, cls_last[, cls_rows[, patch_row0]]]); a_offset in elements."""
@@ -202,6 +202,7 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
     d.out_f8 = 0 if out_f8 is None else ((out_f8[0] & 0xff) | ((out_f8[1] & 0xff) << 8))
     d.res_f8 = int(res_f8)
     d.f8_wonly_from = f8_wonly_from
+    d.out_lo8_rows = out_lo8_rows
     return d
 
 

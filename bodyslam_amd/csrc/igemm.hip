@@ -211,6 +211,8 @@ extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
     p.qkv_cls_rows = d->qkv_cls_rows;
     p.qkv_patch_row0 = d->qkv_patch_row0;
     p.f8_wonly_from = d->f8_wonly_from;
+    p.out_lo8_rows = d->out_lo8_rows;
+    BS_REQUIRE(d->out_lo8_rows == 0 || (d->out_f8 && d->out_lo8_rows % 256 == 0), "bs_gemm: out_lo8_rows needs out_f8 and a multiple of 256 rows");
     BS_REQUIRE(d->f8_wonly_from == 0 || d->f8_seg > 0, "bs_gemm: f8_wonly_from needs the FP8 correction segment");
     BS_REQUIRE(d->qkv_cls_rows == 0 || (d->out_mode == BS_OUT_QKV && d->qkv_cls_last && d->qkv_tokens > 1 && d->qkv_patch_row0 >= d->qkv_cls_rows &&
                                         d->M == d->qkv_patch_row0 + d->qkv_cls_rows * (d->qkv_tokens - 1)),

@@ -71,6 +71,8 @@ struct IgemmParams {
     int f8_stages;       // number of trailing 128-byte K stages that are FP8 (host: f8_seg / 128, times the taps for a conv)
     int res_f8;          // != 0: the 16-bit residual(s) are (hi16 | hi8 | lo8) rows of N channels; value = hi16 + lo8 * 2^-BS_F8_ACT_LO_EXP
     int out_f8;          // > 0 with split_off: the output pair is (hi16 | hi8 | lo8), see store8_f8
+    int out_lo8_rows;    // > 0: only output rows below this index need their lo8 plane (the consumer drops the activation-rounding
+                         //      correction on the others, f8_wonly_from): tiles past it skip that plane
     int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue, 8 = no tail split (host side)
 };
 
@@ -140,32 +142,37 @@ __device__ __forceinline__ void store8(void* base, int64_t off, int out_dtype, c
 // e4m3((y - hi) * 2^el) in the lo8 plane.  Planes (in 16-bit element units from the row start): hi16 [0, N), hi8 [N, N + N/2),
 // lo8 [N + N/2, 2N).  `off` = row start + n, plane_off = N (= split_off).
 template <typename T>
-__device__ __forceinline__ void store8_f8(void* base, int64_t row_off, int n, int plane_off, const float (&y)[8], int ea, int el) {
+__device__ __forceinline__ void store8_f8(void* base, int64_t row_off, int n, int plane_off, const float (&y)[8], int ea, int el, bool lo = true) {
     typedef typename T16<T>::v8 v8;
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
     v8 h;
-    float yl[8], yh[8];
+    float yh[8];
     const float sa = __builtin_ldexpf(1.0f, ea), sl = __builtin_ldexpf(1.0f, el);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         h[e] = T16<T>::from_f32(y[e]);
         yh[e] = fminf(fmaxf(y[e] * sa, -448.0f), 448.0f);
-        yl[e] = fminf(fmaxf((y[e] - T16<T>::to_f32(h[e])) * sl, -448.0f), 448.0f);
     }
     T* rowp = reinterpret_cast<T*>(base) + row_off;
     *reinterpret_cast<v8*>(rowp + n) = h;
-    int ph0 = 0, ph1 = 0, pl0 = 0, pl1 = 0;
+    int ph0 = 0, ph1 = 0;
     ph0 = __builtin_amdgcn_cvt_pk_fp8_f32(yh[0], yh[1], ph0, false);
     ph0 = __builtin_amdgcn_cvt_pk_fp8_f32(yh[2], yh[3], ph0, true);
     ph1 = __builtin_amdgcn_cvt_pk_fp8_f32(yh[4], yh[5], ph1, false);
     ph1 = __builtin_amdgcn_cvt_pk_fp8_f32(yh[6], yh[7], ph1, true);
-    pl0 = __builtin_amdgcn_cvt_pk_fp8_f32(yl[0], yl[1], pl0, false);
-    pl0 = __builtin_amdgcn_cvt_pk_fp8_f32(yl[2], yl[3], pl0, true);
-    pl1 = __builtin_amdgcn_cvt_pk_fp8_f32(yl[4], yl[5], pl1, false);
-    pl1 = __builtin_amdgcn_cvt_pk_fp8_f32(yl[6], yl[7], pl1, true);
     char* bytes = reinterpret_cast<char*>(rowp + plane_off);
-    typedef int i32x2 __attribute__((ext_vector_type(2)));
     *reinterpret_cast<i32x2*>(bytes + n) = i32x2{ph0, ph1};
-    *reinterpret_cast<i32x2*>(bytes + plane_off + n) = i32x2{pl0, pl1};
+    if (lo) {       // (wave-uniform) the plane of the rounding residuals: only where the consumer evaluates A_lo8 W_hi8
+        float yl[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) yl[e] = fminf(fmaxf((y[e] - T16<T>::to_f32(h[e])) * sl, -448.0f), 448.0f);
+        int pl0 = 0, pl1 = 0;
+        pl0 = __builtin_amdgcn_cvt_pk_fp8_f32(yl[0], yl[1], pl0, false);
+        pl0 = __builtin_amdgcn_cvt_pk_fp8_f32(yl[2], yl[3], pl0, true);
+        pl1 = __builtin_amdgcn_cvt_pk_fp8_f32(yl[4], yl[5], pl1, false);
+        pl1 = __builtin_amdgcn_cvt_pk_fp8_f32(yl[6], yl[7], pl1, true);
+        *reinterpret_cast<i32x2*>(bytes + plane_off + n) = i32x2{pl0, pl1};
+    }
 }
 
 // y[0..3] += the lo8 plane of a (hi16 | hi8 | lo8) row of C channels at columns n..n+3
@@ -672,6 +679,81 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                 }
             }
         };
+        // ---- two specialised forms of the same arithmetic for the backbone's hot shapes (wave-uniform selection) -----------------
+        const bool plain_full = p.out_mode == BS_OUT_PLAIN && !p.out_group_rows && p.bias && !p.bias_group_rows && p.N % BN == 0 &&
+                                p.ldo % 8 == 0 && !(p.ablate & 16);
+        if (plain_full && p.act == BS_ACT_NONE && p.res && p.res_dtype == BS_F32 && !p.res2 && p.out_dtype == BS_F32 && p.split_off == 0 &&
+            !(F8 && p.out_f8) && p.scale && p.ldr % 4 == 0) {
+            // o_proj / fc2: x += scale * (acc + bias), fp32 in place.  The generic loop reads the residual where it needs it and the
+            // kernel has no register to spare for the compiler to hoist those loads: every fragment pair waited out a full memory
+            // latency (220 us of a 500 us o_proj launch).  Here the loads run DEPTH pairs ahead of their use.
+            constexpr int NP = FM * (FN / 2), DEPTH = 4;
+            const float* resp = reinterpret_cast<const float*>(p.res);
+            float* outp = reinterpret_cast<float*>(p.out);
+            f32x4 bj[FN], sj[FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n0 = n_wave + (j >> 1) * 32 + fq * 8 + (j & 1) * 4;
+                bj[j] = *reinterpret_cast<const f32x4*>(p.bias + n0);
+                sj[j] = *reinterpret_cast<const f32x4*>(p.scale + n0);
+            }
+            const int mrow = m0 + wm * TM + frow;
+            f32x4 rq[DEPTH][2];
+            auto issue = [&](int it, int slot) {
+                const int i = it / (FN / 2), jp = it - i * (FN / 2);
+                int m = mrow + i * 16;
+                m = m < p.M ? m : p.M - 1;
+                const float* rp = resp + (int64_t)m * p.ldr + n_wave + jp * 32 + fq * 8;
+                rq[slot][0] = *reinterpret_cast<const f32x4*>(rp);
+                rq[slot][1] = *reinterpret_cast<const f32x4*>(rp + 4);
+            };
+#pragma unroll
+            for (int it = 0; it < DEPTH; ++it) issue(it, it);
+#pragma unroll
+            for (int it = 0; it < NP; ++it) {
+                const int i = it / (FN / 2), jp = it - i * (FN / 2);
+                const int m = mrow + i * 16;
+                f32x4 y0, y1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y0[e] = (acc[i][2 * jp][e] + bj[2 * jp][e]) * sj[2 * jp][e] + rq[it % DEPTH][0][e];
+                    y1[e] = (acc[i][2 * jp + 1][e] + bj[2 * jp + 1][e]) * sj[2 * jp + 1][e] + rq[it % DEPTH][1][e];
+                }
+                if (it + DEPTH < NP) issue(it + DEPTH, it % DEPTH);
+                if (m < p.M) {
+                    float* op = outp + (int64_t)m * p.ldo + n_wave + jp * 32 + fq * 8;
+                    *reinterpret_cast<f32x4*>(op) = y0;
+                    *reinterpret_cast<f32x4*>(op + 4) = y1;
+                }
+            }
+            return;
+        }
+        if constexpr (F8) {
+            if (plain_full && p.act == BS_ACT_GELU && !p.res && p.out_f8 && !p.scale && p.split_off == p.N && p.N % 8 == 0) {
+                // fc1: gelu(acc + bias) as (hi16 | hi8 | lo8) rows; VALU-bound (a third of the launch): no scale multiply, and past
+                // out_lo8_rows no lo8 plane
+                const bool lo = !(p.out_lo8_rows > 0 && m0 >= p.out_lo8_rows);
+                f32x4 bj[FN];
+#pragma unroll
+                for (int j = 0; j < FN; ++j) bj[j] = *reinterpret_cast<const f32x4*>(p.bias + n_wave + (j >> 1) * 32 + fq * 8 + (j & 1) * 4);
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int m = m0 + wm * TM + i * 16 + frow;
+                    if (m >= p.M) continue;
+#pragma unroll
+                    for (int jp = 0; jp < FN / 2; ++jp) {
+                        float y8[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            y8[e] = gelu_erf(acc[i][2 * jp][e] + bj[2 * jp][e]);
+                            y8[4 + e] = gelu_erf(acc[i][2 * jp + 1][e] + bj[2 * jp + 1][e]);
+                        }
+                        store8_f8<T>(p.out, (int64_t)m * p.ldo, n_wave + jp * 32 + fq * 8, p.split_off, y8, p.out_f8 & 0xff, (p.out_f8 >> 8) & 0xff, lo);
+                    }
+                }
+                return;
+            }
+        }
         if (p.act == BS_ACT_GELU) epi(std::integral_constant<int, BS_ACT_GELU>{});
         else if (p.act == BS_ACT_RELU) epi(std::integral_constant<int, BS_ACT_RELU>{});
         else if (p.act == BS_ACT_SOFTPLUS) epi(std::integral_constant<int, BS_ACT_SOFTPLUS>{});

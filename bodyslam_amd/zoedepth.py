@@ -603,7 +603,9 @@ class _ZoePlan:
             hfmt = fmt(f"l{l}.fc2.w")
             bgemm(f"l{l}.fc1", xn, f"l{l}.fc1.w", hid, MT, c.intermediate, Hd, bias=w[f"l{l}.fc1.b"], act=L.ACT_GELU,
                   ldo=c.intermediate * am(f"l{l}.fc2.w"), out_split_off=c.intermediate if hfmt else 0,
-                  out_f8=(L.F8_ACT_HI_EXP, L.F8_ACT_LO_EXP) if hfmt == 32 else None)
+                  out_f8=(L.F8_ACT_HI_EXP, L.F8_ACT_LO_EXP) if hfmt == 32 else None,
+                  # fc2 in "wcls" mode reads the lo8 plane of its cls tile only
+                  out_lo8_rows=CP if (hfmt == 32 and grouped and eng.wmode.get(f"l{l}.fc2.w") == "wcls") else 0)
             bgemm(f"l{l}.fc2", hid, f"l{l}.fc2.w", x, MT, Hd, c.intermediate, bias=w[f"l{l}.fc2.b"], scale=w[f"l{l}.lam2"], res=x, ldr=Hd)
             P.mark(f"layer{l + 1}", x, TOK)
             if (l + 1) in c.taps:

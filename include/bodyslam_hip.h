@@ -126,6 +126,8 @@ typedef struct bs_gemm_desc {
                                     * Activation rounding is per-row noise that stays incoherent in the depth map except on the
                                     * cls-token rows, whose error shifts the whole map (Numerics): grouped cls rows + this
                                     * switch run the backbone at 1.5 instead of 2 pass-equivalents. */
+    int32_t out_lo8_rows;          /* with out_f8, > 0: only output rows below this index store their lo8 plane (their consumer is a
+                                    * GEMM with f8_wonly_from = this value, which never reads it on the other rows) */
 } bs_gemm_desc;
 int bs_gemm(const bs_gemm_desc* d, void* stream);
 /* the tile variant bs_gemm will pick for this descriptor (1: 128x128, 2: 128x64, 3: 128x32, 4: 256x128) */

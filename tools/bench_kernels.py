@@ -59,7 +59,8 @@ def main():
     # the first (cls) tile only -- the shapes of the grouped token layout (256 cls / padding rows + NB x 768 patch rows)
     if not a.only or "f8" in a.only:
         MT = 256 + NB * 768
-        for name, N_, K_, epi in (("f8 qkv  K1024 N3072", 3072, 1024, "qkv"), ("f8 o    K1024 N1024 f32res", 1024, 1024, "res"),
+        for name, N_, K_, epi in (("f8 qkv  K1024 N3072", 3072, 1024, "qkv"), ("f8 qkv-shape plain 16-bit out K1024 N3072", 3072, 1024, "plain16"),
+                                  ("f8 fc1  K1024 N4096 gelu pair-out lo8 on cls tile only", 4096, 1024, "gelu8lo"), ("f8 o    K1024 N1024 f32res", 1024, 1024, "res"),
                                   ("f8 fc1  K1024 N4096 gelu pair-out", 4096, 1024, "gelu8"), ("f8 fc2  K4096 N1024 f32res", 1024, 4096, "res")):
             A32 = torch.randn(MT, K_, device=dev)
             A8 = torch.empty(MT, 2 * K_, device=dev, dtype=dt)
@@ -73,9 +74,12 @@ def main():
             if epi == "res":
                 out = torch.randn(MT, N_, device=dev)
                 kw.update(scale=bias, res=out, ldr=N_)
-            elif epi == "gelu8":
+            elif epi in ("gelu8", "gelu8lo"):
                 out = torch.empty(MT, 2 * N_, device=dev, dtype=dt)
-                kw.update(act=L.ACT_GELU, ldo=2 * N_, out_split_off=N_, out_f8=(L.F8_ACT_HI_EXP, L.F8_ACT_LO_EXP))
+                kw.update(act=L.ACT_GELU, ldo=2 * N_, out_split_off=N_, out_f8=(L.F8_ACT_HI_EXP, L.F8_ACT_LO_EXP),
+                          out_lo8_rows=256 if epi == "gelu8lo" else 0)
+            elif epi == "plain16":      # diagnostics: the QKV product with a plain row-major 16-bit output (no head scatter, no V^T)
+                out = torch.empty(MT, N_, device=dev, dtype=dt)
             else:
                 Sp = 832
                 out = torch.zeros(NB, 16, Sp, 64, device=dev, dtype=dt)
