@@ -66,6 +66,7 @@ _SIGS = {
     "bs_preprocess_image": [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p],
     "bs_fill_rows": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
     "bs_resize_bilinear_nhwc": [C.c_void_p, C.c_void_p] + [C.c_int32] * 8 + [C.c_void_p],
+    "bs_upconv_tapsum": [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p],
     "bs_attractor_step": [C.c_void_p] * 4 + [C.c_int32] * 8 + [C.c_void_p],
     "bs_add_resized": [C.c_void_p] * 3 + [C.c_int32] * 7 + [C.c_void_p],
     "bs_logbinom_depth": [C.c_void_p] * 8 + [C.c_int32] * 5 + [C.c_float, C.c_float, C.c_int32, C.c_void_p],
@@ -480,6 +481,13 @@ def fill_rows(x, v, B, rows_per_image, cols):
 def resize_bilinear_nhwc(x, out, B, Hin, Win, Cch, Hout, Wout, align_corners=True, split=False):
     check(load_library().bs_resize_bilinear_nhwc(p(x), p(out), B, Hin, Win, Cch, Hout, Wout, int(align_corners) | (4 if split == 2 else (2 if split else 0)), dt(x),
                                                  stream_ptr()), "bs_resize_bilinear_nhwc")
+
+
+def upconv_tapsum(y, bias, out, B, Hin, Win, Cout, Hout, Wout, align_corners=True, split=False, relu=True):
+    """conv3x3(interpolate x2(x)) from the low-resolution tap products y [B, Hin, Win, 9*Cout] fp32 (include/bodyslam_hip.h)"""
+    check(load_library().bs_upconv_tapsum(p(y), p(bias), p(out), B, Hin, Win, Cout, Hout, Wout,
+                                          int(align_corners) | (4 if split == 2 else (2 if split else 0)), int(relu), dt(out), stream_ptr()),
+          "bs_upconv_tapsum")
 
 
 def attractor_step(A, bins_prev, bins_out, route, B, Hp, Wp, H, W, groups, n_bins, n_attr):

@@ -331,6 +331,83 @@ __global__ __launch_bounds__(256) void resize_nhwc_f8_kernel(const T* x, T* out,
     *reinterpret_cast<i32x4*>(planes + C + c16 * 16) = pl;
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv3x3(upsample x2(x)) from tap products taken at the LOW resolution (the relative head's conv2, HF modeling_zoedepth.py:358-362).
+// Both steps are linear and the bilinear resize acts on each channel alone, so with y[q, tap, o] = sum_c W[o, c, tap] x[q, c] (one plain
+// GEMM over the low-resolution pixels q: a quarter of the conv's FLOPs, and N = 9 Cout instead of an N = 32 conv that the LDS fill
+// rate bounds)   out(p, o) = act(bias[o] + sum_tap [p + d_tap inside] * bilinear(y[., tap, o])(p + d_tap)):   the zero padding of the
+// conv applies to the UPSAMPLED map, hence the inside test on p + d.  The upsampled map (13 GB at the bench batch) is never written.
+// Thread = 4 output channels of one output pixel; the 36 16-byte reads per thread hit L1 / L2 (neighbouring pixels share corners).
+template <typename T, int SPLIT>
+__global__ __launch_bounds__(256) void upconv_tapsum_kernel(const float* y, const float* bias, T* out, int B, int Hin, int Win, int Co, int Hout,
+                                                             int Wout, float sy, float sx, int align, int relu) {
+    const int groups = Co >> 2;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (unsigned)Wout * groups) return;
+    const int g = idx % groups, ox = idx / groups;
+    const int b = blockIdx.y / Hout, oy = blockIdx.y - b * Hout;
+    const int ld = 9 * Co;
+    const float* yb = y + (int64_t)b * Hin * Win * ld + 4 * g;
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    f32x4_ acc = *reinterpret_cast<const f32x4_*>(bias + 4 * g);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int r = oy + ky - 1;
+        if (r < 0 || r >= Hout) continue;
+        const float fy = align ? sy * (float)r : fmaxf(__fmaf_rn(sy, (float)r + 0.5f, -0.5f), 0.0f);
+        int y0 = (int)fy;
+        y0 = y0 > Hin - 1 ? Hin - 1 : y0;
+        const int y1 = y0 + (y0 < Hin - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, hy = 1.0f - ly;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int c = ox + kx - 1;
+            if (c < 0 || c >= Wout) continue;
+            const float fx = align ? sx * (float)c : fmaxf(__fmaf_rn(sx, (float)c + 0.5f, -0.5f), 0.0f);
+            int x0 = (int)fx;
+            x0 = x0 > Win - 1 ? Win - 1 : x0;
+            const int x1 = x0 + (x0 < Win - 1 ? 1 : 0);
+            const float lx = fx - (float)x0, hx = 1.0f - lx;
+            const float* yt = yb + (ky * 3 + kx) * Co;
+            const f32x4_ q00 = *reinterpret_cast<const f32x4_*>(yt + ((int64_t)y0 * Win + x0) * ld);
+            const f32x4_ q01 = *reinterpret_cast<const f32x4_*>(yt + ((int64_t)y0 * Win + x1) * ld);
+            const f32x4_ q10 = *reinterpret_cast<const f32x4_*>(yt + ((int64_t)y1 * Win + x0) * ld);
+            const f32x4_ q11 = *reinterpret_cast<const f32x4_*>(yt + ((int64_t)y1 * Win + x1) * ld);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += hy * (hx * q00[e] + lx * q01[e]) + ly * (hx * q10[e] + lx * q11[e]);
+        }
+    }
+    if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.0f);
+    }
+    const int64_t pix = ((int64_t)b * Hout + oy) * Wout + ox;
+    typedef T t4 __attribute__((ext_vector_type(4)));
+    t4 hi;
+    float rl[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = T16<T>::from_f32(acc[e]);
+        rl[e] = acc[e] - T16<T>::to_f32(hi[e]);
+    }
+    if (SPLIT == 0) {
+        *reinterpret_cast<t4*>(out + pix * Co + 4 * g) = hi;
+    } else if (SPLIT == 1) {      // (hi | lo) 16-bit pairs
+        t4 lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lo[e] = T16<T>::from_f32(rl[e]);
+        *reinterpret_cast<t4*>(out + pix * 2 * Co + 4 * g) = hi;
+        *reinterpret_cast<t4*>(out + pix * 2 * Co + Co + 4 * g) = lo;
+    } else {                      // (hi16 | hi8 | lo8)
+        T* op = out + pix * 2 * Co;
+        *reinterpret_cast<t4*>(op + 4 * g) = hi;
+        const float sh = __builtin_ldexpf(1.0f, F8_ACT_HI_EXP), sl = __builtin_ldexpf(1.0f, F8_ACT_LO_EXP);
+        char* planes = reinterpret_cast<char*>(op + Co);
+        *reinterpret_cast<int*>(planes + 4 * g) = f8_pack4(acc[0] * sh, acc[1] * sh, acc[2] * sh, acc[3] * sh);
+        *reinterpret_cast<int*>(planes + Co + 4 * g) = f8_pack4(rl[0] * sl, rl[1] * sl, rl[2] * sl, rl[3] * sl);
+    }
+}
+
 // NHWC bilinear resize (+ optional add): thread = one 8-channel group of one output pixel
 // ---------------------------------------------------------------------------------------------
 template <typename T, bool ADD, int SPLIT>
@@ -598,6 +675,43 @@ static int launch_resize(const void* x, const void* addend, void* out, int B, in
                            Hin, Win, C, Hout, Wout, sy, sx, align);
     BS_CHECK_LAUNCH();
     return BS_OK;
+}
+
+template <typename T>
+static int launch_tapsum(const float* y, const float* bias, void* out, int B, int Hin, int Win, int Co, int Hout, int Wout, int align, int split,
+                         int relu, hipStream_t st) {
+    float sy, sx;
+    if (align) {
+        sy = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f;
+        sx = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
+    } else {
+        sy = (float)Hin / (float)Hout;
+        sx = (float)Win / (float)Wout;
+    }
+    const dim3 blocks(cdiv(Wout * (Co / 4), 256), B * Hout);
+    if (split == 2)
+        hipLaunchKernelGGL((upconv_tapsum_kernel<T, 2>), blocks, dim3(256), 0, st, y, bias, (T*)out, B, Hin, Win, Co, Hout, Wout, sy, sx, align, relu);
+    else if (split == 1)
+        hipLaunchKernelGGL((upconv_tapsum_kernel<T, 1>), blocks, dim3(256), 0, st, y, bias, (T*)out, B, Hin, Win, Co, Hout, Wout, sy, sx, align, relu);
+    else
+        hipLaunchKernelGGL((upconv_tapsum_kernel<T, 0>), blocks, dim3(256), 0, st, y, bias, (T*)out, B, Hin, Win, Co, Hout, Wout, sy, sx, align, relu);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+extern "C" int bs_upconv_tapsum(const float* y, const float* bias, void* out, int32_t B, int32_t Hin, int32_t Win, int32_t Cout, int32_t Hout,
+                                int32_t Wout, int32_t align_corners, int32_t relu, int32_t dtype, void* stream) {
+    BS_ENTRY("bs_upconv_tapsum");
+    BS_REQUIRE(y && bias && out, "bs_upconv_tapsum: null operand");
+    BS_REQUIRE(B > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "bs_upconv_tapsum: empty problem");
+    BS_REQUIRE(Cout > 0 && Cout % 4 == 0, "bs_upconv_tapsum: Cout=%d must be a multiple of 4", Cout);
+    BS_REQUIRE((int64_t)B * Hout <= 0x7fffffffll && (int64_t)Wout * (Cout / 4) <= 0x7fffffffll, "bs_upconv_tapsum: grid too large");
+    const int split = (align_corners & 4) ? 2 : ((align_corners & 2) ? 1 : 0);
+    const int align = align_corners & 1;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_upconv_tapsum: dtype must be f16 or bf16");
+    return dtype == BS_F16 ? launch_tapsum<f16>(y, bias, out, B, Hin, Win, Cout, Hout, Wout, align, split, relu, st)
+                           : launch_tapsum<bf16>(y, bias, out, B, Hin, Win, Cout, Hout, Wout, align, split, relu, st);
 }
 
 extern "C" int bs_resize_bilinear_nhwc(const void* x, void* out, int32_t B, int32_t Hin, int32_t Win, int32_t C, int32_t Hout,

@@ -294,9 +294,14 @@ class ZoeDepthEngine:
                     w[f"fu{i}.r{r}.c{cv}.b"] = self._f(g(p + f"residual_layer{r}.convolution{cv}.bias"))
         # relative_head.projection exists only in checkpoints converted with config.add_projection (HF modeling_zoedepth.py:344-346)
         self.add_projection = "relative_head.projection.weight" in sd
-        for n in (("projection",) if self.add_projection else ()) + ("conv1", "conv2"):
+        for n in (("projection",) if self.add_projection else ()) + ("conv1",):
             w[f"rh.{n}.w"] = self._wc(f"rh.{n}.w", g(f"relative_head.{n}.weight"))
             w[f"rh.{n}.b"] = self._f(g(f"relative_head.{n}.bias"))
+        # conv2 follows the x2 upsampling; it is evaluated as nine 1x1 tap products at the LOW resolution (one GEMM, n = tap * Cout + o)
+        # that bs_upconv_tapsum interpolates and sums (see the plan): weight [O, I, 3, 3] -> [(ky, kx, o), I]
+        w2 = g("relative_head.conv2.weight")
+        w["rh.conv2.w"] = self._wp("rh.conv2.w", w2.permute(2, 3, 0, 1).reshape(9 * w2.shape[0], w2.shape[1]))
+        w["rh.conv2.b"] = self._f(g("relative_head.conv2.bias"))
         # ---- metric head
         mh = "metric_head."
         B_, E = c.bottleneck, c.bin_dim
@@ -821,12 +826,16 @@ class _ZoePlan:
         nconv("rh.conv1", rp, "rh.conv1.w", r1, h3, w3, Fc, Fc // 2, bias=w["rh.conv1.b"])
         if eng.add_projection:
             free(rp)
-        r1u = e16(NB, 2 * h3, 2 * w3, (Fc // 2) * m2)
-        P.add("rh.up", "bs_resize_bilinear_nhwc", r1, r1u, NB, h3, w3, Fc // 2, 2 * h3, 2 * w3, RZ, L.dt(r1))
+        # HF: interpolate x2 (align_corners), conv2 3x3 128 -> 32, ReLU (modeling_zoedepth.py:358-362).  Both are linear and the resize acts
+        # per channel, so conv2(up(x))(p) = sum_tap up(W_tap x)(p + d_tap): the nine 1x1 tap products run as ONE plain GEMM at the low
+        # resolution (N = 9 * 32, a quarter of the conv's FLOPs; the N = 32 conv ran at 20 % of the MFMA peak, bound by the LDS fill
+        # rate) and bs_upconv_tapsum gathers / interpolates / sums them -- the upsampled map is never materialised.
+        y9 = e32(NB, h3, w3, 9 * c.rel_features)
+        nplain("rh.conv2", r1, "rh.conv2.w", y9, NB * h3 * w3, 9 * c.rel_features, Fc // 2, out_pairs=False)
         free(r1)
         last = e16(NB, 2 * h3, 2 * w3, c.rel_features * m2)
-        nconv("rh.conv2", r1u, "rh.conv2.w", last, 2 * h3, 2 * w3, Fc // 2, c.rel_features, bias=w["rh.conv2.b"], act=L.ACT_RELU)
-        free(r1u)
+        P.add("rh.tapsum", "bs_upconv_tapsum", y9, w["rh.conv2.b"], last, NB, h3, w3, c.rel_features, 2 * h3, 2 * w3, RZ, 1, L.dt(last))
+        free(y9)
         P.mark("rel_features", last, ("nhwc", NB, 2 * h3, 2 * w3, c.rel_features, (2 if nf8 else 1) if acc else 0))
         # ---- Z7 (continued): projector / attractor levels on the fusion outputs, after the side lane's router + seeds
         # (putting this chain on the side lane as well, beside the relative head, measured neutral)

@@ -193,6 +193,15 @@ int bs_fill_rows(float* x, const float* v, int32_t B, int32_t rows_per_image, in
 int bs_resize_bilinear_nhwc(const void* x, void* out, int32_t B, int32_t Hin, int32_t Win, int32_t C,
                             int32_t Hout, int32_t Wout, int32_t align_corners, int32_t dtype, void* stream);
 
+/* conv3x3(pad 1)(interpolate x2(x)) evaluated from tap products taken at the low resolution -- the relative head's
+ * `upsample` + `conv2` (+ ReLU), HF modeling_zoedepth.py:358-362.  y fp32 [B, Hin, Win, 9*Cout] holds, per low-resolution pixel,
+ * y[(ky*3+kx)*Cout + o] = sum_c W[o, c, ky, kx] x[c] (one bs_gemm over the low-resolution map); this call gathers, per output pixel
+ * p and tap d, the bilinear sample of y's tap plane at p + d (zero when p + d lies outside the Hout x Wout map: the conv's zero
+ * padding), adds bias fp32 [Cout], applies ReLU when `relu`, and writes an NHWC 16-bit map [B, Hout, Wout, Cout] (`align_corners`
+ * bits 1 / 2 select the (hi | lo) / (hi16 | hi8 | lo8) pair formats as for bs_resize_bilinear_nhwc). */
+int bs_upconv_tapsum(const float* y, const float* bias, void* out, int32_t B, int32_t Hin, int32_t Win, int32_t Cout,
+                     int32_t Hout, int32_t Wout, int32_t align_corners, int32_t relu, int32_t dtype, void* stream);
+
 /* metric-bins head ---------------------------------------------------------------------------- *
  * Both heads (nyu | kitti) are carried side by side as channel groups; `route` int32 [B] (from
  * bs_route_argmax) says which group an image uses -- per image, because the reference always runs

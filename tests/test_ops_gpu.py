@@ -524,6 +524,38 @@ def test_resize_and_add(L, dtype):
     assert (o3.float() - ref3).abs().max().item() < tol(dtype, 1) * 4
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("split", [0, 1, 2])
+@pytest.mark.parametrize("geom", [(2, 12, 16, 24, 32, True), (1, 5, 7, 10, 14, True), (1, 6, 5, 12, 10, False), (1, 1, 1, 2, 2, True)])
+def test_upconv_tapsum(L, dtype, split, geom):
+    """relu(conv3x3(interpolate(x))) from low-resolution tap products (the relative head's upsample + conv2, HF
+    modeling_zoedepth.py:358-362) against torch's conv2d(interpolate(x)) in fp64: the two orders of the linear steps agree to fp32
+    rounding, and the conv's zero padding applies to the UPSAMPLED map (border rows / columns)."""
+    B, H, W, Ho, Wo, align = geom
+    C, Co = 16, 8
+    x = rnd(B, H, W, C, seed=3).double()
+    w = (rnd(Co, C, 3, 3, seed=4) * 0.2).double()
+    bias = rnd(Co, seed=5)
+    y = torch.einsum("bhwc,ocyx->bhwyxo", x, w).reshape(B, H, W, 9 * Co).float().contiguous()      # n = (ky*3 + kx)*Co + o
+    up = F.interpolate(x.permute(0, 3, 1, 2), size=(Ho, Wo), mode="bilinear", align_corners=align)
+    ref = F.relu(F.conv2d(up, w, bias.double(), padding=1)).permute(0, 2, 3, 1)
+    out = torch.zeros(B, Ho, Wo, Co * (2 if split else 1), device=dev(), dtype=dtype)
+    L.upconv_tapsum(y, bias, out, B, H, W, Co, Ho, Wo, align, split, True)
+    if split == 2:
+        hi, val = from_f8_pairs(out, Co)
+    elif split == 1:
+        hi, val = out[..., :Co].float(), out[..., :Co].double() + out[..., Co:].double()
+    else:
+        hi = val = out.float()
+    scale = ref.abs().max().item() + 1.0
+    e_hi = (hi.double() - ref).abs().max().item()
+    e_val = (val.double() - ref).abs().max().item()
+    report(f"upconv_tapsum {dtype} split{split} {geom}: hi err {e_hi:.2e}, value err {e_val:.2e}")
+    assert e_hi < tol(dtype, 1) * scale
+    if split:
+        assert e_val < (2.0 ** -15 if dtype == torch.float16 else 2.0 ** -12) * scale
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_split_pointwise(L, dtype):
     """(hi | lo) carriers of accurate mode: cast_split, relu_split, split resize and split add_resized keep ~2x the mantissa."""
