@@ -2,7 +2,7 @@
 (BodySLAM_not_refactored/3DM/slam_utils.py:71-122, scaling_system.py:72-77)."""
 import numpy as np
 
-from .posegraph import update_global_extrinsic  # noqa: F401
+from .posegraph import PoseGraph, update_global_extrinsic  # noqa: F401
 from .geom3d import (REF_DEPTH_SCALE, REF_DEPTH_TRUNC, REF_INTRINSICS, add_pose_to_list,  # noqa: F401
                      compute_curr_estimate_global_pose, ensure_so3_v2, pixel_to_3d)
 
