@@ -45,6 +45,7 @@ class GemmDesc(C.Structure):
         ("tile", C.c_int32), ("seg1", C.c_int32), ("out_split_off", C.c_int32), ("res_split_off", C.c_int32),
         ("f8_seg", C.c_int32), ("f8_scales", C.c_uint32), ("out_f8", C.c_int32), ("res_f8", C.c_int32),
         ("qkv_cls_last", C.c_int32), ("qkv_cls_rows", C.c_int32), ("qkv_patch_row0", C.c_int32), ("f8_wonly_from", C.c_int32), ("out_lo8_rows", C.c_int32),
+        ("f8_skip_from", C.c_int32), ("bias2_row0", C.c_int32), ("bias2_group_rows", C.c_int32), ("bias2", C.c_void_p),
     ]
 
 
@@ -67,6 +68,8 @@ _SIGS = {
     "bs_fill_rows": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
     "bs_resize_bilinear_nhwc": [C.c_void_p, C.c_void_p] + [C.c_int32] * 8 + [C.c_void_p],
     "bs_upconv_tapsum": [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p],
+    "bs_col_mean": [C.c_void_p, C.c_int64] + [C.c_int32] * 5 + [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p],
+    "bs_rank1_bias": [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p],
     "bs_attractor_step": [C.c_void_p] * 4 + [C.c_int32] * 8 + [C.c_void_p],
     "bs_add_resized": [C.c_void_p] * 3 + [C.c_int32] * 7 + [C.c_void_p],
     "bs_logbinom_depth": [C.c_void_p] * 8 + [C.c_int32] * 5 + [C.c_float, C.c_float, C.c_int32, C.c_void_p],
@@ -150,10 +153,11 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
                    res2: Optional[torch.Tensor] = None, ldr: int = 0, ldo: Optional[int] = None, out_group=None,
                    shuffle=None, qkv=None, a_offset: int = 0, tile: int = 0, seg1: int = 0, out_split_off: int = 0,
                    res_split_off: int = 0, f8_seg: int = 0, f8_scales=(127, 127, 127, 127), out_f8=None, res_f8: bool = False,
-                   f8_wonly_from: int = 0, out_lo8_rows: int = 0) -> GemmDesc:
+                   f8_wonly_from: int = 0, out_lo8_rows: int = 0, f8_skip_from: int = 0, bias2=None) -> GemmDesc:
     """Fill a bs_gemm_desc.  conv = (Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_h, pad_w) or None;
     out_group = (rows, stride, offset); shuffle = (s, Cout, Hgrid, Wgrid);
-    qkv = (hidden, tokens, Sp, q_scale, out_k, out_vt[, cls_last[, cls_rows[, patch_row0]]]); a_offset in elements."""
+    qkv = (hidden, tokens, Sp, q_scale, out_k, out_vt[, cls_last[, cls_rows[, patch_row0]]]); a_offset in elements;
+    bias2 = (fp32 [groups, N], row0, group_rows)."""
     d = GemmDesc()
     d.A = A.data_ptr() + a_offset * A.element_size()
     d.W = W.data_ptr()
@@ -204,6 +208,11 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
     d.res_f8 = int(res_f8)
     d.f8_wonly_from = f8_wonly_from
     d.out_lo8_rows = out_lo8_rows
+    d.f8_skip_from = f8_skip_from
+    if bias2 is not None:
+        b2, row0, grows = bias2
+        assert b2.dtype == torch.float32 and b2.shape[-1] == N
+        d.bias2, d.bias2_row0, d.bias2_group_rows = b2.data_ptr(), row0, grows
     return d
 
 
@@ -277,7 +286,9 @@ class Plan:
             name=name, tile=load_library().bs_gemm_tile(C.byref(d)), conv=bool(d.conv),
             # executed work in 16-bit-MFMA-equivalents: an FP8 correction stage covers 128 k in the time of 64
             # (tiles past f8_wonly_from run only the first FP8 half)
-            flops=2.0 * d.M * d.N * (d.K + (d.KH * d.KW if d.conv else 1) * d.f8_seg / (4 if d.f8_wonly_from else 2)),
+            # (tiles past f8_skip_from run none)
+            flops=2.0 * d.N * (d.M * d.K + (min(d.f8_skip_from, d.M) if d.f8_skip_from else d.M) * (d.KH * d.KW if d.conv else 1) * d.f8_seg
+                               / (4 if d.f8_wonly_from else 2)),
             # algorithmic FLOPs exclude the extra passes of a split-precision product
             alg_flops=2.0 * d.M * d.N * (d.K / kw.get("precision_passes", 1)),
             # algorithmic HBM bytes: A once (16-bit values + the FP8 planes of a pair row), W once, the output (+ the fp32 residual read)
@@ -481,6 +492,23 @@ def fill_rows(x, v, B, rows_per_image, cols):
 def resize_bilinear_nhwc(x, out, B, Hin, Win, Cch, Hout, Wout, align_corners=True, split=False):
     check(load_library().bs_resize_bilinear_nhwc(p(x), p(out), B, Hin, Win, Cch, Hout, Wout, int(align_corners) | (4 if split == 2 else (2 if split else 0)), dt(x),
                                                  stream_ptr()), "bs_resize_bilinear_nhwc")
+
+
+def col_mean(A, lda, row0, rows_per_group, groups, row_step, K, out, zero=None):
+    """bf16 [groups, K] means over every row_step-th row of each group of the 16-bit matrix A; `zero` (fp32) is cleared as well
+    (include/bodyslam_hip.h)"""
+    assert out.dtype == torch.bfloat16 and (zero is None or zero.dtype == torch.float32)
+    check(load_library().bs_col_mean(p(A), lda, row0, rows_per_group, groups, row_step, K, p(out), p(zero), 0 if zero is None else zero.numel(),
+                                     dt(A), stream_ptr()), "bs_col_mean")
+
+
+def rank1_bias(abar, dw, out):
+    """out [G, N] fp32 (zeroed) += abar [G, K] bf16 @ dw [N, K]^T bf16 (include/bodyslam_hip.h)"""
+    assert abar.dtype == torch.bfloat16 and dw.dtype == torch.bfloat16 and out.dtype == torch.float32
+    G, K = abar.shape
+    N = dw.shape[0]
+    assert dw.shape[1] == K and tuple(out.shape) == (G, N)
+    check(load_library().bs_rank1_bias(p(abar), p(dw), p(out), G, N, K, stream_ptr()), "bs_rank1_bias")
 
 
 def upconv_tapsum(y, bias, out, B, Hin, Win, Cout, Hout, Wout, align_corners=True, split=False, relu=True):

@@ -677,6 +677,133 @@ static int launch_resize(const void* x, const void* addend, void* out, int B, in
     return BS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// column means over a sample of each group's rows (bs_col_mean): block = one group x 256 columns; 32 lanes x 16 bytes cover the
+// 256 columns of a row, the 8 row lanes of a block stride over the sampled rows; fp32 sums, LDS reduction over the row lanes
+template <typename T>
+__global__ __launch_bounds__(256) void col_mean_kernel(const T* A, int64_t lda, int row0, int rows_per_group, int row_step, int K,
+                                                        bf16* out, float* zero_out, int64_t zero_n) {
+    // (the accumulation target of bs_rank1_bias, cleared by the kernel that precedes it anyway)
+    for (int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < zero_n; i += (int64_t)gridDim.x * gridDim.y * 256)
+        zero_out[i] = 0.0f;
+    typedef typename T16<T>::v8 v8;
+    __shared__ float red[8][32][8];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int g = blockIdx.y, c0 = (blockIdx.x * 32 + tx) * 8;
+    const T* base = A + ((int64_t)row0 + (int64_t)g * rows_per_group) * lda;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c0 < K) {
+        for (int j = ty * row_step; j < rows_per_group; j += 8 * row_step) {
+            const v8 v = *reinterpret_cast<const v8*>(base + (int64_t)j * lda + c0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += T16<T>::to_f32(v[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[ty][tx][e] = acc[e];
+    __syncthreads();
+    if (ty == 0 && c0 < K) {
+        const int count = (rows_per_group + row_step - 1) / row_step;
+        const float inv = 1.0f / (float)count;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float s_ = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) s_ += red[r][tx][e];
+            out[(int64_t)g * K + c0 + e] = T16<bf16>::from_f32(s_ * inv);
+        }
+    }
+}
+
+extern "C" int bs_col_mean(const void* A, int64_t lda, int32_t row0, int32_t rows_per_group, int32_t groups, int32_t row_step, int32_t K,
+                           void* out_bf16, float* zero_out, int64_t zero_n, int32_t dtype, void* stream) {
+    BS_ENTRY("bs_col_mean");
+    BS_REQUIRE(A && out_bf16, "bs_col_mean: null operand");
+    BS_REQUIRE(row0 >= 0 && rows_per_group > 0 && groups > 0 && row_step > 0 && K > 0 && K % 8 == 0 && lda >= K && lda % 8 == 0,
+               "bs_col_mean: bad geometry (K and lda must be multiples of 8)");
+    BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_col_mean: dtype must be f16 or bf16");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(cdiv(K, 256), groups);
+    if (dtype == BS_F16)
+        hipLaunchKernelGGL((col_mean_kernel<f16>), grid, dim3(256), 0, st, (const f16*)A, lda, row0, rows_per_group, row_step, K,
+                           (bf16*)out_bf16, zero_out, zero_out ? zero_n : 0);
+    else
+        hipLaunchKernelGGL((col_mean_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)A, lda, row0, rows_per_group, row_step, K,
+                           (bf16*)out_bf16, zero_out, zero_out ? zero_n : 0);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bs_rank1_bias: out[g, n] += sum_k abar[g, k] dW[n, k] -- a [G, K] x [K, N] product with G ~ 128 rows.  As a tile GEMM it is 8-32
+// blocks walking a long K (latency-bound, ~100 us); here a block owns 32 columns x HALF of K for all G rows, fragments go straight
+// from L2 to registers (both operands are a few MB and re-read by few blocks), 16x16x32 bf16 MFMA, and the two K halves meet by
+// fp32 atomics on a zeroed target (two addends: the sum does not depend on their order, results stay run-to-run identical).
+__global__ __launch_bounds__(256) void rank1_bias_kernel(const bf16* abar, const bf16* dW, float* out, int G, int N, int K) {
+    typedef T16<bf16>::v8 v8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * 32, kh = K >> 1, k0 = blockIdx.y * kh;
+    for (int g0 = wave * 32; g0 < G; g0 += 128) {
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bf16* ap[2];
+        const bf16* bp[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int g = g0 + i * 16 + frow;
+            g = g < G ? g : G - 1;
+            ap[i] = abar + (int64_t)g * K + k0 + fq * 8;
+            int n = n0 + i * 16 + frow;
+            n = n < N ? n : N - 1;
+            bp[i] = dW + (int64_t)n * K + k0 + fq * 8;
+        }
+        auto step = [&](int k) {
+            v8 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const v8*>(ap[i] + k);
+                bf[i] = *reinterpret_cast<const v8*>(bp[i] + k);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = T16<bf16>::mfma16(bf[j], af[i], acc[i][j]);
+        };
+        int k = 0;
+        for (; k + 128 <= kh; k += 128) {      // four steps' loads in flight
+#pragma unroll
+            for (int u = 0; u < 4; ++u) step(k + 32 * u);
+        }
+        for (; k < kh; k += 32) step(k);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int g = g0 + i * 16 + frow;
+            if (g >= G) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = n0 + j * 16 + fq * 4 + e;
+                    if (n < N) unsafeAtomicAdd(out + (int64_t)g * N + n, acc[i][j][e]);
+                }
+        }
+    }
+}
+
+extern "C" int bs_rank1_bias(const void* abar_bf16, const void* dw_bf16, float* out, int32_t G, int32_t N, int32_t K, void* stream) {
+    BS_ENTRY("bs_rank1_bias");
+    BS_REQUIRE(abar_bf16 && dw_bf16 && out, "bs_rank1_bias: null operand");
+    BS_REQUIRE(G > 0 && N > 0 && K > 0 && K % 64 == 0, "bs_rank1_bias: K=%d must be a multiple of 64", K);
+    hipLaunchKernelGGL(rank1_bias_kernel, dim3(cdiv(N, 32), 2), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const bf16*)abar_bf16,
+                       (const bf16*)dw_bf16, out, G, N, K);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
 template <typename T>
 static int launch_tapsum(const float* y, const float* bias, void* out, int B, int Hin, int Win, int Co, int Hout, int Wout, int align, int split,
                          int relu, hipStream_t st) {

@@ -212,6 +212,15 @@ extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
     p.qkv_patch_row0 = d->qkv_patch_row0;
     p.f8_wonly_from = d->f8_wonly_from;
     p.out_lo8_rows = d->out_lo8_rows;
+    p.f8_skip_from = d->f8_skip_from;
+    p.bias2 = d->bias2;
+    p.bias2_row0 = d->bias2_row0;
+    p.bias2_group_rows = d->bias2_group_rows;
+    BS_REQUIRE(d->f8_skip_from == 0 || (d->f8_seg > 0 && d->f8_skip_from > 0 && d->f8_skip_from % 256 == 0 && !d->conv),
+               "bs_gemm: f8_skip_from needs the FP8 correction segment of a plain GEMM and a multiple of 256 rows");
+    BS_REQUIRE(!d->bias2 || (d->bias2_group_rows > 0 && d->bias2_row0 >= 0 && d->bias_group_rows == 0 && !d->conv && d->out_mode != BS_OUT_SHUFFLE &&
+                             d->N % 4 == 0),
+               "bs_gemm: bias2 needs bias2_group_rows > 0, a plain GEMM (PLAIN or QKV output) and no bias_group_rows");
     BS_REQUIRE(d->out_lo8_rows == 0 || (d->out_f8 && d->out_lo8_rows % 256 == 0), "bs_gemm: out_lo8_rows needs out_f8 and a multiple of 256 rows");
     BS_REQUIRE(d->f8_wonly_from == 0 || d->f8_seg > 0, "bs_gemm: f8_wonly_from needs the FP8 correction segment");
     BS_REQUIRE(d->qkv_cls_rows == 0 || (d->out_mode == BS_OUT_QKV && d->qkv_cls_last && d->qkv_tokens > 1 && d->qkv_patch_row0 >= d->qkv_cls_rows &&

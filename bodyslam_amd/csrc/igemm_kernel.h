@@ -73,6 +73,9 @@ struct IgemmParams {
     int out_f8;          // > 0 with split_off: the output pair is (hi16 | hi8 | lo8), see store8_f8
     int out_lo8_rows;    // > 0: only output rows below this index need their lo8 plane (the consumer drops the activation-rounding
                          //      correction on the others, f8_wonly_from): tiles past it skip that plane
+    int f8_skip_from;    // > 0: tiles that start at a row >= this run no FP8 stage at all
+    const float* bias2;  // optional fp32 [groups, N] added to rows >= bias2_row0, group = (m - bias2_row0) / bias2_group_rows
+    int bias2_row0, bias2_group_rows;
     int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue, 8 = no tail split (host side)
 };
 
@@ -199,7 +202,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // F8: the instantiation that knows the FP8 correction stages and the (hi16 | hi8 | lo8) epilogue formats (accurate mode);
 // the plain instantiation carries none of that code, so fast-mode launches are not affected by its register pressure.
 template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int MODE, bool PP = false, bool F8 = false>
-__global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins exist in the device pass only; the host pass needs just the stub
     constexpr bool CONV = MODE != 0;
     constexpr bool RELU_A = MODE == 2;
@@ -372,7 +375,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
     const int nt16 = F8 ? nt_all - p.f8_stages : nt_all;   // stages multiplied as 16-bit data; the rest are FP8 correction stages (BK = 64 tiles)
     // the second half of the FP8 stages (A_lo8 W_hi8) is dropped for tiles past f8_wonly_from: they stop after the first half
     const bool wonly = F8 && p.f8_wonly_from != 0 && (p.f8_wonly_from < 0 || m0 >= p.f8_wonly_from);
-    const int nt = wonly ? nt_all - (p.f8_stages >> 1) : nt_all;
+    const bool skip8 = F8 && p.f8_skip_from > 0 && m0 >= p.f8_skip_from;
+    const int nt = skip8 ? nt16 : (wonly ? nt_all - (p.f8_stages >> 1) : nt_all);
     if constexpr (!PP) {
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s)
@@ -533,6 +537,17 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.out)[0] = 1.f;   // keep the accumulators live
         return;
     }
+    // bias2 (per-group second bias): g2 >= 0 when every row of this tile belongs to one group (folded into the column biases),
+    // b2_rows when the tile straddles groups or the first covered row (looked up per row)
+    int g2 = -1;
+    bool b2_rows = false;
+    if (p.bias2) {
+        const int lo = m0 - p.bias2_row0, hi = (m0 + BM < p.M ? m0 + BM : p.M) - 1 - p.bias2_row0;
+        if (hi >= 0) {
+            if (lo >= 0 && lo / p.bias2_group_rows == hi / p.bias2_group_rows) g2 = lo / p.bias2_group_rows;
+            else b2_rows = true;
+        }
+    }
     if (!v_tile) {
         auto epi = [&](auto act_tag) {
             constexpr int ACT = decltype(act_tag)::value;
@@ -546,6 +561,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                 n0j[j] = n0;
                 const bool ok = n0 < p.N;
                 bj[j] = (p.bias && !p.bias_group_rows && ok) ? *reinterpret_cast<const f32x4*>(p.bias + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (g2 >= 0 && ok) bj[j] += *reinterpret_cast<const f32x4*>(p.bias2 + (int64_t)g2 * p.N + n0);
                 sj[j] = (p.scale && ok) ? *reinterpret_cast<const f32x4*>(p.scale + n0) : f32x4{1.f, 1.f, 1.f, 1.f};
                 which[j] = 0;
                 if (p.out_mode == BS_OUT_PLAIN) {
@@ -576,6 +592,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                 int64_t roff;            // row part of the store offset (elements)
                 const float* brow = nullptr;
                 if (p.bias && p.bias_group_rows) brow = p.bias + (int64_t)(m / p.bias_group_rows) * p.N;
+                const float* brow2 = (b2_rows && m >= p.bias2_row0) ? p.bias2 + (int64_t)((m - p.bias2_row0) / p.bias2_group_rows) * p.N : nullptr;
                 if (p.out_mode == BS_OUT_PLAIN) {
                     if (p.out_group_rows) {
                         const int g = m / p.out_group_rows;
@@ -617,6 +634,11 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) y[e] = acc[i][j][e] + bj[j][e];
+                        }
+                        if (brow2) {
+                            const f32x4 bb = *reinterpret_cast<const f32x4*>(brow2 + n0j[j]);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[e] += bb[e];
                         }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -681,7 +703,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
         };
         // ---- two specialised forms of the same arithmetic for the backbone's hot shapes (wave-uniform selection) -----------------
         const bool plain_full = p.out_mode == BS_OUT_PLAIN && !p.out_group_rows && p.bias && !p.bias_group_rows && p.N % BN == 0 &&
-                                p.ldo % 8 == 0 && !(p.ablate & 16);
+                                p.ldo % 8 == 0 && !b2_rows && !(p.ablate & 16);
         if (plain_full && p.act == BS_ACT_NONE && p.res && p.res_dtype == BS_F32 && !p.res2 && p.out_dtype == BS_F32 && p.split_off == 0 &&
             !(F8 && p.out_f8) && p.scale && p.ldr % 4 == 0) {
             // o_proj / fc2: x += scale * (acc + bias), fp32 in place.  The generic loop reads the residual where it needs it and the
@@ -695,6 +717,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
             for (int j = 0; j < FN; ++j) {
                 const int n0 = n_wave + (j >> 1) * 32 + fq * 8 + (j & 1) * 4;
                 bj[j] = *reinterpret_cast<const f32x4*>(p.bias + n0);
+                if (g2 >= 0) bj[j] += *reinterpret_cast<const f32x4*>(p.bias2 + (int64_t)g2 * p.N + n0);
                 sj[j] = *reinterpret_cast<const f32x4*>(p.scale + n0);
             }
             const int mrow = m0 + wm * TM + frow;
@@ -735,7 +758,11 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                 const bool lo = !(p.out_lo8_rows > 0 && m0 >= p.out_lo8_rows);
                 f32x4 bj[FN];
 #pragma unroll
-                for (int j = 0; j < FN; ++j) bj[j] = *reinterpret_cast<const f32x4*>(p.bias + n_wave + (j >> 1) * 32 + fq * 8 + (j & 1) * 4);
+                for (int j = 0; j < FN; ++j) {
+                    const int n0 = n_wave + (j >> 1) * 32 + fq * 8 + (j & 1) * 4;
+                    bj[j] = *reinterpret_cast<const f32x4*>(p.bias + n0);
+                    if (g2 >= 0) bj[j] += *reinterpret_cast<const f32x4*>(p.bias2 + (int64_t)g2 * p.N + n0);
+                }
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     const int m = m0 + wm * TM + i * 16 + frow;
@@ -799,6 +826,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                 otok = m - ob * p.qkv_tokens;
                 if (p.qkv_cls_last) otok = otok == 0 ? p.qkv_tokens - 1 : otok - 1;
             }
+            const float* b2 = (p.bias2 && m < p.M && m >= p.bias2_row0) ? p.bias2 + (int64_t)((m - p.bias2_row0) / p.bias2_group_rows) * p.N : nullptr;
             if (m < p.M && !pad_row) {
                 for (int c0 = 0; c0 < TN; c0 += CPS) {
                     const int c = c0 + csub;
@@ -806,6 +834,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
                     if (n >= p.N) continue;
                     float y = sc[r * TN + ((((c >> 2) ^ (r & (S4 - 1))) << 2) | (c & 3))];
                     if (p.bias) y += p.bias[n];
+                    if (b2) y += b2[n];
                     const int rem = n - 2 * p.qkv_hidden;
                     vt[(((int64_t)ob * nh + (rem >> 6)) * 64 + (rem & 63)) * p.qkv_sp + otok] = T16<T>::from_f32(y);
                 }

@@ -24,6 +24,7 @@ PyTorch is used for allocation, views and one-off weight re-layout only.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -84,12 +85,16 @@ class ZoeConfig:
         return self.level_attractors[level] if self.single_head else self.n_attractors
 
 
-# Which correction products accurate mode evaluates per backbone GEMM class (tools/probes/precision_classes.py, DESIGN.md
-# Numerics).  "wcls": weight-rounding correction on every row, activation-rounding correction on the cls-token rows only --
-# measured depth L1 vs the fp32 oracle 2.1e-5 / 4.1e-5 m on two weight seeds (both corrections everywhere: 1.3e-5; none on the
-# patch rows AND none on the cls rows: 1.4e-4, a coherent offset of the whole map that enters through the cls row alone).
+# Which correction products accurate mode evaluates per backbone GEMM class (tools/probes/precision_classes.py,
+# tools/probes/weight_mean_correction.py, DESIGN.md Numerics).
+#   "full"  A_hi W_hi + A_hi8 W_lo8 + A_lo8 W_hi8 on every row (2 pass-equivalents): depth L1 vs the fp32 oracle 1.3e-5 m
+#   "wcls"  the activation-rounding correction on the cls-token tile only (its error is the only coherent one): 1.5 passes,
+#           4.3e-5 / 2.0e-5 m on two weight seeds
+#   "wmean" patch tiles run ONE 16-bit pass; the weight-rounding error A dW^T, a coherent offset, is replaced by its
+#           token-independent part 1 (mean_tokens(A) dW^T) -- a per-image bias from a column mean and a tiny GEMM; the cls tile
+#           keeps both corrections: ~1.0 pass, 5.0e-5 / 3.1e-5 m
 # The neck keeps both products (weight correction only: 0.9-2.0e-4).
-ACCURATE_CLASS_MODES: Dict[str, str] = {"qkv": "wcls", "o": "wcls", "fc1": "wcls", "fc2": "wcls"}
+ACCURATE_CLASS_MODES: Dict[str, str] = {"qkv": "wmean", "o": "wmean", "fc1": "wmean", "fc2": "wmean"}
 ACCURATE_NECK_MODE = "full"
 
 ZOED_NK = ZoeConfig()
@@ -166,8 +171,10 @@ class ZoeDepthEngine:
         self._raw_tables = []
         self.f8s: Dict[str, Tuple[int, int]] = {}
         self.class_modes = dict(ACCURATE_CLASS_MODES)
+        if os.environ.get("BS_ACCURATE_CLASS_MODE"):          # diagnostics (A/B runs of bench.py): one mode for all four classes
+            self.class_modes = {k: os.environ["BS_ACCURATE_CLASS_MODE"] for k in self.class_modes}
         self.class_modes.update(class_modes or {})
-        assert all(v in ("full", "w", "wcls", "a", "single") for v in self.class_modes.values()), self.class_modes
+        assert all(v in ("full", "w", "wcls", "wmean", "a", "single") for v in self.class_modes.values()), self.class_modes
         self.single_keys = set()
         self.wmode: Dict[str, str] = {}
         # DPT neck / heads (no cls rows there): "full" = both correction products, "w" = the weight-rounding correction only
@@ -210,9 +217,11 @@ class ZoeDepthEngine:
             return self._wn(t)
         if mode == "w" and t.shape[1] % 256 != 0:
             mode = "full"
-        w8, sb = L.f8_weight(t, self.dtype, planes={"full": "both", "wcls": "both", "w": "lo", "a": "hi_only"}[mode])
+        w8, sb = L.f8_weight(t, self.dtype, planes={"full": "both", "wcls": "both", "wmean": "both", "w": "lo", "a": "hi_only"}[mode])
         self.f8s[key] = sb
         self.wmode[key] = mode
+        if mode == "wmean":        # dW = W - round16(W) as bf16 (fp32's exponent range): the W operand of the rank-1 correction GEMM
+            self.w[key + ".lo"] = (t - t.to(self.dtype).float()).to(torch.bfloat16).to(self.dev).contiguous()
         return w8.to(self.dev)
 
     def _w8conv(self, key: str, t: torch.Tensor) -> torch.Tensor:
@@ -559,6 +568,8 @@ class _ZoePlan:
             """row multiplier of the activation a backbone GEMM reads: 1 = single rows, 2 = pair rows"""
             return 2 if fmt(wkey) else 1
 
+        MEAN_STEP = 8      # the rank-1 correction's token mean uses every 8th patch row (probe: same depth result as the full mean)
+
         def bgemm(name, A, wkey, out, M, N, K, **kw):
             """backbone GEMM.  Accurate mode: A_hi W_hi + A_hi W_lo + A_lo W_hi in one launch -- the two corrections on the
             block-scaled FP8 MFMA where the weight was packed for it (A = [hi16 | hi8 | lo8], 2 pass-equivalents), else as
@@ -570,6 +581,18 @@ class _ZoePlan:
                 sb0, _ = f8s[wkey]
                 P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=2 * K, f8_seg=K,
                        f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_HI_EXP, sb0), precision_passes=1, **kw)
+            elif acc and wkey in f8s and eng.wmode.get(wkey) == "wmean" and grouped:
+                # cls tile: both FP8 corrections.  Patch tiles: ONE 16-bit pass; the weight-rounding error A dW^T is replaced by its
+                # token-independent part 1 (mean_tokens(A) dW^T), a per-image bias formed by a column-mean kernel over a sample of
+                # the image's patch rows and bs_rank1_bias, a [NB, K] x [K, N] product (Numerics)
+                sb0, sb1 = f8s[wkey]
+                abar = pool.alloc((NB, K), torch.bfloat16)
+                b2 = e32(NB, N)
+                P.add(name + ".cm", "bs_col_mean", A, 2 * K, CP, T0, NB, MEAN_STEP, K, abar, b2, NB * N, L.dt(A))
+                P.add(name + ".r1", "bs_rank1_bias", abar, w[wkey + ".lo"], b2, NB, N, K)
+                P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=2 * K, f8_seg=2 * K, f8_skip_from=CP, bias2=(b2, CP, T0),
+                       f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1), precision_passes=1, **kw)
+                free(abar, b2)
             elif acc and wkey in f8s:
                 sb0, sb1 = f8s[wkey]
                 wonly = CP if (eng.wmode.get(wkey) == "wcls" and grouped) else 0      # tiles past the cls group: weight correction only
@@ -610,7 +633,7 @@ class _ZoePlan:
                   ldo=c.intermediate * am(f"l{l}.fc2.w"), out_split_off=c.intermediate if hfmt else 0,
                   out_f8=(L.F8_ACT_HI_EXP, L.F8_ACT_LO_EXP) if hfmt == 32 else None,
                   # fc2 in "wcls" mode reads the lo8 plane of its cls tile only
-                  out_lo8_rows=CP if (hfmt == 32 and grouped and eng.wmode.get(f"l{l}.fc2.w") == "wcls") else 0)
+                  out_lo8_rows=CP if (hfmt == 32 and grouped and eng.wmode.get(f"l{l}.fc2.w") in ("wcls", "wmean")) else 0)
             bgemm(f"l{l}.fc2", hid, f"l{l}.fc2.w", x, MT, Hd, c.intermediate, bias=w[f"l{l}.fc2.b"], scale=w[f"l{l}.lam2"], res=x, ldr=Hd)
             P.mark(f"layer{l + 1}", x, TOK)
             if (l + 1) in c.taps:
@@ -831,7 +854,9 @@ class _ZoePlan:
         # resolution (N = 9 * 32, a quarter of the conv's FLOPs; the N = 32 conv ran at 20 % of the MFMA peak, bound by the LDS fill
         # rate) and bs_upconv_tapsum gathers / interpolates / sums them -- the upsampled map is never materialised.
         y9 = e32(NB, h3, w3, 9 * c.rel_features)
-        nplain("rh.conv2", r1, "rh.conv2.w", y9, NB * h3 * w3, 9 * c.rel_features, Fc // 2, out_pairs=False)
+        # (K = 128: a block's main loop is four K steps, the launch is bound by block turnover -- the 128x64 tile, 3 blocks per CU,
+        # takes 3.8 ms where the 128x128 one takes 5.9, tools/probes/rh_conv2_tiles.py)
+        nplain("rh.conv2", r1, "rh.conv2.w", y9, NB * h3 * w3, 9 * c.rel_features, Fc // 2, out_pairs=False, tile=2)
         free(r1)
         last = e16(NB, 2 * h3, 2 * w3, c.rel_features * m2)
         P.add("rh.tapsum", "bs_upconv_tapsum", y9, w["rh.conv2.b"], last, NB, h3, w3, c.rel_features, 2 * h3, 2 * w3, RZ, 1, L.dt(last))

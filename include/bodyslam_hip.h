@@ -128,10 +128,28 @@ typedef struct bs_gemm_desc {
                                     * switch run the backbone at 1.5 instead of 2 pass-equivalents. */
     int32_t out_lo8_rows;          /* with out_f8, > 0: only output rows below this index store their lo8 plane (their consumer is a
                                     * GEMM with f8_wonly_from = this value, which never reads it on the other rows) */
+    int32_t f8_skip_from;          /* with f8_seg, k > 0: tiles that start at a row >= k run NO FP8 stage (one 16-bit pass); their
+                                    * weight-rounding error is corrected by its token-independent part instead, see bias2 */
+    int32_t bias2_row0;            /* bias2 applies to rows m >= bias2_row0 ... */
+    int32_t bias2_group_rows;      /* ... with group (m - bias2_row0) / bias2_group_rows (> 0 when bias2 is given) */
+    const float* bias2;            /* optional fp32 [groups, N], added like the bias: y = acc + bias[n] + bias2[group, n].  The backbone
+                                    * uses it for the rank-1 part of the weight-rounding error of a single-pass product:
+                                    * A dW^T ~ 1 (mean_tokens(A) dW^T) per image (Numerics); excludes bias_group_rows */
 } bs_gemm_desc;
 int bs_gemm(const bs_gemm_desc* d, void* stream);
 /* the tile variant bs_gemm will pick for this descriptor (1: 128x128, 2: 128x64, 3: 128x32, 4: 256x128) */
 int bs_gemm_tile(const bs_gemm_desc* d);
+
+/* column means over a sample of the rows of each group: out[g, k] = mean_{j < rows_per_group, j % row_step == 0} A[row0 + g*rows_per_group + j, k]
+ * for the 16-bit matrix A (row stride lda elements; the hi16 plane of a pair row), written as bf16 [groups, K] -- the A operand of
+ * bs_rank1_bias, which forms bias2 above (mean over the patch tokens of an image; a sample of every 8th token changes the depth
+ * result by < 1e-6 m, tools/probes/weight_mean_correction.py). */
+int bs_col_mean(const void* A, int64_t lda, int32_t row0, int32_t rows_per_group, int32_t groups, int32_t row_step, int32_t K,
+                void* out_bf16, float* zero_out, int64_t zero_n, int32_t dtype, void* stream);
+/* out[g, n] += sum_k abar[g, k] * dW[n, k]: bf16 [G, K] x bf16 [N, K]^T accumulated into fp32 [G, N], which the caller has zeroed
+ * (bs_col_mean clears `zero_out[0 .. zero_n)` for it).  With dW = W - round16(W) this is bias2 of the backbone's single-pass
+ * products.  The K axis is cut in two halves that meet by atomics: two addends, so the result is order-independent. */
+int bs_rank1_bias(const void* abar_bf16, const void* dw_bf16, float* out, int32_t G, int32_t N, int32_t K, void* stream);
 
 /* BEiT attention: softmax(Q K^T + relpos_bias) V -------------------------------------------- *
  * HF modeling_beit.py:268-341 (eager_attention_forward with the additive relative-position bias

@@ -261,6 +261,65 @@ def test_f8_correction_gemm(L, dtype, tile):
     assert ((hi + lo8 - out).abs() <= out.abs() * (2.0 ** -15 if dtype == torch.float16 else 2.0 ** -12) + 2.0 ** -20).all()
 
 
+@pytest.mark.parametrize("tile,G", [(9, 256), (9, 192), (1, 256)])
+def test_gemm_skip_f8_and_group_bias(L, tile, G):
+    """bs_gemm f8_skip_from + bias2 (the backbone's "wmean" products): tiles before `skip` evaluate the full split-precision
+    product, tiles from `skip` on exactly ONE 16-bit pass plus the per-group bias2 row -- checked against both statements in
+    fp64, for groups that coincide with tiles (bias folded per tile) and groups that straddle tiles (per-row lookup)."""
+    dtype = torch.float16
+    skip, M, N, K = 256, 256 + 3 * 256, 512, 256
+    groups = -(-(M - skip) // G)
+    x = rnd(M, K, seed=1)
+    A8 = to_f8_pairs(x, dtype)
+    w = rnd(N, K, seed=2, scale=1 / math.sqrt(K))
+    W8, (sb0, sb1) = L.f8_weight(w, dtype)
+    bias, b2 = rnd(N, seed=3), rnd(groups, N, seed=4)
+    out = torch.empty(M, N, device=dev())
+    L.gemm(A8, W8.to(dev()), out, M=M, N=N, K=K, lda=2 * K, f8_seg=2 * K, f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1),
+           bias=bias, f8_skip_from=skip, bias2=(b2, skip, G), tile=tile)
+    xv = from_f8_pairs(A8, K)[1].double()
+    full = xv @ w.double().t() + bias.double()
+    hi = A8[:, :K].double() @ w.to(dtype).double().t() + bias.double()
+    grp = (torch.arange(M - skip, device=dev()) // G)
+    hi[skip:] += b2.double()[grp]
+    e_head = (out[:skip].double() - full[:skip]).abs().max().item()
+    e_tail = (out[skip:].double() - hi[skip:]).abs().max().item()
+    report(f"gemm f8_skip_from/bias2 tile{tile} G{G}: cls tile vs split-precision product {e_head:.2e}, patch tiles vs one pass + bias2 {e_tail:.2e}")
+    assert e_head < 1e-4 and e_tail < 2e-5           # (the tail differs from its statement by fp32 accumulation order only)
+    # the fc2 / o_proj epilogue (fp32 residual + layer scale) and the QKV scatter take the same bias
+    res, lam = rnd(M, N, seed=5), rnd(N, seed=6)
+    o2 = res.clone()
+    L.gemm(A8, W8.to(dev()), o2, M=M, N=N, K=K, lda=2 * K, f8_seg=2 * K, f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1),
+           bias=bias, scale=lam, res=o2, ldr=N, f8_skip_from=skip, bias2=(b2, skip, G), tile=tile)
+    ref2 = res.double() + lam.double() * hi
+    assert (o2[skip:].double() - ref2[skip:]).abs().max().item() < 1e-4
+
+
+def test_col_mean(L):
+    dtype = torch.float16
+    K, G, rows, row0, step = 512, 5, 96, 256, 8
+    A = rnd(row0 + G * rows, 2 * K, seed=7, dtype=dtype)          # pair rows: only the first K columns (the hi16 plane) are averaged
+    out = torch.zeros(G, K, device=dev(), dtype=torch.bfloat16)
+    junk = torch.ones(G, 300, device=dev())
+    L.col_mean(A, 2 * K, row0, rows, G, step, K, out, zero=junk)
+    ref = A[row0:, :K].float().view(G, rows, K)[:, ::step].mean(1)
+    assert (out.float() - ref).abs().max().item() < 2.0 ** -8 * ref.abs().max().item() + 1e-6
+    assert not junk.any()
+
+
+@pytest.mark.parametrize("G,N,K", [(128, 1024, 1024), (2, 96, 128), (130, 3072, 1024), (128, 1024, 4096)])
+def test_rank1_bias(L, G, N, K):
+    a = rnd(G, K, seed=8).to(torch.bfloat16)
+    dw = (rnd(N, K, seed=9) * 1e-5).to(torch.bfloat16)            # weight-rounding residues are ~2^-12 of the weights
+    out = torch.zeros(G, N, device=dev())
+    L.rank1_bias(a, dw, out)
+    ref = a.double() @ dw.double().t()
+    assert (out.double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item() + 1e-12
+    again = torch.zeros(G, N, device=dev())
+    L.rank1_bias(a, dw, again)
+    assert torch.equal(out, again)                                # two atomic addends per element: order-independent
+
+
 def to_f8_pairs(x, dtype):
     """fp32 [..., C] -> [..., 2C] `dtype`-typed rows of (hi16 | hi8 | lo8) -- the torch statement of the operand format."""
     import bodyslam_amd._lib as L_

@@ -17,5 +17,5 @@ print(f"  conv stack: {b.get('roofline_conv_stack')}")
 o = b.get("other_mode")
 if o:
     print(f"{o['precision']}: {o['value']} frames/s, {o['ms_per_step']} ms/step, L1 {o.get('depth_l1_vs_oracle_m')}, frac {o['roofline']['frac']}")
-for k, v in sorted(b.get("kernels", {}).items(), key=lambda kv: -kv[1].get("share_of_step", 0))[:12]:
+for k, v in sorted(b.get("kernels", {}).items(), key=lambda kv: -kv[1].get("share_of_step", 0))[:int(__import__("os").environ.get("TOP", "12"))]:
     print(f"  {k:36s} n={v['launches']:4d} avg {v['avg_us']:9.1f} us share {v.get('share_of_step', 0):.3f} exec {v.get('executed_tflops', 0):7.1f} TF")

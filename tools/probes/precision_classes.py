@@ -17,8 +17,9 @@ from oracle import zoedepth_ref as Z               # noqa: E402
 
 ALL = ("qkv", "o", "fc1", "fc2")
 WC = {c: "wcls" for c in ALL}
-CONFIGS = [(WC, "full"), (WC, "w"), (WC, "ro"), (WC, "ro,ra"), (WC, "ro,ra,nc"), (WC, "ro,ra,nc,fu"), (WC, "rh"), (WC, "fu"), (WC, "rh,pj"), (WC, "ro,ra,nc,rh,pj"),
-           (WC, "ro,ra,nc,fu,pj")]
+WM = {c: "wmean" for c in ALL}                       # one 16-bit pass on the patch tiles + the rank-1 weight-rounding correction
+WM3 = dict(WM, fc1="wcls")                           # ... except fc1, whose weight-rounding error is not token-independent (GELU)
+CONFIGS = [(WC, "full"), (WM3, "full"), (WM, "full"), (dict(WC, qkv="wmean", o="wmean"), "full"), (dict(WC, fc2="wmean"), "full")]
 seeds = [int(a) for a in sys.argv[1:]] or [1, 2]
 out = open(os.path.join(ROOT, "gpurun_out", "precision_classes.txt"), "a")
 for seed in seeds:
