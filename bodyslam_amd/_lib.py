@@ -45,7 +45,8 @@ class GemmDesc(C.Structure):
         ("tile", C.c_int32), ("seg1", C.c_int32), ("out_split_off", C.c_int32), ("res_split_off", C.c_int32),
         ("f8_seg", C.c_int32), ("f8_scales", C.c_uint32), ("out_f8", C.c_int32), ("res_f8", C.c_int32),
         ("qkv_cls_last", C.c_int32), ("qkv_cls_rows", C.c_int32), ("qkv_patch_row0", C.c_int32), ("f8_wonly_from", C.c_int32), ("out_lo8_rows", C.c_int32),
-        ("f8_skip_from", C.c_int32), ("bias2_row0", C.c_int32), ("bias2_group_rows", C.c_int32), ("bias2", C.c_void_p),
+        ("f8_skip_from", C.c_int32), ("bias2_row0", C.c_int32), ("bias2_group_rows", C.c_int32), ("out_planes_rows", C.c_int32),
+        ("bias2", C.c_void_p),
     ]
 
 
@@ -153,7 +154,7 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
                    res2: Optional[torch.Tensor] = None, ldr: int = 0, ldo: Optional[int] = None, out_group=None,
                    shuffle=None, qkv=None, a_offset: int = 0, tile: int = 0, seg1: int = 0, out_split_off: int = 0,
                    res_split_off: int = 0, f8_seg: int = 0, f8_scales=(127, 127, 127, 127), out_f8=None, res_f8: bool = False,
-                   f8_wonly_from: int = 0, out_lo8_rows: int = 0, f8_skip_from: int = 0, bias2=None) -> GemmDesc:
+                   f8_wonly_from: int = 0, out_lo8_rows: int = 0, f8_skip_from: int = 0, bias2=None, out_planes_rows: int = 0) -> GemmDesc:
     """Fill a bs_gemm_desc.  conv = (Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_h, pad_w) or None;
     out_group = (rows, stride, offset); shuffle = (s, Cout, Hgrid, Wgrid);
     qkv = (hidden, tokens, Sp, q_scale, out_k, out_vt[, cls_last[, cls_rows[, patch_row0]]]); a_offset in elements;
@@ -209,6 +210,7 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
     d.f8_wonly_from = f8_wonly_from
     d.out_lo8_rows = out_lo8_rows
     d.f8_skip_from = f8_skip_from
+    d.out_planes_rows = out_planes_rows
     if bias2 is not None:
         b2, row0, grows = bias2
         assert b2.dtype == torch.float32 and b2.shape[-1] == N

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict_
 //   planes [32][64] bytes (64-byte rows, chunk c at c ^ ((r >> 1) & 3)).
 template <typename T>
 __device__ __forceinline__ void store_out_tile(char* wlds, const f32x16 (&oacc)[2], float inv, T* __restrict__ out, int split, int nh, int head,
-                                               int64_t row0, int64_t row_cls, int S, int q0, bool active, int lane) {
+                                               int64_t row0, int64_t row_cls, int S, int q0, bool active, int lane, bool cls_planes = false) {
     typedef typename T16<T>::v8 v8;
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     const int r = lane & 31, h2 = lane >> 5;
@@ -233,6 +233,9 @@ __device__ __forceinline__ void store_out_tile(char* wlds, const f32x16 (&oacc)[
     char* lh8 = wlds + 4096;
     char* ll8 = wlds + 6144;
     char* llo = wlds + 4096;     // split == 1: the 16-bit lo plane, same image as hi16
+    // cls_planes: only the cls query's row needs its FP8 planes (the consumer runs no FP8 stage on patch rows): tiles without
+    // that row skip the packing and the plane stores (wave-uniform)
+    const bool planes = split == 2 && (!cls_planes || (q0 <= S - 1 && S - 1 < q0 + 32));
 #pragma unroll
     for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
@@ -249,7 +252,7 @@ __device__ __forceinline__ void store_out_tile(char* wlds, const f32x16 (&oacc)[
             const int d0 = dh * 32 + 8 * gg + 4 * h2;                 // first of this lane's 4 consecutive d
             const int c16 = d0 >> 3, w16 = (d0 & 7) * 2;              // 16-byte chunk of the 128-byte hi16 row, byte inside it
             *reinterpret_cast<typename T16<T>::v4*>(l16 + r * 128 + ((c16 ^ (r & 7)) << 4) + w16) = o;
-            if (split == 2) {
+            if (planes) {
                 const float sh = __builtin_ldexpf(1.0f, F8_ACT_HI_EXP), sl = __builtin_ldexpf(1.0f, F8_ACT_LO_EXP);
                 const int c8 = d0 >> 4, w8 = d0 & 15;                  // 16-byte chunk of the 64-byte plane row
                 const int pos = r * 64 + ((c8 ^ ((r >> 1) & 3)) << 4) + w8;
@@ -279,12 +282,12 @@ __device__ __forceinline__ void store_out_tile(char* wlds, const f32x16 (&oacc)[
             if (split == 1) *reinterpret_cast<v8*>(orow + nh * 64 + head * 64 + c * 8) = *reinterpret_cast<const v8*>(llo + rr * 128 + ((c ^ (rr & 7)) << 4));
         }
     }
-    if (split == 2) {   // FP8 planes: 4 lanes cover one 64-byte row, a wave-instruction 16 rows
+    if (planes) {   // FP8 planes: 4 lanes cover one 64-byte row, a wave-instruction 16 rows
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
             const int rr = ps * 16 + (lane >> 2), c = lane & 3;
             T* orow = out_row(rr);
-            if (orow) {
+            if (orow && (!cls_planes || q0 + rr == S - 1)) {
                 char* planes = reinterpret_cast<char*>(orow + nh * 64);
                 const int pos = rr * 64 + ((c ^ ((rr >> 1) & 3)) << 4);
                 *reinterpret_cast<i32x4*>(planes + head * 64 + c * 16) = *reinterpret_cast<const i32x4*>(lh8 + pos);
@@ -328,6 +331,8 @@ template <typename T, int QW>
 __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ Vt,
                                                                  const float* __restrict__ table, T* __restrict__ out, int split, int B, int nh,
                                                                  int hp, int Sp, int nqb, int ntab, int grouped, int ablate) {
+    const bool cls_planes = (split & 4) != 0;   // FP8 planes for the cls query's row only (bs_attention_table, dtype bit 6)
+    split &= 3;
     typedef typename T16<T>::v8 v8;
     constexpr int STAGE = 16 * 1024;  // K tile 8 KiB + V^T tile 8 KiB
     constexpr int WP = 32;
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restr
     const float inv = 1.0f / l_tot;
     __syncthreads();                     // every wave is done with the K / V^T ring and the table: the LDS becomes the store staging
     store_out_tile<T>(smem + wave * 8192, oacc, inv, out, split, nh, head, grouped ? (int64_t)grouped + (int64_t)b * (S - 1) : (int64_t)b * S + 1,
-                      grouped ? (int64_t)b : (int64_t)b * S, S, q0, active, lane);
+                      grouped ? (int64_t)b : (int64_t)b * S, S, q0, active, lane, cls_planes);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -523,6 +528,8 @@ template <typename T, int QW, int WPE>
 __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ Vt,
                                                                   const float* __restrict__ table, T* __restrict__ out, int split, int B, int nh,
                                                                   int hp, int Sp, int nqb, int ntab, int grouped) {
+    const bool cls_planes = (split & 4) != 0;   // FP8 planes for the cls query's row only (bs_attention_table, dtype bit 6)
+    split &= 3;
     typedef typename T16<T>::v8 v8;
     constexpr int STAGE = 16 * 1024;  // K tile 8 KiB + V^T tile 8 KiB
     constexpr int WP = 32, RW = 2 * WP - 1;
@@ -698,7 +705,7 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
     const float inv = 1.0f / l_tot;
     __syncthreads();                     // every wave is done with the K / V^T ring and the table: the LDS becomes the store staging
     store_out_tile<T>(smem + wave * 8192, oacc, inv, out, split, nh, head, grouped ? (int64_t)grouped + (int64_t)b * (S - 1) : (int64_t)b * S + 1,
-                      grouped ? (int64_t)b : (int64_t)b * S, S, q0, active, lane);
+                      grouped ? (int64_t)b : (int64_t)b * S, S, q0, active, lane, cls_planes);
 }
 
 template <typename T>
@@ -784,7 +791,8 @@ extern "C" int bs_attention_table(const void* q, const void* k, const void* vt, 
     BS_REQUIRE(grouped == 0 || grouped >= B, "bs_attention_table: grouped=%d is the first patch row, >= B", grouped);
     const int S = hp * wp + 1;
     BS_REQUIRE(Sp % 64 == 0 && Sp >= S, "bs_attention_table: Sp=%d must be a multiple of 64 and >= S=%d", Sp, S);
-    const int split = (dtype & 32) ? 2 : ((dtype & 16) ? 1 : 0);
+    int split = (dtype & 32) ? 2 : ((dtype & 16) ? 1 : 0);
+    if ((dtype & 64) && split == 2) split |= 4;     // bit 6: only the cls rows of `out` need their FP8 planes
     dtype &= 15;
     BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_attention_table: dtype");
     if (B == 0) return BS_OK;

@@ -12,7 +12,7 @@ namespace bs {
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* gamma, const float* beta, T* out16, float* out32,
-                                                         int rows, int cols, float eps, int split) {
+                                                         int rows, int cols, float eps, int split, int plane_rows) {
     // split: out16 is [rows, 2*cols] = (hi | lo) pairs, y = hi + lo to ~22 bits (operand of a split-precision GEMM)
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -78,7 +78,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
             typename T16<T>::v4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = T16<T>::from_f32(y[e]);
-            if (split == 2) {          // (hi16 | hi8 | lo8) planes of a 4*cols-byte row
+            if (split == 2 && plane_rows > 0 && row >= plane_rows) {   // a row whose consumer runs no FP8 stage: hi16 only
+                *reinterpret_cast<typename T16<T>::v4*>(out16 + (int64_t)row * cols * 2 + vi * 4) = o;
+            } else if (split == 2) {   // (hi16 | hi8 | lo8) planes of a 4*cols-byte row
                 T* rowp = out16 + (int64_t)row * cols * 2;
                 *reinterpret_cast<typename T16<T>::v4*>(rowp + vi * 4) = o;
                 const float sh = __builtin_ldexpf(1.0f, F8_ACT_HI_EXP), sl = __builtin_ldexpf(1.0f, F8_ACT_LO_EXP);
@@ -564,15 +566,16 @@ extern "C" int bs_layernorm(const float* x, const float* gamma, const float* bet
     BS_ENTRY("bs_layernorm");
     BS_REQUIRE(x && gamma && beta && (out16 || out32) && rows >= 0 && cols > 0 && cols % 4 == 0, "bs_layernorm: bad argument");
     const int split = (dtype & 32) ? 2 : ((dtype & 16) ? 1 : 0);   // bit 4: (hi | lo) 16-bit pairs; bit 5: (hi16 | hi8 | lo8)
+    const int plane_rows = dtype >> 8;     // bits 8..: with bit 5, > 0: only rows below this index write their FP8 planes
     dtype &= 15;
     BS_REQUIRE(!out16 || dtype == BS_F16 || dtype == BS_BF16, "bs_layernorm: dtype");
     if (rows == 0) return BS_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(cdiv(rows, 4));
     if (dtype == BS_BF16)
-        hipLaunchKernelGGL(layernorm_kernel<bf16>, grid, dim3(256), 0, st, x, gamma, beta, (bf16*)out16, out32, rows, cols, eps, split);
+        hipLaunchKernelGGL(layernorm_kernel<bf16>, grid, dim3(256), 0, st, x, gamma, beta, (bf16*)out16, out32, rows, cols, eps, split, plane_rows);
     else
-        hipLaunchKernelGGL(layernorm_kernel<f16>, grid, dim3(256), 0, st, x, gamma, beta, (f16*)out16, out32, rows, cols, eps, split);
+        hipLaunchKernelGGL(layernorm_kernel<f16>, grid, dim3(256), 0, st, x, gamma, beta, (f16*)out16, out32, rows, cols, eps, split, plane_rows);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }

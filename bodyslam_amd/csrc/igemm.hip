@@ -213,6 +213,9 @@ extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
     p.f8_wonly_from = d->f8_wonly_from;
     p.out_lo8_rows = d->out_lo8_rows;
     p.f8_skip_from = d->f8_skip_from;
+    p.out_planes_rows = d->out_planes_rows;
+    BS_REQUIRE(d->out_planes_rows == 0 || (d->out_f8 && d->out_planes_rows > 0 && d->out_planes_rows % 256 == 0),
+               "bs_gemm: out_planes_rows needs out_f8 and a multiple of 256 rows");
     p.bias2 = d->bias2;
     p.bias2_row0 = d->bias2_row0;
     p.bias2_group_rows = d->bias2_group_rows;

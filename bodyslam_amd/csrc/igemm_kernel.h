@@ -74,6 +74,7 @@ struct IgemmParams {
     int out_lo8_rows;    // > 0: only output rows below this index need their lo8 plane (the consumer drops the activation-rounding
                          //      correction on the others, f8_wonly_from): tiles past it skip that plane
     int f8_skip_from;    // > 0: tiles that start at a row >= this run no FP8 stage at all
+    int out_planes_rows; // > 0: tiles that start at a row >= this store hi16 only (no FP8 plane; fc1 -> fc2 with f8_skip_from)
     const float* bias2;  // optional fp32 [groups, N] added to rows >= bias2_row0, group = (m - bias2_row0) / bias2_group_rows
     int bias2_row0, bias2_group_rows;
     int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue, 8 = no tail split (host side)
@@ -756,6 +757,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                 // fc1: gelu(acc + bias) as (hi16 | hi8 | lo8) rows; VALU-bound (a third of the launch): no scale multiply, and past
                 // out_lo8_rows no lo8 plane
                 const bool lo = !(p.out_lo8_rows > 0 && m0 >= p.out_lo8_rows);
+                const bool planes = !(p.out_planes_rows > 0 && m0 >= p.out_planes_rows);
                 f32x4 bj[FN];
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
@@ -775,7 +777,14 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                             y8[e] = gelu_erf(acc[i][2 * jp][e] + bj[2 * jp][e]);
                             y8[4 + e] = gelu_erf(acc[i][2 * jp + 1][e] + bj[2 * jp + 1][e]);
                         }
-                        store8_f8<T>(p.out, (int64_t)m * p.ldo, n_wave + jp * 32 + fq * 8, p.split_off, y8, p.out_f8 & 0xff, (p.out_f8 >> 8) & 0xff, lo);
+                        if (planes) {
+                            store8_f8<T>(p.out, (int64_t)m * p.ldo, n_wave + jp * 32 + fq * 8, p.split_off, y8, p.out_f8 & 0xff, (p.out_f8 >> 8) & 0xff, lo);
+                        } else {
+                            typename T16<T>::v8 h;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) h[e] = T16<T>::from_f32(y8[e]);
+                            *reinterpret_cast<typename T16<T>::v8*>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.ldo + n_wave + jp * 32 + fq * 8) = h;
+                        }
                     }
                 }
                 return;

@@ -568,6 +568,11 @@ class _ZoePlan:
             """row multiplier of the activation a backbone GEMM reads: 1 = single rows, 2 = pair rows"""
             return 2 if fmt(wkey) else 1
 
+        def prow(wkey):
+            """dtype-argument bits of a producer whose consumer GEMM runs no FP8 stage on the patch rows ("wmean"): only the rows
+            below CP (the cls tile) need their FP8 planes.  bs_layernorm: rows << 8"""
+            return (CP << 8) if (acc and grouped and fmt(wkey) == 32 and eng.wmode.get(wkey) == "wmean") else 0
+
         MEAN_STEP = 8      # the rank-1 correction's token mean uses every 8th patch row (probe: same depth result as the full mean)
 
         def bgemm(name, A, wkey, out, M, N, K, **kw):
@@ -617,23 +622,24 @@ class _ZoePlan:
         ti = 0
         for l in range(c.layers):
             P.add(f"l{l}.ln1", "bs_layernorm", x, w[f"l{l}.ln1.g"], w[f"l{l}.ln1.b"], xn, None, MT, Hd, c.ln_eps,
-                  L.dt(xn) | fmt(f"l{l}.qkv.w"))
+                  L.dt(xn) | fmt(f"l{l}.qkv.w") | prow(f"l{l}.qkv.w"))
             bgemm(f"l{l}.qkv", xn, f"l{l}.qkv.w", q, MT, 3 * Hd, Hd, bias=w[f"l{l}.qkv.b"],
                   qkv=(Hd, S, Sp, LOG2E / math.sqrt(64.0), k, vt, use_tab, NB if grouped else 0, CP))
             if use_tab:
                 P.add(f"l{l}.attn", "bs_attention_table", q, k, vt, bias[l], ao, NB, c.heads, hp, wp, Sp, CP,
-                      L.dt(q) | fmt(f"l{l}.o.w"))
+                      L.dt(q) | fmt(f"l{l}.o.w") | (64 if prow(f"l{l}.o.w") else 0))
             else:
                 P.add(f"l{l}.attn", "bs_attention", q, k, vt, bias[l], ao, NB, c.heads, S, Sp, L.dt(q) | fmt(f"l{l}.o.w"))
             bgemm(f"l{l}.o", ao, f"l{l}.o.w", x, MT, Hd, Hd, bias=w[f"l{l}.o.b"], scale=w[f"l{l}.lam1"], res=x, ldr=Hd)
             P.add(f"l{l}.ln2", "bs_layernorm", x, w[f"l{l}.ln2.g"], w[f"l{l}.ln2.b"], xn, None, MT, Hd, c.ln_eps,
-                  L.dt(xn) | fmt(f"l{l}.fc1.w"))
+                  L.dt(xn) | fmt(f"l{l}.fc1.w") | prow(f"l{l}.fc1.w"))
             hfmt = fmt(f"l{l}.fc2.w")
             bgemm(f"l{l}.fc1", xn, f"l{l}.fc1.w", hid, MT, c.intermediate, Hd, bias=w[f"l{l}.fc1.b"], act=L.ACT_GELU,
                   ldo=c.intermediate * am(f"l{l}.fc2.w"), out_split_off=c.intermediate if hfmt else 0,
                   out_f8=(L.F8_ACT_HI_EXP, L.F8_ACT_LO_EXP) if hfmt == 32 else None,
                   # fc2 in "wcls" mode reads the lo8 plane of its cls tile only
-                  out_lo8_rows=CP if (hfmt == 32 and grouped and eng.wmode.get(f"l{l}.fc2.w") in ("wcls", "wmean")) else 0)
+                  out_lo8_rows=CP if (hfmt == 32 and grouped and eng.wmode.get(f"l{l}.fc2.w") in ("wcls", "wmean")) else 0,
+                  out_planes_rows=CP if prow(f"l{l}.fc2.w") else 0)
             bgemm(f"l{l}.fc2", hid, f"l{l}.fc2.w", x, MT, Hd, c.intermediate, bias=w[f"l{l}.fc2.b"], scale=w[f"l{l}.lam2"], res=x, ldr=Hd)
             P.mark(f"layer{l + 1}", x, TOK)
             if (l + 1) in c.taps:

@@ -61,7 +61,8 @@ int bs_version(void);
  */
 /* The (hi16 | hi8 | lo8) operand format of accurate mode's FP8 correction passes: a row of C features is
  * [round16(y) x C | e4m3(y * 2^BS_F8_ACT_HI_EXP) x C | e4m3((y - round16(y)) * 2^BS_F8_ACT_LO_EXP) x C] = 4C bytes.
- * Producers take the flag `| 32` on their dtype argument (bs_layernorm, bs_attention, bs_preprocess_patches) or
+ * Producers take the flag `| 32` on their dtype argument (bs_layernorm, bs_attention, bs_preprocess_patches; bs_layernorm also
+ * `| (rows << 8)`: only rows below `rows` write the planes; bs_attention_table `| 64`: only the cls rows do) or
  * bs_gemm_desc.out_f8; the consumer is bs_gemm with f8_seg = 2C. */
 #define BS_F8_ACT_HI_EXP 0
 #define BS_F8_ACT_LO_EXP 11
@@ -132,6 +133,8 @@ typedef struct bs_gemm_desc {
                                     * weight-rounding error is corrected by its token-independent part instead, see bias2 */
     int32_t bias2_row0;            /* bias2 applies to rows m >= bias2_row0 ... */
     int32_t bias2_group_rows;      /* ... with group (m - bias2_row0) / bias2_group_rows (> 0 when bias2 is given) */
+    int32_t out_planes_rows;       /* with out_f8, > 0: 256-row tiles that start at a row >= this store the hi16 values only (no FP8
+                                    * plane: their consumer sets f8_skip_from to this value) */
     const float* bias2;            /* optional fp32 [groups, N], added like the bias: y = acc + bias[n] + bias2[group, n].  The backbone
                                     * uses it for the rank-1 part of the weight-rounding error of a single-pass product:
                                     * A dW^T ~ 1 (mean_tokens(A) dW^T) per image (Numerics); excludes bias_group_rows */
