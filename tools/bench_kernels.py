@@ -85,12 +85,22 @@ def main():
                 out = torch.zeros(NB, 16, Sp, 64, device=dev, dtype=dt)
                 k2, vt2 = torch.zeros_like(out), torch.zeros(NB, 16, 64, Sp, device=dev, dtype=dt)
                 kw.update(qkv=(1024, 769, Sp, 0.18, k2, vt2, True, NB, 256))
-            for t in tiles:
-                if t % 100 not in (0, 9, 1):
-                    continue
-                pl = L.Plan()
-                pl.gemm(name, A8, w8, out, tile=t, **kw)
-                results.append((name, t, 2.0 * MT * N_ * K_, pl.run))
+            b2 = torch.randn(NB, N_, device=dev)
+            for variant in ("wcls", "wmean", "wmean-compactA"):       # 1.5 passes / one pass + per-image bias2 on the patch tiles (the default)
+                kv = dict(kw)
+                if variant == "wmean-compactA":      # timing experiment only: rows of K 16-bit values, no room for the planes
+                    kv.update(lda=K_)
+                if variant != "wcls":
+                    kv.pop("f8_wonly_from")
+                    kv.update(f8_skip_from=256, bias2=(b2, 256, 768))
+                    if epi == "gelu8lo":
+                        kv.update(out_planes_rows=256)
+                for t in tiles:
+                    if t % 100 not in (0, 9, 1):
+                        continue
+                    pl = L.Plan()
+                    pl.gemm(name, A8, w8, out, tile=t, **kv)
+                    results.append((f"{name} [{variant}]", t, 2.0 * MT * N_ * K_, pl.run))
     for name, H, W_, Ci, Co in convs:
         if a.only and a.only not in name:
             continue
