@@ -223,6 +223,27 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, **kw) -> None:
     check(load_library().bs_gemm(C.byref(d), stream_ptr()), "bs_gemm")
 
 
+def _gemm_bytes(d) -> float:
+    rows_in = float(d.M if not d.conv else d.M / max(d.stride * d.stride, 1))
+    rows_f8 = rows_in if (d.conv or not d.f8_skip_from) else float(min(d.f8_skip_from, d.M))
+    taps = d.KH * d.KW if d.conv else 1
+    a = rows_in * (d.Cin if d.conv else d.K) * 2 + rows_f8 * d.f8_seg
+    w = float(d.N) * (d.K * 2 + taps * d.f8_seg)
+    if d.out_dtype == F32:
+        per_row = [4.0, 4.0, 4.0]
+    elif d.out_f8:              # (hi16 | hi8 | lo8): 4 B; without the lo8 plane 3 B; hi16 alone 2 B
+        per_row = [4.0, 3.0, 2.0]
+    else:
+        per_row = [2.0 * (2 if d.out_split_off else 1)] * 3
+    full = float(d.M)
+    r_planes = float(min(d.out_planes_rows, d.M)) if d.out_planes_rows else full            # rows that keep any plane
+    r_lo = float(min(d.out_lo8_rows, d.M)) if d.out_lo8_rows else r_planes                   # rows that keep the lo8 plane
+    r_lo = min(r_lo, r_planes)
+    out = d.N * (r_lo * per_row[0] + (r_planes - r_lo) * per_row[1] + (full - r_planes) * per_row[2])
+    res = float(d.M) * d.N * (4 if (d.res and d.res_dtype == F32) else 0)
+    return a + w + out + res
+
+
 class Plan:
     """A prebuilt sequence of C-ABI calls over static buffers: descriptors and pointer arguments are
     marshalled once, so replaying a forward costs one ctypes call per kernel (and the whole sequence
@@ -293,10 +314,9 @@ class Plan:
                                / (4 if d.f8_wonly_from else 2)),
             # algorithmic FLOPs exclude the extra passes of a split-precision product
             alg_flops=2.0 * d.M * d.N * (d.K / kw.get("precision_passes", 1)),
-            # algorithmic HBM bytes: A once (16-bit values + the FP8 planes of a pair row), W once, the output (+ the fp32 residual read)
-            bytes=(float(d.M if not d.conv else d.M / max(d.stride * d.stride, 1)) * ((d.Cin if d.conv else d.K) * 2 + d.f8_seg)
-                   + float(d.N) * (d.K * 2 + (d.KH * d.KW if d.conv else 1) * d.f8_seg)
-                   + float(d.M) * d.N * ((4 if d.out_dtype == F32 else 2) * (2 if d.out_split_off else 1) + (4 if (d.res and d.res_dtype == F32) else 0))))
+            # algorithmic HBM bytes: A once (16-bit values + the FP8 planes of the rows that run FP8 stages), W once, the output
+            # (+ the fp32 residual read)
+            bytes=_gemm_bytes(d))
 
     def add(self, name, fn_name, *args):
         cargs = []
