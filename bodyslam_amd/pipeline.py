@@ -180,6 +180,20 @@ class BodySlamPipeline:
             t_all = gather_relative_poses(t_local, counts, group) if world > 1 else t_local
         return self.chain_and_backproject(N, start, end, depth, depth_m, t_all, keep_points, on_points)
 
+    def integrate_tsdf(self, tsdf, frames, result: SequenceResult) -> None:
+        """The map step of the loop (3DM/slam.py:117,179): every local frame's pseudo-RGBD (3DM/slam_utils.py:212-220: depth / depth_scale,
+        values >= depth_trunc dropped) goes into `tsdf` (bodyslam_amd.tsdf.TSDF) with the frame's absolute pose as the extrinsic
+        argument, exactly as the reference passes it."""
+        from .tsdf import PinholeCameraIntrinsic, create_rgbd_from_color_and_depth
+        frames = frames.cpu().numpy() if isinstance(frames, torch.Tensor) else np.asarray(frames)
+        du = result.depth_u16.cpu().numpy().view(np.uint16)
+        H, W = du.shape[1:]
+        intr = PinholeCameraIntrinsic(W, H, *[float(v) for v in self.K])
+        g = result.g_abs.cpu().numpy()
+        for j in range(du.shape[0]):
+            rgbd = create_rgbd_from_color_and_depth(frames[result.start + j], du[j], self.depth_scale, self.depth_trunc)
+            tsdf.build_3D_map(rgbd, intr, g[result.start + j])
+
     def chain_and_backproject(self, N: int, start: int, end: int, depth: torch.Tensor, depth_m: Optional[torch.Tensor],
                               t_all: torch.Tensor, keep_points: bool = False, on_points: Optional[Callable] = None) -> SequenceResult:
         """Stage 3 of a rank: the replicated fp64 chain over the gathered relatives, then the rank's own back-projection."""

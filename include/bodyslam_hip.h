@@ -313,6 +313,24 @@ int bs_pose_chain(const float* t_rel, int32_t N, const double* g0_host, double* 
  * steps continues its chain without a host round trip -- 3DM/slam.py:148-153 keeps current_global_extrinsic_matrix) */
 int bs_pose_chain_from(const float* t_rel, int32_t N, const double* g0_dev, double* g_abs, void* stream);
 
+/* TSDF map (N4) ---------------------------------------------------------------------------------- *
+ * Open3D ScalableTSDFVolume as wrapped by BodySLAM_not_refactored/3DM/tsdf.py:5-52 (voxel_length 0.001, sdf_trunc 0.1, RGB8,
+ * volume_unit_resolution 32, depth_sampling_stride 8; integrate per frame at 3DM/slam.py:117,179, extract_point_cloud at :126,195).
+ * A volume unit is res^3 voxels x 5 fp32 (tsdf, weight, r, g, b), voxel x*res^2 + y*res + z; the table of units is host state.
+ *
+ * bs_tsdf_integrate: UniformTSDFVolume::IntegrateWithDepthToCameraDistanceMultiplier on `units` units: depth fp32 [H, W] metres
+ * (<= 0 invalid), color u8 [H, W, 3] or NULL, K = (fx, fy, cx, cy), extrinsic = rows 0..2 of the world->camera 4x4 (12 doubles,
+ * host), unit_index int32 [units, 3] (origin = index * res * voxel_length), unit_ptr = device array of `units` float* (the blocks).
+ * bs_tsdf_extract: ScalableTSDFVolume::ExtractPointCloud (points + colours, no normals) in two passes over the same units:
+ * points == NULL counts into unit_count int32 [units]; otherwise unit_offset int64 [units] (exclusive prefix sums of the counts)
+ * places each unit's points, points / colors fp32 [total, 3].  nbr_ptr = device array [units, 3] of the +x / +y / +z neighbour
+ * unit's block or NULL. */
+int bs_tsdf_integrate(const float* depth, const uint8_t* color, int32_t H, int32_t W, const double* K, const double* extrinsic,
+                      const int32_t* unit_index, const void* unit_ptr, int32_t units, int32_t res, double voxel_length,
+                      double sdf_trunc, void* stream);
+int bs_tsdf_extract(const int32_t* unit_index, const void* unit_ptr, const void* nbr_ptr, int32_t units, int32_t res,
+                    double voxel_length, int32_t* unit_count, const int64_t* unit_offset, float* points, float* colors, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

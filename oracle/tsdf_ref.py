@@ -1,0 +1,118 @@
+"""CPU oracle for the TSDF map -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/ may import this file.  The reference's TSDF class (BodySLAM_not_refactored/3DM/tsdf.py:5-52) wraps Open3D's
+``ScalableTSDFVolume(voxel_length=0.001, sdf_trunc=0.1, color_type=RGB8, volume_unit_resolution=32, depth_sampling_stride=8)``:
+``integrate(rgbd, intrinsic, extrinsic)`` per frame (3DM/slam.py:117,179) and ``extract_point_cloud()`` (:126,195).  Open3D is a
+third-party C++ dependency that is neither vendored under /root/reference nor installed here: **parity unpinned**.  This file
+restates the published algorithm of Open3D's pipelines/integration/{ScalableTSDFVolume,UniformTSDFVolume}.cpp in plain numpy,
+unit by unit:
+
+  Integrate:  P = points of the depth image sampled every `stride` pixels, back-projected and moved to the world by
+              extrinsic^-1; every volume unit (res^3 voxels, edge L = res * voxel_length, index = floor(p / L)) that meets the
+              box [p - sdf_trunc, p + sdf_trunc] of a point is opened and integrated once:
+              voxel centre c = (0.5 + idx) * voxel_length + index * L;  q = extrinsic c;  skip if q.z <= 0;
+              u_f = q.x fx / q.z + cx + 0.5, v_f likewise; skip unless 0.0001 <= u_f < W - 0.0001 (same for v);
+              d = depth[int(v_f), int(u_f)]; skip if d <= 0;  sdf = (d - q.z) * sqrt(1 + ((u - cx)/fx)^2 + ((v - cy)/fy)^2);
+              if sdf > -sdf_trunc:  t = min(1, sdf / sdf_trunc);  tsdf = (tsdf w + t) / (w + 1);  colour alike;  w += 1.
+  ExtractPointCloud (without normals):  a voxel with w != 0 and -0.98 <= tsdf < 0.98 and its +x / +y / +z neighbour (in the
+              next unit when it is the last of its row, if that unit exists) with the same property and the opposite sign give a
+              point on the segment between the two centres at the zero of the linear interpolant; colour interpolated, / 255.
+Open3D evaluates the projection in float with an incremental walk along z; here (and in the product) it is the closed form in
+fp64, and voxel values are fp32."""
+from __future__ import annotations
+
+import numpy as np
+
+
+class TSDFRef:
+    def __init__(self, voxel_length=0.001, sdf_trunc=0.1, res=32, stride=8):
+        self.vl, self.trunc, self.res, self.stride = float(voxel_length), float(sdf_trunc), int(res), int(stride)
+        self.L = self.vl * self.res
+        self.units = {}           # (ix, iy, iz) -> float32 [res, res, res, 5]  (tsdf, weight, r, g, b)
+
+    def touched(self, depth, K, extrinsic):
+        fx, fy, cx, cy = K
+        H, W = depth.shape
+        pose = np.linalg.inv(np.asarray(extrinsic, dtype=np.float64))
+        keys = set()
+        for i in range(0, H, self.stride):
+            for j in range(0, W, self.stride):
+                z = float(depth[i, j])
+                if z > 0:
+                    p = pose @ np.array([(j - cx) * z / fx, (i - cy) * z / fy, z, 1.0])
+                    lo = np.floor((p[:3] - self.trunc) / self.L).astype(int)
+                    hi = np.floor((p[:3] + self.trunc) / self.L).astype(int)
+                    for x in range(lo[0], hi[0] + 1):
+                        for y in range(lo[1], hi[1] + 1):
+                            for zz in range(lo[2], hi[2] + 1):
+                                keys.add((x, y, zz))
+        return keys
+
+    def integrate(self, depth, color, K, extrinsic):
+        fx, fy, cx, cy = K
+        depth = np.asarray(depth, dtype=np.float32)
+        H, W = depth.shape
+        E = np.asarray(extrinsic, dtype=np.float64)
+        r = self.res
+        g = (np.arange(r) + 0.5) * self.vl
+        for key in sorted(self.touched(depth, K, extrinsic)):
+            vox = self.units.setdefault(key, np.zeros((r, r, r, 5), dtype=np.float32))
+            o = np.array(key, dtype=np.float64) * self.L
+            X, Y, Z = np.meshgrid(g + o[0], g + o[1], g + o[2], indexing="ij")
+            qx = E[0, 0] * X + E[0, 1] * Y + E[0, 2] * Z + E[0, 3]
+            qy = E[1, 0] * X + E[1, 1] * Y + E[1, 2] * Z + E[1, 3]
+            qz = E[2, 0] * X + E[2, 1] * Y + E[2, 2] * Z + E[2, 3]
+            ok = qz > 0
+            qzs = np.where(ok, qz, 1.0)
+            uf = qx * fx / qzs + cx + 0.5
+            vf = qy * fy / qzs + cy + 0.5
+            ok &= (uf >= 0.0001) & (uf < W - 0.0001) & (vf >= 0.0001) & (vf < H - 0.0001)
+            ui = np.where(ok, uf, 0).astype(int)
+            vi = np.where(ok, vf, 0).astype(int)
+            d = depth[vi, ui]
+            ok &= d > 0
+            xx = ((ui - cx) / fx).astype(np.float32)
+            yy = ((vi - cy) / fy).astype(np.float32)
+            mult = np.sqrt(xx * xx + yy * yy + np.float32(1.0), dtype=np.float32)
+            sdf = ((d.astype(np.float64) - qz) * mult.astype(np.float64)).astype(np.float32)
+            ok &= sdf > -np.float32(self.trunc)
+            t = np.minimum(np.float32(1.0), sdf * np.float32(1.0 / self.trunc))
+            w0 = vox[..., 1]
+            w1 = w0 + np.float32(1.0)
+            vox[..., 0] = np.where(ok, (vox[..., 0] * w0 + t) / w1, vox[..., 0])
+            if color is not None:
+                c = np.asarray(color)[vi, ui].astype(np.float32)
+                for k in range(3):
+                    vox[..., 2 + k] = np.where(ok, (vox[..., 2 + k] * w0 + c[..., k]) / w1, vox[..., 2 + k])
+            vox[..., 1] = np.where(ok, w1, w0)
+
+    def extract_point_cloud(self):
+        r, pts, cols = self.res, [], []
+        for key, vox in self.units.items():
+            f0, w0 = vox[..., 0], vox[..., 1]
+            good0 = (w0 != 0) & (f0 < np.float32(0.98)) & (f0 >= np.float32(-0.98))
+            idx = np.stack(np.meshgrid(np.arange(r), np.arange(r), np.arange(r), indexing="ij"), -1)
+            p0 = (idx + 0.5) * self.vl + np.array(key, dtype=np.float64) * self.L
+            for a in range(3):
+                nk = list(key)
+                nk[a] += 1
+                nxt = self.units.get(tuple(nk))
+                shifted = np.zeros_like(vox)
+                sl_src = [slice(None)] * 3
+                sl_dst = [slice(None)] * 3
+                sl_src[a], sl_dst[a] = slice(1, r), slice(0, r - 1)
+                shifted[tuple(sl_dst)] = vox[tuple(sl_src)]
+                if nxt is not None:
+                    sl_src[a], sl_dst[a] = slice(0, 1), slice(r - 1, r)
+                    shifted[tuple(sl_dst)] = nxt[tuple(sl_src)]
+                f1, w1 = shifted[..., 0], shifted[..., 1]
+                hit = good0 & (w1 != 0) & (f1 < np.float32(0.98)) & (f1 >= np.float32(-0.98)) & (f0 * f1 < 0)
+                r0, r1 = np.abs(f0[hit]), np.abs(f1[hit])
+                p = p0[hit].copy()
+                p[:, a] = (p0[hit][:, a] * r1.astype(np.float64) + (p0[hit][:, a] + self.vl) * r0.astype(np.float64)) / (r0.astype(np.float64) + r1)
+                pts.append(p.astype(np.float32))
+                c = (vox[..., 2:][hit] * r1[:, None] + shifted[..., 2:][hit] * r0[:, None]) / (r0 + r1)[:, None] / np.float32(255.0)
+                cols.append(c.astype(np.float32))
+        if not pts:
+            return np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32)
+        return np.concatenate(pts), np.concatenate(cols)

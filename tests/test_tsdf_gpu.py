@@ -1,0 +1,111 @@
+"""TSDF map on the GPU (bodyslam_amd/tsdf.py + csrc/tsdf.hip) against the numpy oracle (oracle/tsdf_ref.py): same units opened,
+same voxels, same extracted surface points.  Reference: BodySLAM_not_refactored/3DM/tsdf.py:5-52 (Open3D ScalableTSDFVolume;
+parity against Open3D itself is unpinned, see the oracle's header)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+H, W = 48, 64
+K = (60.0, 60.0, 32.0, 24.0)
+
+
+def scene(seed):
+    rng = np.random.default_rng(seed)
+    v, u = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    depth = (0.5 + 0.05 * np.sin(u / 9.0 + seed) * np.cos(v / 7.0)).astype(np.float32)
+    depth[rng.random((H, W)) < 0.03] = 0.0                                  # holes
+    color = rng.integers(0, 256, size=(H, W, 3)).astype(np.uint8)
+    a = 0.05 * seed
+    pose = np.eye(4)
+    pose[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    pose[:3, 3] = (0.03 * seed, -0.02 * seed, 0.01 * seed)
+    return depth, color, np.linalg.inv(pose)
+
+
+def sort_rows(p, c):
+    o = np.lexsort((p[:, 2], p[:, 1], p[:, 0]))
+    return p[o], c[o]
+
+
+@pytest.mark.parametrize("res,stride", [(8, 4), (4, 8)])
+def test_tsdf_matches_oracle(res, stride, tmp_path):
+    from bodyslam_amd.tsdf import TSDF, PinholeCameraIntrinsic, RGBDImage
+    from oracle.tsdf_ref import TSDFRef
+    vl, trunc = 0.01, 0.04
+    prod = TSDF(vl, trunc, volume_unit_resolution=res, depth_sampling_stride=stride, slab_bytes=1 << 16)   # several slabs
+    ref = TSDFRef(vl, trunc, res=res, stride=stride)
+    intr = PinholeCameraIntrinsic(W, H, *K)
+    for seed in range(3):
+        depth, color, E = scene(seed)
+        prod.build_3D_map(RGBDImage(color, depth), intr, torch.from_numpy(E) if seed == 1 else E)
+        ref.integrate(depth, color, K, E)
+    assert set(prod.index) == set(ref.units)
+    worst = 0.0
+    for key, vox in ref.units.items():
+        got = prod.unit(key)
+        assert np.array_equal(got[..., 1], vox[..., 1]), f"weights of unit {key}"
+        worst = max(worst, float(np.abs(got - vox).max()))
+    assert worst < 2e-4                   # colours are 0..255 running means: a last-bit difference is 1.5e-5
+    pcd = prod.extract_pcd()
+    rp, rc = ref.extract_point_cloud()
+    assert pcd.points.shape == rp.shape and rp.shape[0] > 500
+    gp, gc = sort_rows(pcd.points, pcd.colors)
+    rp, rc = sort_rows(rp, rc)
+    assert np.abs(gp - rp).max() < 1e-6 and np.abs(gc - rc).max() < 1e-5
+    # the surface is where it was put: camera-frame depth of every point of the first view's neighbourhood ~ the scene's range
+    assert 0.40 < gp[:, 2].min() and gp[:, 2].max() < 0.75
+    path = tmp_path / "map.ply"
+    prod.save_pcd(str(path))
+    raw = path.read_bytes()
+    head, body = raw.split(b"end_header\n", 1)
+    assert f"element vertex {gp.shape[0]}".encode() in head and len(body) == gp.shape[0] * 15
+    with pytest.raises(NotImplementedError):
+        prod.save_mesh(str(tmp_path / "m.ply"))
+
+
+def test_tsdf_copy_and_reference_parameters():
+    """build_copy_3D_map leaves the original untouched; the reference's own parameters (1 mm voxels, 0.1 m truncation, 32^3 units,
+    stride 8) run on a small image: a point opens the ~7^3 units around it."""
+    from bodyslam_amd.tsdf import TSDF, PinholeCameraIntrinsic, RGBDImage
+    depth = np.zeros((16, 16), np.float32)
+    depth[8, 8] = 0.3
+    intr = PinholeCameraIntrinsic(16, 16, 20.0, 20.0, 8.0, 8.0)
+    t = TSDF()                                     # tsdf.py:6 defaults
+    t.build_3D_map(RGBDImage(None, depth), intr, np.eye(4))
+    n = len(t.index)
+    assert 6 ** 3 <= n <= 8 ** 3
+    t2 = t.build_copy_3D_map(RGBDImage(None, depth), intr, np.eye(4))
+    # only the voxels that project onto the one measured pixel are updated (most opened units stay empty): the unit that holds
+    # the surface point (0, 0, 0.3) is one of them
+    L_ = 0.001 * 32
+    k = (int(np.floor(0.0 / L_)), int(np.floor(0.0 / L_)), int(np.floor(0.3 / L_)))
+    assert k in t.index and t.unit(k)[..., 1].max() == 1.0
+    for key in t.index[:: max(1, n // 40)] + [k]:
+        assert np.array_equal(t2.unit(key)[..., 1], 2 * t.unit(key)[..., 1])
+    assert len(t2.index) == n
+    pcd = t.extract_pcd()
+    assert pcd.points.shape[0] > 0 and np.abs(pcd.points[:, 2] - 0.3).max() < 2e-3
+
+
+def test_pipeline_integrates_its_frames():
+    """the loop's map step (3DM/slam.py:179): run_sequence's depth + poses go into the TSDF"""
+    import dataclasses
+    from bodyslam_amd.pipeline import BodySlamPipeline
+    from bodyslam_amd.synthetic import make_sequence
+    from bodyslam_amd.tsdf import TSDF
+    from bodyslam_amd.zoedepth import ZoeConfig
+    from oracle import cyclepose_ref as CP
+    from oracle import zoedepth_ref as Z
+    cfg_o = Z.ZoeConfig(hidden=128, layers=4, heads=2, intermediate=256, taps=(1, 2, 3, 4), image_size=64)
+    names = {f.name for f in dataclasses.fields(ZoeConfig)}
+    cfg_p = ZoeConfig(**{k: v for k, v in dataclasses.asdict(cfg_o).items() if k in names})
+    frames = make_sequence(3, 160, 192, seed=5)
+    pipe = BodySlamPipeline(Z.synth_weights(cfg_o, seed=2), CP.synth_weights(seed=2), cfg_p, batch=2, target_hw=(64, 96))
+    res = pipe.run_sequence(frames)
+    t = TSDF(voxel_length=0.02, sdf_trunc=0.06, volume_unit_resolution=8, depth_sampling_stride=8)
+    pipe.integrate_tsdf(t, frames, res)
+    assert len(t.index) > 0
+    w = sum(float(t.unit(k)[..., 1].sum()) for k in t.index[:50])
+    assert w > 0
