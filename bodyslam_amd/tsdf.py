@@ -6,8 +6,9 @@ accumulated pose as ``extrinsic``), ``extract_pcd`` / ``save_pcd`` read the surf
 names and defaults here.  The voxels live in HBM (one contiguous block of res^3 x 5 fp32 per volume unit, allocated in slabs and
 zero-filled once) and are integrated / extracted by the HIP kernels of csrc/tsdf.hip; which units exist is host state (a dict, as
 Open3D's unordered_map), found per frame from the strided depth sample exactly as Open3D does.  With the reference's parameters a
-unit is 3.2 cm wide and a point opens the ~7^3 units within 0.1 m of it: a frame touches 10^4 units = several GB of voxels, which is
-what 288 GB of HBM are for.  Open3D is not vendored and not installable offline: parity against it is unpinned (oracle/tsdf_ref.py
+unit is 3.2 cm wide and a point opens the ~7^3 units within 0.1 m of it; a 640x480 frame of a surface at 12 cm touches ~1 600 units
+= 1 GB of voxel state (measured, tools/probes/tsdf_full_size.py: kernel 0.33 ms, the numpy unit discovery ~90 ms -- the step is
+host-bound), metre-scale scenes proportionally more: the voxel store is sized for 288 GB of HBM.  Open3D is not vendored and not installable offline: parity against it is unpinned (oracle/tsdf_ref.py
 restates the same algorithm in numpy; tests/ compare the two).  Not built: normals of the extracted points and
 ``extract_mesh`` / ``save_mesh`` (marching cubes) -- they raise NotImplementedError.
 """
@@ -87,7 +88,11 @@ class TSDF:
         H, W = depth.shape
         E = np.ascontiguousarray(np.asarray(self._np(extrinsic), dtype=np.float64))
         K = np.array([intrinsic.fx, intrinsic.fy, intrinsic.cx, intrinsic.cy], dtype=np.float64)
+        import time
+        t0 = time.perf_counter()
         slots = self._touch(depth, K, E)
+        self.last_discovery_s = time.perf_counter() - t0            # host side of the step (diagnostics, tools/probes/tsdf_full_size.py)
+        self.last_units = int(slots.size)
         if slots.size == 0:
             return
         d_dev = torch.from_numpy(depth).to(self.dev)
@@ -95,10 +100,14 @@ class TSDF:
         idx = torch.from_numpy(np.array([self.index[s] for s in slots], dtype=np.int32)).to(self.dev)
         ptr = torch.from_numpy(self._ptrs(slots)).to(self.dev)
         e12 = np.ascontiguousarray(E[:3].reshape(12))
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
         L.check(L.load_library().bs_tsdf_integrate(L.p(d_dev), L.p(c_dev), H, W, K.ctypes.data_as(C.c_void_p), e12.ctypes.data_as(C.c_void_p),
                                                    L.p(idx), L.p(ptr), int(slots.size), self.res, self.voxel_length, self.sdf_trunc,
                                                    L.stream_ptr()), "bs_tsdf_integrate")
+        ev1.record()
         torch.cuda.current_stream(self.dev).synchronize()          # (the host arrays above must outlive the launch)
+        self.last_kernel_ms = ev0.elapsed_time(ev1)
 
     def build_copy_3D_map(self, rgbd, intrinsic, extrinsic) -> "TSDF":
         other = copy.copy(self)
