@@ -6,7 +6,8 @@
 // HBM-bound streaming work, laid out for it: a volume unit is one contiguous block of res^3 voxels x 5 floats
 // (tsdf, weight, r, g, b), voxel index x*res^2 + y*res + z as Open3D's IndexOf; a thread owns one voxel with z fastest, so a wave
 // reads and writes 64 x 20 = 1280 contiguous bytes; the depth / colour images (1.2 MB) stay in L2.  The unit table (which units
-// exist, where their blocks live) is host state, as in Open3D (an unordered_map); the kernels get per-call pointer lists.
+// exist, which block each owns) is an open-addressing hash table in HBM filled by atomicCAS (Open3D: an unordered_map on the host);
+// blocks are carved from zero-filled slabs whose base addresses the kernels get as a small device array.
 #include "common.h"
 
 namespace bs {
@@ -16,11 +17,96 @@ struct TsdfCam {
     double e[12];            // extrinsic, rows 0..2 of the 4x4 (world -> camera)
 };
 
+// ---- the table of volume units: an open-addressing hash table in HBM (Open3D: std::unordered_map<Vector3i, VolumeUnit>) ----------
+// key = three 21-bit biased unit indices; keys[h] == -1 is empty; slots[h] is the unit's block number (assigned in the second pass),
+// stamp[h] the id of the last frame that touched it.
+constexpr long long TS_EMPTY = -1ll;
+constexpr int TS_OFF = 1 << 20;
+
+__device__ __forceinline__ long long ts_pack(int ix, int iy, int iz) {
+    return ((long long)(ix + TS_OFF) << 42) | ((long long)(iy + TS_OFF) << 21) | (long long)(iz + TS_OFF);
+}
+__device__ __forceinline__ unsigned ts_hash(long long k, unsigned mask) {
+    unsigned long long x = (unsigned long long)k;
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return (unsigned)x & mask;
+}
+__device__ __forceinline__ int ts_find(const long long* __restrict__ keys, const int32_t* __restrict__ slots, unsigned mask, long long k) {
+    for (unsigned h = ts_hash(k, mask), n = 0; n <= mask; h = (h + 1) & mask, ++n) {
+        const long long cur = keys[h];
+        if (cur == k) return slots[h];
+        if (cur == TS_EMPTY) return -1;
+    }
+    return -1;
+}
+__device__ __forceinline__ float* ts_block(const int64_t* __restrict__ slab_base, int slab_units, int64_t unit_bytes, int slot) {
+    return reinterpret_cast<float*>(slab_base[slot / slab_units] + (int64_t)(slot % slab_units) * unit_bytes);
+}
+
+// ScalableTSDFVolume::Integrate, first half: every unit that meets the +-sdf_trunc box of a point of the strided depth sample is
+// looked up / inserted and stamped with this frame.  Thread = (sampled pixel, candidate offset inside the (span)^3 box).
+__global__ __launch_bounds__(256) void tsdf_touch_kernel(const float* __restrict__ depth, int H, int W, int stride, TsdfCam cam /* e = camera -> world */,
+                                                          double unit_length, double sdf_trunc, int span, long long* keys, int32_t* stamp,
+                                                          unsigned mask, int frame_id, int32_t* counters) {
+    const int cand = span * span * span;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int ws = (W + stride - 1) / stride, hs = (H + stride - 1) / stride;
+    if (t >= (int64_t)ws * hs * cand) return;
+    const int c = (int)(t % cand), pix = (int)(t / cand);
+    const int i = (pix / ws) * stride, j = (pix % ws) * stride;
+    const double z = (double)depth[(int64_t)i * W + j];
+    if (!(z > 0.0)) return;
+    const double x = ((double)j - cam.cx) * z / cam.fx, y = ((double)i - cam.cy) * z / cam.fy;
+    const double p[3] = {cam.e[0] * x + cam.e[1] * y + cam.e[2] * z + cam.e[3], cam.e[4] * x + cam.e[5] * y + cam.e[6] * z + cam.e[7],
+                         cam.e[8] * x + cam.e[9] * y + cam.e[10] * z + cam.e[11]};
+    const int o[3] = {c / (span * span), (c / span) % span, c % span};
+    int u[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int lo = (int)floor((p[a] - sdf_trunc) / unit_length), hi = (int)floor((p[a] + sdf_trunc) / unit_length);
+        u[a] = lo + o[a];
+        if (u[a] > hi) return;
+    }
+    const long long k = ts_pack(u[0], u[1], u[2]);
+    for (unsigned h = ts_hash(k, mask), n = 0; n <= mask; h = (h + 1) & mask, ++n) {
+        long long cur = keys[h];
+        if (cur == TS_EMPTY) cur = (long long)atomicCAS(reinterpret_cast<unsigned long long*>(keys + h), (unsigned long long)TS_EMPTY, (unsigned long long)k);
+        if (cur == TS_EMPTY || cur == k) {
+            stamp[h] = frame_id;
+            return;
+        }
+    }
+    counters[2] = 1;      // table full
+}
+
+// second half: entries stamped by this frame get a block number if they have none, and go on the frame's list
+__global__ __launch_bounds__(256) void tsdf_assign_kernel(const long long* __restrict__ keys, int32_t* slots, const int32_t* __restrict__ stamp,
+                                                           unsigned cap, int frame_id, int32_t* unit_index, int max_units, int32_t* counters,
+                                                           int32_t* touched) {
+    const unsigned h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= cap || keys[h] == TS_EMPTY || stamp[h] != frame_id) return;
+    int s = slots[h];
+    if (s < 0) {
+        s = atomicAdd(counters + 0, 1);
+        if (s >= max_units) {
+            counters[2] = 2;  // more units than blocks
+            return;
+        }
+        slots[h] = s;
+        const long long k = keys[h];
+        unit_index[3 * s + 0] = (int)(k >> 42) - TS_OFF;
+        unit_index[3 * s + 1] = (int)((k >> 21) & ((1 << 21) - 1)) - TS_OFF;
+        unit_index[3 * s + 2] = (int)(k & ((1 << 21) - 1)) - TS_OFF;
+    }
+    touched[atomicAdd(counters + 1, 1)] = s;
+}
+
 // Open3D UniformTSDFVolume::IntegrateWithDepthToCameraDistanceMultiplier, one thread per voxel
 __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float* __restrict__ depth, const uint8_t* __restrict__ color, int H, int W,
-                                                              TsdfCam cam, const int32_t* __restrict__ unit_index, float* const* __restrict__ unit_ptr,
-                                                              int res, double voxel_length, double sdf_trunc) {
-    const int u = blockIdx.y;
+                                                              TsdfCam cam, const int32_t* __restrict__ unit_index, const int32_t* __restrict__ touched,
+                                                              const int64_t* __restrict__ slab_base, int slab_units, int res, double voxel_length,
+                                                              double sdf_trunc) {
+    const int u = touched[blockIdx.y];
     const int v = blockIdx.x * 256 + threadIdx.x;
     const int nvox = res * res * res;
     if (v >= nvox) return;
@@ -44,7 +130,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float* __rest
     const float sdf = (float)(((double)d - cz_) * (double)mult);
     if (!(sdf > -(float)sdf_trunc)) return;
     const float tsdf = fminf(1.0f, sdf * (float)(1.0 / sdf_trunc));
-    float* vox = unit_ptr[u] + (int64_t)v * 5;
+    float* vox = ts_block(slab_base, slab_units, (int64_t)nvox * 20, u) + (int64_t)v * 5;
     const float w0 = vox[1], w1 = w0 + 1.0f;
     vox[0] = (vox[0] * w0 + tsdf) / w1;
     if (color) {
@@ -57,35 +143,39 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float* __rest
 }
 
 // Open3D ScalableTSDFVolume::ExtractPointCloud without the normals: a voxel with weight != 0 and |tsdf| < 0.98 looks at its +x, +y,
-// +z neighbour (possibly in the neighbouring unit); a sign change puts a point at the linear zero crossing, colour interpolated
-// alike.  WRITE = false counts per unit, WRITE = true writes at unit_offset[u] + a per-unit cursor (order inside a unit is arbitrary,
-// as the order of units is in Open3D's hash map).
+// +z neighbour (in the neighbouring unit, found through the table, when it is the last of its row); a sign change puts a point at the
+// linear zero crossing, colour interpolated alike.  WRITE = false counts per unit, WRITE = true writes at unit_offset[u] + a
+// per-unit cursor (order inside a unit is arbitrary, as the order of units is in Open3D's hash map).
 template <bool WRITE>
-__global__ __launch_bounds__(256) void tsdf_extract_kernel(const int32_t* __restrict__ unit_index, float* const* __restrict__ unit_ptr,
-                                                            float* const* __restrict__ nbr_ptr, int res, double voxel_length,
-                                                            int32_t* __restrict__ unit_count, const int64_t* __restrict__ unit_offset,
-                                                            float* __restrict__ points, float* __restrict__ colors) {
+__global__ __launch_bounds__(256) void tsdf_extract_kernel(const int32_t* __restrict__ unit_index, const long long* __restrict__ keys,
+                                                            const int32_t* __restrict__ slots, unsigned mask, const int64_t* __restrict__ slab_base,
+                                                            int slab_units, int res, double voxel_length, int32_t* __restrict__ unit_count,
+                                                            const int64_t* __restrict__ unit_offset, float* __restrict__ points,
+                                                            float* __restrict__ colors) {
     const int u = blockIdx.y;
     const int v = blockIdx.x * 256 + threadIdx.x;
     const int nvox = res * res * res;
+    const int64_t unit_bytes = (int64_t)nvox * 20;
     int found = 0;
     float pts[3][3], cols[3][3];
     if (v < nvox) {
-        const float* base = unit_ptr[u];
+        const float* base = ts_block(slab_base, slab_units, unit_bytes, u);
         const float f0 = base[(int64_t)v * 5], w0 = base[(int64_t)v * 5 + 1];
         if (w0 != 0.0f && f0 < 0.98f && f0 >= -0.98f) {
             const int idx[3] = {v / (res * res), (v / res) % res, v % res};
+            const int ui3[3] = {unit_index[3 * u], unit_index[3 * u + 1], unit_index[3 * u + 2]};
             const double unit_len = voxel_length * res, half = voxel_length * 0.5;
             double p0[3];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) p0[a] = half + voxel_length * idx[a] + unit_len * unit_index[3 * u + a];
+            for (int a = 0; a < 3; ++a) p0[a] = half + voxel_length * idx[a] + unit_len * ui3[a];
             const int stride[3] = {res * res, res, 1};
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const float* nb = base;
                 int64_t nv = (int64_t)v + stride[a];
                 if (idx[a] + 1 >= res) {             // the neighbour lives in the next unit along this axis
-                    nb = nbr_ptr[3 * u + a];
+                    const int ns = ts_find(keys, slots, mask, ts_pack(ui3[0] + (a == 0), ui3[1] + (a == 1), ui3[2] + (a == 2)));
+                    nb = ns >= 0 ? ts_block(slab_base, slab_units, unit_bytes, ns) : nullptr;
                     nv = (int64_t)v - (int64_t)(res - 1) * stride[a];
                 }
                 if (!nb) continue;
@@ -127,42 +217,72 @@ __global__ __launch_bounds__(256) void tsdf_extract_kernel(const int32_t* __rest
 
 using namespace bs;
 
-extern "C" int bs_tsdf_integrate(const float* depth, const uint8_t* color, int32_t H, int32_t W, const double* K, const double* extrinsic,
-                                 const int32_t* unit_index, const void* unit_ptr, int32_t units, int32_t res, double voxel_length,
-                                 double sdf_trunc, void* stream) {
-    if (!initialized()) { set_error("bs_tsdf_integrate: call bs_init first"); return BS_ERR_NOT_INIT; }
-    BS_REQUIRE(units >= 0 && H > 0 && W > 0 && res > 0 && res <= 64 && voxel_length > 0.0 && sdf_trunc > 0.0, "bs_tsdf_integrate: bad geometry");
-    if (units == 0) return BS_OK;
-    BS_REQUIRE(depth && K && extrinsic && unit_index && unit_ptr, "bs_tsdf_integrate: null argument");
-    TsdfCam cam;
+static void tsdf_cam(TsdfCam& cam, const double* K, const double* m12) {
     cam.fx = K[0]; cam.fy = K[1]; cam.cx = K[2]; cam.cy = K[3];
-    for (int i = 0; i < 12; ++i) cam.e[i] = extrinsic[i];
-    const int nvox = res * res * res;
-    hipLaunchKernelGGL(tsdf_integrate_kernel, dim3(cdiv(nvox, 256), units), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), depth, color, H, W,
-                       cam, unit_index, reinterpret_cast<float* const*>(unit_ptr), res, voxel_length, sdf_trunc);
+    for (int i = 0; i < 12; ++i) cam.e[i] = m12[i];
+}
+
+extern "C" int bs_tsdf_touch(const float* depth, int32_t H, int32_t W, int32_t stride, const double* K, const double* pose, double unit_length,
+                             double sdf_trunc, void* table_keys, int32_t* table_slots, int32_t* table_stamp, int32_t table_cap, int32_t frame_id,
+                             int32_t* unit_index, int32_t max_units, int32_t* counters, int32_t* touched, void* stream) {
+    if (!initialized()) { set_error("bs_tsdf_touch: call bs_init first"); return BS_ERR_NOT_INIT; }
+    BS_REQUIRE(depth && K && pose && table_keys && table_slots && table_stamp && unit_index && counters && touched, "bs_tsdf_touch: null argument");
+    BS_REQUIRE(H > 0 && W > 0 && stride > 0 && unit_length > 0.0 && sdf_trunc > 0.0 && max_units > 0, "bs_tsdf_touch: bad geometry");
+    BS_REQUIRE(table_cap >= 256 && (table_cap & (table_cap - 1)) == 0, "bs_tsdf_touch: table_cap=%d must be a power of two >= 256", table_cap);
+    TsdfCam cam;
+    tsdf_cam(cam, K, pose);
+    const int span = (int)floor(2.0 * sdf_trunc / unit_length) + 2;          // hi - lo + 1 never exceeds this
+    BS_REQUIRE(span <= 64, "bs_tsdf_touch: sdf_trunc / unit_length too large");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    BS_CHECK_HIP(hipMemsetAsync(counters + 1, 0, 2 * sizeof(int32_t), st));    // n_touched, overflow flag (n_units persists)
+    const int64_t threads = (int64_t)cdiv(W, stride) * cdiv(H, stride) * span * span * span;
+    hipLaunchKernelGGL(tsdf_touch_kernel, dim3((unsigned)cdiv64(threads, 256)), dim3(256), 0, st, depth, H, W, stride, cam, unit_length, sdf_trunc, span,
+                       reinterpret_cast<long long*>(table_keys), table_stamp, (unsigned)(table_cap - 1), frame_id, counters);
+    BS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(tsdf_assign_kernel, dim3(cdiv(table_cap, 256)), dim3(256), 0, st, reinterpret_cast<const long long*>(table_keys), table_slots,
+                       table_stamp, (unsigned)table_cap, frame_id, unit_index, max_units, counters, touched);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }
 
-extern "C" int bs_tsdf_extract(const int32_t* unit_index, const void* unit_ptr, const void* nbr_ptr, int32_t units, int32_t res,
-                               double voxel_length, int32_t* unit_count, const int64_t* unit_offset, float* points, float* colors,
-                               void* stream) {
+extern "C" int bs_tsdf_integrate(const float* depth, const uint8_t* color, int32_t H, int32_t W, const double* K, const double* extrinsic,
+                                 const int32_t* unit_index, const int32_t* touched, int32_t n_touched, const int64_t* slab_base, int32_t slab_units,
+                                 int32_t res, double voxel_length, double sdf_trunc, void* stream) {
+    if (!initialized()) { set_error("bs_tsdf_integrate: call bs_init first"); return BS_ERR_NOT_INIT; }
+    BS_REQUIRE(n_touched >= 0 && H > 0 && W > 0 && res > 0 && res <= 64 && slab_units > 0 && voxel_length > 0.0 && sdf_trunc > 0.0,
+               "bs_tsdf_integrate: bad geometry");
+    if (n_touched == 0) return BS_OK;
+    BS_REQUIRE(depth && K && extrinsic && unit_index && touched && slab_base, "bs_tsdf_integrate: null argument");
+    TsdfCam cam;
+    tsdf_cam(cam, K, extrinsic);
+    const int nvox = res * res * res;
+    hipLaunchKernelGGL(tsdf_integrate_kernel, dim3(cdiv(nvox, 256), n_touched), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), depth, color, H, W,
+                       cam, unit_index, touched, slab_base, slab_units, res, voxel_length, sdf_trunc);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+extern "C" int bs_tsdf_extract(const int32_t* unit_index, int32_t units, const void* table_keys, const int32_t* table_slots, int32_t table_cap,
+                               const int64_t* slab_base, int32_t slab_units, int32_t res, double voxel_length, int32_t* unit_count,
+                               const int64_t* unit_offset, float* points, float* colors, void* stream) {
     if (!initialized()) { set_error("bs_tsdf_extract: call bs_init first"); return BS_ERR_NOT_INIT; }
-    BS_REQUIRE(units >= 0 && res > 0 && res <= 64 && voxel_length > 0.0, "bs_tsdf_extract: bad geometry");
+    BS_REQUIRE(units >= 0 && res > 0 && res <= 64 && slab_units > 0 && voxel_length > 0.0, "bs_tsdf_extract: bad geometry");
     if (units == 0) return BS_OK;
-    BS_REQUIRE(unit_index && unit_ptr && nbr_ptr && unit_count, "bs_tsdf_extract: null argument");
+    BS_REQUIRE(unit_index && table_keys && table_slots && slab_base && unit_count, "bs_tsdf_extract: null argument");
+    BS_REQUIRE(table_cap >= 256 && (table_cap & (table_cap - 1)) == 0, "bs_tsdf_extract: table_cap must be a power of two >= 256");
     BS_REQUIRE((points == nullptr) == (unit_offset == nullptr) && (points == nullptr) == (colors == nullptr),
                "bs_tsdf_extract: the write pass needs unit_offset, points and colors; the count pass none of them");
     const int nvox = res * res * res;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     BS_CHECK_HIP(hipMemsetAsync(unit_count, 0, sizeof(int32_t) * units, st));
     const dim3 grid(cdiv(nvox, 256), units);
+    const long long* keys = reinterpret_cast<const long long*>(table_keys);
     if (!points)
-        hipLaunchKernelGGL(tsdf_extract_kernel<false>, grid, dim3(256), 0, st, unit_index, reinterpret_cast<float* const*>(unit_ptr),
-                           reinterpret_cast<float* const*>(nbr_ptr), res, voxel_length, unit_count, unit_offset, points, colors);
+        hipLaunchKernelGGL(tsdf_extract_kernel<false>, grid, dim3(256), 0, st, unit_index, keys, table_slots, (unsigned)(table_cap - 1), slab_base,
+                           slab_units, res, voxel_length, unit_count, unit_offset, points, colors);
     else
-        hipLaunchKernelGGL(tsdf_extract_kernel<true>, grid, dim3(256), 0, st, unit_index, reinterpret_cast<float* const*>(unit_ptr),
-                           reinterpret_cast<float* const*>(nbr_ptr), res, voxel_length, unit_count, unit_offset, points, colors);
+        hipLaunchKernelGGL(tsdf_extract_kernel<true>, grid, dim3(256), 0, st, unit_index, keys, table_slots, (unsigned)(table_cap - 1), slab_base,
+                           slab_units, res, voxel_length, unit_count, unit_offset, points, colors);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }

@@ -4,11 +4,11 @@ The reference's ``TSDF`` wraps Open3D's ``ScalableTSDFVolume(voxel_length=0.001,
 depth_sampling_stride=8)``: ``build_3D_map(rgbd, intrinsic, extrinsic)`` integrates a frame (3DM/slam.py:117,179 -- it passes the
 accumulated pose as ``extrinsic``), ``extract_pcd`` / ``save_pcd`` read the surface points back (:126,191,195).  Same class, method
 names and defaults here.  The voxels live in HBM (one contiguous block of res^3 x 5 fp32 per volume unit, allocated in slabs and
-zero-filled once) and are integrated / extracted by the HIP kernels of csrc/tsdf.hip; which units exist is host state (a dict, as
-Open3D's unordered_map), found per frame from the strided depth sample exactly as Open3D does.  With the reference's parameters a
+zero-filled once) and are integrated / extracted by the HIP kernels of csrc/tsdf.hip; which units exist is an open-addressing hash
+table in HBM (Open3D: an unordered_map on the host), filled per frame from the strided depth sample exactly as Open3D does.  With the reference's parameters a
 unit is 3.2 cm wide and a point opens the ~7^3 units within 0.1 m of it; a 640x480 frame of a surface at 12 cm touches ~1 600 units
-= 1 GB of voxel state (measured, tools/probes/tsdf_full_size.py: kernel 0.33 ms, the numpy unit discovery ~90 ms -- the step is
-host-bound), metre-scale scenes proportionally more: the voxel store is sized for 288 GB of HBM.  Open3D is not vendored and not installable offline: parity against it is unpinned (oracle/tsdf_ref.py
+= 1 GB of voxel state and takes ~1 ms (measured, tools/probes/tsdf_full_size.py: unit discovery 0.1 ms, integrate kernel 0.27 ms),
+metre-scale scenes proportionally more: the voxel store is sized for 288 GB of HBM.  Open3D is not vendored and not installable offline: parity against it is unpinned (oracle/tsdf_ref.py
 restates the same algorithm in numpy; tests/ compare the two).  Not built: normals of the extracted points and
 ``extract_mesh`` / ``save_mesh`` (marching cubes) -- they raise NotImplementedError.
 """
@@ -61,16 +61,13 @@ class PointCloud:
     colors: np.ndarray      # [M, 3] float32 in [0, 1]
 
 
-_OFF = 1 << 20              # unit indices are packed as three 21-bit fields
-
-
-def _pack(ix, iy, iz):
-    return ((ix + _OFF).astype(np.int64) << 42) | ((iy + _OFF).astype(np.int64) << 21) | (iz + _OFF).astype(np.int64)
+_OFF = 1 << 20              # unit indices are packed as three 21-bit fields (csrc/tsdf.hip ts_pack)
 
 
 class TSDF:
     def __init__(self, voxel_length: float = 0.001, sdf_trunc: float = 0.1, volume_unit_resolution: int = 32,
-                 depth_sampling_stride: int = 8, device: int = 0, slab_bytes: int = 1 << 30):
+                 depth_sampling_stride: int = 8, device: int = 0, slab_bytes: int = 1 << 30, max_units: Optional[int] = None):
+        """max_units bounds the map (default: as many 32^3-voxel-sized blocks as fit 64 GB); the unit table is 4x that, a power of two."""
         self.voxel_length, self.sdf_trunc = float(voxel_length), float(sdf_trunc)
         self.res, self.stride = int(volume_unit_resolution), int(depth_sampling_stride)
         self.unit_length = self.voxel_length * self.res
@@ -78,9 +75,24 @@ class TSDF:
         L.init(device)
         self.unit_floats = self.res ** 3 * 5
         self.slab_units = max(1, slab_bytes // (self.unit_floats * 4))
-        self.slabs = []                 # fp32 [slab_units, unit_floats] tensors, zero-filled
-        self.slot = {}                  # packed unit index -> slot
-        self.index = []                 # slot -> (ix, iy, iz)
+        self.max_units = int(max_units) if max_units else max(1024, min(1 << 20, (64 << 30) // (self.unit_floats * 4)))
+        self.table_cap = 256
+        while self.table_cap < 4 * self.max_units:
+            self.table_cap *= 2
+        self.max_slabs = -(-self.max_units // self.slab_units)
+        self._alloc_state()
+
+    def _alloc_state(self):
+        d = self.dev
+        self.slabs = []                                                   # fp32 [slab_units, unit_floats] tensors, zero-filled
+        self.slab_base = torch.zeros(self.max_slabs, dtype=torch.int64, device=d)
+        self.table_keys = torch.full((self.table_cap,), -1, dtype=torch.int64, device=d)
+        self.table_slots = torch.full((self.table_cap,), -1, dtype=torch.int32, device=d)
+        self.table_stamp = torch.full((self.table_cap,), -1, dtype=torch.int32, device=d)
+        self.unit_index = torch.zeros(self.max_units, 3, dtype=torch.int32, device=d)
+        self.counters = torch.zeros(3, dtype=torch.int32, device=d)
+        self.touched = torch.zeros(self.max_units, dtype=torch.int32, device=d)
+        self.n_units, self.frame_id = 0, 0
 
     # ---- the reference's surface -----------------------------------------------------------------
     def build_3D_map(self, rgbd: RGBDImage, intrinsic: PinholeCameraIntrinsic, extrinsic) -> None:
@@ -88,60 +100,60 @@ class TSDF:
         H, W = depth.shape
         E = np.ascontiguousarray(np.asarray(self._np(extrinsic), dtype=np.float64))
         K = np.array([intrinsic.fx, intrinsic.fy, intrinsic.cx, intrinsic.cy], dtype=np.float64)
-        import time
-        t0 = time.perf_counter()
-        slots = self._touch(depth, K, E)
-        self.last_discovery_s = time.perf_counter() - t0            # host side of the step (diagnostics, tools/probes/tsdf_full_size.py)
-        self.last_units = int(slots.size)
-        if slots.size == 0:
-            return
+        pose12 = np.ascontiguousarray(np.linalg.inv(E)[:3].reshape(12))
+        e12 = np.ascontiguousarray(E[:3].reshape(12))
         d_dev = torch.from_numpy(depth).to(self.dev)
         c_dev = None if rgbd.color is None else torch.from_numpy(np.ascontiguousarray(rgbd.color)).to(self.dev)
-        idx = torch.from_numpy(np.array([self.index[s] for s in slots], dtype=np.int32)).to(self.dev)
-        ptr = torch.from_numpy(self._ptrs(slots)).to(self.dev)
-        e12 = np.ascontiguousarray(E[:3].reshape(12))
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        L.check(L.load_library().bs_tsdf_integrate(L.p(d_dev), L.p(c_dev), H, W, K.ctypes.data_as(C.c_void_p), e12.ctypes.data_as(C.c_void_p),
-                                                   L.p(idx), L.p(ptr), int(slots.size), self.res, self.voxel_length, self.sdf_trunc,
-                                                   L.stream_ptr()), "bs_tsdf_integrate")
-        ev1.record()
-        torch.cuda.current_stream(self.dev).synchronize()          # (the host arrays above must outlive the launch)
-        self.last_kernel_ms = ev0.elapsed_time(ev1)
+        lib, st = L.load_library(), L.stream_ptr()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        self.frame_id += 1
+        ev[0].record()
+        L.check(lib.bs_tsdf_touch(L.p(d_dev), H, W, self.stride, K.ctypes.data_as(C.c_void_p), pose12.ctypes.data_as(C.c_void_p), self.unit_length,
+                                  self.sdf_trunc, L.p(self.table_keys), L.p(self.table_slots), L.p(self.table_stamp), self.table_cap, self.frame_id,
+                                  L.p(self.unit_index), self.max_units, L.p(self.counters), L.p(self.touched), st), "bs_tsdf_touch")
+        ev[1].record()
+        n_units, n_touched, overflow = (int(v) for v in self.counters.cpu())          # the one host round trip of the step (12 bytes)
+        if overflow:
+            raise L.BodySlamHipError("TSDF: " + ("unit table full" if overflow == 1 else f"more than max_units={self.max_units} volume units")
+                                     + "; construct TSDF with a larger max_units")
+        while len(self.slabs) * self.slab_units < n_units:                              # new units: more zero-filled slabs
+            self.slabs.append(torch.zeros(self.slab_units, self.unit_floats, device=self.dev))
+            self.slab_base[len(self.slabs) - 1] = self.slabs[-1].data_ptr()
+        self.n_units, self.last_units = n_units, n_touched
+        ev[2].record()
+        L.check(lib.bs_tsdf_integrate(L.p(d_dev), L.p(c_dev), H, W, K.ctypes.data_as(C.c_void_p), e12.ctypes.data_as(C.c_void_p), L.p(self.unit_index),
+                                      L.p(self.touched), n_touched, L.p(self.slab_base), self.slab_units, self.res, self.voxel_length, self.sdf_trunc,
+                                      st), "bs_tsdf_integrate")
+        ev[3].record()
+        torch.cuda.current_stream(self.dev).synchronize()          # (the host arrays above must outlive the launches)
+        self.last_touch_ms, self.last_kernel_ms = ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3])      # diagnostics
 
     def build_copy_3D_map(self, rgbd, intrinsic, extrinsic) -> "TSDF":
         other = copy.copy(self)
+        for name in ("table_keys", "table_slots", "table_stamp", "unit_index", "counters", "touched"):
+            setattr(other, name, getattr(self, name).clone())
         other.slabs = [s.clone() for s in self.slabs]
-        other.slot, other.index = dict(self.slot), list(self.index)
+        other.slab_base = torch.zeros_like(self.slab_base)
+        for n, sl in enumerate(other.slabs):
+            other.slab_base[n] = sl.data_ptr()
         other.build_3D_map(rgbd, intrinsic, extrinsic)
         return other
 
     def extract_pcd(self) -> PointCloud:
-        U = len(self.index)
+        U = self.n_units
         if U == 0:
             return PointCloud(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
-        slots = np.arange(U)
-        idx_np = np.array(self.index, dtype=np.int32)
-        ptr_np = self._ptrs(slots)
-        nbr = np.zeros((U, 3), dtype=np.int64)
-        for a in range(3):
-            nk = idx_np.copy()
-            nk[:, a] += 1
-            keys = _pack(nk[:, 0], nk[:, 1], nk[:, 2])
-            ns = np.array([self.slot.get(int(k), -1) for k in keys])
-            nbr[:, a] = np.where(ns >= 0, ptr_np[np.maximum(ns, 0)], 0)
-        idx, ptr, nb = (torch.from_numpy(a).to(self.dev) for a in (idx_np, ptr_np, nbr))
         count = torch.zeros(U, dtype=torch.int32, device=self.dev)
         lib = L.load_library()
-        L.check(lib.bs_tsdf_extract(L.p(idx), L.p(ptr), L.p(nb), U, self.res, self.voxel_length, L.p(count), None, None, None, L.stream_ptr()),
-                "bs_tsdf_extract")
+        args = (L.p(self.unit_index), U, L.p(self.table_keys), L.p(self.table_slots), self.table_cap, L.p(self.slab_base), self.slab_units, self.res,
+                self.voxel_length, L.p(count))
+        L.check(lib.bs_tsdf_extract(*args, None, None, None, L.stream_ptr()), "bs_tsdf_extract")
         counts = count.cpu().numpy().astype(np.int64)
         total = int(counts.sum())
         pts = torch.empty(max(total, 1), 3, device=self.dev)
         cols = torch.empty(max(total, 1), 3, device=self.dev)
         off = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)).to(self.dev)
-        L.check(lib.bs_tsdf_extract(L.p(idx), L.p(ptr), L.p(nb), U, self.res, self.voxel_length, L.p(count), L.p(off), L.p(pts), L.p(cols),
-                                    L.stream_ptr()), "bs_tsdf_extract")
+        L.check(lib.bs_tsdf_extract(*args, L.p(off), L.p(pts), L.p(cols), L.stream_ptr()), "bs_tsdf_extract")
         return PointCloud(pts[:total].cpu().numpy(), cols[:total].cpu().numpy())
 
     def save_pcd(self, saving_path: str) -> None:
@@ -153,57 +165,19 @@ class TSDF:
     def save_mesh(self, saving_path: str) -> None:
         self.extract_mesh()
 
-    # ---- host bookkeeping --------------------------------------------------------------------------
+    # ---- views of the device state (tests, diagnostics) ---------------------------------------------
     @staticmethod
     def _np(m):
         return m.detach().cpu().numpy() if isinstance(m, torch.Tensor) else np.asarray(m)
 
-    def _ptrs(self, slots: np.ndarray) -> np.ndarray:
-        base = np.array([s.data_ptr() for s in self.slabs], dtype=np.int64)
-        slots = np.asarray(slots, dtype=np.int64)
-        return base[slots // self.slab_units] + (slots % self.slab_units) * (self.unit_floats * 4)
-
-    def _touch(self, depth: np.ndarray, K: np.ndarray, E: np.ndarray) -> np.ndarray:
-        """slots of the volume units this frame integrates into (ScalableTSDFVolume::Integrate: every unit that meets the
-        +-sdf_trunc box of a point of the strided depth sample; missing ones are opened)"""
-        fx, fy, cx, cy = K
-        H, W = depth.shape
-        ii, jj = np.meshgrid(np.arange(0, H, self.stride), np.arange(0, W, self.stride), indexing="ij")
-        z = depth[ii, jj].astype(np.float64)
-        m = z > 0
-        if not m.any():
-            return np.zeros(0, dtype=np.int64)
-        z, ii, jj = z[m], ii[m], jj[m]
-        cam = np.stack([(jj - cx) * z / fx, (ii - cy) * z / fy, z, np.ones_like(z)], 1)
-        p = (cam @ np.linalg.inv(E).T)[:, :3]
-        lo = np.floor((p - self.sdf_trunc) / self.unit_length).astype(np.int64)
-        hi = np.floor((p + self.sdf_trunc) / self.unit_length).astype(np.int64)
-        span = int((hi - lo).max()) + 1
-        o = np.stack(np.meshgrid(*(np.arange(span),) * 3, indexing="ij"), -1).reshape(-1, 3)
-        keys = []
-        step = max(1, (1 << 22) // o.shape[0])          # bound the temporary: ~4 M candidate units at a time
-        for s in range(0, p.shape[0], step):
-            c = lo[s:s + step, None, :] + o[None]
-            ok = (c <= hi[s:s + step, None, :]).all(-1)
-            c = c[ok]
-            keys.append(np.unique(_pack(c[:, 0], c[:, 1], c[:, 2])))
-        keys = np.unique(np.concatenate(keys))
-        slots = np.empty(keys.shape[0], dtype=np.int64)
-        for n, k in enumerate(keys):
-            k = int(k)
-            s = self.slot.get(k)
-            if s is None:
-                s = len(self.index)
-                if s >= len(self.slabs) * self.slab_units:
-                    self.slabs.append(torch.zeros(self.slab_units, self.unit_floats, device=self.dev))
-                self.slot[k] = s
-                self.index.append(((k >> 42) - _OFF, ((k >> 21) & ((1 << 21) - 1)) - _OFF, (k & ((1 << 21) - 1)) - _OFF))
-            slots[n] = s
-        return slots
+    @property
+    def index(self) -> list:
+        """unit indices (ix, iy, iz) in block order"""
+        return [tuple(int(v) for v in r) for r in self.unit_index[:self.n_units].cpu().numpy()]
 
     def unit(self, key) -> np.ndarray:
-        """voxels of one unit as fp32 [res, res, res, 5] (tests, diagnostics)"""
-        s = self.slot[int(_pack(*(np.array([v]) for v in key))[0])]
+        """voxels of one unit as fp32 [res, res, res, 5]"""
+        s = self.index.index(tuple(int(v) for v in key))
         return self.slabs[s // self.slab_units][s % self.slab_units].view(self.res, self.res, self.res, 5).cpu().numpy()
 
 

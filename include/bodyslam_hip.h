@@ -316,20 +316,33 @@ int bs_pose_chain_from(const float* t_rel, int32_t N, const double* g0_dev, doub
 /* TSDF map (N4) ---------------------------------------------------------------------------------- *
  * Open3D ScalableTSDFVolume as wrapped by BodySLAM_not_refactored/3DM/tsdf.py:5-52 (voxel_length 0.001, sdf_trunc 0.1, RGB8,
  * volume_unit_resolution 32, depth_sampling_stride 8; integrate per frame at 3DM/slam.py:117,179, extract_point_cloud at :126,195).
- * A volume unit is res^3 voxels x 5 fp32 (tsdf, weight, r, g, b), voxel x*res^2 + y*res + z; the table of units is host state.
+ * State, all in device memory and owned by the caller:
+ *   blocks      one per volume unit: res^3 voxels x 5 fp32 (tsdf, weight, r, g, b), voxel x*res^2 + y*res + z, zero-filled; block s
+ *               lives at slab_base[s / slab_units] + (s % slab_units) * res^3 * 20 bytes (slab_base: int64 device array)
+ *   unit table  open addressing: table_keys int64 [table_cap] (-1 = empty; table_cap a power of two), table_slots int32 [table_cap]
+ *               (-1 until a block is assigned), table_stamp int32 [table_cap]; unit_index int32 [max_units, 3]
+ *   counters    int32 [3]: number of units (persists across calls), units touched by the last bs_tsdf_touch, overflow flag
+ *               (1: table full, 2: more units than max_units -- the caller must check it before integrating)
  *
- * bs_tsdf_integrate: UniformTSDFVolume::IntegrateWithDepthToCameraDistanceMultiplier on `units` units: depth fp32 [H, W] metres
- * (<= 0 invalid), color u8 [H, W, 3] or NULL, K = (fx, fy, cx, cy), extrinsic = rows 0..2 of the world->camera 4x4 (12 doubles,
- * host), unit_index int32 [units, 3] (origin = index * res * voxel_length), unit_ptr = device array of `units` float* (the blocks).
- * bs_tsdf_extract: ScalableTSDFVolume::ExtractPointCloud (points + colours, no normals) in two passes over the same units:
- * points == NULL counts into unit_count int32 [units]; otherwise unit_offset int64 [units] (exclusive prefix sums of the counts)
- * places each unit's points, points / colors fp32 [total, 3].  nbr_ptr = device array [units, 3] of the +x / +y / +z neighbour
- * unit's block or NULL. */
+ * bs_tsdf_touch: ScalableTSDFVolume::Integrate's unit discovery -- every unit that meets the +-sdf_trunc box of a point of the
+ *   depth image sampled every `stride` pixels (depth fp32 [H, W] metres, <= 0 invalid; pose = rows 0..2 of the camera->world 4x4,
+ *   i.e. extrinsic^-1; K = (fx, fy, cx, cy); both host doubles) is inserted, gets a block number and goes on `touched`
+ *   (int32 [max_units]); frame_id must differ from call to call.
+ * bs_tsdf_integrate: UniformTSDFVolume::IntegrateWithDepthToCameraDistanceMultiplier on the n_touched units of `touched`
+ *   (extrinsic = rows 0..2 of the world->camera 4x4; color u8 [H, W, 3] or NULL).  The caller has made sure the slabs cover
+ *   counters[0] blocks.
+ * bs_tsdf_extract: ScalableTSDFVolume::ExtractPointCloud (points + colours, no normals) over blocks 0 .. units-1 in two passes:
+ *   points == NULL counts into unit_count int32 [units]; otherwise unit_offset int64 [units] (exclusive prefix sums of the counts)
+ *   places each unit's points, points / colors fp32 [total, 3]. */
+int bs_tsdf_touch(const float* depth, int32_t H, int32_t W, int32_t stride, const double* K, const double* pose, double unit_length,
+                  double sdf_trunc, void* table_keys, int32_t* table_slots, int32_t* table_stamp, int32_t table_cap, int32_t frame_id,
+                  int32_t* unit_index, int32_t max_units, int32_t* counters, int32_t* touched, void* stream);
 int bs_tsdf_integrate(const float* depth, const uint8_t* color, int32_t H, int32_t W, const double* K, const double* extrinsic,
-                      const int32_t* unit_index, const void* unit_ptr, int32_t units, int32_t res, double voxel_length,
-                      double sdf_trunc, void* stream);
-int bs_tsdf_extract(const int32_t* unit_index, const void* unit_ptr, const void* nbr_ptr, int32_t units, int32_t res,
-                    double voxel_length, int32_t* unit_count, const int64_t* unit_offset, float* points, float* colors, void* stream);
+                      const int32_t* unit_index, const int32_t* touched, int32_t n_touched, const int64_t* slab_base, int32_t slab_units,
+                      int32_t res, double voxel_length, double sdf_trunc, void* stream);
+int bs_tsdf_extract(const int32_t* unit_index, int32_t units, const void* table_keys, const int32_t* table_slots, int32_t table_cap,
+                    const int64_t* slab_base, int32_t slab_units, int32_t res, double voxel_length, int32_t* unit_count,
+                    const int64_t* unit_offset, float* points, float* colors, void* stream);
 
 #ifdef __cplusplus
 }

@@ -24,11 +24,14 @@ for f in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
     pose[:3, 3] = (0.002 * f, 0.0, 0.001 * f)
     E = np.linalg.inv(pose)
     n0 = len(t.index)
+    tw = time.perf_counter()
     t.build_3D_map(RGBDImage(color, depth), intr, E)
     nv = t.last_units * 32 ** 3
+    t1 = time.perf_counter()
     print(f"frame {f}: {t.last_units} units touched ({len(t.index) - n0} new), {nv / 1e6:.0f} M voxels = {nv * 20 / 1e9:.2f} GB of voxel state; "
-          f"unit discovery {t.last_discovery_s * 1e3:.0f} ms (host numpy), integrate kernel {t.last_kernel_ms:.3f} ms (HIP events) = "
-          f"{nv * 40 / (t.last_kernel_ms * 1e-3) / 1e12:.2f} TB/s of voxel read + write", flush=True)
+          f"unit discovery (device hash table) {t.last_touch_ms:.3f} ms, integrate kernel {t.last_kernel_ms:.3f} ms (HIP events; upper bound of its "
+          f"traffic, 40 B x every voxel of the touched units: {nv * 40 / (t.last_kernel_ms * 1e-3) / 1e12:.2f} TB/s); whole build_3D_map call "
+          f"{(t1 - tw) * 1e3:.1f} ms wall", flush=True)
 t0 = time.perf_counter()
 pcd = t.extract_pcd()
 torch.cuda.synchronize()
