@@ -15,10 +15,14 @@ MPEM's matrix with the filter state (:90).  Built here:
     MPEM's translation to filterpy as the ``dt`` argument, which the identity process model ignores -- so MPEM contributes the
     rotation only and the translation is the filtered RGB-D odometry displacement.  Kept as is.
 
-NOT built: the RGB-D odometry itself (Open3D's tensor ``rgbd_odometry_multi_scale``; third-party C++ / CUDA with no in-repo
-statement of its preprocessing, pyramid, robust weights or convergence test to restate faithfully).  ``VO`` takes it as a callable
-``rgbd_odometry(curr_rgbd, prev_rgbd) -> 4x4`` (the relative pose, i.e. what ``_compute_vo_o3d`` returns) and raises
-NotImplementedError when none is given and ``rgbd_odo`` is requested -- it never substitutes anything silently.
+  * the RGB-D odometry: bodyslam_amd/rgbd_odometry.py (``RGBDOdometry``: dense hybrid photometric + geometric Gauss-Newton on a
+    3-level pyramid with 20 / 10 / 5 iterations, the scheme of Open3D's Hybrid method; HIP kernels in csrc/odometry.hip).  It is an
+    implementation of the published scheme, not a restatement of Open3D's source: parity with Open3D is unpinned and looser than
+    for the filter; what pins it is rendered ground truth (tests/).  ``VO`` uses it by default when ``intrinsic`` = (fx, fy, cx, cy)
+    is given; ``rgbd_odometry=callable(curr_rgbd, prev_rgbd) -> 4x4`` overrides it (e.g. with Open3D's own, where installed).
+    Without either, ``estimate_relative_pose_between`` raises -- it never substitutes anything silently.
+
+NOT built: the sparse-feature scaling path (``rgbd_odo=False``: scaling_system.compute_scaling_factor, OpenCV).
 """
 from __future__ import annotations
 
@@ -144,6 +148,9 @@ class VO:
 
     def _compute_vo_o3d(self, curr_rgbd, ref_rgbd) -> np.ndarray:
         if self.rgbd_odometry is None:
-            raise NotImplementedError("RGB-D odometry (Open3D rgbd_odometry_multi_scale, Hybrid, 20/10/5) is not built: pass "
-                                      "VO(..., rgbd_odometry=callable(curr_rgbd, prev_rgbd) -> 4x4)")
+            if self.intrinsic is None or len(tuple(self.intrinsic)) != 4:
+                raise NotImplementedError("RGB-D odometry needs VO(..., intrinsic=(fx, fy, cx, cy)) for the built-in RGBDOdometry, or "
+                                          "VO(..., rgbd_odometry=callable(curr_rgbd, prev_rgbd) -> 4x4)")
+            from .rgbd_odometry import RGBDOdometry
+            self.rgbd_odometry = RGBDOdometry(tuple(self.intrinsic))
         return np.asarray(self.rgbd_odometry(curr_rgbd, ref_rgbd), dtype=np.float64)

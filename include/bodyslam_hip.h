@@ -344,6 +344,27 @@ int bs_tsdf_extract(const int32_t* unit_index, int32_t units, const void* table_
                     const int64_t* slab_base, int32_t slab_units, int32_t res, double voxel_length, int32_t* unit_count,
                     const int64_t* unit_offset, float* points, float* colors, void* stream);
 
+/* dense RGB-D odometry (N3) -------------------------------------------------------------------- *
+ * The role of Open3D's rgbd_odometry_multi_scale (Method.Hybrid, 20 / 10 / 5 iterations) at
+ * BodySLAM_not_refactored/3DM/visual_odometry.py:97-120; the algorithm is stated in oracle/rgbd_odometry_ref.py (parity with Open3D
+ * unpinned).  Images are fp32 [H, W] in device memory, NaN = invalid depth; K = (fx, fy, cx, cy) and T (rows 0..2 of the
+ * source -> target 4x4) are host doubles.
+ *   bs_odo_prepare     intensity = (0.299 R + 0.587 G + 0.114 B) / 255 of color u8 [H, W, 3]; depth metres, <= 0 or > depth_max -> NaN
+ *   bs_odo_pyrdown     next pyramid level [(H+1)/2, (W+1)/2]: [1 4 6 4 1]^2 / 256 at the even pixels, replicate borders; is_depth: the
+ *                      weights run over the neighbours within depth_threshold of the centre, NaN where the centre is invalid
+ *   bs_odo_sobel       3x3 Sobel / 8 in x and y, replicate borders, NaN propagates
+ *   bs_odo_accumulate  the sums of one Gauss-Newton step at pose T: out29 = [21 upper-triangle terms of sum w J^T J (row-major),
+ *                      6 terms of sum w J^T r, the weighted cost, the inlier count]; hybrid residuals (intensity + depth), Huber
+ *                      weights, target sampled bilinearly; partial = scratch double [ceil(H*W/256), 29]; deterministic */
+int bs_odo_prepare(const uint8_t* color, const float* depth, int32_t H, int32_t W, double depth_max, float* intensity, float* depth_out,
+                   void* stream);
+int bs_odo_pyrdown(const float* src, int32_t H, int32_t W, float* dst, int32_t is_depth, double depth_threshold, void* stream);
+int bs_odo_sobel(const float* img, int32_t H, int32_t W, float* gx, float* gy, void* stream);
+int bs_odo_accumulate(const float* src_intensity, const float* src_depth, const float* tgt_intensity, const float* tgt_depth,
+                      const float* tgt_dIx, const float* tgt_dIy, const float* tgt_dDx, const float* tgt_dDy, int32_t H, int32_t W,
+                      const double* K, const double* T, double depth_outlier_trunc, double depth_huber, double intensity_huber,
+                      double* partial, double* out29, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
