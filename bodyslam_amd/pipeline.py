@@ -180,6 +180,50 @@ class BodySlamPipeline:
             t_all = gather_relative_poses(t_local, counts, group) if world > 1 else t_local
         return self.chain_and_backproject(N, start, end, depth, depth_m, t_all, keep_points, on_points)
 
+    def run_slam_loop(self, frames, vo: bool = False, tsdf=None, keep_points: bool = False, keep_depth_m: bool = False) -> SequenceResult:
+        """The reference's whole per-frame loop (``SLAM._sequential_loop``, 3DM/slam.py:131-205) on one GPU, in its order of
+        dependencies: depth of every frame (MDEM), the relative pose of every consecutive pair (MPEM), with ``vo=True`` the VO
+        fusion of each pair in frame order (slam.py:144 -> visual_odometry.py:60-93: RGB-D odometry between the two pseudo-RGBD frames,
+        3-state UKF, MPEM's translation replaced by the filter state), the fp64 pose chain (+ the pose-graph step every
+        ``posegraph_every`` frames), back-projection, and with ``tsdf`` the map integration of every frame (slam.py:179).  MDEM and
+        MPEM stay batched -- they do not depend on the filter; only the fusion is sequential, its state carries from pair to pair,
+        which is also why this entry point does not shard (``run_sequence`` does)."""
+        frames = torch.as_tensor(frames)
+        assert frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[-1] == 3
+        N = frames.shape[0]
+        depth, depth_m, t_rel = self.depth_and_pose_block(frames, 0, N, keep_depth_m, 0)
+        if vo and N > 1:
+            t_rel = self.fuse_vo(frames, depth, t_rel)
+        res = self.chain_and_backproject(N, 0, N, depth, depth_m, t_rel, keep_points, None)
+        if tsdf is not None:
+            self.integrate_tsdf(tsdf, frames, res)
+        return res
+
+    def fuse_vo(self, frames, depth_u16: torch.Tensor, t_rel: torch.Tensor) -> torch.Tensor:
+        """visual_odometry.py:60-93 over the pairs (i-1, i) in order: returns t_rel with each translation replaced by the UKF state"""
+        from .tsdf import create_rgbd_from_color_and_depth
+        from .visual_odometry import VO
+
+        class _Batched:                              # MPEM already ran batched: hand VO its result for the pair it asks about
+            def __init__(self, t):
+                self.t, self.i = t, 0
+
+            def infer_relative_pose_between(self, prev, curr):
+                return self.t[self.i]
+
+        t_np = t_rel.view(-1, 4, 4).cpu().numpy().copy()
+        mp = _Batched(t_np)
+        vo = VO(mp, intrinsic=tuple(float(v) for v in self.K))
+        fr = frames.cpu().numpy()
+        du = depth_u16.cpu().numpy().view(np.uint16)
+        rgbd = [None, create_rgbd_from_color_and_depth(fr[0], du[0], self.depth_scale, self.depth_trunc)]
+        out = np.empty_like(t_np)
+        for i in range(1, fr.shape[0]):
+            rgbd = [rgbd[1], create_rgbd_from_color_and_depth(fr[i], du[i], self.depth_scale, self.depth_trunc)]
+            mp.i = i - 1
+            out[i - 1] = vo.estimate_relative_pose_between(i - 1, i, rgbd[0], rgbd[1], i)
+        return torch.from_numpy(out).to(t_rel.device, t_rel.dtype).view(t_rel.shape)
+
     def integrate_tsdf(self, tsdf, frames, result: SequenceResult) -> None:
         """The map step of the loop (3DM/slam.py:117,179): every local frame's pseudo-RGBD (3DM/slam_utils.py:212-220: depth / depth_scale,
         values >= depth_trunc dropped) goes into `tsdf` (bodyslam_amd.tsdf.TSDF) with the frame's absolute pose as the extrinsic

@@ -109,3 +109,48 @@ def test_pipeline_integrates_its_frames():
     assert len(t.index) > 0
     w = sum(float(t.unit(k)[..., 1].sum()) for k in t.index[:50])
     assert w > 0
+
+
+def test_run_slam_loop_orders_the_steps_like_the_reference():
+    """SLAM._sequential_loop (3DM/slam.py:131-205): depth, MPEM, VO fusion pair by pair, chain, map.  Structural checks on a small
+    configuration: the fused relatives keep MPEM's rotations, their translations are the UKF states of a VO run by hand on the
+    same inputs, the chain is the chain of the fused relatives, and every frame went into the TSDF."""
+    import dataclasses
+    from bodyslam_amd import geom3d
+    from bodyslam_amd.pipeline import BodySlamPipeline
+    from bodyslam_amd.synthetic import make_sequence
+    from bodyslam_amd.tsdf import TSDF, create_rgbd_from_color_and_depth
+    from bodyslam_amd.visual_odometry import VO
+    from bodyslam_amd.zoedepth import ZoeConfig
+    from oracle import cyclepose_ref as CP
+    from oracle import geom3d_ref as G
+    from oracle import zoedepth_ref as Z
+    cfg_o = Z.ZoeConfig(hidden=128, layers=4, heads=2, intermediate=256, taps=(1, 2, 3, 4), image_size=64)
+    names = {f.name for f in dataclasses.fields(ZoeConfig)}
+    cfg_p = ZoeConfig(**{k: v for k, v in dataclasses.asdict(cfg_o).items() if k in names})
+    frames = make_sequence(4, 160, 192, seed=5)
+    pipe = BodySlamPipeline(Z.synth_weights(cfg_o, seed=2), CP.synth_weights(seed=2), cfg_p, batch=2, target_hw=(64, 96))
+    plain = pipe.run_sequence(frames)
+    t = TSDF(voxel_length=0.02, sdf_trunc=0.06, volume_unit_resolution=8, depth_sampling_stride=8)
+    res = pipe.run_slam_loop(frames, vo=True, tsdf=t)
+    assert torch.equal(res.depth_u16, plain.depth_u16)
+    tp, tf = plain.t_rel.cpu().numpy(), res.t_rel.cpu().numpy()
+    assert np.array_equal(tf[:, :3, :3], tp[:, :3, :3]) and not np.allclose(tf[:, :3, 3], tp[:, :3, 3])
+
+    class Stored:
+        def __init__(self):
+            self.i = 0
+
+        def infer_relative_pose_between(self, a, b):
+            return tp[self.i]
+
+    mp = Stored()
+    vo = VO(mp, intrinsic=tuple(pipe.K))
+    du = res.depth_u16.cpu().numpy().view(np.uint16)
+    rg = [create_rgbd_from_color_and_depth(frames[i], du[i], pipe.depth_scale, pipe.depth_trunc) for i in range(4)]
+    for i in range(1, 4):
+        mp.i = i - 1
+        T = vo.estimate_relative_pose_between(i - 1, i, rg[i - 1], rg[i], i)
+        assert np.array_equal(T.astype(np.float32), tf[i - 1])
+    assert np.abs(res.g_abs.cpu().numpy() - G.pose_chain(tf)).max() < 1e-10
+    assert t.n_units > 0 and t.frame_id == 4
