@@ -71,6 +71,7 @@ _SIGS = {
     "bs_upconv_tapsum": [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p],
     "bs_col_mean": [C.c_void_p, C.c_int64] + [C.c_int32] * 5 + [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p],
     "bs_rank1_bias": [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p],
+    "bs_depth_u16_to_m": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p],
     "bs_odo_prepare": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p],
     "bs_odo_pyrdown": [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_double, C.c_void_p],
     "bs_odo_sobel": [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
@@ -525,6 +526,15 @@ def fill_rows(x, v, B, rows_per_image, cols):
 def resize_bilinear_nhwc(x, out, B, Hin, Win, Cch, Hout, Wout, align_corners=True, split=False):
     check(load_library().bs_resize_bilinear_nhwc(p(x), p(out), B, Hin, Win, Cch, Hout, Wout, int(align_corners) | (4 if split == 2 else (2 if split else 0)), dt(x),
                                                  stream_ptr()), "bs_resize_bilinear_nhwc")
+
+
+def depth_u16_to_m(depth_u16: torch.Tensor, depth_scale: float, depth_trunc: float) -> torch.Tensor:
+    """int16-stored uint16 depth [..., H, W] on the device -> fp32 metres, values >= depth_trunc -> 0 (include/bodyslam_hip.h)"""
+    assert depth_u16.dtype == torch.int16 and depth_u16.is_cuda and depth_u16.is_contiguous()
+    out = torch.empty(depth_u16.shape, dtype=torch.float32, device=depth_u16.device)
+    check(load_library().bs_depth_u16_to_m(p(depth_u16), depth_u16.numel(), float(depth_scale), float(depth_trunc), p(out), stream_ptr()),
+          "bs_depth_u16_to_m")
+    return out
 
 
 def col_mean(A, lda, row0, rows_per_group, groups, row_step, K, out, zero=None):

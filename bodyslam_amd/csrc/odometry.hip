@@ -23,6 +23,14 @@ __global__ __launch_bounds__(256) void odo_prepare_kernel(const uint8_t* __restr
     dout[i] = (d > 0.0f && d <= depth_max) ? d : __builtin_nanf("");
 }
 
+// pseudo-RGBD depth of the 3DM loop (3DM/slam_utils.py:212-220): z = u16 / depth_scale as fp32, z >= depth_trunc -> 0 (no measurement)
+__global__ __launch_bounds__(256) void depth_u16_to_m_kernel(const uint16_t* __restrict__ d, int64_t n, float scale, float trunc, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float z = __fdiv_rn((float)d[i], scale);
+    out[i] = z >= trunc ? 0.0f : z;
+}
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // level l -> l + 1: [1 4 6 4 1]^2 / 256 at every even pixel, replicate borders.  DEPTH: the weights run over the neighbours whose
@@ -156,6 +164,16 @@ __global__ __launch_bounds__(64) void odo_finish_kernel(const double* __restrict
 using namespace bs;
 #define ODO_ENTRY(name) \
     if (!initialized()) { set_error(name ": call bs_init first"); return BS_ERR_NOT_INIT; }
+
+extern "C" int bs_depth_u16_to_m(const uint16_t* depth_u16, int64_t n, double depth_scale, double depth_trunc, float* out, void* stream) {
+    ODO_ENTRY("bs_depth_u16_to_m");
+    BS_REQUIRE(depth_u16 && out && n >= 0 && depth_scale > 0.0, "bs_depth_u16_to_m: bad argument");
+    if (n == 0) return BS_OK;
+    hipLaunchKernelGGL(depth_u16_to_m_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), depth_u16, n,
+                       (float)depth_scale, (float)depth_trunc, out);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
 
 extern "C" int bs_odo_prepare(const uint8_t* color, const float* depth, int32_t H, int32_t W, double depth_max, float* intensity, float* depth_out,
                               void* stream) {

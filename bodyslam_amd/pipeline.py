@@ -201,7 +201,6 @@ class BodySlamPipeline:
 
     def fuse_vo(self, frames, depth_u16: torch.Tensor, t_rel: torch.Tensor) -> torch.Tensor:
         """visual_odometry.py:60-93 over the pairs (i-1, i) in order: returns t_rel with each translation replaced by the UKF state"""
-        from .tsdf import create_rgbd_from_color_and_depth
         from .visual_odometry import VO
 
         class _Batched:                              # MPEM already ran batched: hand VO its result for the pair it asks about
@@ -211,32 +210,30 @@ class BodySlamPipeline:
             def infer_relative_pose_between(self, prev, curr):
                 return self.t[self.i]
 
+        from .tsdf import RGBDImage
         t_np = t_rel.view(-1, 4, 4).cpu().numpy().copy()
         mp = _Batched(t_np)
         vo = VO(mp, intrinsic=tuple(float(v) for v in self.K))
-        fr = frames.cpu().numpy()
-        du = depth_u16.cpu().numpy().view(np.uint16)
-        rgbd = [None, create_rgbd_from_color_and_depth(fr[0], du[0], self.depth_scale, self.depth_trunc)]
+        fr = frames.to(self.dev)                                                   # images and depth stay on the device
+        dm = L.depth_u16_to_m(depth_u16.contiguous(), self.depth_scale, self.depth_trunc)
         out = np.empty_like(t_np)
         for i in range(1, fr.shape[0]):
-            rgbd = [rgbd[1], create_rgbd_from_color_and_depth(fr[i], du[i], self.depth_scale, self.depth_trunc)]
             mp.i = i - 1
-            out[i - 1] = vo.estimate_relative_pose_between(i - 1, i, rgbd[0], rgbd[1], i)
+            out[i - 1] = vo.estimate_relative_pose_between(i - 1, i, RGBDImage(fr[i - 1], dm[i - 1]), RGBDImage(fr[i], dm[i]), i)
         return torch.from_numpy(out).to(t_rel.device, t_rel.dtype).view(t_rel.shape)
 
     def integrate_tsdf(self, tsdf, frames, result: SequenceResult) -> None:
         """The map step of the loop (3DM/slam.py:117,179): every local frame's pseudo-RGBD (3DM/slam_utils.py:212-220: depth / depth_scale,
         values >= depth_trunc dropped) goes into `tsdf` (bodyslam_amd.tsdf.TSDF) with the frame's absolute pose as the extrinsic
         argument, exactly as the reference passes it."""
-        from .tsdf import PinholeCameraIntrinsic, create_rgbd_from_color_and_depth
-        frames = frames.cpu().numpy() if isinstance(frames, torch.Tensor) else np.asarray(frames)
-        du = result.depth_u16.cpu().numpy().view(np.uint16)
-        H, W = du.shape[1:]
+        from .tsdf import PinholeCameraIntrinsic, RGBDImage
+        fr = torch.as_tensor(frames).to(self.dev)                                 # images and depth stay on the device
+        dm = L.depth_u16_to_m(result.depth_u16.contiguous(), self.depth_scale, self.depth_trunc)
+        H, W = dm.shape[1:]
         intr = PinholeCameraIntrinsic(W, H, *[float(v) for v in self.K])
         g = result.g_abs.cpu().numpy()
-        for j in range(du.shape[0]):
-            rgbd = create_rgbd_from_color_and_depth(frames[result.start + j], du[j], self.depth_scale, self.depth_trunc)
-            tsdf.build_3D_map(rgbd, intr, g[result.start + j])
+        for j in range(dm.shape[0]):
+            tsdf.build_3D_map(RGBDImage(fr[result.start + j], dm[j]), intr, g[result.start + j])
 
     def chain_and_backproject(self, N: int, start: int, end: int, depth: torch.Tensor, depth_m: Optional[torch.Tensor],
                               t_all: torch.Tensor, keep_points: bool = False, on_points: Optional[Callable] = None) -> SequenceResult:

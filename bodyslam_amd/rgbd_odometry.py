@@ -57,8 +57,7 @@ class RGBDOdometry:
     # ---- device-side image preparation ---------------------------------------------------------------
     def _pyramid(self, color_u8, depth_m, depth_max: float, gradients: bool):
         lib, st = L.load_library(), L.stream_ptr()
-        color = torch.from_numpy(np.ascontiguousarray(np.asarray(color_u8, dtype=np.uint8))).to(self.dev)
-        depth = torch.from_numpy(np.ascontiguousarray(np.asarray(depth_m, dtype=np.float32))).to(self.dev)
+        color, depth = self._dev(color_u8, torch.uint8), self._dev(depth_m, torch.float32)      # numpy, host or device tensors
         H, W = depth.shape
         levels = []
         lv = _Level()
@@ -120,7 +119,14 @@ class RGBDOdometry:
         T = self.estimate(curr_rgbd.color, curr_rgbd.depth, prev_rgbd.color, prev_rgbd.depth, dmax)
         return np.linalg.inv(T)
 
+    def _dev(self, x, dtype) -> torch.Tensor:
+        t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+        return t.to(device=self.dev, dtype=dtype).contiguous()
+
     @staticmethod
     def _depth_max(rgbd) -> float:
         m = getattr(rgbd, "depth_max", None)
-        return float(m) if m is not None else float(np.nanmax(np.asarray(rgbd.depth)))
+        if m is not None:
+            return float(m)
+        d = rgbd.depth
+        return float(d.max()) if isinstance(d, torch.Tensor) else float(np.nanmax(np.asarray(d)))

@@ -96,14 +96,17 @@ class TSDF:
 
     # ---- the reference's surface -----------------------------------------------------------------
     def build_3D_map(self, rgbd: RGBDImage, intrinsic: PinholeCameraIntrinsic, extrinsic) -> None:
-        depth = np.ascontiguousarray(np.asarray(rgbd.depth, dtype=np.float32))
-        H, W = depth.shape
+        d_dev = (rgbd.depth if isinstance(rgbd.depth, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(rgbd.depth, dtype=np.float32))))
+        d_dev = d_dev.to(device=self.dev, dtype=torch.float32).contiguous()                    # numpy, host or device tensors
+        H, W = d_dev.shape
         E = np.ascontiguousarray(np.asarray(self._np(extrinsic), dtype=np.float64))
         K = np.array([intrinsic.fx, intrinsic.fy, intrinsic.cx, intrinsic.cy], dtype=np.float64)
         pose12 = np.ascontiguousarray(np.linalg.inv(E)[:3].reshape(12))
         e12 = np.ascontiguousarray(E[:3].reshape(12))
-        d_dev = torch.from_numpy(depth).to(self.dev)
-        c_dev = None if rgbd.color is None else torch.from_numpy(np.ascontiguousarray(rgbd.color)).to(self.dev)
+        c_dev = None
+        if rgbd.color is not None:
+            c_dev = rgbd.color if isinstance(rgbd.color, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(rgbd.color, dtype=np.uint8)))
+            c_dev = c_dev.to(device=self.dev, dtype=torch.uint8).contiguous()
         lib, st = L.load_library(), L.stream_ptr()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         self.frame_id += 1

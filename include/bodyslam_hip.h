@@ -356,6 +356,8 @@ int bs_tsdf_extract(const int32_t* unit_index, int32_t units, const void* table_
  *   bs_odo_accumulate  the sums of one Gauss-Newton step at pose T: out29 = [21 upper-triangle terms of sum w J^T J (row-major),
  *                      6 terms of sum w J^T r, the weighted cost, the inlier count]; hybrid residuals (intensity + depth), Huber
  *                      weights, target sampled bilinearly; partial = scratch double [ceil(H*W/256), 29]; deterministic */
+/* the pseudo-RGBD depth of the 3DM loop (3DM/slam_utils.py:212-220): out = u16 / depth_scale as fp32 metres, values >= depth_trunc -> 0 */
+int bs_depth_u16_to_m(const uint16_t* depth_u16, int64_t n, double depth_scale, double depth_trunc, float* out, void* stream);
 int bs_odo_prepare(const uint8_t* color, const float* depth, int32_t H, int32_t W, double depth_max, float* intensity, float* depth_out,
                    void* stream);
 int bs_odo_pyrdown(const float* src, int32_t H, int32_t W, float* dst, int32_t is_depth, double depth_threshold, void* stream);
