@@ -82,7 +82,12 @@ struct OdoPose {
 __global__ __launch_bounds__(256) void odo_accumulate_kernel(const float* __restrict__ Is, const float* __restrict__ Ds, const float* __restrict__ It,
                                                               const float* __restrict__ Dt, const float* __restrict__ dIx, const float* __restrict__ dIy,
                                                               const float* __restrict__ dDx, const float* __restrict__ dDy, int H, int W, OdoPose P,
-                                                              double outlier, double huber_d, double huber_i, double* __restrict__ partial) {
+                                                              const double* __restrict__ T_dev, double outlier, double huber_d, double huber_i,
+                                                              double* __restrict__ partial) {
+    if (T_dev) {          // the pose lives on the device (bs_odo_step chains steps without a host round trip)
+#pragma unroll
+        for (int i = 0; i < 12; ++i) P.t[i] = T_dev[i];
+    }
     const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double acc[ODO_TERMS];
 #pragma unroll
@@ -159,6 +164,76 @@ __global__ __launch_bounds__(64) void odo_finish_kernel(const double* __restrict
     if (threadIdx.x == 0) out[k] = s;
 }
 
+// delta = -(A + 1e-12 I)^-1 b by Gaussian elimination with partial pivoting, T <- exp(delta) T (left twist: omega = delta[0:3],
+// nu = delta[3:6]); fewer than 6 inliers or a singular system leave T alone.  One thread: 6x6.
+__global__ void odo_solve_kernel(const double* __restrict__ s29, double* __restrict__ T) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (s29[28] < 6.0) return;
+    double M[6][7];
+    int k = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b) {
+            M[a][b] = s29[k];
+            M[b][a] = s29[k];
+            ++k;
+        }
+    for (int a = 0; a < 6; ++a) {
+        M[a][a] += 1e-12;
+        M[a][6] = -s29[21 + a];
+    }
+    for (int c = 0; c < 6; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 6; ++r)
+            if (fabs(M[r][c]) > fabs(M[piv][c])) piv = r;
+        if (!(fabs(M[piv][c]) > 0.0)) return;
+        if (piv != c)
+            for (int j = 0; j < 7; ++j) {
+                const double t = M[c][j];
+                M[c][j] = M[piv][j];
+                M[piv][j] = t;
+            }
+        for (int r = c + 1; r < 6; ++r) {
+            const double f = M[r][c] / M[c][c];
+            for (int j = c; j < 7; ++j) M[r][j] -= f * M[c][j];
+        }
+    }
+    double d[6];
+    for (int r = 5; r >= 0; --r) {
+        double v = M[r][6];
+        for (int j = r + 1; j < 6; ++j) v -= M[r][j] * d[j];
+        d[r] = v / M[r][r];
+    }
+    const double wx = d[0], wy = d[1], wz = d[2];
+    const double th = sqrt(wx * wx + wy * wy + wz * wz);
+    const double Wx[3][3] = {{0.0, -wz, wy}, {wz, 0.0, -wx}, {-wy, wx, 0.0}};
+    double W2[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) W2[i][j] = Wx[i][0] * Wx[0][j] + Wx[i][1] * Wx[1][j] + Wx[i][2] * Wx[2][j];
+    double a, b, c;
+    if (th < 1e-12) {
+        a = 1.0; b = 0.5; c = 0.0;                 // R = I + Wx, V = I + Wx / 2 (the oracle's small-angle branch)
+    } else {
+        a = sin(th) / th;
+        b = (1.0 - cos(th)) / (th * th);
+        c = (th - sin(th)) / (th * th * th);
+    }
+    double R[3][3], V[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const double I = i == j ? 1.0 : 0.0;
+            R[i][j] = I + a * Wx[i][j] + (th < 1e-12 ? 0.0 : b * W2[i][j]);
+            V[i][j] = I + b * Wx[i][j] + c * W2[i][j];
+        }
+    const double t[3] = {V[0][0] * d[3] + V[0][1] * d[4] + V[0][2] * d[5], V[1][0] * d[3] + V[1][1] * d[4] + V[1][2] * d[5],
+                         V[2][0] * d[3] + V[2][1] * d[4] + V[2][2] * d[5]};
+    double N[12];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 4; ++j) N[4 * i + j] = R[i][0] * T[j] + R[i][1] * T[4 + j] + R[i][2] * T[8 + j];
+        N[4 * i + 3] += t[i];
+    }
+    for (int i = 0; i < 12; ++i) T[i] = N[i];
+}
+
 }  // namespace bs
 
 using namespace bs;
@@ -222,9 +297,34 @@ extern "C" int bs_odo_accumulate(const float* src_intensity, const float* src_de
     const int nblocks = (int)cdiv64((int64_t)H * W, 256);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(odo_accumulate_kernel, dim3(nblocks), dim3(256), 0, st, src_intensity, src_depth, tgt_intensity, tgt_depth, tgt_dIx, tgt_dIy,
-                       tgt_dDx, tgt_dDy, H, W, P, depth_outlier_trunc, depth_huber, intensity_huber, partial);
+                       tgt_dDx, tgt_dDy, H, W, P, (const double*)nullptr, depth_outlier_trunc, depth_huber, intensity_huber, partial);
     BS_CHECK_LAUNCH();
     hipLaunchKernelGGL(odo_finish_kernel, dim3(ODO_TERMS), dim3(64), 0, st, partial, nblocks, out29);
     BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+extern "C" int bs_odo_step(const float* src_intensity, const float* src_depth, const float* tgt_intensity, const float* tgt_depth,
+                           const float* tgt_dIx, const float* tgt_dIy, const float* tgt_dDx, const float* tgt_dDy, int32_t H, int32_t W,
+                           const double* K, double* T_dev, int32_t iterations, double depth_outlier_trunc, double depth_huber,
+                           double intensity_huber, double* partial, double* out29, void* stream) {
+    ODO_ENTRY("bs_odo_step");
+    BS_REQUIRE(src_intensity && src_depth && tgt_intensity && tgt_depth && tgt_dIx && tgt_dIy && tgt_dDx && tgt_dDy && K && T_dev && partial && out29,
+               "bs_odo_step: null argument");
+    BS_REQUIRE(H > 1 && W > 1 && iterations >= 0, "bs_odo_step: bad geometry");
+    OdoPose P;
+    for (int i = 0; i < 12; ++i) P.t[i] = 0.0;
+    P.fx = K[0]; P.fy = K[1]; P.cx = K[2]; P.cy = K[3];
+    const int nblocks = (int)cdiv64((int64_t)H * W, 256);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    for (int it = 0; it < iterations; ++it) {
+        hipLaunchKernelGGL(odo_accumulate_kernel, dim3(nblocks), dim3(256), 0, st, src_intensity, src_depth, tgt_intensity, tgt_depth, tgt_dIx, tgt_dIy,
+                           tgt_dDx, tgt_dDy, H, W, P, (const double*)T_dev, depth_outlier_trunc, depth_huber, intensity_huber, partial);
+        BS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(odo_finish_kernel, dim3(ODO_TERMS), dim3(64), 0, st, partial, nblocks, out29);
+        BS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(odo_solve_kernel, dim3(1), dim3(64), 0, st, out29, T_dev);
+        BS_CHECK_LAUNCH();
+    }
     return BS_OK;
 }

@@ -9,8 +9,8 @@ oracle/rgbd_odometry_ref.py; parity with Open3D is unpinned.  One deliberate dif
 bilinearly, not at the nearest pixel -- with nearest-pixel sampling the cost is piecewise constant and the Gauss-Newton steps are
 rounding noise at the sub-pixel motions of consecutive endoscopy frames (measured on rendered scenes).
 
-The images, pyramids, gradients and the 29 sums of every Gauss-Newton step are computed by the kernels of csrc/odometry.hip; the
-host solves the 6x6 system and composes the pose (35 solves per pair).  ``RGBDOdometry()(curr_rgbd, prev_rgbd)`` returns what
+The images, pyramids, gradients, the 29 sums of every Gauss-Newton step, the 6x6 solve and the pose update all run in the kernels of
+csrc/odometry.hip: a pair is 35 x 3 launches with no host round trip until the pose is read back.  ``RGBDOdometry()(curr_rgbd, prev_rgbd)`` returns what
 ``_compute_vo_o3d`` returns: the inverse of the estimated source -> target transform."""
 from __future__ import annotations
 
@@ -88,6 +88,22 @@ class RGBDOdometry:
         pt = self._pyramid(tgt_color, tgt_depth, depth_max, gradients=True)
         T = np.eye(4) if init is None else np.array(init, dtype=np.float64)
         out = torch.zeros(29, dtype=torch.float64, device=self.dev)
+        if not trace:
+            # the whole coarse-to-fine loop on the device: 35 x (sums, fixed-order reduction, 6x6 solve + pose update), no host
+            # round trip until the pose is read back.  trace=True below walks the same steps from the host (tests, diagnostics).
+            partial = torch.empty((ps[0].H * ps[0].W + 255) // 256, 29, dtype=torch.float64, device=self.dev)
+            T_dev = torch.from_numpy(np.ascontiguousarray(T[:3].reshape(12))).to(self.dev)
+            keep = []
+            for level, iters in zip(range(len(ps) - 1, -1, -1), self.iterations):
+                s, t = ps[level], pt[level]
+                Kl = np.array(s.K, dtype=np.float64)
+                keep.append(Kl)
+                L.check(lib.bs_odo_step(L.p(s.I), L.p(s.D), L.p(t.I), L.p(t.D), L.p(t.gIx), L.p(t.gIy), L.p(t.gDx), L.p(t.gDy), s.H, s.W,
+                                        Kl.ctypes.data_as(C.c_void_p), L.p(T_dev), iters, DEPTH_OUTLIER_TRUNC, DEPTH_HUBER, INTENSITY_HUBER,
+                                        L.p(partial), L.p(out), st), "bs_odo_step")
+            T[:3] = T_dev.cpu().numpy().reshape(3, 4)
+            self.last_trace = None
+            return T
         partial = torch.empty((ps[0].H * ps[0].W + 255) // 256, 29, dtype=torch.float64, device=self.dev)
         iu = np.triu_indices(6)
         log = [] if trace else None

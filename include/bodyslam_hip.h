@@ -358,6 +358,13 @@ int bs_tsdf_extract(const int32_t* unit_index, int32_t units, const void* table_
  *                      weights, target sampled bilinearly; partial = scratch double [ceil(H*W/256), 29]; deterministic */
 /* the pseudo-RGBD depth of the 3DM loop (3DM/slam_utils.py:212-220): out = u16 / depth_scale as fp32 metres, values >= depth_trunc -> 0 */
 int bs_depth_u16_to_m(const uint16_t* depth_u16, int64_t n, double depth_scale, double depth_trunc, float* out, void* stream);
+/* `iterations` Gauss-Newton steps of one pyramid level entirely on the device: bs_odo_accumulate's sums at the pose in T_dev (12
+ * doubles in device memory, rows 0..2 of source -> target), delta = -(A + 1e-12 I)^-1 b, T_dev <- exp(delta) T_dev; a step with
+ * fewer than 6 inliers leaves T_dev alone.  No host round trip between steps. */
+int bs_odo_step(const float* src_intensity, const float* src_depth, const float* tgt_intensity, const float* tgt_depth,
+                const float* tgt_dIx, const float* tgt_dIy, const float* tgt_dDx, const float* tgt_dDy, int32_t H, int32_t W,
+                const double* K, double* T_dev, int32_t iterations, double depth_outlier_trunc, double depth_huber,
+                double intensity_huber, double* partial, double* out29, void* stream);
 int bs_odo_prepare(const uint8_t* color, const float* depth, int32_t H, int32_t W, double depth_max, float* intensity, float* depth_out,
                    void* stream);
 int bs_odo_pyrdown(const float* src, int32_t H, int32_t W, float* dst, int32_t is_depth, double depth_threshold, void* stream);

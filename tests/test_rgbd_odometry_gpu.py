@@ -51,8 +51,9 @@ def test_matches_oracle_and_truth(holes):
     assert np.abs(T - T_ref).max() < 2e-6
     assert np.abs(T[:3, 3] - pose_s[:3, 3]).max() < (1e-4 if holes else 5e-5)
     assert np.abs(T[:3, :3] - pose_s[:3, :3]).max() < 2e-4
-    again = odo.estimate(cs, ds, ct, dt, 3.0)
-    assert np.array_equal(again, T)                     # fixed-order reduction: run-to-run identical
+    dev1 = odo.estimate(cs, ds, ct, dt, 3.0)            # the device-side loop (no trace): same steps, solve and pose update in a kernel
+    assert np.abs(dev1 - T).max() < 1e-9 and odo.last_trace is None
+    assert np.array_equal(odo.estimate(cs, ds, ct, dt, 3.0), dev1)       # fixed-order reduction: run-to-run identical
 
 
 def test_full_resolution_and_vo_fusion():
