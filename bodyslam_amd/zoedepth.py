@@ -92,7 +92,8 @@ class ZoeConfig:
 #           4.3e-5 / 2.0e-5 m on two weight seeds
 #   "wmean" patch tiles run ONE 16-bit pass; the weight-rounding error A dW^T, a coherent offset, is replaced by its
 #           token-independent part 1 (mean_tokens(A) dW^T) -- a per-image bias from a column mean and a tiny GEMM; the cls tile
-#           keeps both corrections: ~1.0 pass, 5.0e-5 / 3.1e-5 m
+#           keeps both corrections: ~1.0 pass, 4.8e-5 / 2.6e-5 m on those two seeds, 1.7e-5 ... 6.3e-5 m over eight
+#           (profiles/r02_accurate_seeds.txt: "wcls" 1.6e-5 ... 5.6e-5, "full" <= 2.1e-5 on the same seeds)
 # The neck keeps both products (weight correction only: 0.9-2.0e-4).
 ACCURATE_CLASS_MODES: Dict[str, str] = {"qkv": "wmean", "o": "wmean", "fc1": "wmean", "fc2": "wmean"}
 ACCURATE_NECK_MODE = "full"
