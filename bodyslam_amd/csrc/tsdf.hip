@@ -142,7 +142,45 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float* __rest
     vox[1] = w1;
 }
 
-// Open3D ScalableTSDFVolume::ExtractPointCloud without the normals: a voxel with weight != 0 and |tsdf| < 0.98 looks at its +x, +y,
+// ScalableTSDFVolume::GetTSDFAt: trilinear interpolation of the tsdf over the 8 voxel centres around p (a corner in a unit that does
+// not exist contributes 0; the first corner's unit missing gives 0 altogether)
+__device__ double ts_tsdf_at(const double p[3], const long long* __restrict__ keys, const int32_t* __restrict__ slots, unsigned mask,
+                             const int64_t* __restrict__ slab_base, int slab_units, int res, double voxel_length) {
+    const double unit_len = voxel_length * res;
+    const int64_t unit_bytes = (int64_t)res * res * res * 20;
+    int index0[3], idx0[3];
+    double r[3];
+    for (int a = 0; a < 3; ++a) {
+        const double pl = p[a] - 0.5 * voxel_length;
+        index0[a] = (int)floor(pl / unit_len);
+        const double pg = (pl - (double)index0[a] * unit_len) / voxel_length;
+        int i0 = (int)floor(pg);
+        i0 = i0 < 0 ? 0 : (i0 >= res ? res - 1 : i0);
+        idx0[a] = i0;
+        r[a] = pg - (double)i0;
+    }
+    if (ts_find(keys, slots, mask, ts_pack(index0[0], index0[1], index0[2])) < 0) return 0.0;
+    double sum = 0.0;
+    for (int c = 0; c < 8; ++c) {
+        int index1[3], idx1[3];
+        double w = 1.0;
+        for (int a = 0; a < 3; ++a) {
+            const int sh = (c >> (2 - a)) & 1;
+            w *= sh ? r[a] : 1.0 - r[a];
+            idx1[a] = idx0[a] + sh;
+            index1[a] = index0[a];
+            if (idx1[a] >= res) {
+                idx1[a] -= res;
+                index1[a] += 1;
+            }
+        }
+        const int s = ts_find(keys, slots, mask, ts_pack(index1[0], index1[1], index1[2]));
+        if (s >= 0) sum += w * (double)ts_block(slab_base, slab_units, unit_bytes, s)[((int64_t)idx1[0] * res * res + idx1[1] * res + idx1[2]) * 5];
+    }
+    return sum;
+}
+
+// Open3D ScalableTSDFVolume::ExtractPointCloud (normals: GetNormalAt, the normalised central difference of GetTSDFAt at +-0.99 voxel): a voxel with weight != 0 and |tsdf| < 0.98 looks at its +x, +y,
 // +z neighbour (in the neighbouring unit, found through the table, when it is the last of its row); a sign change puts a point at the
 // linear zero crossing, colour interpolated alike.  WRITE = false counts per unit, WRITE = true writes at unit_offset[u] + a
 // per-unit cursor (order inside a unit is arbitrary, as the order of units is in Open3D's hash map).
@@ -151,13 +189,14 @@ __global__ __launch_bounds__(256) void tsdf_extract_kernel(const int32_t* __rest
                                                             const int32_t* __restrict__ slots, unsigned mask, const int64_t* __restrict__ slab_base,
                                                             int slab_units, int res, double voxel_length, int32_t* __restrict__ unit_count,
                                                             const int64_t* __restrict__ unit_offset, float* __restrict__ points,
-                                                            float* __restrict__ colors) {
+                                                            float* __restrict__ colors, float* __restrict__ normals) {
     const int u = blockIdx.y;
     const int v = blockIdx.x * 256 + threadIdx.x;
     const int nvox = res * res * res;
     const int64_t unit_bytes = (int64_t)nvox * 20;
     int found = 0;
     float pts[3][3], cols[3][3];
+    double ptd[3][3];
     if (v < nvox) {
         const float* base = ts_block(slab_base, slab_units, unit_bytes, u);
         const float f0 = base[(int64_t)v * 5], w0 = base[(int64_t)v * 5 + 1];
@@ -187,6 +226,7 @@ __global__ __launch_bounds__(256) void tsdf_extract_kernel(const int32_t* __rest
                         p[a] = (p0[a] * (double)r1 + (p0[a] + voxel_length) * (double)r0) / ((double)r0 + (double)r1);
 #pragma unroll
                         for (int k = 0; k < 3; ++k) {
+                            ptd[found][k] = p[k];
                             pts[found][k] = (float)p[k];
                             const float c0 = base[(int64_t)v * 5 + 2 + k], c1 = nb[nv * 5 + 2 + k];
                             cols[found][k] = (c0 * r1 + c1 * r0) / (r0 + r1) / 255.0f;
@@ -208,6 +248,19 @@ __global__ __launch_bounds__(256) void tsdf_extract_kernel(const int32_t* __rest
             for (int c = 0; c < 3; ++c) {
                 points[(at + k) * 3 + c] = pts[k][c];
                 colors[(at + k) * 3 + c] = cols[k][c];
+            }
+            if (normals) {
+                const double gap = 0.99 * voxel_length;
+                double n[3];
+                for (int a = 0; a < 3; ++a) {
+                    double pp[3] = {ptd[k][0], ptd[k][1], ptd[k][2]}, pm[3] = {ptd[k][0], ptd[k][1], ptd[k][2]};
+                    pp[a] += gap;
+                    pm[a] -= gap;
+                    n[a] = ts_tsdf_at(pp, keys, slots, mask, slab_base, slab_units, res, voxel_length) -
+                           ts_tsdf_at(pm, keys, slots, mask, slab_base, slab_units, res, voxel_length);
+                }
+                const double len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                for (int c = 0; c < 3; ++c) normals[(at + k) * 3 + c] = (float)(len > 0.0 ? n[c] / len : n[c]);      // Eigen's normalized(): a zero vector stays zero
             }
         }
     }
@@ -264,7 +317,7 @@ extern "C" int bs_tsdf_integrate(const float* depth, const uint8_t* color, int32
 
 extern "C" int bs_tsdf_extract(const int32_t* unit_index, int32_t units, const void* table_keys, const int32_t* table_slots, int32_t table_cap,
                                const int64_t* slab_base, int32_t slab_units, int32_t res, double voxel_length, int32_t* unit_count,
-                               const int64_t* unit_offset, float* points, float* colors, void* stream) {
+                               const int64_t* unit_offset, float* points, float* colors, float* normals, void* stream) {
     if (!initialized()) { set_error("bs_tsdf_extract: call bs_init first"); return BS_ERR_NOT_INIT; }
     BS_REQUIRE(units >= 0 && res > 0 && res <= 64 && slab_units > 0 && voxel_length > 0.0, "bs_tsdf_extract: bad geometry");
     if (units == 0) return BS_OK;
@@ -279,10 +332,10 @@ extern "C" int bs_tsdf_extract(const int32_t* unit_index, int32_t units, const v
     const long long* keys = reinterpret_cast<const long long*>(table_keys);
     if (!points)
         hipLaunchKernelGGL(tsdf_extract_kernel<false>, grid, dim3(256), 0, st, unit_index, keys, table_slots, (unsigned)(table_cap - 1), slab_base,
-                           slab_units, res, voxel_length, unit_count, unit_offset, points, colors);
+                           slab_units, res, voxel_length, unit_count, unit_offset, points, colors, (float*)nullptr);
     else
         hipLaunchKernelGGL(tsdf_extract_kernel<true>, grid, dim3(256), 0, st, unit_index, keys, table_slots, (unsigned)(table_cap - 1), slab_base,
-                           slab_units, res, voxel_length, unit_count, unit_offset, points, colors);
+                           slab_units, res, voxel_length, unit_count, unit_offset, points, colors, normals);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }

@@ -9,8 +9,8 @@ table in HBM (Open3D: an unordered_map on the host), filled per frame from the s
 unit is 3.2 cm wide and a point opens the ~7^3 units within 0.1 m of it; a 640x480 frame of a surface at 12 cm touches ~1 600 units
 = 1 GB of voxel state and takes ~1 ms (measured, tools/probes/tsdf_full_size.py: unit discovery 0.1 ms, integrate kernel 0.27 ms),
 metre-scale scenes proportionally more: the voxel store is sized for 288 GB of HBM.  Open3D is not vendored and not installable offline: parity against it is unpinned (oracle/tsdf_ref.py
-restates the same algorithm in numpy; tests/ compare the two).  Not built: normals of the extracted points and
-``extract_mesh`` / ``save_mesh`` (marching cubes) -- they raise NotImplementedError.
+restates the same algorithm in numpy; tests/ compare the two).  ``extract_pcd`` returns points, colours and normals, as Open3D's
+``extract_point_cloud``.  Not built: ``extract_mesh`` / ``save_mesh`` (marching cubes) -- they raise NotImplementedError.
 """
 from __future__ import annotations
 
@@ -57,8 +57,9 @@ def create_rgbd_from_color_and_depth(color_u8, depth_u16, depth_scale: float = 1
 
 @dataclass
 class PointCloud:
-    points: np.ndarray      # [M, 3] float32
-    colors: np.ndarray      # [M, 3] float32 in [0, 1]
+    points: np.ndarray                      # [M, 3] float32
+    colors: np.ndarray                      # [M, 3] float32 in [0, 1]
+    normals: Optional[np.ndarray] = None    # [M, 3] float32, unit length (zero where the tsdf gradient vanishes)
 
 
 _OFF = 1 << 20              # unit indices are packed as three 21-bit fields (csrc/tsdf.hip ts_pack)
@@ -145,19 +146,20 @@ class TSDF:
     def extract_pcd(self) -> PointCloud:
         U = self.n_units
         if U == 0:
-            return PointCloud(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+            return PointCloud(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
         count = torch.zeros(U, dtype=torch.int32, device=self.dev)
         lib = L.load_library()
         args = (L.p(self.unit_index), U, L.p(self.table_keys), L.p(self.table_slots), self.table_cap, L.p(self.slab_base), self.slab_units, self.res,
                 self.voxel_length, L.p(count))
-        L.check(lib.bs_tsdf_extract(*args, None, None, None, L.stream_ptr()), "bs_tsdf_extract")
+        L.check(lib.bs_tsdf_extract(*args, None, None, None, None, L.stream_ptr()), "bs_tsdf_extract")
         counts = count.cpu().numpy().astype(np.int64)
         total = int(counts.sum())
         pts = torch.empty(max(total, 1), 3, device=self.dev)
         cols = torch.empty(max(total, 1), 3, device=self.dev)
+        nrm = torch.empty(max(total, 1), 3, device=self.dev)
         off = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)).to(self.dev)
-        L.check(lib.bs_tsdf_extract(*args, L.p(off), L.p(pts), L.p(cols), L.stream_ptr()), "bs_tsdf_extract")
-        return PointCloud(pts[:total].cpu().numpy(), cols[:total].cpu().numpy())
+        L.check(lib.bs_tsdf_extract(*args, L.p(off), L.p(pts), L.p(cols), L.p(nrm), L.stream_ptr()), "bs_tsdf_extract")
+        return PointCloud(pts[:total].cpu().numpy(), cols[:total].cpu().numpy(), nrm[:total].cpu().numpy())
 
     def save_pcd(self, saving_path: str) -> None:
         write_ply(saving_path, self.extract_pcd())
@@ -185,15 +187,20 @@ class TSDF:
 
 
 def write_ply(path: str, pcd: PointCloud) -> None:
-    """binary little-endian PLY: x y z (float32), red green blue (uchar) -- the container o3d.io.write_point_cloud produces for a
-    .ply path (Open3D stores the coordinates as doubles; the points here are fp32)"""
+    """binary little-endian PLY: x y z (float32) [nx ny nz (float32)] red green blue (uchar) -- the container o3d.io.write_point_cloud
+    produces for a .ply path (Open3D stores coordinates and normals as doubles; the values here are fp32)"""
     n = pcd.points.shape[0]
-    rec = np.empty(n, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("red", "u1"), ("green", "u1"), ("blue", "u1")])
+    has_n = pcd.normals is not None
+    fields = [("x", "<f4"), ("y", "<f4"), ("z", "<f4")] + ([("nx", "<f4"), ("ny", "<f4"), ("nz", "<f4")] if has_n else []) + \
+             [("red", "u1"), ("green", "u1"), ("blue", "u1")]
+    rec = np.empty(n, dtype=fields)
     rec["x"], rec["y"], rec["z"] = pcd.points[:, 0], pcd.points[:, 1], pcd.points[:, 2]
+    if has_n:
+        rec["nx"], rec["ny"], rec["nz"] = pcd.normals[:, 0], pcd.normals[:, 1], pcd.normals[:, 2]
     c = np.clip(np.rint(pcd.colors * 255.0), 0, 255).astype(np.uint8) if n else np.zeros((0, 3), np.uint8)
     rec["red"], rec["green"], rec["blue"] = c[:, 0], c[:, 1], c[:, 2]
+    props = "property float x\nproperty float y\nproperty float z\n" + ("property float nx\nproperty float ny\nproperty float nz\n" if has_n else "")
     with open(path, "wb") as f:
-        f.write((f"ply\nformat binary_little_endian 1.0\ncomment bodyslam_amd TSDF point cloud\nelement vertex {n}\n"
-                 "property float x\nproperty float y\nproperty float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\n"
-                 "end_header\n").encode("ascii"))
+        f.write((f"ply\nformat binary_little_endian 1.0\ncomment bodyslam_amd TSDF point cloud\nelement vertex {n}\n" + props +
+                 "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n").encode("ascii"))
         f.write(rec.tobytes())

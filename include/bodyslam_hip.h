@@ -331,9 +331,10 @@ int bs_pose_chain_from(const float* t_rel, int32_t N, const double* g0_dev, doub
  * bs_tsdf_integrate: UniformTSDFVolume::IntegrateWithDepthToCameraDistanceMultiplier on the n_touched units of `touched`
  *   (extrinsic = rows 0..2 of the world->camera 4x4; color u8 [H, W, 3] or NULL).  The caller has made sure the slabs cover
  *   counters[0] blocks.
- * bs_tsdf_extract: ScalableTSDFVolume::ExtractPointCloud (points + colours, no normals) over blocks 0 .. units-1 in two passes:
+ * bs_tsdf_extract: ScalableTSDFVolume::ExtractPointCloud (points, colours, normals) over blocks 0 .. units-1 in two passes:
  *   points == NULL counts into unit_count int32 [units]; otherwise unit_offset int64 [units] (exclusive prefix sums of the counts)
- *   places each unit's points, points / colors fp32 [total, 3]. */
+ *   places each unit's points, points / colors fp32 [total, 3]; normals fp32 [total, 3] or NULL: ScalableTSDFVolume::GetNormalAt,
+ *   the normalised central difference of the trilinearly interpolated tsdf (GetTSDFAt) at +-0.99 voxel_length. */
 int bs_tsdf_touch(const float* depth, int32_t H, int32_t W, int32_t stride, const double* K, const double* pose, double unit_length,
                   double sdf_trunc, void* table_keys, int32_t* table_slots, int32_t* table_stamp, int32_t table_cap, int32_t frame_id,
                   int32_t* unit_index, int32_t max_units, int32_t* counters, int32_t* touched, void* stream);
@@ -342,7 +343,7 @@ int bs_tsdf_integrate(const float* depth, const uint8_t* color, int32_t H, int32
                       int32_t res, double voxel_length, double sdf_trunc, void* stream);
 int bs_tsdf_extract(const int32_t* unit_index, int32_t units, const void* table_keys, const int32_t* table_slots, int32_t table_cap,
                     const int64_t* slab_base, int32_t slab_units, int32_t res, double voxel_length, int32_t* unit_count,
-                    const int64_t* unit_offset, float* points, float* colors, void* stream);
+                    const int64_t* unit_offset, float* points, float* colors, float* normals, void* stream);
 
 /* dense RGB-D odometry (N3) -------------------------------------------------------------------- *
  * The role of Open3D's rgbd_odometry_multi_scale (Method.Hybrid, 20 / 10 / 5 iterations) at

@@ -14,9 +14,10 @@ unit by unit:
               u_f = q.x fx / q.z + cx + 0.5, v_f likewise; skip unless 0.0001 <= u_f < W - 0.0001 (same for v);
               d = depth[int(v_f), int(u_f)]; skip if d <= 0;  sdf = (d - q.z) * sqrt(1 + ((u - cx)/fx)^2 + ((v - cy)/fy)^2);
               if sdf > -sdf_trunc:  t = min(1, sdf / sdf_trunc);  tsdf = (tsdf w + t) / (w + 1);  colour alike;  w += 1.
-  ExtractPointCloud (without normals):  a voxel with w != 0 and -0.98 <= tsdf < 0.98 and its +x / +y / +z neighbour (in the
+  ExtractPointCloud:  a voxel with w != 0 and -0.98 <= tsdf < 0.98 and its +x / +y / +z neighbour (in the
               next unit when it is the last of its row, if that unit exists) with the same property and the opposite sign give a
-              point on the segment between the two centres at the zero of the linear interpolant; colour interpolated, / 255.
+              point on the segment between the two centres at the zero of the linear interpolant; colour interpolated, / 255;
+              normal = normalised central difference (+-0.99 voxel) of the trilinearly interpolated tsdf (GetNormalAt / GetTSDFAt).
 Open3D evaluates the projection in float with an incremental walk along z; here (and in the product) it is the closed form in
 fp64, and voxel values are fp32."""
 from __future__ import annotations
@@ -86,7 +87,45 @@ class TSDFRef:
                     vox[..., 2 + k] = np.where(ok, (vox[..., 2 + k] * w0 + c[..., k]) / w1, vox[..., 2 + k])
             vox[..., 1] = np.where(ok, w1, w0)
 
-    def extract_point_cloud(self):
+    def tsdf_at(self, p):
+        """ScalableTSDFVolume::GetTSDFAt: trilinear interpolation over the 8 voxel centres around p; a corner in a missing unit adds 0"""
+        pl = np.asarray(p, dtype=np.float64) - 0.5 * self.vl
+        index0 = np.floor(pl / self.L).astype(int)
+        if tuple(index0) not in self.units:
+            return 0.0
+        pg = (pl - index0 * self.L) / self.vl
+        idx0 = np.clip(np.floor(pg).astype(int), 0, self.res - 1)
+        rr = pg - idx0
+        total = 0.0
+        for c in range(8):
+            sh = np.array([(c >> 2) & 1, (c >> 1) & 1, c & 1])
+            w = float(np.prod(np.where(sh == 1, rr, 1.0 - rr)))
+            idx1, index1 = idx0 + sh, index0.copy()
+            over = idx1 >= self.res
+            idx1[over] -= self.res
+            index1[over] += 1
+            vox = self.units.get(tuple(index1))
+            if vox is not None:
+                total += w * float(vox[idx1[0], idx1[1], idx1[2], 0])
+        return total
+
+    def normal_at(self, p):
+        """ScalableTSDFVolume::GetNormalAt: normalised central difference of tsdf_at at +-0.99 voxel_length"""
+        gap, n = 0.99 * self.vl, np.zeros(3)
+        for a in range(3):
+            e = np.zeros(3)
+            e[a] = gap
+            n[a] = self.tsdf_at(np.asarray(p, dtype=np.float64) + e) - self.tsdf_at(np.asarray(p, dtype=np.float64) - e)
+        ln = np.linalg.norm(n)
+        return n / ln if ln > 0 else n
+
+    def extract_point_cloud(self, normals=False):
+        pts, cols = self._extract()
+        if not normals:
+            return pts, cols
+        return pts, cols, np.array([self.normal_at(p) for p in pts.astype(np.float64)], dtype=np.float32).reshape(-1, 3)
+
+    def _extract(self):
         r, pts, cols = self.res, [], []
         for key, vox in self.units.items():
             f0, w0 = vox[..., 0], vox[..., 1]

@@ -23,6 +23,8 @@ def test_plane_surface_and_weights():
         assert -0.04 - 0.08 <= (iz + 0.5) * 0.08 - 0.5 <= 0.04 + 0.08
     pts, cols = t.extract_point_cloud()
     assert pts.shape[0] > 100
+    n = np.array([t.normal_at(p) for p in pts[:: max(1, pts.shape[0] // 60)].astype(np.float64)])
+    assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-9) and (n[:, 2] < -0.95).all()     # a plane facing the camera at z < plane
     # the zero crossing of the projective distance of a fronto-parallel plane is the plane itself: (d - z) * mult = 0 at z = d
     assert np.abs(pts[:, 2] - 0.5).max() < 1e-3
     assert np.allclose(cols, np.array([200, 50, 0]) / 255.0, atol=1e-6)

@@ -49,18 +49,24 @@ def test_tsdf_matches_oracle(res, stride, tmp_path):
         worst = max(worst, float(np.abs(got - vox).max()))
     assert worst < 2e-4                   # colours are 0..255 running means: a last-bit difference is 1.5e-5
     pcd = prod.extract_pcd()
-    rp, rc = ref.extract_point_cloud()
+    rp, rc, rn = ref.extract_point_cloud(normals=True)
     assert pcd.points.shape == rp.shape and rp.shape[0] > 500
-    gp, gc = sort_rows(pcd.points, pcd.colors)
-    rp, rc = sort_rows(rp, rc)
+    og, orf = np.lexsort((pcd.points[:, 2], pcd.points[:, 1], pcd.points[:, 0])), np.lexsort((rp[:, 2], rp[:, 1], rp[:, 0]))
+    gp, gc, gn = pcd.points[og], pcd.colors[og], pcd.normals[og]
+    rp, rc, rn = rp[orf], rc[orf], rn[orf]
     assert np.abs(gp - rp).max() < 1e-6 and np.abs(gc - rc).max() < 1e-5
+    # normals (GetNormalAt): the product evaluates them at the fp64 point, the oracle at the fp32-rounded one -> 1e-4 on unit vectors
+    assert np.abs(gn - rn).max() < 2e-4
+    ln = np.linalg.norm(gn, axis=1)
+    assert np.all((np.abs(ln - 1.0) < 1e-5) | (ln == 0.0)) and (ln > 0).mean() > 0.99
+    assert (gn[:, 2] < 0).mean() > 0.9           # the tsdf grows towards the camera (at z ~ 0): normals point back at it
     # the surface is where it was put: camera-frame depth of every point of the first view's neighbourhood ~ the scene's range
     assert 0.40 < gp[:, 2].min() and gp[:, 2].max() < 0.75
     path = tmp_path / "map.ply"
     prod.save_pcd(str(path))
     raw = path.read_bytes()
     head, body = raw.split(b"end_header\n", 1)
-    assert f"element vertex {gp.shape[0]}".encode() in head and len(body) == gp.shape[0] * 15
+    assert f"element vertex {gp.shape[0]}".encode() in head and b"property float nx" in head and len(body) == gp.shape[0] * 27
     with pytest.raises(NotImplementedError):
         prod.save_mesh(str(tmp_path / "m.ply"))
 
