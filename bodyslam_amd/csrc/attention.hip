@@ -21,6 +21,20 @@
 #include "common.h"
 
 namespace bs {
+// Maximum of a float over the two lane halves (lane l and lane l ^ 32), the same value in both: one v_permlane32_swap on the
+// order-preserving integer image of the float.  (An fmaxf of the two halves of the swap is FOLDED AWAY by hipcc / ROCm 7.2 -- the
+// ISA compared sw[0] alone, so every lane took the lower half's value: consistent between the halves, which kept the softmax
+// right, but a large score among the upper half's keys never moved the running max.  The integer maximum is emitted as written.)
+__device__ __forceinline__ float half_swap_max(float v) {
+    int k = __builtin_bit_cast(int, v);
+    k ^= (k >> 31) & 0x7fffffff;
+    const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)k, (unsigned)k, false, false);
+    const int a = (int)sw[0], b = (int)sw[1];
+    int m = a > b ? a : b;
+    m ^= (m >> 31) & 0x7fffffff;
+    return __builtin_bit_cast(float, m);
+}
+
 
 template <typename T, int QW>
 __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ Vt,
@@ -457,10 +471,7 @@ __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restr
 #pragma unroll
             for (int i = 3; i < 15; i += 2) mloc = fmaxf(fmaxf(mloc, sacc[i]), sacc[i + 1]);
             mloc = fmaxf(mloc, sacc[15]);
-            {   // the other lane half holds the other 16 keys of this query: one v_permlane32_swap instead of a trip through LDS
-                const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mloc), __builtin_bit_cast(unsigned, mloc), false, false);
-                mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
-            }
+            mloc = half_swap_max(mloc);      // the other lane half holds the other 16 keys of this query
             if (first || __any(mloc > THR)) {
                 const float alpha = __builtin_amdgcn_exp2f(-mloc);
                 l_run *= alpha;
@@ -627,10 +638,7 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
 #pragma unroll
         for (int i = 3; i < 15; i += 2) mloc = fmaxf(fmaxf(mloc, sacc[i]), sacc[i + 1]);
         mloc = fmaxf(mloc, sacc[15]);
-        {   // the other lane half holds the other 16 keys of this query: one v_permlane32_swap instead of a trip through LDS
-            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mloc), __builtin_bit_cast(unsigned, mloc), false, false);
-            mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
-        }
+        mloc = half_swap_max(mloc);          // the other lane half holds the other 16 keys of this query
         if (first || __any(mloc > THR)) {
             const float alpha = __builtin_amdgcn_exp2f(-mloc);
             l_run *= alpha;

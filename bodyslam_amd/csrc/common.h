@@ -132,6 +132,11 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// F4-format pointwise producers (f4_pointwise.hip), reached through bs_cast_split / bs_relu_split / bs_resize_bilinear_nhwc
+int f4_cast(const float* x, void* out, int64_t rows, int C, int dtype, hipStream_t st);
+int f4_relu(const void* x, void* out, int64_t rows, int C, int dtype, hipStream_t st);
+int f4_resize(const void* x, void* out, int B, int Hin, int Win, int C, int Hout, int Wout, int align, int dtype, hipStream_t st);
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

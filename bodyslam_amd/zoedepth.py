@@ -97,6 +97,11 @@ class ZoeConfig:
 # The neck keeps both products (weight correction only: 0.9-2.0e-4).
 ACCURATE_CLASS_MODES: Dict[str, str] = {"qkv": "wmean", "o": "wmean", "fc1": "wmean", "fc2": "wmean"}
 ACCURATE_NECK_MODE = "full"
+# Operand format of the neck's two correction products: "f8" = e4m3 planes with one scale per tensor (2 pass-equivalents, neck error
+# ~7e-6 m on its own), "f4" = e2m1 planes with one E8M0 scale per 64 channels at 4x the 16-bit MFMA rate (1.5 pass-equivalents,
+# 2.5-4e-5 m: tools/probes/neck_precision_study.py, profiles/r03_neck_precision_study.txt).  "f4" needs every K / Cin of the neck to
+# be whole 256-value units and the grouped token layout (512-wide network inputs); the engine falls back to "f8" otherwise.
+ACCURATE_NECK_CORR = "f8"
 
 ZOED_NK = ZoeConfig()
 ZOED_N = ZoeConfig(head_names=("nyu",))
@@ -147,7 +152,7 @@ class ZoeDepthEngine:
 
     def __init__(self, weights: Dict[str, torch.Tensor], cfg: Optional[ZoeConfig] = None, dtype=torch.float16,
                  device: int = 0, target_hw: Tuple[int, int] = (384, 512), precision: str = "fast",
-                 class_modes: Optional[Dict[str, str]] = None, neck_mode: Optional[str] = None):
+                 class_modes: Optional[Dict[str, str]] = None, neck_mode: Optional[str] = None, neck_corr: Optional[str] = None):
         """precision: "fast" = one MFMA pass per product (16-bit operands, fp32 accumulate);
         "accurate" = split-precision products (Numerics): every GEMM / conv operand of the backbone, the DPT neck,
         the relative head and the projector path of the bins head is a (hi, lo) pair of 16-bit values; one launch evaluates
@@ -179,11 +184,18 @@ class ZoeDepthEngine:
         self.single_keys = set()
         self.wmode: Dict[str, str] = {}
         # DPT neck / heads (no cls rows there): "full" = both correction products, "w" = the weight-rounding correction only
-        self.neck_mode = neck_mode or ACCURATE_NECK_MODE
+        self.neck_mode = neck_mode or os.environ.get("BS_NECK_MODE") or ACCURATE_NECK_MODE
         # (probes: a comma-separated list of weight-key prefixes that KEEP both products, e.g. "ro,ra,nc": everything else "w")
         c_ = self.cfg
         # the neck switches to the (hi16 | hi8 | lo8) operand format as a whole: every K / Cin on it must be whole 128-byte FP8 stages
         self.neck_f8 = self.acc and all(v % 128 == 0 for v in (c_.hidden, c_.fusion, c_.fusion // 2, *c_.neck_hidden))
+        # ... and to the F4 format (e2m1 correction planes, 1.5 pass-equivalents) where every K / Cin but the relative head's
+        # 128-channel map is whole 256-value units
+        self.neck_corr = neck_corr or os.environ.get("BS_NECK_CORR") or ACCURATE_NECK_CORR
+        assert self.neck_corr in ("f8", "f4"), self.neck_corr
+        self.neck_f4 = (self.neck_f8 and self.neck_corr == "f4" and self.neck_mode == "full" and
+                        all(v % 256 == 0 for v in (c_.hidden, c_.fusion, *c_.neck_hidden)))
+        self.f4s: Dict[str, Tuple[int, int, int, int]] = {}
         with torch.no_grad():
             self._ingest(weights)
 
@@ -232,10 +244,16 @@ class ZoeDepthEngine:
         return w8.to(self.dev)
 
     def _wp(self, key: str, t: torch.Tensor) -> torch.Tensor:
-        """plain neck / head weight: FP8-correction packing when the whole neck runs that format, else three 16-bit passes"""
+        """plain neck / head weight: FP4- or FP8-correction packing when the whole neck runs that format, else three 16-bit passes"""
+        if self.neck_f4 and t.shape[1] % 256 == 0:
+            w4, self.f4s[key] = L.f4_weight(t, self.dtype)
+            return w4.to(self.dev)
         return self._w8(key, t) if self.neck_f8 else self._wn(t)
 
     def _wc(self, key: str, t: torch.Tensor) -> torch.Tensor:
+        if self.neck_f4 and t.shape[1] % 256 == 0:
+            w4, self.f4s[key] = L.f4_conv_weight(t.permute(0, 2, 3, 1), self.dtype)
+            return w4.to(self.dev)
         return self._w8conv(key, t) if self.neck_f8 else self._wn_conv(t)
 
     def _wn(self, t: torch.Tensor) -> torch.Tensor:
@@ -551,7 +569,15 @@ class _ZoePlan:
         q, k, vt = z16(NB, c.heads, Sp, 64), z16(NB, c.heads, Sp, 64), z16(NB, c.heads, 64, Sp)
         ao = z16(MT, Hd * m2)
         hid = z16(MT, c.intermediate * m2)
-        taps16 = [z16(MT, Hd * m2) for _ in c.taps]
+        nf4 = eng.neck_f4 and grouped                       # F4 neck format (e2m1 correction planes); needs the grouped token rows
+        if eng.neck_f4 and not grouped:
+            raise L.BodySlamHipError("neck_corr='f4' needs a 512-wide network input (grouped token rows); build the engine with neck_corr='f8'")
+
+        def PE(C):
+            """elements between consecutive pixels / rows of a neck activation with C channels"""
+            return L.f4_pitch(C) if (nf4 and C % 256 == 0) else C * m2
+
+        taps16 = [z16(MT, PE(Hd)) for _ in c.taps]
 
         f8s = eng.f8s
 
@@ -645,18 +671,28 @@ class _ZoePlan:
             P.mark(f"layer{l + 1}", x, TOK)
             if (l + 1) in c.taps:
                 if acc:
-                    P.add(f"tap{ti}", "bs_cast_split", x, taps16[ti], MT, Hd, L.dt(xn) | (32 if eng.neck_f8 else 0))
+                    P.add(f"tap{ti}", "bs_cast_split", x, taps16[ti], MT, Hd, L.dt(xn) | (64 if nf4 else (32 if eng.neck_f8 else 0)))
                 else:
                     P.add(f"tap{ti}", "bs_cast", x, taps16[ti], x.numel(), L.dt(xn))
                 ti += 1
 
-        # ---- neck helpers.  Activations are NHWC 16-bit; in accurate mode every tensor is a pair per pixel (stride 2C): either
-        # (hi16 | hi8 | lo8) with the correction products on the FP8 MFMA (nf8: the whole neck, when every K is whole FP8 stages)
-        # or (hi | lo) 16-bit pairs with the product as three K segments.
+        # ---- neck helpers.  Activations are NHWC 16-bit; in accurate mode every tensor is a pair per pixel: the F4 format (hi16, two
+        # e2m1 planes with block scales, an e4m3 residual plane; pitch PE(C)) with the correction products on the FP4 MFMA, or
+        # (hi16 | hi8 | lo8) with them on the FP8 MFMA (nf8: the whole neck, when every K is whole FP8 stages), or (hi | lo) 16-bit
+        # pairs with the product as three K segments.
         nf8 = eng.neck_f8
-        NSP = (32 if nf8 else 16) if acc else 0          # format flag of the pointwise producers (dtype bit 5 / bit 4)
+        f4s = eng.f4s
+        NSP = (32 if nf8 else 16) if acc else 0          # format flag of the pointwise producers whose output stays (hi16 | hi8 | lo8)
         RZ = 1 | ((4 if nf8 else 2) if acc else 0)       # bs_resize_bilinear_nhwc flag: align_corners | pair format
+        RZ4 = 1 | 8                                      # ... F4 maps
         F8O = (L.F8_ACT_HI_EXP, L.F8_ACT_LO_EXP)
+
+        def is4(C):
+            return nf4 and C % 256 == 0
+
+        def mfmt(C):
+            """format code of a marked neck tensor (tests/test_zoedepth_gpu.py to_nchw): 3 = F4, 2 = (hi16 | hi8 | lo8), 1 = (hi | lo)"""
+            return (3 if is4(C) else (2 if nf8 else 1)) if acc else 0
 
         def f8kw(wkey):
             sb0, sb1 = f8s[wkey]
@@ -667,26 +703,44 @@ class _ZoePlan:
                 wonly = False
             return dict(f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1), f8_wonly_from=-1 if wonly else 0)
 
+        def okw(Cout, out_pairs, out8):
+            """output-format arguments of a neck GEMM writing Cout channels per row / pixel"""
+            if not (acc and out_pairs):
+                return dict(ldo=Cout, out_split_off=0)
+            if is4(Cout) and out8:
+                return dict(ldo=PE(Cout), out_split_off=Cout, out_f4=True)
+            return dict(ldo=Cout * m2, out_split_off=Cout, out_f8=F8O if (nf8 and out8) else None)
+
         def nplain(name, A, wkey, out, M, N, K, shuffle=None, out_pairs=True, **kw):
             """plain GEMM on pair operands; out_pairs=False leaves the output alone (fp32 or caller-specified)"""
-            ldo = kw.pop("ldo", N * m2 if out_pairs else N)
-            so = kw.pop("split_off", N)
-            use8 = acc and wkey in f8s
             out8 = kw.pop("out8", True)
-            if use8:
-                P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=kw.pop("lda", 2 * K), f8_seg=2 * K, ldo=ldo, shuffle=shuffle,
-                       out_split_off=so if out_pairs else 0, out_f8=F8O if (out_pairs and nf8 and out8) else None,
-                       precision_passes=1, **f8kw(wkey), **kw)
+            ok = okw(shuffle[1] if shuffle else N, out_pairs, out8)
+            if "ldo" in kw:
+                ok["ldo"] = kw.pop("ldo")
+            if "split_off" in kw:
+                ok["out_split_off"] = kw.pop("split_off")
+            if not out_pairs:
+                ok = dict(ldo=ok["ldo"], out_split_off=0)
+            if acc and wkey in f4s:
+                P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=kw.pop("lda", PE(K)), f4=f4s[wkey], shuffle=shuffle, precision_passes=1, **ok, **kw)
+            elif acc and wkey in f8s:
+                P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=kw.pop("lda", 2 * K), f8_seg=2 * K, shuffle=shuffle,
+                       precision_passes=1, **ok, **f8kw(wkey), **kw)
             else:
-                P.gemm(name, A, w[wkey], out, M=M, N=N, K=K * np3, lda=kw.pop("lda", K * m2), seg1=K if acc else 0, ldo=ldo,
-                       out_split_off=so if (acc and out_pairs) else 0, shuffle=shuffle, precision_passes=np3, **kw)
+                ok.pop("out_f8", None)
+                P.gemm(name, A, w[wkey], out, M=M, N=N, K=K * np3, lda=kw.pop("lda", K * m2), seg1=K if acc else 0,
+                       shuffle=shuffle, precision_passes=np3, **ok, **kw)
 
         def nconv(name, A, wkey, out, hh, ww, Ci, Co, stride=1, **kw):
+            use4 = acc and wkey in f4s
             use8 = acc and wkey in f8s
-            g_ = L.conv_geom(hh, ww, Ci if use8 else Ci * m2, 3, 3, stride, 1)
+            g_ = L.conv_geom(hh, ww, Ci if (use8 or use4) else Ci * m2, 3, 3, stride, 1)
             ho, wo = g_[3], g_[4]
             has_res = "res" in kw
-            if use8:
+            if use4:
+                P.gemm(name, A, w[wkey], out, M=NB * ho * wo, N=Co, K=9 * Ci, lda=PE(Ci), conv=g_, f4=f4s[wkey],
+                       ldr=PE(Co) if has_res else 0, res_f8=has_res, precision_passes=1, **okw(Co, True, True), **kw)
+            elif use8:
                 P.gemm(name, A, w[wkey], out, M=NB * ho * wo, N=Co, K=9 * Ci, lda=2 * Ci, conv=g_, f8_seg=2 * Ci, ldo=2 * Co,
                        ldr=2 * Co if has_res else 0, res_f8=has_res, out_split_off=Co, out_f8=F8O, precision_passes=1, **f8kw(wkey), **kw)
             else:
@@ -699,15 +753,15 @@ class _ZoePlan:
         # ---- Z4: reassemble (readout project, 1x1 projection, resize) + neck 3x3 convs
         feats, fshape = [], []
         cb = e32(NB, Hd)
-        r16 = e16(NB * T0, Hd * m2)
+        r16 = e16(NB * T0, PE(Hd))
         for i, ch in enumerate(c.neck_hidden):
             t16 = taps16[i]
             # cls half of the readout: per-image bias vector  c_b = cls_b @ W_cls^T + b   (A rows = the cls row of every image)
-            nplain(f"ro{i}.cls", t16, f"ro{i}.w_cls", cb, NB, Hd, Hd, out_pairs=False, lda=(1 if grouped else S) * Hd * m2, bias=w[f"ro{i}.b"])
+            nplain(f"ro{i}.cls", t16, f"ro{i}.w_cls", cb, NB, Hd, Hd, out_pairs=False, lda=(1 if grouped else S) * PE(Hd), bias=w[f"ro{i}.b"])
             # token half: the patch rows of every image, + c_b, GELU.  Grouped rows: a plain GEMM over rows NB..; image-major rows:
             # rows 1..S-1 of every image (a 1-row "conv" with a -1 column crop)
             if grouped:
-                nplain(f"ro{i}.tok", t16, f"ro{i}.w_tok", r16, NB * T0, Hd, Hd, a_offset=CP * Hd * m2, bias=cb, bias_group_rows=T0,
+                nplain(f"ro{i}.tok", t16, f"ro{i}.w_tok", r16, NB * T0, Hd, Hd, a_offset=CP * PE(Hd), bias=cb, bias_group_rows=T0,
                        act=L.ACT_GELU)
             elif acc and f"ro{i}.w_tok" in f8s:
                 P.gemm(f"ro{i}.tok", t16, w[f"ro{i}.w_tok"], r16, M=NB * T0, N=Hd, K=Hd, lda=2 * Hd, conv=(1, S, Hd, 1, T0, 1, 1, 1, 0, -1),
@@ -717,27 +771,26 @@ class _ZoePlan:
                 P.gemm(f"ro{i}.tok", t16, w[f"ro{i}.w_tok"], r16, M=NB * T0, N=Hd, K=Hd * np3, lda=Hd * m2, conv=(1, S, Hd * m2, 1, T0, 1, 1, 1, 0, -1),
                        seg1=Hd if acc else 0, bias=cb, bias_group_rows=T0, act=L.ACT_GELU, ldo=Hd * m2, out_split_off=Hd if acc else 0,
                        precision_passes=np3)
-            pr = e16(NB * T0, ch * m2)
+            pr = e16(NB * T0, PE(ch))
             nplain(f"ra{i}.proj", r16, f"ra{i}.proj.w", pr, NB * T0, ch, Hd, bias=w[f"ra{i}.proj.b"])
             if i == 0 or i == 1:
                 s_ = 4 if i == 0 else 2
-                up = e16(NB, hp * s_, wp * s_, ch * m2)
-                nplain(f"ra{i}.up", pr, f"ra{i}.up.w", up, NB * T0, s_ * s_ * ch, ch, shuffle=(s_, ch, hp, wp), bias=w[f"ra{i}.up.b"],
-                       ldo=ch * m2, split_off=ch)
+                up = e16(NB, hp * s_, wp * s_, PE(ch))
+                nplain(f"ra{i}.up", pr, f"ra{i}.up.w", up, NB * T0, s_ * s_ * ch, ch, shuffle=(s_, ch, hp, wp), bias=w[f"ra{i}.up.b"])
                 free(pr)
                 fh, fw, src = hp * s_, wp * s_, up
             elif i == 2:
                 fh, fw, src = hp, wp, pr
             else:
                 fh, fw = (hp + 2 - 3) // 2 + 1, (wp + 2 - 3) // 2 + 1
-                src = e16(NB, fh, fw, ch * m2)
+                src = e16(NB, fh, fw, PE(ch))
                 nconv(f"ra{i}.down", pr, f"ra{i}.down.w", src, hp, wp, ch, ch, stride=2, bias=w[f"ra{i}.down.b"])
                 free(pr)
-            P.mark(f"reassemble{i}", src, ("nhwc", NB, fh, fw, ch, (2 if nf8 else 1) if acc else 0))
-            f16_ = e16(NB, fh, fw, c.fusion * m2)
+            P.mark(f"reassemble{i}", src, ("nhwc", NB, fh, fw, ch, mfmt(ch)))
+            f16_ = e16(NB, fh, fw, PE(c.fusion))
             nconv(f"nc{i}", src, f"nc{i}.w", f16_, fh, fw, ch, c.fusion)
             free(src)                                                  # (level 2: src is pr)
-            P.mark(f"neckconv{i}", f16_, ("nhwc", NB, fh, fw, c.fusion, (2 if nf8 else 1) if acc else 0))
+            P.mark(f"neckconv{i}", f16_, ("nhwc", NB, fh, fw, c.fusion, mfmt(c.fusion)))
             feats.append(f16_)
             fshape.append((fh, fw))
         free(r16, cb)
@@ -751,7 +804,7 @@ class _ZoePlan:
         # ---- Z7: metric-bins head
         Mb = NB * bh_ * bw_
         xb = e16(Mb, c.bottleneck)
-        P.gemm("mh.conv2", bott, w["mh.conv2.w"], xb, M=Mb, N=c.bottleneck, K=c.bottleneck, lda=c.bottleneck * m2, bias=w["mh.conv2.b"])   # hi half of a split map
+        P.gemm("mh.conv2", bott, w["mh.conv2.w"], xb, M=Mb, N=c.bottleneck, K=c.bottleneck, lda=PE(c.bottleneck), bias=w["mh.conv2.b"])   # hi half of a split map
         self.logits = e32(NB, 4)
         self.route = torch.zeros(NB, dtype=torch.int32, device=dev)       # single-head models: every image stays on slot 0
         if not c.single_head:
@@ -805,11 +858,11 @@ class _ZoePlan:
 
         def res_unit(name, xin, hh, ww, other=None):
             """y = conv2(relu(conv1(relu(x)))) + x (+ other)."""
-            t = e16(NB, hh, ww, Fc * m2)
-            y = e16(NB, hh, ww, Fc * m2)
+            t = e16(NB, hh, ww, PE(Fc))
+            y = e16(NB, hh, ww, PE(Fc))
             if acc:
-                xr = e16(NB, hh, ww, Fc * m2)
-                P.add(name + ".relu", "bs_relu_split", xin, xr, NB * hh * ww, Fc, L.dt(xr) | (32 if nf8 else 0))
+                xr = e16(NB, hh, ww, PE(Fc))
+                P.add(name + ".relu", "bs_relu_split", xin, xr, NB * hh * ww, Fc, L.dt(xr) | (64 if is4(Fc) else (32 if nf8 else 0)))
                 nconv(name + ".c1", xr, name + ".c1.w", t, hh, ww, Fc, Fc, bias=w[name + ".c1.b"], act=L.ACT_RELU)
                 free(xr)
             else:
@@ -837,18 +890,18 @@ class _ZoePlan:
             # HF upsamples, then applies the 1x1 projection (modeling_zoedepth.py:316-322).  Both are linear and the bilinear weights
             # sum to 1, so projection(interpolate(x)) = interpolate(projection(x)) exactly in real arithmetic: the projection runs at
             # the LOW resolution (a quarter of the FLOPs and of the bytes), the resize writes the fused map directly.
-            lowp = e16(NB, fh, fw, Fc * m2)
+            lowp = e16(NB, fh, fw, PE(Fc))
             nplain(f"fu{li}.proj", cur, f"fu{li}.proj.w", lowp, NB * fh * fw, Fc, Fc, bias=w[f"fu{li}.proj.b"])
             free(cur)
-            fused = e16(NB, 2 * fh, 2 * fw, Fc * m2)
-            P.add(f"fu{li}.up", "bs_resize_bilinear_nhwc", lowp, fused, NB, fh, fw, Fc, 2 * fh, 2 * fw, RZ, L.dt(fused))
+            fused = e16(NB, 2 * fh, 2 * fw, PE(Fc))
+            P.add(f"fu{li}.up", "bs_resize_bilinear_nhwc", lowp, fused, NB, fh, fw, Fc, 2 * fh, 2 * fw, RZ4 if is4(Fc) else RZ, L.dt(fused))
             free(lowp)
-            P.mark(f"fused{li}", fused, ("nhwc", NB, 2 * fh, 2 * fw, Fc, (2 if nf8 else 1) if acc else 0))
+            P.mark(f"fused{li}", fused, ("nhwc", NB, 2 * fh, 2 * fw, Fc, mfmt(Fc)))
             fused_list.append((fused, 2 * fh, 2 * fw))
         # ---- Z6: relative head (conv3 + ReLU -> relative depth is dead code for the NK output and not launched)
         f3, h3, w3 = fused_list[3]
         if eng.add_projection:
-            rp = e16(NB, h3, w3, Fc * m2)
+            rp = e16(NB, h3, w3, PE(Fc))
             nconv("rh.projection", f3, "rh.projection.w", rp, h3, w3, Fc, Fc, bias=w["rh.projection.b"], act=L.ACT_RELU)
         else:
             rp = f3
