@@ -341,7 +341,11 @@ def main():
                                     f"batch {B} frames/step", "frames_per_step_per_gpu": B, "net_input": list(zplan.geom[k] for k in ("nh", "nw")),
                         "sharding": "contiguous frame blocks per rank, one RCCL all-gather of relative poses per step" if world > 1 else "single GPU"}),
             "roofline": roof, "roofline_conv_stack": roof_conv, "cpu_baseline": cpu,
-            "precision": args.precision, "depth_l1_vs_oracle_m": l1, "depth_l1_frame": "frame 0 of the last timed step's batch, from the timed plan's output",
+            "precision": args.precision,
+            # which correction products the engine evaluates per GEMM class: chosen at load time on the device (ZoeDepthEngine.calibrate)
+            "accurate_modes": ({"class_modes": pipe.zoe.class_modes, "neck_mode": pipe.zoe.neck_mode, "neck_corr": pipe.zoe.neck_corr,
+                                "calibration": pipe.zoe.calibration} if pipe.zoe.acc else None),
+            "depth_l1_vs_oracle_m": l1, "depth_l1_frame": "frame 0 of the last timed step's batch, from the timed plan's output",
             "kernels": kern_table,
             "hbm_allocated_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
         }

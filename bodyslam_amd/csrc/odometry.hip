@@ -1,7 +1,9 @@
 // Dense RGB-D odometry of the VO step: the role Open3D's rgbd_odometry_multi_scale (Hybrid, 20 / 10 / 5
 // iterations) plays at BodySLAM_not_refactored/3DM/visual_odometry.py:97-120.  Open3D is un-vendored: parity unpinned; the algorithm
-// is the statement in oracle/rgbd_odometry_ref.py (hybrid photometric + geometric Gauss-Newton on a 3-level pyramid, Huber losses,
-// bilinear sampling of the target), which these kernels implement term by term.
+// is the statement in oracle/rgbd_odometry_ref.py (hybrid photometric + geometric Gauss-Newton on a 3-level pyramid, Huber losses),
+// which these kernels implement term by term.  Two switches (the `flags` of bs_odo_accumulate / bs_odo_step): bit 0 = the target is
+// read at the NEAREST pixel of the projected point (Open3D's association; default of the product) instead of bilinearly; bit 1 =
+// Open3D's form of the robust step (J^T J unweighted, J^T applied to the Huber-clipped residual) instead of IRLS weights.
 //
 // All of it is HBM-bound streaming / reduction work on 1.2 MB images: images are fp32 in HBM (NaN = invalid depth), the per-pixel
 // arithmetic runs in fp64 (the vector fp64 rate is not the limit), and one Gauss-Newton step is ONE kernel that reduces 29 sums
@@ -12,6 +14,7 @@
 namespace bs {
 
 constexpr int ODO_TERMS = 29;
+constexpr int ODO_GRID = 256;     // blocks of a Gauss-Newton step (one per CU; each walks its pixels in a fixed order: deterministic partials)
 
 __global__ __launch_bounds__(256) void odo_prepare_kernel(const uint8_t* __restrict__ color, const float* __restrict__ depth, int64_t n, float depth_max,
                                                            float* __restrict__ inten, float* __restrict__ dout) {
@@ -78,7 +81,8 @@ struct OdoPose {
     double fx, fy, cx, cy;
 };
 
-// one Gauss-Newton step's sums, per block
+// one Gauss-Newton step's sums, per block.  FLAGS bit 0: nearest-pixel association; bit 1: Open3D's Huber form
+template <int FLAGS>
 __global__ __launch_bounds__(256) void odo_accumulate_kernel(const float* __restrict__ Is, const float* __restrict__ Ds, const float* __restrict__ It,
                                                               const float* __restrict__ Dt, const float* __restrict__ dIx, const float* __restrict__ dIy,
                                                               const float* __restrict__ dDx, const float* __restrict__ dDy, int H, int W, OdoPose P,
@@ -88,11 +92,13 @@ __global__ __launch_bounds__(256) void odo_accumulate_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < 12; ++i) P.t[i] = T_dev[i];
     }
-    const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    double acc[ODO_TERMS];
+    double acc[ODO_TERMS], tot[ODO_TERMS];
+#pragma unroll
+    for (int k = 0; k < ODO_TERMS; ++k) tot[k] = 0.0;
+    for (int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x; pix < (int64_t)H * W; pix += (int64_t)gridDim.x * 256) {
 #pragma unroll
     for (int k = 0; k < ODO_TERMS; ++k) acc[k] = 0.0;
-    if (pix < (int64_t)H * W) {
+    {
         const int v = (int)(pix / W), u = (int)(pix % W);
         const double z = (double)Ds[pix];
         bool ok = z == z;
@@ -104,14 +110,21 @@ __global__ __launch_bounds__(256) void odo_accumulate_kernel(const float* __rest
             ok = pz > 0.0;
             if (ok) {
                 const double uf = P.fx * px / pz + P.cx, vf = P.fy * py / pz + P.cy;
-                ok = uf >= 0.0 && uf <= (double)(W - 1) && vf >= 0.0 && vf <= (double)(H - 1);
+                constexpr bool NEAREST = (FLAGS & 1) != 0;
+                const double ur = round(uf), vr = round(vf);           // (round half away from zero, as roundf)
+                ok = NEAREST ? (ur >= 0.0 && ur <= (double)(W - 1) && vr >= 0.0 && vr <= (double)(H - 1))
+                             : (uf >= 0.0 && uf <= (double)(W - 1) && vf >= 0.0 && vf <= (double)(H - 1));
                 if (ok) {
                     int u0 = (int)floor(uf), v0 = (int)floor(vf);
                     u0 = u0 > W - 2 ? W - 2 : u0;
                     v0 = v0 > H - 2 ? H - 2 : v0;
+                    u0 = u0 < 0 ? 0 : u0;
+                    v0 = v0 < 0 ? 0 : v0;
                     const double au = uf - (double)u0, av = vf - (double)v0;
                     const int64_t o00 = (int64_t)v0 * W + u0;
+                    const int64_t onn = (int64_t)(int)vr * W + (int)ur;
                     auto bil = [&](const float* __restrict__ img) {
+                        if (NEAREST) return (double)img[onn];
                         return (1.0 - av) * ((1.0 - au) * (double)img[o00] + au * (double)img[o00 + 1]) +
                                av * ((1.0 - au) * (double)img[o00 + W] + au * (double)img[o00 + W + 1]);
                     };
@@ -126,27 +139,44 @@ __global__ __launch_bounds__(256) void odo_accumulate_kernel(const float* __rest
                         const double d0 = hx * P.fx * iz, d1 = hy * P.fy * iz, d2 = -(d0 * px + d1 * py) * iz;
                         const double JI[6] = {-pz * c1 + py * c2, pz * c0 - px * c2, -py * c0 + px * c1, c0, c1, c2};
                         const double JD[6] = {(-pz * d1 + py * d2) - py, (pz * d0 - px * d2) + px, -py * d0 + px * d1, d0, d1, d2 - 1.0};
-                        const double wI = fabs(rI) <= huber_i ? 1.0 : huber_i / fabs(rI);
-                        const double wD = fabs(rD) <= huber_d ? 1.0 : huber_d / fabs(rD);
-                        int k = 0;
+                        if constexpr ((FLAGS & 2) != 0) {
+                            // Open3D: sum J^T J unweighted, sum J^T huber'(r), cost = sum huber(r)
+                            const double qI = fabs(rI) < huber_i ? rI : copysign(huber_i, rI), qD = fabs(rD) < huber_d ? rD : copysign(huber_d, rD);
+                            int k = 0;
 #pragma unroll
-                        for (int a = 0; a < 6; ++a)
+                            for (int a = 0; a < 6; ++a)
 #pragma unroll
-                            for (int b = a; b < 6; ++b) acc[k++] = wI * JI[a] * JI[b] + wD * JD[a] * JD[b];
+                                for (int b = a; b < 6; ++b) acc[k++] = JI[a] * JI[b] + JD[a] * JD[b];
 #pragma unroll
-                        for (int a = 0; a < 6; ++a) acc[21 + a] = wI * JI[a] * rI + wD * JD[a] * rD;
-                        acc[27] = wI * rI * rI + wD * rD * rD;
+                            for (int a = 0; a < 6; ++a) acc[21 + a] = JI[a] * qI + JD[a] * qD;
+                            acc[27] = (fabs(rI) < huber_i ? 0.5 * rI * rI : huber_i * (fabs(rI) - 0.5 * huber_i)) +
+                                      (fabs(rD) < huber_d ? 0.5 * rD * rD : huber_d * (fabs(rD) - 0.5 * huber_d));
+                        } else {
+                            const double wI = fabs(rI) <= huber_i ? 1.0 : huber_i / fabs(rI);
+                            const double wD = fabs(rD) <= huber_d ? 1.0 : huber_d / fabs(rD);
+                            int k = 0;
+#pragma unroll
+                            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                                for (int b = a; b < 6; ++b) acc[k++] = wI * JI[a] * JI[b] + wD * JD[a] * JD[b];
+#pragma unroll
+                            for (int a = 0; a < 6; ++a) acc[21 + a] = wI * JI[a] * rI + wD * JD[a] * rD;
+                            acc[27] = wI * rI * rI + wD * rD * rD;
+                        }
                         acc[28] = 1.0;
                     }
                 }
             }
         }
     }
+#pragma unroll
+    for (int k = 0; k < ODO_TERMS; ++k) tot[k] += acc[k];
+    }
     __shared__ double red[4][ODO_TERMS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < ODO_TERMS; ++k) {
-        double s = acc[k];
+        double s = tot[k];
         for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
         if (lane == 0) red[wave][k] = s;
     }
@@ -166,8 +196,7 @@ __global__ __launch_bounds__(64) void odo_finish_kernel(const double* __restrict
 
 // delta = -(A + 1e-12 I)^-1 b by Gaussian elimination with partial pivoting, T <- exp(delta) T (left twist: omega = delta[0:3],
 // nu = delta[3:6]); fewer than 6 inliers or a singular system leave T alone.  One thread: 6x6.
-__global__ void odo_solve_kernel(const double* __restrict__ s29, double* __restrict__ T) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void odo_solve(const double* __restrict__ s29, double* __restrict__ T) {
     if (s29[28] < 6.0) return;
     double M[6][7];
     int k = 0;
@@ -234,6 +263,46 @@ __global__ void odo_solve_kernel(const double* __restrict__ s29, double* __restr
     for (int i = 0; i < 12; ++i) T[i] = N[i];
 }
 
+__global__ void odo_solve_kernel(const double* __restrict__ s29, double* __restrict__ T) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    odo_solve(s29, T);
+}
+
+// the fixed-order reduction of the block partials (wave w: terms w and w + 16, the same lane-strided order as odo_finish_kernel: bit-equal
+// sums) and the 6x6 solve + pose update in ONE launch: a Gauss-Newton step is two dependent launches instead of three
+__global__ __launch_bounds__(1024) void odo_finish_solve_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ out, double* __restrict__ T) {
+    __shared__ double s29[ODO_TERMS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave; k < ODO_TERMS; k += 16) {
+        double s = 0.0;
+        for (int b = lane; b < nblocks; b += 64) s += partial[(int64_t)b * ODO_TERMS + k];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0) {
+            s29[k] = s;
+            out[k] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) odo_solve(s29, T);
+}
+
+template <int FLAGS>
+static void launch_accumulate(int nblocks, hipStream_t st, const float* a, const float* b, const float* c, const float* d, const float* e, const float* f,
+                              const float* g, const float* h, int H, int W, const OdoPose& P, const double* T_dev, double o, double hd, double hi,
+                              double* partial) {
+    hipLaunchKernelGGL(odo_accumulate_kernel<FLAGS>, dim3(nblocks), dim3(256), 0, st, a, b, c, d, e, f, g, h, H, W, P, T_dev, o, hd, hi, partial);
+}
+static void launch_accumulate_flags(int flags, int nblocks, hipStream_t st, const float* a, const float* b, const float* c, const float* d, const float* e,
+                                    const float* f, const float* g, const float* h, int H, int W, const OdoPose& P, const double* T_dev, double o,
+                                    double hd, double hi, double* partial) {
+    switch (flags & 3) {
+        case 0: launch_accumulate<0>(nblocks, st, a, b, c, d, e, f, g, h, H, W, P, T_dev, o, hd, hi, partial); break;
+        case 1: launch_accumulate<1>(nblocks, st, a, b, c, d, e, f, g, h, H, W, P, T_dev, o, hd, hi, partial); break;
+        case 2: launch_accumulate<2>(nblocks, st, a, b, c, d, e, f, g, h, H, W, P, T_dev, o, hd, hi, partial); break;
+        default: launch_accumulate<3>(nblocks, st, a, b, c, d, e, f, g, h, H, W, P, T_dev, o, hd, hi, partial); break;
+    }
+}
+
 }  // namespace bs
 
 using namespace bs;
@@ -286,7 +355,7 @@ extern "C" int bs_odo_sobel(const float* img, int32_t H, int32_t W, float* gx, f
 extern "C" int bs_odo_accumulate(const float* src_intensity, const float* src_depth, const float* tgt_intensity, const float* tgt_depth,
                                  const float* tgt_dIx, const float* tgt_dIy, const float* tgt_dDx, const float* tgt_dDy, int32_t H, int32_t W,
                                  const double* K, const double* T, double depth_outlier_trunc, double depth_huber, double intensity_huber,
-                                 double* partial, double* out29, void* stream) {
+                                 double* partial, double* out29, int32_t flags, void* stream) {
     ODO_ENTRY("bs_odo_accumulate");
     BS_REQUIRE(src_intensity && src_depth && tgt_intensity && tgt_depth && tgt_dIx && tgt_dIy && tgt_dDx && tgt_dDy && K && T && partial && out29,
                "bs_odo_accumulate: null argument");
@@ -294,10 +363,10 @@ extern "C" int bs_odo_accumulate(const float* src_intensity, const float* src_de
     OdoPose P;
     for (int i = 0; i < 12; ++i) P.t[i] = T[i];
     P.fx = K[0]; P.fy = K[1]; P.cx = K[2]; P.cy = K[3];
-    const int nblocks = (int)cdiv64((int64_t)H * W, 256);
+    const int nblocks = (int)(cdiv64((int64_t)H * W, 256) < ODO_GRID ? cdiv64((int64_t)H * W, 256) : ODO_GRID);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(odo_accumulate_kernel, dim3(nblocks), dim3(256), 0, st, src_intensity, src_depth, tgt_intensity, tgt_depth, tgt_dIx, tgt_dIy,
-                       tgt_dDx, tgt_dDy, H, W, P, (const double*)nullptr, depth_outlier_trunc, depth_huber, intensity_huber, partial);
+    launch_accumulate_flags(flags, nblocks, st, src_intensity, src_depth, tgt_intensity, tgt_depth, tgt_dIx, tgt_dIy, tgt_dDx, tgt_dDy, H, W, P,
+                            (const double*)nullptr, depth_outlier_trunc, depth_huber, intensity_huber, partial);
     BS_CHECK_LAUNCH();
     hipLaunchKernelGGL(odo_finish_kernel, dim3(ODO_TERMS), dim3(64), 0, st, partial, nblocks, out29);
     BS_CHECK_LAUNCH();
@@ -307,7 +376,7 @@ extern "C" int bs_odo_accumulate(const float* src_intensity, const float* src_de
 extern "C" int bs_odo_step(const float* src_intensity, const float* src_depth, const float* tgt_intensity, const float* tgt_depth,
                            const float* tgt_dIx, const float* tgt_dIy, const float* tgt_dDx, const float* tgt_dDy, int32_t H, int32_t W,
                            const double* K, double* T_dev, int32_t iterations, double depth_outlier_trunc, double depth_huber,
-                           double intensity_huber, double* partial, double* out29, void* stream) {
+                           double intensity_huber, double* partial, double* out29, int32_t flags, void* stream) {
     ODO_ENTRY("bs_odo_step");
     BS_REQUIRE(src_intensity && src_depth && tgt_intensity && tgt_depth && tgt_dIx && tgt_dIy && tgt_dDx && tgt_dDy && K && T_dev && partial && out29,
                "bs_odo_step: null argument");
@@ -315,15 +384,13 @@ extern "C" int bs_odo_step(const float* src_intensity, const float* src_depth, c
     OdoPose P;
     for (int i = 0; i < 12; ++i) P.t[i] = 0.0;
     P.fx = K[0]; P.fy = K[1]; P.cx = K[2]; P.cy = K[3];
-    const int nblocks = (int)cdiv64((int64_t)H * W, 256);
+    const int nblocks = (int)(cdiv64((int64_t)H * W, 256) < ODO_GRID ? cdiv64((int64_t)H * W, 256) : ODO_GRID);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     for (int it = 0; it < iterations; ++it) {
-        hipLaunchKernelGGL(odo_accumulate_kernel, dim3(nblocks), dim3(256), 0, st, src_intensity, src_depth, tgt_intensity, tgt_depth, tgt_dIx, tgt_dIy,
-                           tgt_dDx, tgt_dDy, H, W, P, (const double*)T_dev, depth_outlier_trunc, depth_huber, intensity_huber, partial);
+        launch_accumulate_flags(flags, nblocks, st, src_intensity, src_depth, tgt_intensity, tgt_depth, tgt_dIx, tgt_dIy, tgt_dDx, tgt_dDy, H, W, P,
+                                (const double*)T_dev, depth_outlier_trunc, depth_huber, intensity_huber, partial);
         BS_CHECK_LAUNCH();
-        hipLaunchKernelGGL(odo_finish_kernel, dim3(ODO_TERMS), dim3(64), 0, st, partial, nblocks, out29);
-        BS_CHECK_LAUNCH();
-        hipLaunchKernelGGL(odo_solve_kernel, dim3(1), dim3(64), 0, st, out29, T_dev);
+        hipLaunchKernelGGL(odo_finish_solve_kernel, dim3(1), dim3(1024), 0, st, partial, nblocks, out29, T_dev);
         BS_CHECK_LAUNCH();
     }
     return BS_OK;

@@ -8,6 +8,8 @@
 // reads and writes 64 x 20 = 1280 contiguous bytes; the depth / colour images (1.2 MB) stay in L2.  The unit table (which units
 // exist, which block each owns) is an open-addressing hash table in HBM filled by atomicCAS (Open3D: an unordered_map on the host);
 // blocks are carved from zero-filled slabs whose base addresses the kernels get as a small device array.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace bs {
@@ -89,7 +91,11 @@ __global__ __launch_bounds__(256) void tsdf_assign_kernel(const long long* __res
     if (s < 0) {
         s = atomicAdd(counters + 0, 1);
         if (s >= max_units) {
-            counters[2] = 2;  // more units than blocks
+            // more units than blocks (max_units = the blocks that EXIST: the caller keeps slabs allocated ahead of the map).  The
+            // count is put back, so the table entry stays without a block and a later frame -- after the caller has added slabs or
+            // raised the error -- can still assign one.
+            atomicSub(counters + 0, 1);
+            counters[2] = 2;
             return;
         }
         slots[h] = s;
@@ -101,17 +107,52 @@ __global__ __launch_bounds__(256) void tsdf_assign_kernel(const long long* __res
     touched[atomicAdd(counters + 1, 1)] = s;
 }
 
-// Open3D UniformTSDFVolume::IntegrateWithDepthToCameraDistanceMultiplier, one thread per voxel
-__global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float* __restrict__ depth, const uint8_t* __restrict__ color, int H, int W,
-                                                              TsdfCam cam, const int32_t* __restrict__ unit_index, const int32_t* __restrict__ touched,
-                                                              const int64_t* __restrict__ slab_base, int slab_units, int res, double voxel_length,
-                                                              double sdf_trunc) {
-    const int u = touched[blockIdx.y];
-    const int v = blockIdx.x * 256 + threadIdx.x;
+// Open3D UniformTSDFVolume::IntegrateWithDepthToCameraDistanceMultiplier, one thread per voxel.  Grid: blocks_per_unit x an UPPER
+// BOUND of the touched units, folded into blockIdx.x (no 65 535 limit); the number of units this frame really touched is read
+// from device memory (counters[1], written by tsdf_assign_kernel), so the host never has to wait for it.
+// Culling: a block's 256 voxels are one x-slice of 8 rows x 32 (res = 32) -- a box 1 x 8 x 32 voxels.  Units are opened in a +-sdf_trunc
+// box around every sampled point, far wider than the view frustum at endoscopic range (PMC, round 2: 90 % of the threads projected
+// outside the image and left); the box's bounding sphere is projected once per block and the block leaves when the sphere lies
+// behind the camera or wholly outside the image (conservative: a block that might hold one updated voxel is never skipped).
+__device__ __forceinline__ void tsdf_integrate_block(int work, const float* __restrict__ depth, const uint8_t* __restrict__ color, int H, int W,
+                                                     const TsdfCam& cam, const int32_t* __restrict__ unit_index, const int32_t* __restrict__ touched,
+                                                     int blocks_per_unit, const int64_t* __restrict__ slab_base, int slab_units, int res,
+                                                     double voxel_length, double sdf_trunc, int cull) {
+    const int ti = work / blocks_per_unit, bx = work - ti * blocks_per_unit;
+    const int u = touched[ti];
+    const int v = bx * 256 + threadIdx.x;
     const int nvox = res * res * res;
+    const double unit_len = voxel_length * res, half = voxel_length * 0.5;
+    if (cull) {
+        // bounding sphere of the voxels [bx * 256, bx * 256 + 256) of this unit (whole x-slices / rows: res divides 256 or 256 divides res^2)
+        const int v0 = bx * 256, v1 = (v0 + 255 < nvox - 1 ? v0 + 255 : nvox - 1);
+        const int x0 = v0 / (res * res), x1 = v1 / (res * res);
+        int y0 = (v0 / res) % res, y1 = (v1 / res) % res;
+        if (x1 > x0) { y0 = 0; y1 = res - 1; }
+        const double lo[3] = {(double)x0, (double)y0, 0.0}, hi[3] = {(double)x1 + 1.0, (double)y1 + 1.0, (double)res};
+        double c[3], r2 = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            c[a] = 0.5 * (lo[a] + hi[a]) * voxel_length + unit_len * unit_index[3 * u + a];
+            const double e = 0.5 * (hi[a] - lo[a]) * voxel_length;
+            r2 += e * e;
+        }
+        const double r = sqrt(r2);
+        const double qx = cam.e[0] * c[0] + cam.e[1] * c[1] + cam.e[2] * c[2] + cam.e[3];
+        const double qy = cam.e[4] * c[0] + cam.e[5] * c[1] + cam.e[6] * c[2] + cam.e[7];
+        const double qz = cam.e[8] * c[0] + cam.e[9] * c[1] + cam.e[10] * c[2] + cam.e[11];
+        if (qz + r <= 0.0) return;                                   // wholly behind the camera
+        if (qz > r) {                                                // (a sphere that reaches the camera plane is never culled)
+            // the sphere lies inside the cone of half-angle asin(r / |q|) around q: compare the tangent-cone's pixel footprint with the
+            // image.  |pixel - centre pixel| <= f * r / (qz - r) * (1 + (|qx| + |qy|) / qz) bounds the footprint for the small r here.
+            const double inv = 1.0 / (qz - r);
+            const double spread = 1.0 + (fabs(qx) + fabs(qy)) * inv;
+            const double ru = cam.fx * r * inv * spread + 1.0, rv = cam.fy * r * inv * spread + 1.0;
+            const double uc = qx * cam.fx / qz + cam.cx + 0.5, vc = qy * cam.fy / qz + cam.cy + 0.5;
+            if (uc + ru < 0.0 || uc - ru > (double)W || vc + rv < 0.0 || vc - rv > (double)H) return;
+        }
+    }
     if (v >= nvox) return;
     const int x = v / (res * res), y = (v / res) % res, z = v % res;
-    const double unit_len = voxel_length * res, half = voxel_length * 0.5;
     const double px = half + voxel_length * x + unit_len * unit_index[3 * u + 0];
     const double py = half + voxel_length * y + unit_len * unit_index[3 * u + 1];
     const double pz = half + voxel_length * z + unit_len * unit_index[3 * u + 2];
@@ -140,6 +181,17 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float* __rest
         vox[4] = (vox[4] * w0 + (float)c[2]) / w1;
     }
     vox[1] = w1;
+}
+
+// a fixed grid walks the (touched unit, 256-voxel block) work items; their number comes from device memory
+__global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float* __restrict__ depth, const uint8_t* __restrict__ color, int H, int W,
+                                                              TsdfCam cam, const int32_t* __restrict__ unit_index, const int32_t* __restrict__ touched,
+                                                              const int32_t* __restrict__ n_touched_dev, int blocks_per_unit,
+                                                              const int64_t* __restrict__ slab_base, int slab_units, int res, double voxel_length,
+                                                              double sdf_trunc, int cull) {
+    const long long total = (long long)(*n_touched_dev) * blocks_per_unit;
+    for (long long w = blockIdx.x; w < total; w += gridDim.x)
+        tsdf_integrate_block((int)w, depth, color, H, W, cam, unit_index, touched, blocks_per_unit, slab_base, slab_units, res, voxel_length, sdf_trunc, cull);
 }
 
 // ScalableTSDFVolume::GetTSDFAt: trilinear interpolation of the tsdf over the 8 voxel centres around p (a corner in a unit that does
@@ -190,9 +242,10 @@ __global__ __launch_bounds__(256) void tsdf_extract_kernel(const int32_t* __rest
                                                             int slab_units, int res, double voxel_length, int32_t* __restrict__ unit_count,
                                                             const int64_t* __restrict__ unit_offset, float* __restrict__ points,
                                                             float* __restrict__ colors, float* __restrict__ normals) {
-    const int u = blockIdx.y;
-    const int v = blockIdx.x * 256 + threadIdx.x;
     const int nvox = res * res * res;
+    const int bpu = (nvox + 255) / 256;                      // the unit is folded into blockIdx.x (no 65 535-unit limit)
+    const int u = blockIdx.x / bpu;
+    const int v = (blockIdx.x - u * bpu) * 256 + threadIdx.x;
     const int64_t unit_bytes = (int64_t)nvox * 20;
     int found = 0;
     float pts[3][3], cols[3][3];
@@ -266,6 +319,102 @@ __global__ __launch_bounds__(256) void tsdf_extract_kernel(const int32_t* __rest
     }
 }
 
+// ScalableTSDFVolume::ExtractTriangleMesh: marching cubes over every voxel cube of every unit.  Thread = the cube whose corner 0 is
+// voxel v of unit u; corner c sits at voxel + (c & 1, (c >> 1) & 1, (c >> 2) & 1), in a neighbouring unit (found through the table)
+// when it runs off this one.  A cube with a corner of weight 0 (or in a unit that does not exist) is skipped, as in Open3D; bit c of
+// the case = tsdf(corner c) < 0; mc_tab = [tri table int32 [256][tri_width], -1 terminated, three edge ids per triangle | edge
+// corners int32 [12][2]] (bodyslam_amd/marching_cubes.py).  WRITE = false counts triangles per unit; WRITE = true writes, per
+// triangle corner, the vertex on its cube edge (linear zero crossing between the edge's two corners, colour alike) and the edge's
+// 62-bit identity (global voxel coordinates of its lower corner, 20 bits each, biased, + axis): the host merges equal identities
+// into one vertex.
+template <bool WRITE>
+__global__ __launch_bounds__(256) void tsdf_mesh_kernel(const int32_t* __restrict__ unit_index, const long long* __restrict__ keys,
+                                                         const int32_t* __restrict__ slots, unsigned mask, const int64_t* __restrict__ slab_base,
+                                                         int slab_units, int res, double voxel_length, const int32_t* __restrict__ mc_tab, int tri_width,
+                                                         int32_t* __restrict__ unit_count, const int64_t* __restrict__ unit_offset,
+                                                         float* __restrict__ verts, float* __restrict__ cols, long long* __restrict__ vkeys,
+                                                         int32_t* __restrict__ err) {
+    const int nvox = res * res * res;
+    const int bpu = (nvox + 255) / 256;
+    const int u = blockIdx.x / bpu;
+    const int v = (blockIdx.x - u * bpu) * 256 + threadIdx.x;
+    const int64_t unit_bytes = (int64_t)nvox * 20;
+    int ntri = 0, cs = 0;
+    const float* cp[8];
+    if (v < nvox) {
+        const int idx[3] = {v / (res * res), (v / res) % res, v % res};
+        const int ui3[3] = {unit_index[3 * u], unit_index[3 * u + 1], unit_index[3 * u + 2]};
+        const float* blk[8];
+        bool have[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) have[o] = false;
+        blk[0] = ts_block(slab_base, slab_units, unit_bytes, u);
+        have[0] = true;
+        bool ok = true;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            int q[3], o = 0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                q[a] = idx[a] + ((c >> a) & 1);
+                if (q[a] >= res) {
+                    q[a] -= res;
+                    o |= 1 << a;
+                }
+            }
+            if (!have[o]) {
+                const int ns = ts_find(keys, slots, mask, ts_pack(ui3[0] + (o & 1), ui3[1] + ((o >> 1) & 1), ui3[2] + ((o >> 2) & 1)));
+                blk[o] = ns >= 0 ? ts_block(slab_base, slab_units, unit_bytes, ns) : nullptr;
+                have[o] = true;
+            }
+            cp[c] = blk[o] ? blk[o] + ((int64_t)q[0] * res * res + q[1] * res + q[2]) * 5 : nullptr;
+            if (!cp[c] || cp[c][1] == 0.0f) ok = false;
+            else if (cp[c][0] < 0.0f) cs |= 1 << c;
+        }
+        if (ok && cs != 0 && cs != 255) {
+            const int32_t* t = mc_tab + cs * tri_width;
+            while (t[3 * ntri] >= 0) ++ntri;
+        } else {
+            cs = 0;
+        }
+    }
+    if (!WRITE) {
+        int s = ntri;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(unit_count + u, s);
+        return;
+    }
+    if (!ntri) return;
+    const int idx[3] = {v / (res * res), (v / res) % res, v % res};
+    const int ui3[3] = {unit_index[3 * u], unit_index[3 * u + 1], unit_index[3 * u + 2]};
+    const double unit_len = voxel_length * res, half = voxel_length * 0.5;
+    const int64_t at = (unit_offset[u] + atomicAdd(unit_count + u, ntri)) * 3;          // first triangle corner of this cube
+    const int32_t* t = mc_tab + cs * tri_width;
+    const int32_t* ed = mc_tab + 256 * tri_width;
+    for (int k = 0; k < 3 * ntri; ++k) {
+        const int e = t[k], a = ed[2 * e], b = ed[2 * e + 1];
+        const int axis = (a ^ b) == 1 ? 0 : ((a ^ b) == 2 ? 1 : 2);
+        const float f0 = cp[a][0], f1 = cp[b][0];
+        const double w = (double)(0.0f - f0) / ((double)f1 - (double)f0);           // Open3D: (0 - f0) / (f1 - f0)
+        long long key = (long long)axis;
+        double p[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const int g = ui3[ax] * res + idx[ax] + ((a >> ax) & 1);                 // global voxel coordinate of the edge's lower corner
+            p[ax] = half + voxel_length * (double)(idx[ax] + ((a >> ax) & 1)) + unit_len * (double)ui3[ax];
+            if (g < -(1 << 19) || g >= (1 << 19)) *err = 1;
+            key |= (long long)((g + (1 << 19)) & ((1 << 20) - 1)) << (2 + 20 * ax);
+        }
+        p[axis] += w * voxel_length;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            verts[(at + k) * 3 + c] = (float)p[c];
+            cols[(at + k) * 3 + c] = (float)(((double)cp[a][2 + c] + w * ((double)cp[b][2 + c] - (double)cp[a][2 + c])) / 255.0);
+        }
+        vkeys[at + k] = key;
+    }
+}
+
 }  // namespace bs
 
 using namespace bs;
@@ -287,7 +436,7 @@ extern "C" int bs_tsdf_touch(const float* depth, int32_t H, int32_t W, int32_t s
     const int span = (int)floor(2.0 * sdf_trunc / unit_length) + 2;          // hi - lo + 1 never exceeds this
     BS_REQUIRE(span <= 64, "bs_tsdf_touch: sdf_trunc / unit_length too large");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    BS_CHECK_HIP(hipMemsetAsync(counters + 1, 0, 2 * sizeof(int32_t), st));    // n_touched, overflow flag (n_units persists)
+    BS_CHECK_HIP(hipMemsetAsync(counters + 1, 0, sizeof(int32_t), st));    // n_touched (n_units persists; the overflow flag is sticky: the caller clears it)
     const int64_t threads = (int64_t)cdiv(W, stride) * cdiv(H, stride) * span * span * span;
     hipLaunchKernelGGL(tsdf_touch_kernel, dim3((unsigned)cdiv64(threads, 256)), dim3(256), 0, st, depth, H, W, stride, cam, unit_length, sdf_trunc, span,
                        reinterpret_cast<long long*>(table_keys), table_stamp, (unsigned)(table_cap - 1), frame_id, counters);
@@ -300,17 +449,24 @@ extern "C" int bs_tsdf_touch(const float* depth, int32_t H, int32_t W, int32_t s
 
 extern "C" int bs_tsdf_integrate(const float* depth, const uint8_t* color, int32_t H, int32_t W, const double* K, const double* extrinsic,
                                  const int32_t* unit_index, const int32_t* touched, int32_t n_touched, const int64_t* slab_base, int32_t slab_units,
-                                 int32_t res, double voxel_length, double sdf_trunc, void* stream) {
+                                 int32_t res, double voxel_length, double sdf_trunc, const int32_t* n_touched_dev, void* stream) {
     if (!initialized()) { set_error("bs_tsdf_integrate: call bs_init first"); return BS_ERR_NOT_INIT; }
     BS_REQUIRE(n_touched >= 0 && H > 0 && W > 0 && res > 0 && res <= 64 && slab_units > 0 && voxel_length > 0.0 && sdf_trunc > 0.0,
                "bs_tsdf_integrate: bad geometry");
     if (n_touched == 0) return BS_OK;
-    BS_REQUIRE(depth && K && extrinsic && unit_index && touched && slab_base, "bs_tsdf_integrate: null argument");
+    BS_REQUIRE(depth && K && extrinsic && unit_index && touched && slab_base && n_touched_dev, "bs_tsdf_integrate: null argument");
     TsdfCam cam;
     tsdf_cam(cam, K, extrinsic);
-    const int nvox = res * res * res;
-    hipLaunchKernelGGL(tsdf_integrate_kernel, dim3(cdiv(nvox, 256), n_touched), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), depth, color, H, W,
-                       cam, unit_index, touched, slab_base, slab_units, res, voxel_length, sdf_trunc);
+    const int nvox = res * res * res, bpu = cdiv(nvox, 256);
+    BS_REQUIRE((long long)bpu * n_touched < 0x7fffffffll, "bs_tsdf_integrate: too many units for one launch");
+    // n_touched (host) only sizes the grid; the kernel reads the true count from n_touched_dev, so a caller that has not read it back
+    // passes any generous value (a few blocks per CU walk the work items)
+    const long long want = (long long)bpu * n_touched;
+    const unsigned grid = (unsigned)(want < 16ll * cu_count() ? want : 16ll * cu_count());
+    // the block culling assumes whole rows per block (res divides 256 or the other way round)
+    const int cull = (256 % res == 0 || res % 256 == 0) && getenv("BS_TSDF_NO_CULL") == nullptr;
+    hipLaunchKernelGGL(tsdf_integrate_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), depth, color, H, W,
+                       cam, unit_index, touched, n_touched_dev, bpu, slab_base, slab_units, res, voxel_length, sdf_trunc, cull);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }
@@ -328,7 +484,8 @@ extern "C" int bs_tsdf_extract(const int32_t* unit_index, int32_t units, const v
     const int nvox = res * res * res;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     BS_CHECK_HIP(hipMemsetAsync(unit_count, 0, sizeof(int32_t) * units, st));
-    const dim3 grid(cdiv(nvox, 256), units);
+    BS_REQUIRE((long long)cdiv(nvox, 256) * units < 0x7fffffffll, "bs_tsdf_extract: too many units for one launch");
+    const dim3 grid((unsigned)(cdiv(nvox, 256) * units));
     const long long* keys = reinterpret_cast<const long long*>(table_keys);
     if (!points)
         hipLaunchKernelGGL(tsdf_extract_kernel<false>, grid, dim3(256), 0, st, unit_index, keys, table_slots, (unsigned)(table_cap - 1), slab_base,
@@ -336,6 +493,34 @@ extern "C" int bs_tsdf_extract(const int32_t* unit_index, int32_t units, const v
     else
         hipLaunchKernelGGL(tsdf_extract_kernel<true>, grid, dim3(256), 0, st, unit_index, keys, table_slots, (unsigned)(table_cap - 1), slab_base,
                            slab_units, res, voxel_length, unit_count, unit_offset, points, colors, normals);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+extern "C" int bs_tsdf_mesh(const int32_t* unit_index, int32_t units, const void* table_keys, const int32_t* table_slots, int32_t table_cap,
+                            const int64_t* slab_base, int32_t slab_units, int32_t res, double voxel_length, const int32_t* mc_tab, int32_t tri_width,
+                            int32_t* unit_count, const int64_t* unit_offset, float* vertices, float* colors, int64_t* vertex_keys, int32_t* err,
+                            void* stream) {
+    if (!initialized()) { set_error("bs_tsdf_mesh: call bs_init first"); return BS_ERR_NOT_INIT; }
+    BS_REQUIRE(units >= 0 && res > 0 && res <= 64 && slab_units > 0 && voxel_length > 0.0 && tri_width >= 4, "bs_tsdf_mesh: bad geometry");
+    if (units == 0) return BS_OK;
+    BS_REQUIRE(unit_index && table_keys && table_slots && slab_base && unit_count && mc_tab && err, "bs_tsdf_mesh: null argument");
+    BS_REQUIRE(table_cap >= 256 && (table_cap & (table_cap - 1)) == 0, "bs_tsdf_mesh: table_cap must be a power of two >= 256");
+    BS_REQUIRE((vertices == nullptr) == (unit_offset == nullptr) && (vertices == nullptr) == (colors == nullptr) &&
+                   (vertices == nullptr) == (vertex_keys == nullptr),
+               "bs_tsdf_mesh: the write pass needs unit_offset, vertices, colors and vertex_keys; the count pass none of them");
+    const int nvox = res * res * res;
+    BS_REQUIRE((long long)cdiv(nvox, 256) * units < 0x7fffffffll, "bs_tsdf_mesh: too many units for one launch");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    BS_CHECK_HIP(hipMemsetAsync(unit_count, 0, sizeof(int32_t) * units, st));
+    const dim3 grid((unsigned)(cdiv(nvox, 256) * units));
+    const long long* keys = reinterpret_cast<const long long*>(table_keys);
+    if (!vertices)
+        hipLaunchKernelGGL(tsdf_mesh_kernel<false>, grid, dim3(256), 0, st, unit_index, keys, table_slots, (unsigned)(table_cap - 1), slab_base, slab_units,
+                           res, voxel_length, mc_tab, tri_width, unit_count, unit_offset, vertices, colors, (long long*)nullptr, err);
+    else
+        hipLaunchKernelGGL(tsdf_mesh_kernel<true>, grid, dim3(256), 0, st, unit_index, keys, table_slots, (unsigned)(table_cap - 1), slab_base, slab_units,
+                           res, voxel_length, mc_tab, tri_width, unit_count, unit_offset, vertices, colors, reinterpret_cast<long long*>(vertex_keys), err);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }

@@ -75,6 +75,9 @@ class CyclePoseEngine:
         w["d1.w"], w["d1.b"] = f(g("pose_dense.1.weight")), f(g("pose_dense.1.bias"))
         w["d2.w"], w["d2.b"] = f(g("pose_dense.3.weight")), f(g("pose_dense.3.bias"))
 
+    # (keyed by the number of map positions h' * w', as the reference's lazily created Linear(512 + 256 h' w', 7) is: the flattened NCHW
+    # feature index c * h'w' + p only knows the row-major position p, which is the row of the [7][h'w'][C] layout for every (h', w')
+    # of that product)
     def add_skip(self, weight: torch.Tensor, bias: torch.Tensor) -> int:
         """Register a skip_linear weight [7, 512 + 256*h*w] (h x w = the stride-4 map of the network input); returns h*w."""
         ws = weight.detach().float()

@@ -122,13 +122,21 @@ class PoseGraph:
         L = np.stack([e.information for e in g.edges])
         unc = np.array([e.uncertain for e in g.edges])
         X, lw, log = self._levenberg_marquardt(X, src, tgt, Tinv, L, unc)
+        # edges the line process switched off are dropped (uncertain ones only) and the pruned graph is optimised again: Open3D's
+        # global_optimization runs optimise -> prune -> optimise
+        keep = (~unc) | (lw >= self.edge_prune_threshold)
+        if not keep.all():
+            for e, w_ in zip(g.edges, lw):
+                e.weight = float(w_)
+            g.edges = [e for e, k in zip(g.edges, keep) if k]
+            X, lw2, log2 = self._levenberg_marquardt(X, src[keep], tgt[keep], Tinv[keep], L[keep], unc[keep])
+            log = log + log2 if isinstance(log, list) and isinstance(log2, list) else log2
+            lw = lw2
         self.last_log = log
         for n, P in zip(g.nodes, X):
             n.pose = P
         for e, w_ in zip(g.edges, lw):
             e.weight = float(w_)
-        # edges the line process switched off are dropped (uncertain ones only), as Open3D does after the optimisation
-        g.edges = [e for e in g.edges if (not e.uncertain) or e.weight >= self.edge_prune_threshold]
 
     # ---- Levenberg-Marquardt with line processes ------------------------------------------------
     def _levenberg_marquardt(self, X, src, tgt, Tinv, L, unc):

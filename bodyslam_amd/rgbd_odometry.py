@@ -2,20 +2,26 @@
 ``rgbd_odometry_multi_scale(curr, prev, intrinsic, init, 1000.0, depth_max, [20, 10, 5], Method.Hybrid)``
 (BodySLAM_not_refactored/3DM/visual_odometry.py:97-120): the relative pose between two RGB-D frames.
 
-Open3D is not vendored and not installable offline, so this is not a restatement of its source but an implementation of the same
-published scheme -- hybrid photometric + geometric Gauss-Newton on a 3-level pyramid, coarse to fine with 20 / 10 / 5 iterations,
-Huber losses, 0.07 m depth outlier gate (the defaults of Open3D's OdometryLossParams) -- stated precisely in
-oracle/rgbd_odometry_ref.py; parity with Open3D is unpinned.  One deliberate difference: the target images are sampled
-bilinearly, not at the nearest pixel -- with nearest-pixel sampling the cost is piecewise constant and the Gauss-Newton steps are
-rounding noise at the sub-pixel motions of consecutive endoscopy frames (measured on rendered scenes).
+Open3D is not vendored and not installable offline; the algorithm is restated in oracle/rgbd_odometry_ref.py from the published
+structure of its tensor hybrid odometry (parity with Open3D unpinned): intensity = grey / 255, depth = raw / depth_scale with values
+<= 0 or > depth_max invalid, a 3-level pyramid ([1 4 6 4 1]^2 / 256; depth: the weights over the neighbours within 2 * 0.07 m of the
+centre), target Sobel gradients / 8, coarse to fine with 20 / 10 / 5 Gauss-Newton iterations on the photometric + geometric
+residuals, 0.07 m depth outlier gate, Huber deltas 0.1 / 0.05.
 
-The images, pyramids, gradients, the 29 sums of every Gauss-Newton step, the 6x6 solve and the pose update all run in the kernels of
-csrc/odometry.hip: a pair is 35 x 3 launches with no host round trip until the pose is read back.  ``RGBDOdometry()(curr_rgbd, prev_rgbd)`` returns what
-``_compute_vo_o3d`` returns: the inverse of the estimated source -> target transform."""
+``association="nearest"`` (the default, the faithful mode): the target images and gradients are read at the NEAREST pixel of the
+projected source point, and the robust step has Open3D's form (J^T J unweighted, J^T applied to the Huber-clipped residual).
+``association="bilinear"`` (round 2's variant, kept as an option): the target is sampled bilinearly and the step is IRLS-weighted --
+a smooth cost, which on sub-pixel motions converges to the micrometre where the nearest-pixel cost is piecewise constant.
+
+Everything runs in the kernels of csrc/odometry.hip.  Two ways to call it:
+  * ``RGBDOdometry()(curr_rgbd, prev_rgbd)`` -- what ``_compute_vo_o3d`` returns (the inverse of source -> target), one pair at a time;
+  * ``track(color, depth)`` -- a stream of consecutive frames: each frame's pyramid and gradients are built ONCE (it is the source of
+    one pair and the target of the next), the 11 + 70 launches of a frame are captured in a HIP graph and replayed, and the pose
+    stays on the device, so a sequence is tracked without a host round trip per pair."""
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Sequence
+from typing import List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -24,6 +30,7 @@ from . import _lib as L
 
 DEPTH_OUTLIER_TRUNC, DEPTH_HUBER, INTENSITY_HUBER = 0.07, 0.05, 0.1      # o3d.t.pipelines.odometry.OdometryLossParams defaults
 ITERATIONS = (20, 10, 5)                                                   # visual_odometry.py:103-107, coarse -> fine
+FLAG_NEAREST, FLAG_O3D_LOSS = 1, 2
 
 
 def se3_exp(delta: np.ndarray) -> np.ndarray:
@@ -42,43 +49,74 @@ def se3_exp(delta: np.ndarray) -> np.ndarray:
 
 
 class _Level:
-    __slots__ = ("H", "W", "K", "I", "D", "gIx", "gIy", "gDx", "gDy")
+    __slots__ = ("H", "W", "K", "Kc", "I", "D", "gIx", "gIy", "gDx", "gDy")
 
 
 class RGBDOdometry:
-    def __init__(self, K: Sequence[float], device: int = 0, iterations: Sequence[int] = ITERATIONS):
-        """K = (fx, fy, cx, cy) of the full-resolution frames"""
+    def __init__(self, K: Sequence[float], device: int = 0, iterations: Sequence[int] = ITERATIONS, association: str = "nearest",
+                 loss: Optional[str] = None):
+        """K = (fx, fy, cx, cy) of the full-resolution frames.  association: "nearest" (Open3D's, default) | "bilinear";
+        loss: "o3d" | "irls" (default: "o3d" with nearest, "irls" with bilinear)"""
+        assert association in ("nearest", "bilinear")
+        loss = loss or ("o3d" if association == "nearest" else "irls")
+        assert loss in ("o3d", "irls")
         self.K = tuple(float(v) for v in K)
         self.dev = torch.device("cuda", device)
         self.iterations = tuple(int(i) for i in iterations)
+        self.association, self.loss = association, loss
+        self.flags = (FLAG_NEAREST if association == "nearest" else 0) | (FLAG_O3D_LOSS if loss == "o3d" else 0)
         L.init(device)
         self.last_trace = None
+        self._trk = None
 
     # ---- device-side image preparation ---------------------------------------------------------------
-    def _pyramid(self, color_u8, depth_m, depth_max: float, gradients: bool):
+    def _alloc_levels(self, H: int, W: int) -> List[_Level]:
+        """the six maps of every pyramid level as views of ONE flat buffer (a frame's whole state moves with one copy)"""
+        shapes = []
+        h, w, k = H, W, self.K
+        for _ in range(len(self.iterations)):
+            shapes.append((h, w, k))
+            h, w, k = (h + 1) // 2, (w + 1) // 2, tuple(v / 2.0 for v in k)
+        flat = torch.empty(sum(6 * a * b for a, b, _ in shapes), device=self.dev, dtype=torch.float32)
+        levels, off = [], 0
+        for (h, w, k) in shapes:
+            lv = _Level()
+            lv.H, lv.W, lv.K, lv.Kc = h, w, k, np.array(k, dtype=np.float64)
+            maps = []
+            for _ in range(6):
+                maps.append(flat[off:off + h * w].view(h, w))
+                off += h * w
+            lv.I, lv.D, lv.gIx, lv.gIy, lv.gDx, lv.gDy = maps
+            levels.append(lv)
+        self._last_flat = flat
+        return levels
+
+    def _build(self, levels: List[_Level], color: torch.Tensor, depth: torch.Tensor, depth_max: float, gradients: bool = True):
         lib, st = L.load_library(), L.stream_ptr()
-        color, depth = self._dev(color_u8, torch.uint8), self._dev(depth_m, torch.float32)      # numpy, host or device tensors
-        H, W = depth.shape
-        levels = []
-        lv = _Level()
-        lv.H, lv.W, lv.K = H, W, self.K
-        lv.I, lv.D = torch.empty(H, W, device=self.dev), torch.empty(H, W, device=self.dev)
-        L.check(lib.bs_odo_prepare(L.p(color), L.p(depth), H, W, float(depth_max), L.p(lv.I), L.p(lv.D), st), "bs_odo_prepare")
-        levels.append(lv)
-        for _ in range(len(self.iterations) - 1):
-            p = levels[-1]
-            n = _Level()
-            n.H, n.W, n.K = (p.H + 1) // 2, (p.W + 1) // 2, tuple(v / 2.0 for v in p.K)
-            n.I, n.D = torch.empty(n.H, n.W, device=self.dev), torch.empty(n.H, n.W, device=self.dev)
+        l0 = levels[0]
+        L.check(lib.bs_odo_prepare(L.p(color), L.p(depth), l0.H, l0.W, float(depth_max), L.p(l0.I), L.p(l0.D), st), "bs_odo_prepare")
+        for p, n in zip(levels[:-1], levels[1:]):
             L.check(lib.bs_odo_pyrdown(L.p(p.I), p.H, p.W, L.p(n.I), 0, 0.0, st), "bs_odo_pyrdown")
             L.check(lib.bs_odo_pyrdown(L.p(p.D), p.H, p.W, L.p(n.D), 1, 2.0 * DEPTH_OUTLIER_TRUNC, st), "bs_odo_pyrdown")
-            levels.append(n)
         if gradients:
             for lv in levels:
-                lv.gIx, lv.gIy, lv.gDx, lv.gDy = (torch.empty(lv.H, lv.W, device=self.dev) for _ in range(4))
                 L.check(lib.bs_odo_sobel(L.p(lv.I), lv.H, lv.W, L.p(lv.gIx), L.p(lv.gIy), st), "bs_odo_sobel")
                 L.check(lib.bs_odo_sobel(L.p(lv.D), lv.H, lv.W, L.p(lv.gDx), L.p(lv.gDy), st), "bs_odo_sobel")
+
+    def _pyramid(self, color_u8, depth_m, depth_max: float, gradients: bool):
+        color, depth = self._dev(color_u8, torch.uint8), self._dev(depth_m, torch.float32)      # numpy, host or device tensors
+        levels = self._alloc_levels(*depth.shape)
+        self._build(levels, color, depth, depth_max, gradients)
         return levels
+
+    def _steps(self, ps: List[_Level], pt: List[_Level], T_dev: torch.Tensor, partial: torch.Tensor, out: torch.Tensor):
+        """the coarse-to-fine loop on the device: sum(iterations) x (sums kernel, fixed-order reduction + 6x6 solve + pose update)"""
+        lib, st = L.load_library(), L.stream_ptr()
+        for level, iters in zip(range(len(ps) - 1, -1, -1), self.iterations):
+            s, t = ps[level], pt[level]
+            L.check(lib.bs_odo_step(L.p(s.I), L.p(s.D), L.p(t.I), L.p(t.D), L.p(t.gIx), L.p(t.gIy), L.p(t.gDx), L.p(t.gDy), s.H, s.W,
+                                    s.Kc.ctypes.data_as(C.c_void_p), L.p(T_dev), iters, DEPTH_OUTLIER_TRUNC, DEPTH_HUBER, INTENSITY_HUBER,
+                                    L.p(partial), L.p(out), self.flags, st), "bs_odo_step")
 
     # ---- the estimate ----------------------------------------------------------------------------------
     def estimate(self, src_color, src_depth, tgt_color, tgt_depth, depth_max: float, init: Optional[np.ndarray] = None, trace: bool = False):
@@ -88,40 +126,29 @@ class RGBDOdometry:
         pt = self._pyramid(tgt_color, tgt_depth, depth_max, gradients=True)
         T = np.eye(4) if init is None else np.array(init, dtype=np.float64)
         out = torch.zeros(29, dtype=torch.float64, device=self.dev)
+        partial = torch.empty((ps[0].H * ps[0].W + 255) // 256, 29, dtype=torch.float64, device=self.dev)
         if not trace:
-            # the whole coarse-to-fine loop on the device: 35 x (sums, fixed-order reduction, 6x6 solve + pose update), no host
-            # round trip until the pose is read back.  trace=True below walks the same steps from the host (tests, diagnostics).
-            partial = torch.empty((ps[0].H * ps[0].W + 255) // 256, 29, dtype=torch.float64, device=self.dev)
+            # no host round trip until the pose is read back; trace=True below walks the same steps from the host (tests, diagnostics)
             T_dev = torch.from_numpy(np.ascontiguousarray(T[:3].reshape(12))).to(self.dev)
-            keep = []
-            for level, iters in zip(range(len(ps) - 1, -1, -1), self.iterations):
-                s, t = ps[level], pt[level]
-                Kl = np.array(s.K, dtype=np.float64)
-                keep.append(Kl)
-                L.check(lib.bs_odo_step(L.p(s.I), L.p(s.D), L.p(t.I), L.p(t.D), L.p(t.gIx), L.p(t.gIy), L.p(t.gDx), L.p(t.gDy), s.H, s.W,
-                                        Kl.ctypes.data_as(C.c_void_p), L.p(T_dev), iters, DEPTH_OUTLIER_TRUNC, DEPTH_HUBER, INTENSITY_HUBER,
-                                        L.p(partial), L.p(out), st), "bs_odo_step")
+            self._steps(ps, pt, T_dev, partial, out)
             T[:3] = T_dev.cpu().numpy().reshape(3, 4)
             self.last_trace = None
             return T
-        partial = torch.empty((ps[0].H * ps[0].W + 255) // 256, 29, dtype=torch.float64, device=self.dev)
         iu = np.triu_indices(6)
-        log = [] if trace else None
+        log = []
         for level, iters in zip(range(len(ps) - 1, -1, -1), self.iterations):
             s, t = ps[level], pt[level]
-            Kl = np.array(s.K, dtype=np.float64)
             for _ in range(iters):
                 T12 = np.ascontiguousarray(T[:3].reshape(12))
                 L.check(lib.bs_odo_accumulate(L.p(s.I), L.p(s.D), L.p(t.I), L.p(t.D), L.p(t.gIx), L.p(t.gIy), L.p(t.gDx), L.p(t.gDy), s.H, s.W,
-                                              Kl.ctypes.data_as(C.c_void_p), T12.ctypes.data_as(C.c_void_p), DEPTH_OUTLIER_TRUNC, DEPTH_HUBER,
-                                              INTENSITY_HUBER, L.p(partial), L.p(out), st), "bs_odo_accumulate")
-                r = out.cpu().numpy()                    # (synchronises: T12 / Kl outlive the launch)
+                                              s.Kc.ctypes.data_as(C.c_void_p), T12.ctypes.data_as(C.c_void_p), DEPTH_OUTLIER_TRUNC, DEPTH_HUBER,
+                                              INTENSITY_HUBER, L.p(partial), L.p(out), self.flags, st), "bs_odo_accumulate")
+                r = out.cpu().numpy()                    # (synchronises: T12 / Kc outlive the launch)
                 A = np.zeros((6, 6))
                 A[iu] = r[:21]
                 A = A + np.triu(A, 1).T
                 b, res, n = r[21:27], float(r[27]), int(round(r[28]))
-                if log is not None:
-                    log.append((level, A.copy(), b.copy(), res, n))
+                log.append((level, A.copy(), b.copy(), res, n))
                 if n < 6:
                     break
                 T = se3_exp(np.linalg.solve(A + 1e-12 * np.eye(6), -b)) @ T
@@ -134,6 +161,65 @@ class RGBDOdometry:
         dmax = max(self._depth_max(curr_rgbd), self._depth_max(prev_rgbd))
         T = self.estimate(curr_rgbd.color, curr_rgbd.depth, prev_rgbd.color, prev_rgbd.depth, dmax)
         return np.linalg.inv(T)
+
+    # ---- a stream of consecutive frames --------------------------------------------------------------
+    def reset(self):
+        """forget the previous frame of track()"""
+        if self._trk is not None:
+            self._trk["have_prev"] = False
+
+    def track(self, color_u8: torch.Tensor, depth_m: torch.Tensor, graph: bool = True) -> Optional[torch.Tensor]:
+        """The next frame of a sequence (device tensors: color uint8 [H, W, 3], depth fp32 metres [H, W]).  Returns None for the first
+        frame, then a fresh device tensor: the 12 doubles (rows 0..2) of T(current -> previous), as ``estimate(current, previous)``
+        gives them -- nothing is read back to the host here.  depth_max of the pair is max(depth of either frame)
+        (visual_odometry.py:99), which invalidates nothing, so the frames are prepared once and the previous frame's pyramid is
+        reused as the target."""
+        assert color_u8.is_cuda and depth_m.is_cuda and color_u8.dtype == torch.uint8 and depth_m.dtype == torch.float32
+        H, W = depth_m.shape
+        k = self._trk
+        if k is None or k["hw"] != (H, W):
+            prev = self._alloc_levels(H, W)
+            prev_flat = self._last_flat
+            cur = self._alloc_levels(H, W)
+            cur_flat = self._last_flat
+            k = self._trk = dict(hw=(H, W), prev=prev, cur=cur, prev_flat=prev_flat, cur_flat=cur_flat, have_prev=False, graph=None, warm=False,
+                                 color=torch.empty(H, W, 3, dtype=torch.uint8, device=self.dev), depth=torch.empty(H, W, device=self.dev),
+                                 T=torch.zeros(12, dtype=torch.float64, device=self.dev),
+                                 T0=torch.tensor([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=torch.float64, device=self.dev),
+                                 partial=torch.empty((H * W + 255) // 256, 29, dtype=torch.float64, device=self.dev),
+                                 out=torch.zeros(29, dtype=torch.float64, device=self.dev))
+        k["color"].copy_(color_u8)
+        k["depth"].copy_(depth_m)
+        if not k["have_prev"]:
+            self._build(k["prev"], k["color"], k["depth"], 3.0e38)
+            k["have_prev"] = True
+            return None
+
+        def pair():
+            k["T"].copy_(k["T0"])
+            self._build(k["cur"], k["color"], k["depth"], 3.0e38)
+            self._steps(k["cur"], k["prev"], k["T"], k["partial"], k["out"])
+            k["prev_flat"].copy_(k["cur_flat"])                 # the current frame becomes the next pair's target
+
+        if not graph:
+            pair()
+        elif k["graph"] is None and not k["warm"]:
+            pair()                                              # first pair eagerly (lazy one-off initialisations), the second is captured
+            k["warm"] = True
+        elif k["graph"] is None:
+            torch.cuda.synchronize(self.dev)
+            g = torch.cuda.CUDAGraph()
+            cap = torch.cuda.Stream(device=self.dev)
+            cap.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(cap):
+                with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
+                    pair()
+            torch.cuda.current_stream(self.dev).wait_stream(cap)
+            k["graph"] = g
+            g.replay()
+        else:
+            k["graph"].replay()
+        return k["T"].clone()
 
     def _dev(self, x, dtype) -> torch.Tensor:
         t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(x)))

@@ -10,7 +10,9 @@ unit is 3.2 cm wide and a point opens the ~7^3 units within 0.1 m of it; a 640x4
 = 1 GB of voxel state and takes ~1 ms (measured, tools/probes/tsdf_full_size.py: unit discovery 0.1 ms, integrate kernel 0.27 ms),
 metre-scale scenes proportionally more: the voxel store is sized for 288 GB of HBM.  Open3D is not vendored and not installable offline: parity against it is unpinned (oracle/tsdf_ref.py
 restates the same algorithm in numpy; tests/ compare the two).  ``extract_pcd`` returns points, colours and normals, as Open3D's
-``extract_point_cloud``.  Not built: ``extract_mesh`` / ``save_mesh`` (marching cubes) -- they raise NotImplementedError.
+``extract_point_cloud``; ``extract_mesh`` / ``save_mesh`` (tsdf.py:42-52, called on the last frame at 3DM/slam.py:189-193) run marching
+cubes over every voxel cube on the device (bs_tsdf_mesh) with the case table of bodyslam_amd/marching_cubes.py and merge the
+vertices of shared cube edges on the host.
 """
 from __future__ import annotations
 
@@ -62,6 +64,13 @@ class PointCloud:
     normals: Optional[np.ndarray] = None    # [M, 3] float32, unit length (zero where the tsdf gradient vanishes)
 
 
+@dataclass
+class TriangleMesh:
+    vertices: np.ndarray                    # [V, 3] float32
+    vertex_colors: np.ndarray               # [V, 3] float32 in [0, 1]
+    triangles: np.ndarray                   # [T, 3] int32, wound so that the normal points from tsdf < 0 to tsdf > 0
+
+
 _OFF = 1 << 20              # unit indices are packed as three 21-bit fields (csrc/tsdf.hip ts_pack)
 
 
@@ -94,9 +103,47 @@ class TSDF:
         self.counters = torch.zeros(3, dtype=torch.int32, device=d)
         self.touched = torch.zeros(self.max_units, dtype=torch.int32, device=d)
         self.n_units, self.frame_id = 0, 0
+        self._max_new_per_frame, self._frames_since_sync = 0, 0
+
+    # ---- block capacity ------------------------------------------------------------------------------
+    @property
+    def alloc_units(self) -> int:
+        """blocks that exist (zero-filled slabs): the unit table never hands out more"""
+        return min(len(self.slabs) * self.slab_units, self.max_units)
+
+    def reserve(self, units: int) -> None:
+        """make sure at least `units` blocks exist (new slabs are allocated and zero-filled here, not inside a frame)"""
+        units = min(int(units), self.max_units)
+        while len(self.slabs) * self.slab_units < units:
+            self.slabs.append(torch.zeros(self.slab_units, self.unit_floats, device=self.dev))
+            self.slab_base[len(self.slabs) - 1] = self.slabs[-1].data_ptr()
+
+    def reserve_ahead(self, n_frames: int) -> None:
+        """capacity for `n_frames` un-synchronised frames: the known unit count plus, per frame, twice the most units one frame has
+        opened so far (at least 2048, the order a 640x480 endoscopic frame touches)"""
+        self.reserve(self.n_units + n_frames * max(2048, 2 * self._max_new_per_frame))
+
+    def n_units_known(self) -> int:
+        return self.n_units
+
+    def sync(self):
+        """the round trip a stream of build_3D_map(sync=False) calls owes: unit counts, and the overflow check"""
+        n_units, n_touched, overflow = (int(v) for v in self.counters.cpu())
+        if overflow:
+            self.counters[2] = 0
+            raise L.BodySlamHipError("TSDF: " + ("unit table full" if overflow == 1 else
+                                                 f"a frame needed more than the {self.alloc_units} blocks that existed (reserve() more ahead of a "
+                                                 f"stream, or raise max_units={self.max_units})"))
+        self._max_new_per_frame = max(self._max_new_per_frame, (n_units - self.n_units) // max(self._frames_since_sync, 1) + 1)
+        self._frames_since_sync = 0
+        self.n_units, self.last_units = n_units, n_touched
+        return n_units, n_touched
 
     # ---- the reference's surface -----------------------------------------------------------------
-    def build_3D_map(self, rgbd: RGBDImage, intrinsic: PinholeCameraIntrinsic, extrinsic) -> None:
+    def build_3D_map(self, rgbd: RGBDImage, intrinsic: PinholeCameraIntrinsic, extrinsic, sync: bool = True) -> None:
+        """ScalableTSDFVolume.integrate(rgbd, intrinsic, extrinsic).  sync=True (one frame at a time, as the reference calls it): the
+        unit count is read back (12 bytes) and slabs are added on demand.  sync=False: nothing is read back -- the frame is enqueued
+        against the blocks that exist (reserve / reserve_ahead) and ``sync()`` later collects the counts and the overflow flag."""
         d_dev = (rgbd.depth if isinstance(rgbd.depth, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(rgbd.depth, dtype=np.float32))))
         d_dev = d_dev.to(device=self.dev, dtype=torch.float32).contiguous()                    # numpy, host or device tensors
         H, W = d_dev.shape
@@ -109,27 +156,50 @@ class TSDF:
             c_dev = rgbd.color if isinstance(rgbd.color, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(rgbd.color, dtype=np.uint8)))
             c_dev = c_dev.to(device=self.dev, dtype=torch.uint8).contiguous()
         lib, st = L.load_library(), L.stream_ptr()
+        if not self.slabs:
+            self.reserve(1)
+
+        def touch():
+            self.frame_id += 1
+            L.check(lib.bs_tsdf_touch(L.p(d_dev), H, W, self.stride, K.ctypes.data_as(C.c_void_p), pose12.ctypes.data_as(C.c_void_p), self.unit_length,
+                                      self.sdf_trunc, L.p(self.table_keys), L.p(self.table_slots), L.p(self.table_stamp), self.table_cap, self.frame_id,
+                                      L.p(self.unit_index), self.alloc_units, L.p(self.counters), L.p(self.touched), st), "bs_tsdf_touch")
+
+        def integrate(n_hint):
+            # (K / pose are copied into the kernel arguments at launch: nothing here has to outlive the call)
+            L.check(lib.bs_tsdf_integrate(L.p(d_dev), L.p(c_dev), H, W, K.ctypes.data_as(C.c_void_p), e12.ctypes.data_as(C.c_void_p), L.p(self.unit_index),
+                                          L.p(self.touched), n_hint, L.p(self.slab_base), self.slab_units, self.res, self.voxel_length, self.sdf_trunc,
+                                          L.p(self.counters[1:]), st), "bs_tsdf_integrate")
+
+        self._frames_since_sync += 1
+        if not sync:
+            touch()
+            integrate(self.alloc_units)
+            return
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        self.frame_id += 1
         ev[0].record()
-        L.check(lib.bs_tsdf_touch(L.p(d_dev), H, W, self.stride, K.ctypes.data_as(C.c_void_p), pose12.ctypes.data_as(C.c_void_p), self.unit_length,
-                                  self.sdf_trunc, L.p(self.table_keys), L.p(self.table_slots), L.p(self.table_stamp), self.table_cap, self.frame_id,
-                                  L.p(self.unit_index), self.max_units, L.p(self.counters), L.p(self.touched), st), "bs_tsdf_touch")
+        touch()
         ev[1].record()
-        n_units, n_touched, overflow = (int(v) for v in self.counters.cpu())          # the one host round trip of the step (12 bytes)
+        while True:
+            n_units, n_touched, overflow = (int(v) for v in self.counters.cpu())          # the one host round trip of the step (12 bytes)
+            if overflow == 2 and self.alloc_units < self.max_units:
+                # more new units than blocks existed: add slabs and discover again (a fresh frame id re-stamps this frame's units)
+                self.counters[2] = 0
+                self.reserve(max(2 * self.alloc_units, self.alloc_units + self.slab_units))
+                touch()
+                continue
+            break
         if overflow:
+            self.counters[2] = 0
             raise L.BodySlamHipError("TSDF: " + ("unit table full" if overflow == 1 else f"more than max_units={self.max_units} volume units")
                                      + "; construct TSDF with a larger max_units")
-        while len(self.slabs) * self.slab_units < n_units:                              # new units: more zero-filled slabs
-            self.slabs.append(torch.zeros(self.slab_units, self.unit_floats, device=self.dev))
-            self.slab_base[len(self.slabs) - 1] = self.slabs[-1].data_ptr()
+        self._max_new_per_frame = max(self._max_new_per_frame, n_units - self.n_units)
+        self._frames_since_sync = 0
         self.n_units, self.last_units = n_units, n_touched
         ev[2].record()
-        L.check(lib.bs_tsdf_integrate(L.p(d_dev), L.p(c_dev), H, W, K.ctypes.data_as(C.c_void_p), e12.ctypes.data_as(C.c_void_p), L.p(self.unit_index),
-                                      L.p(self.touched), n_touched, L.p(self.slab_base), self.slab_units, self.res, self.voxel_length, self.sdf_trunc,
-                                      st), "bs_tsdf_integrate")
+        integrate(max(n_touched, 1))
         ev[3].record()
-        torch.cuda.current_stream(self.dev).synchronize()          # (the host arrays above must outlive the launches)
+        ev[3].synchronize()
         self.last_touch_ms, self.last_kernel_ms = ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3])      # diagnostics
 
     def build_copy_3D_map(self, rgbd, intrinsic, extrinsic) -> "TSDF":
@@ -164,11 +234,40 @@ class TSDF:
     def save_pcd(self, saving_path: str) -> None:
         write_ply(saving_path, self.extract_pcd())
 
-    def extract_mesh(self):
-        raise NotImplementedError("extract_triangle_mesh (marching cubes) is not built; extract_pcd / save_pcd are")
+    def extract_mesh(self) -> TriangleMesh:
+        """ScalableTSDFVolume.extract_triangle_mesh(): marching cubes over every voxel cube whose eight corners carry weight"""
+        from . import marching_cubes as MC
+        U = self.n_units
+        if U == 0:
+            return TriangleMesh(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32))
+        if getattr(self, "_mc_tab", None) is None:
+            tab = np.concatenate([MC.TRI_TABLE.reshape(-1), np.array(MC.EDGES, dtype=np.int32).reshape(-1)]).astype(np.int32)
+            self._mc_tab = torch.from_numpy(tab).to(self.dev)
+        lib = L.load_library()
+        count = torch.zeros(U, dtype=torch.int32, device=self.dev)
+        err = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        args = (L.p(self.unit_index), U, L.p(self.table_keys), L.p(self.table_slots), self.table_cap, L.p(self.slab_base), self.slab_units, self.res,
+                self.voxel_length, L.p(self._mc_tab), int(MC.TRI_TABLE.shape[1]), L.p(count))
+        L.check(lib.bs_tsdf_mesh(*args, None, None, None, None, L.p(err), L.stream_ptr()), "bs_tsdf_mesh")
+        counts = count.cpu().numpy().astype(np.int64)
+        total = int(counts.sum())
+        if total == 0:
+            return TriangleMesh(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32))
+        off = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)).to(self.dev)
+        verts = torch.empty(3 * total, 3, device=self.dev)
+        cols = torch.empty(3 * total, 3, device=self.dev)
+        keys = torch.empty(3 * total, dtype=torch.int64, device=self.dev)
+        L.check(lib.bs_tsdf_mesh(*args, L.p(off), L.p(verts), L.p(cols), L.p(keys), L.p(err), L.stream_ptr()), "bs_tsdf_mesh")
+        if int(err.cpu()):
+            raise L.BodySlamHipError("TSDF.extract_mesh: the map spans more than 2^20 voxels along an axis (vertex identity overflow)")
+        # equal edge identities are one vertex (every cube that shares the edge computed the same position)
+        uniq, first, inverse = np.unique(keys.cpu().numpy(), return_index=True, return_inverse=True)
+        v = verts.cpu().numpy()[first]
+        c = cols.cpu().numpy()[first]
+        return TriangleMesh(v, c, inverse.reshape(-1, 3).astype(np.int32))
 
     def save_mesh(self, saving_path: str) -> None:
-        self.extract_mesh()
+        write_ply_mesh(saving_path, self.extract_mesh())
 
     # ---- views of the device state (tests, diagnostics) ---------------------------------------------
     @staticmethod
@@ -204,3 +303,23 @@ def write_ply(path: str, pcd: PointCloud) -> None:
         f.write((f"ply\nformat binary_little_endian 1.0\ncomment bodyslam_amd TSDF point cloud\nelement vertex {n}\n" + props +
                  "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n").encode("ascii"))
         f.write(rec.tobytes())
+
+
+def write_ply_mesh(path: str, mesh: TriangleMesh) -> None:
+    """binary little-endian PLY of a triangle mesh: vertices x y z (float32) red green blue (uchar), faces as uchar-counted int32 lists
+    -- what o3d.io.write_triangle_mesh writes for a .ply path (Open3D stores coordinates as doubles; the values here are fp32)"""
+    nv, nt = mesh.vertices.shape[0], mesh.triangles.shape[0]
+    vrec = np.empty(nv, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("red", "u1"), ("green", "u1"), ("blue", "u1")])
+    vrec["x"], vrec["y"], vrec["z"] = mesh.vertices[:, 0], mesh.vertices[:, 1], mesh.vertices[:, 2]
+    c = np.clip(np.rint(mesh.vertex_colors * 255.0), 0, 255).astype(np.uint8) if nv else np.zeros((0, 3), np.uint8)
+    vrec["red"], vrec["green"], vrec["blue"] = c[:, 0], c[:, 1], c[:, 2]
+    frec = np.empty(nt, dtype=[("n", "u1"), ("a", "<i4"), ("b", "<i4"), ("c", "<i4")])
+    frec["n"] = 3
+    if nt:
+        frec["a"], frec["b"], frec["c"] = mesh.triangles[:, 0], mesh.triangles[:, 1], mesh.triangles[:, 2]
+    with open(path, "wb") as f:
+        f.write((f"ply\nformat binary_little_endian 1.0\ncomment bodyslam_amd TSDF triangle mesh\nelement vertex {nv}\n"
+                 "property float x\nproperty float y\nproperty float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\n"
+                 f"element face {nt}\nproperty list uchar int vertex_indices\nend_header\n").encode("ascii"))
+        f.write(vrec.tobytes())
+        f.write(frec.tobytes())

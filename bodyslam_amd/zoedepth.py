@@ -95,7 +95,16 @@ class ZoeConfig:
 #           keeps both corrections: ~1.0 pass, 4.8e-5 / 2.6e-5 m on those two seeds, 1.7e-5 ... 6.3e-5 m over eight
 #           (profiles/r02_accurate_seeds.txt: "wcls" 1.6e-5 ... 5.6e-5, "full" <= 2.1e-5 on the same seeds)
 # The neck keeps both products (weight correction only: 0.9-2.0e-4).
-ACCURATE_CLASS_MODES: Dict[str, str] = {"qkv": "wmean", "o": "wmean", "fc1": "wmean", "fc2": "wmean"}
+# "auto" (the default): the engine measures, on the device and with the weights it was given, which of these each class tolerates
+# (ZoeDepthEngine.calibrate, run before the first plan is built): the random-weight studies above say nothing about a trained
+# checkpoint's outlier channels and layer-scale, so no fixed choice is trusted.
+BACKBONE_CLASSES = ("qkv", "o", "fc1", "fc2")
+ACCURATE_CLASS_MODES = "auto"
+AUTO_CANDIDATES = ("wmean", "wcls", "full")       # cheapest first
+AUTO_TOL_CLASS_M = 4.0e-5                        # depth L1 against the all-"full" result that ONE class may cost
+AUTO_TOL_TOTAL_M = 6.0e-5                        # ... and the chosen combination as a whole
+# neck: "full", or the list of weight-key prefixes that keep both products (the rest: weight-rounding correction only).
+NECK_RELHEAD_WONLY = "ro,ra,nc,fu,pj"            # everything but the relative head keeps both
 ACCURATE_NECK_MODE = "full"
 # Operand format of the neck's two correction products: "f8" = e4m3 planes with one scale per tensor (2 pass-equivalents, neck error
 # ~7e-6 m on its own), "f4" = e2m1 planes with one E8M0 scale per 64 channels at 4x the 16-bit MFMA rate (1.5 pass-equivalents,
@@ -176,10 +185,15 @@ class ZoeDepthEngine:
         self._plans: Dict[Tuple, "_ZoePlan"] = {}
         self._raw_tables = []
         self.f8s: Dict[str, Tuple[int, int]] = {}
-        self.class_modes = dict(ACCURATE_CLASS_MODES)
-        if os.environ.get("BS_ACCURATE_CLASS_MODE"):          # diagnostics (A/B runs of bench.py): one mode for all four classes
-            self.class_modes = {k: os.environ["BS_ACCURATE_CLASS_MODE"] for k in self.class_modes}
-        self.class_modes.update(class_modes or {})
+        cm = class_modes if class_modes is not None else (os.environ.get("BS_ACCURATE_CLASS_MODE") or ACCURATE_CLASS_MODES)
+        if isinstance(cm, str) and cm != "auto":          # one mode for all four classes (diagnostics, A/B runs of bench.py)
+            cm = {k: cm for k in BACKBONE_CLASSES}
+        # "auto": every class starts at "full" and calibrate() -- run before the first plan is built -- lowers what the weights allow
+        self.auto_modes = self.acc and isinstance(cm, str)
+        self.calibration: Optional[dict] = None
+        self.class_modes = {k: "full" for k in BACKBONE_CLASSES}
+        if isinstance(cm, dict):
+            self.class_modes.update(cm)
         assert all(v in ("full", "w", "wcls", "wmean", "a", "single") for v in self.class_modes.values()), self.class_modes
         self.single_keys = set()
         self.wmode: Dict[str, str] = {}
@@ -233,9 +247,98 @@ class ZoeDepthEngine:
         w8, sb = L.f8_weight(t, self.dtype, planes={"full": "both", "wcls": "both", "wmean": "both", "w": "lo", "a": "hi_only"}[mode])
         self.f8s[key] = sb
         self.wmode[key] = mode
-        if mode == "wmean":        # dW = W - round16(W) as bf16 (fp32's exponent range): the W operand of the rank-1 correction GEMM
+        if key[0] == "l" and mode in ("full", "wcls", "wmean"):
+            # "full" / "wcls" / "wmean" read the same packed rows; "wmean" also needs dW = W - round16(W) as bf16 (fp32's exponent
+            # range), the W operand of the rank-1 correction GEMM: kept for all three, so the mode is a PLAN-time choice
+            # (set_class_modes / calibrate) and not a re-ingestion
             self.w[key + ".lo"] = (t - t.to(self.dtype).float()).to(torch.bfloat16).to(self.dev).contiguous()
         return w8.to(self.dev)
+
+    def mode_of(self, wkey: str) -> Optional[str]:
+        """correction mode of a weight at plan time: a backbone class packed for the switchable modes follows class_modes"""
+        m = self.wmode.get(wkey)
+        if m in ("full", "wcls", "wmean") and wkey[0] == "l":
+            return self.class_modes.get(wkey.split(".")[-2], m)
+        return m
+
+    def set_class_modes(self, modes: Dict[str, str], neck_mode: Optional[str] = None) -> None:
+        """switch the backbone classes between "full" / "wcls" / "wmean" (and the neck mode) without re-ingesting the weights;
+        plans built so far are dropped"""
+        for k, v in modes.items():
+            assert k in BACKBONE_CLASSES and v in ("full", "wcls", "wmean"), (k, v)
+            assert self.class_modes[k] in ("full", "wcls", "wmean"), f"class {k} was ingested as {self.class_modes[k]!r}: not switchable"
+        self.class_modes.update(modes)
+        if neck_mode is not None:
+            assert not self.neck_f4 or neck_mode == "full"
+            self.neck_mode = neck_mode
+        self._plans.clear()
+
+    def calibrate(self, H: int = 480, W: int = 640, frames_u8: Optional[torch.Tensor] = None, tol_class: float = AUTO_TOL_CLASS_M,
+                  tol_total: float = AUTO_TOL_TOTAL_M) -> dict:
+        """Choose, with THESE weights on THIS device, the cheapest correction mode per backbone GEMM class (and for the neck) that keeps
+        the depth map of a calibration frame within `tol_class` metres (L1) of the all-"full" result, then check the combination
+        against `tol_total` and step the most expensive offender back up until it holds.  One B = 1 forward per candidate (about a
+        dozen plans, each dropped after use).  The report is kept in ``self.calibration`` (bench.py prints it)."""
+        assert self.acc, "calibrate() is for precision='accurate'"
+        if frames_u8 is None:
+            from .synthetic import make_sequence
+            frames_u8 = torch.from_numpy(make_sequence(1, H, W, seed=11)).to(self.dev)
+        frames_u8 = frames_u8[:1].contiguous()
+        H, W = int(frames_u8.shape[1]), int(frames_u8.shape[2])
+        switchable = [k for k in BACKBONE_CLASSES if self.class_modes[k] in ("full", "wcls", "wmean")]
+        neck_cands = ["full"] if (self.neck_f4 or not self.neck_f8) else [NECK_RELHEAD_WONLY, "full"]
+        saved_auto, self.auto_modes = self.auto_modes, False
+
+        def depth(modes, neck):
+            self.set_class_modes(modes, neck)
+            plan = _ZoePlan(self, 1, H, W, True)
+            plan.frames.copy_(frames_u8)
+            plan.run(None)
+            d = plan.depth_m.clone()
+            torch.cuda.synchronize(self.dev)
+            del plan
+            return d
+
+        full = {k: "full" for k in switchable}
+        ref = depth(full, "full")
+        report = {"frame": f"{H}x{W}", "tol_class_m": tol_class, "tol_total_m": tol_total, "l1_vs_full_m": {}}
+        chosen, cost = dict(full), {}
+        for k in switchable:
+            for cand in AUTO_CANDIDATES:
+                if cand == "full":
+                    chosen[k], cost[k] = "full", 0.0
+                    break
+                l1 = (depth({**full, k: cand}, "full") - ref).abs().mean().item()
+                report["l1_vs_full_m"][f"{k}:{cand}"] = l1
+                if l1 <= tol_class:
+                    chosen[k], cost[k] = cand, l1
+                    break
+        neck = "full"
+        for cand in neck_cands:
+            if cand == "full":
+                break
+            l1 = (depth(full, cand) - ref).abs().mean().item()
+            report["l1_vs_full_m"][f"neck:{cand}"] = l1
+            if l1 <= tol_class:
+                neck, cost["neck"] = cand, l1
+                break
+        # the combination
+        while True:
+            total = (depth(chosen, neck) - ref).abs().mean().item() if (any(v != "full" for v in chosen.values()) or neck != "full") else 0.0
+            if total <= tol_total:
+                break
+            worst = max(cost, key=lambda k_: cost[k_])               # step the largest single contribution back up
+            if worst == "neck":
+                neck = "full"
+            else:
+                chosen[worst] = AUTO_CANDIDATES[min(AUTO_CANDIDATES.index(chosen[worst]) + 1, len(AUTO_CANDIDATES) - 1)]
+            cost[worst] = 0.0 if (worst == "neck" or chosen[worst] == "full") else report["l1_vs_full_m"].get(f"{worst}:{chosen[worst]}", 0.0)
+        report.update(class_modes=dict(chosen), neck_mode=neck, l1_total_vs_full_m=total)
+        self.set_class_modes(chosen, neck)
+        self.auto_modes = saved_auto
+        self.calibration = report
+        torch.cuda.empty_cache()
+        return report
 
     def _w8conv(self, key: str, t: torch.Tensor) -> torch.Tensor:
         """conv weight [O, I, kh, kw] for the FP8-correction conv path (L.f8_conv_weight); scales to self.f8s[key]."""
@@ -459,6 +562,8 @@ class ZoeDepthEngine:
         return out
 
     def plan_for(self, B: int, H: int, W: int, flip: bool = True) -> "_ZoePlan":
+        if self.auto_modes and self.calibration is None:
+            self.calibrate(H, W)
         key = (B, H, W, flip)
         if key not in self._plans:
             self._plans[key] = _ZoePlan(self, B, H, W, flip)
@@ -598,7 +703,7 @@ class _ZoePlan:
         def prow(wkey):
             """dtype-argument bits of a producer whose consumer GEMM runs no FP8 stage on the patch rows ("wmean"): only the rows
             below CP (the cls tile) need their FP8 planes.  bs_layernorm: rows << 8"""
-            return (CP << 8) if (acc and grouped and fmt(wkey) == 32 and eng.wmode.get(wkey) == "wmean") else 0
+            return (CP << 8) if (acc and grouped and fmt(wkey) == 32 and eng.mode_of(wkey) == "wmean") else 0
 
         MEAN_STEP = 8      # the rank-1 correction's token mean uses every 8th patch row (probe: same depth result as the full mean)
 
@@ -608,12 +713,12 @@ class _ZoePlan:
             K segments of 16-bit (hi | lo) pairs (3 passes)."""
             if acc and wkey in single:
                 P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=K, precision_passes=1, **kw)
-            elif acc and wkey in f8s and eng.wmode.get(wkey) == "w":
+            elif acc and wkey in f8s and eng.mode_of(wkey) == "w":
                 # weight-rounding correction only: the FP8 segment is A_hi8 x W_lo8 (K bytes per row, both halves on the same scales)
                 sb0, _ = f8s[wkey]
                 P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=2 * K, f8_seg=K,
                        f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_HI_EXP, sb0), precision_passes=1, **kw)
-            elif acc and wkey in f8s and eng.wmode.get(wkey) == "wmean" and grouped:
+            elif acc and wkey in f8s and eng.mode_of(wkey) == "wmean" and grouped:
                 # cls tile: both FP8 corrections.  Patch tiles: ONE 16-bit pass; the weight-rounding error A dW^T is replaced by its
                 # token-independent part 1 (mean_tokens(A) dW^T), a per-image bias formed by a column-mean kernel over a sample of
                 # the image's patch rows and bs_rank1_bias, a [NB, K] x [K, N] product (DESIGN.md, Numerics)
@@ -627,7 +732,7 @@ class _ZoePlan:
                 free(abar, b2)
             elif acc and wkey in f8s:
                 sb0, sb1 = f8s[wkey]
-                wonly = CP if (eng.wmode.get(wkey) == "wcls" and grouped) else 0      # tiles past the cls group: weight correction only
+                wonly = CP if (eng.mode_of(wkey) == "wcls" and grouped) else 0      # tiles past the cls group: weight correction only
                 P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=2 * K, f8_seg=2 * K, f8_wonly_from=wonly,
                        f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1), precision_passes=1, **kw)
             else:
@@ -665,7 +770,7 @@ class _ZoePlan:
                   ldo=c.intermediate * am(f"l{l}.fc2.w"), out_split_off=c.intermediate if hfmt else 0,
                   out_f8=(L.F8_ACT_HI_EXP, L.F8_ACT_LO_EXP) if hfmt == 32 else None,
                   # fc2 in "wcls" mode reads the lo8 plane of its cls tile only
-                  out_lo8_rows=CP if (hfmt == 32 and grouped and eng.wmode.get(f"l{l}.fc2.w") in ("wcls", "wmean")) else 0,
+                  out_lo8_rows=CP if (hfmt == 32 and grouped and eng.mode_of(f"l{l}.fc2.w") in ("wcls", "wmean")) else 0,
                   out_planes_rows=CP if prow(f"l{l}.fc2.w") else 0)
             bgemm(f"l{l}.fc2", hid, f"l{l}.fc2.w", x, MT, Hd, c.intermediate, bias=w[f"l{l}.fc2.b"], scale=w[f"l{l}.lam2"], res=x, ldr=Hd)
             P.mark(f"layer{l + 1}", x, TOK)

@@ -344,15 +344,18 @@ int bs_pose_chain_from(const float* t_rel, int32_t N, const double* g0_dev, doub
  *   unit table  open addressing: table_keys int64 [table_cap] (-1 = empty; table_cap a power of two), table_slots int32 [table_cap]
  *               (-1 until a block is assigned), table_stamp int32 [table_cap]; unit_index int32 [max_units, 3]
  *   counters    int32 [3]: number of units (persists across calls), units touched by the last bs_tsdf_touch, overflow flag
- *               (1: table full, 2: more units than max_units -- the caller must check it before integrating)
+ *               (1: table full, 2: more new units than blocks -- sticky: set by any frame since the caller last cleared it, so a
+ *               stream of frames can be checked once at its end)
  *
  * bs_tsdf_touch: ScalableTSDFVolume::Integrate's unit discovery -- every unit that meets the +-sdf_trunc box of a point of the
  *   depth image sampled every `stride` pixels (depth fp32 [H, W] metres, <= 0 invalid; pose = rows 0..2 of the camera->world 4x4,
  *   i.e. extrinsic^-1; K = (fx, fy, cx, cy); both host doubles) is inserted, gets a block number and goes on `touched`
  *   (int32 [max_units]); frame_id must differ from call to call.
- * bs_tsdf_integrate: UniformTSDFVolume::IntegrateWithDepthToCameraDistanceMultiplier on the n_touched units of `touched`
- *   (extrinsic = rows 0..2 of the world->camera 4x4; color u8 [H, W, 3] or NULL).  The caller has made sure the slabs cover
- *   counters[0] blocks.
+ * bs_tsdf_integrate: UniformTSDFVolume::IntegrateWithDepthToCameraDistanceMultiplier on the units of `touched`
+ *   (extrinsic = rows 0..2 of the world->camera 4x4; color u8 [H, W, 3] or NULL).  Their number is read on the device from
+ *   n_touched_dev (= counters + 1); the host value n_touched only sizes the grid (any value >= 1 works), so a stream of frames is
+ *   integrated without reading anything back.  The blocks handed out must exist: bs_tsdf_touch's max_units is the number of blocks
+ *   the caller has allocated (it raises overflow flag 2 rather than hand out a block that does not exist).
  * bs_tsdf_extract: ScalableTSDFVolume::ExtractPointCloud (points, colours, normals) over blocks 0 .. units-1 in two passes:
  *   points == NULL counts into unit_count int32 [units]; otherwise unit_offset int64 [units] (exclusive prefix sums of the counts)
  *   places each unit's points, points / colors fp32 [total, 3]; normals fp32 [total, 3] or NULL: ScalableTSDFVolume::GetNormalAt,
@@ -362,10 +365,22 @@ int bs_tsdf_touch(const float* depth, int32_t H, int32_t W, int32_t stride, cons
                   int32_t* unit_index, int32_t max_units, int32_t* counters, int32_t* touched, void* stream);
 int bs_tsdf_integrate(const float* depth, const uint8_t* color, int32_t H, int32_t W, const double* K, const double* extrinsic,
                       const int32_t* unit_index, const int32_t* touched, int32_t n_touched, const int64_t* slab_base, int32_t slab_units,
-                      int32_t res, double voxel_length, double sdf_trunc, void* stream);
+                      int32_t res, double voxel_length, double sdf_trunc, const int32_t* n_touched_dev, void* stream);
 int bs_tsdf_extract(const int32_t* unit_index, int32_t units, const void* table_keys, const int32_t* table_slots, int32_t table_cap,
                     const int64_t* slab_base, int32_t slab_units, int32_t res, double voxel_length, int32_t* unit_count,
                     const int64_t* unit_offset, float* points, float* colors, float* normals, void* stream);
+
+/* ScalableTSDFVolume::ExtractTriangleMesh (BodySLAM_not_refactored/3DM/tsdf.py:42-52, called on the last frame at 3DM/slam.py:189-193):
+ * marching cubes over every voxel cube of blocks 0 .. units-1, in two passes like bs_tsdf_extract.  mc_tab (device int32) = the case
+ * table [256][tri_width] (-1 terminated lists of cube-edge ids, three per triangle) followed by the edge corners [12][2]
+ * (bodyslam_amd/marching_cubes.py: corner c at offset (c & 1, c >> 1 & 1, c >> 2 & 1), bit c of the case = tsdf < 0).  Count pass
+ * (vertices == NULL): unit_count int32 [units] = triangles per unit.  Write pass: unit_offset int64 [units] (exclusive prefix sums,
+ * in triangles); per triangle corner k of triangle t: vertices / colors fp32 [3 * total, 3] and vertex_keys int64 [3 * total], the
+ * identity of the cube edge the vertex lies on -- equal keys are one vertex of the mesh.  *err is set when a voxel coordinate does
+ * not fit the key's 20 bits per axis. */
+int bs_tsdf_mesh(const int32_t* unit_index, int32_t units, const void* table_keys, const int32_t* table_slots, int32_t table_cap,
+                 const int64_t* slab_base, int32_t slab_units, int32_t res, double voxel_length, const int32_t* mc_tab, int32_t tri_width,
+                 int32_t* unit_count, const int64_t* unit_offset, float* vertices, float* colors, int64_t* vertex_keys, int32_t* err, void* stream);
 
 /* dense RGB-D odometry (N3) -------------------------------------------------------------------- *
  * The role of Open3D's rgbd_odometry_multi_scale (Method.Hybrid, 20 / 10 / 5 iterations) at
@@ -378,7 +393,10 @@ int bs_tsdf_extract(const int32_t* unit_index, int32_t units, const void* table_
  *   bs_odo_sobel       3x3 Sobel / 8 in x and y, replicate borders, NaN propagates
  *   bs_odo_accumulate  the sums of one Gauss-Newton step at pose T: out29 = [21 upper-triangle terms of sum w J^T J (row-major),
  *                      6 terms of sum w J^T r, the weighted cost, the inlier count]; hybrid residuals (intensity + depth), Huber
- *                      weights, target sampled bilinearly; partial = scratch double [ceil(H*W/256), 29]; deterministic */
+ *                      weights, target sampled bilinearly; partial = scratch double [ceil(H*W/256), 29]; deterministic.
+ *                      flags bit 0: the target images are read at the NEAREST pixel of the projected point (round half away from zero),
+ *                      Open3D's association; bit 1: Open3D's robust step -- sum J^T J unweighted, sum J^T huber'(r) with
+ *                      huber'(r) = r clipped to +-delta, cost = sum huber(r) */
 /* the pseudo-RGBD depth of the 3DM loop (3DM/slam_utils.py:212-220): out = u16 / depth_scale as fp32 metres, values >= depth_trunc -> 0 */
 int bs_depth_u16_to_m(const uint16_t* depth_u16, int64_t n, double depth_scale, double depth_trunc, float* out, void* stream);
 /* `iterations` Gauss-Newton steps of one pyramid level entirely on the device: bs_odo_accumulate's sums at the pose in T_dev (12
@@ -387,7 +405,7 @@ int bs_depth_u16_to_m(const uint16_t* depth_u16, int64_t n, double depth_scale, 
 int bs_odo_step(const float* src_intensity, const float* src_depth, const float* tgt_intensity, const float* tgt_depth,
                 const float* tgt_dIx, const float* tgt_dIy, const float* tgt_dDx, const float* tgt_dDy, int32_t H, int32_t W,
                 const double* K, double* T_dev, int32_t iterations, double depth_outlier_trunc, double depth_huber,
-                double intensity_huber, double* partial, double* out29, void* stream);
+                double intensity_huber, double* partial, double* out29, int32_t flags, void* stream);
 int bs_odo_prepare(const uint8_t* color, const float* depth, int32_t H, int32_t W, double depth_max, float* intensity, float* depth_out,
                    void* stream);
 int bs_odo_pyrdown(const float* src, int32_t H, int32_t W, float* dst, int32_t is_depth, double depth_threshold, void* stream);
@@ -395,7 +413,7 @@ int bs_odo_sobel(const float* img, int32_t H, int32_t W, float* gx, float* gy, v
 int bs_odo_accumulate(const float* src_intensity, const float* src_depth, const float* tgt_intensity, const float* tgt_depth,
                       const float* tgt_dIx, const float* tgt_dIy, const float* tgt_dDx, const float* tgt_dDy, int32_t H, int32_t W,
                       const double* K, const double* T, double depth_outlier_trunc, double depth_huber, double intensity_huber,
-                      double* partial, double* out29, void* stream);
+                      double* partial, double* out29, int32_t flags, void* stream);
 
 #ifdef __cplusplus
 }

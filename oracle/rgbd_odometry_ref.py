@@ -12,13 +12,18 @@ Open3D's preprocessing, pyramid filters and loss parameters are restated here fr
                weights over the valid pixels whose depth is within 2 * depth_outlier_trunc of the centre, NaN if the centre is
                invalid); intrinsics halved per level; coarse to fine with 20 / 10 / 5 iterations
   per level:   target Sobel gradients of intensity and depth (3x3, scaled by 1/8; NaN where a depth neighbour is invalid)
-  iteration:   for every valid source pixel: p = T v_s;  (u, v) = projection of p, target images and gradients sampled BILINEARLY
-               there (nearest-pixel sampling, tried first, leaves a piecewise-constant cost whose Gauss-Newton steps are rounding
-               noise at the sub-pixel motions of consecutive endoscopy frames);  skip outside / any invalid neighbour /
-               |D_t(u, v) - p.z| > depth_outlier_trunc (0.07);
-               r_I = I_t(u, v) - I_s,  r_D = D_t(u, v) - p.z,  Huber weights with delta 0.1 / 0.05;
+  iteration:   for every valid source pixel: p = T v_s;  (u, v) = projection of p.
+               association="nearest" (Open3D's, the product's default): the target images and gradients are read at the pixel
+               (round(u), round(v)), round half away from zero; skip outside the image / invalid depth or depth gradient there /
+               |D_t - p.z| > depth_outlier_trunc (0.07);  r_I = I_t - I_s,  r_D = D_t - p.z;
+               loss="o3d": (sum J^T J) delta = - sum J^T huber'(r) with huber'(r) = r clipped to +-delta (0.1 intensity, 0.05 depth),
+               J^T J unweighted; cost = sum huber(r).
+               association="bilinear" (round 2's variant, an option): the four neighbours are interpolated (any invalid one skips the
+               pixel) and loss="irls" weights both sides with w = min(1, delta / |r|): a smooth cost -- the nearest-pixel cost is
+               piecewise constant, and its fixed point sits up to half a pixel from the true motion.
                J_I, J_D = the derivatives of the two residuals w.r.t. a left twist (omega, nu) of T (formulas in `_jac`);
-               (sum w J^T J) delta = - sum w J^T r;   T <- exp(delta) T
+               T <- exp(delta) T   (Open3D composes Euler angles instead of the exponential: equal to first order, same fixed point;
+               its early stop on relative fitness / rmse changes of 1e-6 is not restated: all 20 / 10 / 5 iterations run)
   result:      T maps source points into the target frame (the reference then inverts it).
 The product (bodyslam_amd/rgbd_odometry.py + csrc/odometry.hip) implements exactly this statement; tests compare the two per step
 and check both against rendered ground-truth motion."""
@@ -88,8 +93,9 @@ def se3_exp(delta):
     return T
 
 
-def accumulate(Is, Ds, It, Dt, grads, K, T):
+def accumulate(Is, Ds, It, Dt, grads, K, T, association="bilinear", loss=None):
     """(A [6, 6], b [6], residual, inliers) of one Gauss-Newton step at pose T (source -> target)"""
+    loss = loss or ("o3d" if association == "nearest" else "irls")
     fx, fy, cx, cy = K
     H, W = Ds.shape
     dIx, dIy, dDx, dDy = grads
@@ -103,13 +109,22 @@ def accumulate(Is, Ds, It, Dt, grads, K, T):
     ok &= pz > 0
     pzs = np.where(ok, pz, 1.0)
     uf, vf = fx * px / pzs + cx, fy * py / pzs + cy
-    ok &= (uf >= 0) & (uf <= W - 1) & (vf >= 0) & (vf <= H - 1)
-    uf, vf = np.where(ok, uf, 0.0), np.where(ok, vf, 0.0)
-    u0, v0 = np.minimum(np.floor(uf).astype(int), W - 2), np.minimum(np.floor(vf).astype(int), H - 2)
-    au, av = uf - u0, vf - v0
+    if association == "nearest":
+        rnd = lambda a: np.sign(a) * np.floor(np.abs(a) + 0.5)          # round half away from zero (roundf)
+        ur, vr = rnd(np.where(ok, uf, 0.0)), rnd(np.where(ok, vf, 0.0))
+        ok &= (ur >= 0) & (ur <= W - 1) & (vr >= 0) & (vr <= H - 1)
+        ui, vi = np.where(ok, ur, 0).astype(int), np.where(ok, vr, 0).astype(int)
 
-    def bil(img):        # bilinear sample at (vf, uf); NaN if any of the four neighbours is NaN
-        return ((1 - av) * ((1 - au) * img[v0, u0] + au * img[v0, u0 + 1]) + av * ((1 - au) * img[v0 + 1, u0] + au * img[v0 + 1, u0 + 1]))
+        def bil(img):    # the nearest pixel
+            return img[vi, ui]
+    else:
+        ok &= (uf >= 0) & (uf <= W - 1) & (vf >= 0) & (vf <= H - 1)
+        uf, vf = np.where(ok, uf, 0.0), np.where(ok, vf, 0.0)
+        u0, v0 = np.minimum(np.floor(uf).astype(int), W - 2), np.minimum(np.floor(vf).astype(int), H - 2)
+        au, av = uf - u0, vf - v0
+
+        def bil(img):    # bilinear sample at (vf, uf); NaN if any of the four neighbours is NaN
+            return ((1 - av) * ((1 - au) * img[v0, u0] + au * img[v0, u0 + 1]) + av * ((1 - au) * img[v0 + 1, u0] + au * img[v0 + 1, u0 + 1]))
 
     dt = bil(Dt)
     rD = dt - pz
@@ -122,6 +137,11 @@ def accumulate(Is, Ds, It, Dt, grads, K, T):
     m = ok.ravel()
     JI, JD = JI.reshape(6, -1)[:, m], JD.reshape(6, -1)[:, m]
     rI, rD, wI, wD = rI.ravel()[m], rD.ravel()[m], wI.ravel()[m], wD.ravel()[m]
+    if loss == "o3d":
+        qI = np.where(np.abs(rI) < INTENSITY_HUBER, rI, np.sign(rI) * INTENSITY_HUBER)
+        qD = np.where(np.abs(rD) < DEPTH_HUBER, rD, np.sign(rD) * DEPTH_HUBER)
+        hub = lambda r, d: np.where(np.abs(r) < d, 0.5 * r * r, d * (np.abs(r) - 0.5 * d))
+        return JI @ JI.T + JD @ JD.T, JI @ qI + JD @ qD, float((hub(rI, INTENSITY_HUBER) + hub(rD, DEPTH_HUBER)).sum()), int(m.sum())
     A = (JI * wI) @ JI.T + (JD * wD) @ JD.T
     b = (JI * wI) @ rI + (JD * wD) @ rD
     return A, b, float((wI * rI * rI + wD * rD * rD).sum()), int(m.sum())
@@ -148,7 +168,8 @@ def build_pyramid(inten, depth, K, levels=3):
     return out
 
 
-def rgbd_odometry(src_color, src_depth, tgt_color, tgt_depth, K, depth_max, init=None, iterations=ITERATIONS, trace=None):
+def rgbd_odometry(src_color, src_depth, tgt_color, tgt_depth, K, depth_max, init=None, iterations=ITERATIONS, trace=None,
+                  association="bilinear", loss=None):
     """T (4x4): source points -> target frame"""
     ps = build_pyramid(*prepare(src_color, src_depth, depth_max), K)
     pt = build_pyramid(*prepare(tgt_color, tgt_depth, depth_max), K)
@@ -158,7 +179,7 @@ def rgbd_odometry(src_color, src_depth, tgt_color, tgt_depth, K, depth_max, init
         It, Dt, _ = pt[level]
         grads = (*sobel(It), *sobel(Dt))
         for _ in range(iters):
-            A, b, res, n = accumulate(Is, Ds, It, Dt, grads, k, T)
+            A, b, res, n = accumulate(Is, Ds, It, Dt, grads, k, T, association, loss)
             if trace is not None:
                 trace.append((level, A.copy(), b.copy(), res, n))
             if n < 6:

@@ -155,3 +155,108 @@ class TSDFRef:
         if not pts:
             return np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32)
         return np.concatenate(pts), np.concatenate(cols)
+
+
+    # ------------------------------------------------------------------------------------------------------------------------------
+    # ScalableTSDFVolume::ExtractTriangleMesh, restated cube by cube WITHOUT a case table: for every voxel cube whose eight corners
+    # carry weight, the iso-surface tsdf = 0 cuts each cube face in segments (marching squares; a face whose two diagonal corners are
+    # inside is cut so that the inside corners are separated), the segments close into loops, every loop is fanned into triangles
+    # whose normal points from tsdf < 0 to tsdf > 0.  Vertices sit at the linear zero crossing of their cube edge and are shared
+    # between the cubes around the edge.  (The classic 256-case table is not available offline; this construction is the one it
+    # derives from, with a face rule that keeps the mesh watertight -- see bodyslam_amd/marching_cubes.py for the product's table.)
+    def extract_triangle_mesh(self):
+        r = self.res
+        corner = [(c & 1, (c >> 1) & 1, (c >> 2) & 1) for c in range(8)]
+
+        def voxel(key, q):
+            k = list(key)
+            q = list(q)
+            for a in range(3):
+                if q[a] >= r:
+                    q[a] -= r
+                    k[a] += 1
+            vox = self.units.get(tuple(k))
+            return None if vox is None else vox[q[0], q[1], q[2]]
+
+        faces = []
+        for d in range(3):
+            p_, q_ = [a for a in range(3) if a != d]
+            for s_ in (0, 1):
+                cyc = []
+                for (u_, v_) in ((0, 0), (1, 0), (1, 1), (0, 1)):
+                    o = [0, 0, 0]
+                    o[d], o[p_], o[q_] = s_, u_, v_
+                    cyc.append(o[0] + 2 * o[1] + 4 * o[2])
+                faces.append(cyc)
+        vid, verts, cols, tris = {}, [], [], []
+        for key, vox in self.units.items():
+            for x in range(r):
+                for y in range(r):
+                    for z in range(r):
+                        vals = [voxel(key, (x + dx, y + dy, z + dz)) for dx, dy, dz in corner]
+                        if any(v is None or v[1] == 0 for v in vals):
+                            continue
+                        inside = [bool(v[0] < 0) for v in vals]
+                        if all(inside) or not any(inside):
+                            continue
+                        nbr = {}
+                        for cyc in faces:
+                            cr = [k for k in range(4) if inside[cyc[k]] != inside[cyc[(k + 1) % 4]]]
+                            segs = []
+                            if len(cr) == 2:
+                                segs.append((frozenset((cyc[cr[0]], cyc[(cr[0] + 1) % 4])), frozenset((cyc[cr[1]], cyc[(cr[1] + 1) % 4]))))
+                            elif len(cr) == 4:
+                                for j in range(4):
+                                    if inside[cyc[j]]:
+                                        segs.append((frozenset((cyc[j - 1], cyc[j])), frozenset((cyc[j], cyc[(j + 1) % 4]))))
+                            for e0, e1 in segs:
+                                nbr.setdefault(e0, []).append(e1)
+                                nbr.setdefault(e1, []).append(e0)
+
+                        def vertex(e):
+                            a, b = sorted(e)
+                            g = tuple(int(key[i]) * r + (x, y, z)[i] + corner[a][i] for i in range(3))
+                            axis = [i for i in range(3) if corner[a][i] != corner[b][i]][0]
+                            k2 = (g, axis)
+                            if k2 not in vid:
+                                f0, f1 = vals[a][0], vals[b][0]
+                                w = float(np.float32(0.0) - f0) / (float(f1) - float(f0))
+                                p = [(g[i] + 0.5) * self.vl for i in range(3)]
+                                p[axis] += w * self.vl
+                                vid[k2] = len(verts)
+                                verts.append(p)
+                                cols.append([(float(vals[a][2 + i]) + w * (float(vals[b][2 + i]) - float(vals[a][2 + i]))) / 255.0 for i in range(3)])
+                            return vid[k2]
+
+                        seen = set()
+                        for start in nbr:
+                            if start in seen:
+                                continue
+                            loop, prev, cur = [start], None, start
+                            seen.add(start)
+                            while True:
+                                n0, n1 = nbr[cur]
+                                nxt = n0 if n0 != prev else n1
+                                if nxt == start:
+                                    break
+                                loop.append(nxt)
+                                seen.add(nxt)
+                                prev, cur = cur, nxt
+                            mid = np.array([np.mean([corner[c] for c in e], axis=0) for e in loop])
+                            nrm = sum(np.cross(mid[i], mid[(i + 1) % len(mid)]) for i in range(len(mid)))
+                            ins = np.array([[corner[c] for c in e if inside[c]][0] for e in loop], dtype=np.float64)
+                            if np.dot(nrm, mid.mean(0) - ins.mean(0)) < 0:
+                                loop = loop[::-1]
+                            # fan from a vertex whose diagonals all run through the cube's interior (a diagonal inside a cube face
+                            # could coincide with an edge of the neighbouring cube: four triangles on one edge)
+                            in_face = lambda e0, e1: any(set(e0) <= set(cyc) and set(e1) <= set(cyc) for cyc in faces)
+                            for rot in range(len(loop)):
+                                cand = loop[rot:] + loop[:rot]
+                                if all(not in_face(cand[0], cand[i]) for i in range(2, len(cand) - 1)):
+                                    loop = cand
+                                    break
+                            ids = [vertex(e) for e in loop]
+                            for i in range(1, len(ids) - 1):
+                                tris.append((ids[0], ids[i], ids[i + 1]))
+        return (np.array(verts, dtype=np.float32).reshape(-1, 3), np.array(cols, dtype=np.float32).reshape(-1, 3),
+                np.array(tris, dtype=np.int64).reshape(-1, 3))

@@ -67,7 +67,15 @@ def to_nchw(t, meta):
     return t
 
 
-def compare_taps(taps_p, taps_o, route_o, tag, heads=("nyu", "kitti")):
+# Asserted per-tap tolerances: max |error| of an intermediate over max(|reference|, 1), by (precision, storage type).  About 4x the
+# worst value seen over every configuration of this file on MI355X (accurate fp16 3.5e-4 / bins 1.2e-3, fast fp16 1.8e-3 / 3.8e-3,
+# fast bf16 1.5e-2 / 8.4e-3): a regression in one stage fails here even when the log-binomial head happens to absorb it in the
+# final depth L1.
+TAP_TOL = {("accurate", "f16"): (1.5e-3, 5e-3), ("accurate", "bf16"): (2e-2, 2e-2), ("fast", "f16"): (7e-3, 1.5e-2), ("fast", "bf16"): (6e-2, 4e-2)}
+
+
+def compare_taps(taps_p, taps_o, route_o, tag, heads=("nyu", "kitti"), tol=None):
+    """per-tap max errors (reported); with tol = (precision, dtype name) every tap is ASSERTED against TAP_TOL"""
     worst = {}
     for name, (t, meta) in taps_p.items():
         if name in ("logits",):
@@ -95,20 +103,26 @@ def compare_taps(taps_p, taps_o, route_o, tag, heads=("nyu", "kitti")):
             scale = ref.abs().max().item()
         worst[name] = (e, scale)
         report(f"  [{tag}] {name:14s} max|err|={e:.3e}  (ref max {scale:.3e}, rel {e / max(scale, 1e-9):.2e})")
+        if tol is not None:
+            lim = TAP_TOL[tol][1 if name.startswith("bins") else 0]
+            assert e / max(scale, 1.0) <= lim, f"[{tag}] tap {name}: max|err| {e:.3e} over scale {scale:.3e} exceeds {lim:.1e}"
     return worst
 
 
 _ORACLE_CACHE = {}
 
 
-def oracle_case(cfg_o, B, H, W, target_hw, seed, route_bias, flip):
-    """Oracle side of a case (weights, frames, taps, final depth); shared by the dtype variants."""
+def oracle_case(cfg_o, B, H, W, target_hw, seed, route_bias, flip, weights_hook=None):
+    """Oracle side of a case (weights, frames, taps, final depth); shared by the dtype variants.  weights_hook(w) edits the seeded
+    weights in place (adversarial statistics) and must have a __name__."""
     from bodyslam_amd.synthetic import make_sequence
     from oracle import zoedepth_ref as Z
-    key = (repr(cfg_o), B, H, W, target_hw, seed, route_bias, flip)
+    key = (repr(cfg_o), B, H, W, target_hw, seed, route_bias, flip, getattr(weights_hook, "__name__", None))
     if key in _ORACLE_CACHE:
         return _ORACLE_CACHE[key]
     w = Z.synth_weights(cfg_o, seed=seed, route_bias=route_bias)
+    if weights_hook is not None:
+        weights_hook(w)
     frames = torch.from_numpy(make_sequence(B, H, W, seed=seed))
     with torch.no_grad():
         x = Z.preprocess(frames, target_hw)
@@ -123,17 +137,17 @@ def oracle_case(cfg_o, B, H, W, target_hw, seed, route_bias, flip):
     return _ORACLE_CACHE[key]
 
 
-def run_case(cfg_o, dtype, B, H, W, target_hw, seed, route_bias=0.0, flip=True, precision="fast"):
+def run_case(cfg_o, dtype, B, H, W, target_hw, seed, route_bias=0.0, flip=True, precision="fast", weights_hook=None, **eng_kw):
     from bodyslam_amd.zoedepth import ZoeDepthEngine
     from oracle import zoedepth_ref as Z
-    w, frames, taps_o, logits, ref, t_or = oracle_case(cfg_o, B, H, W, target_hw, seed, route_bias, flip)
-    eng = ZoeDepthEngine(w, product_cfg(cfg_o), dtype=dtype, target_hw=target_hw, precision=precision)
+    w, frames, taps_o, logits, ref, t_or = oracle_case(cfg_o, B, H, W, target_hw, seed, route_bias, flip, weights_hook)
+    eng = ZoeDepthEngine(w, product_cfg(cfg_o), dtype=dtype, target_hw=target_hw, precision=precision, **eng_kw)
     taps_p = {}
     dm, du = eng.infer(frames.cuda(), flip_aug=flip, taps=taps_p)
     torch.cuda.synchronize()
     lp = taps_p["logits"][0].cpu()[:, :2] if "logits" in taps_p else None        # single-head models have no router
     return dict(dm=dm.cpu(), du=du.cpu().numpy().view(np.uint16), ref=ref, taps_p=taps_p, taps_o=taps_o, logits_o=logits,
-                logits_p=lp, route_p=eng.plan_for(B, H, W, flip).route.cpu(), t_oracle=t_or, Z=Z)
+                logits_p=lp, route_p=eng.plan_for(B, H, W, flip).route.cpu(), t_oracle=t_or, Z=Z, calibration=eng.calibration, eng=eng)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -143,7 +157,7 @@ def test_small_backbone_full_head(dtype, route_bias):
     kernel and every epilogue mode of the forward runs; both metric heads are forced in turn."""
     r = run_case(small_oracle_cfg(), dtype, B=2, H=120, W=160, target_hw=(96, 128), seed=3, route_bias=route_bias)
     tag = f"small {str(dtype)[6:]} rb{route_bias:+.0f}"
-    compare_taps(r["taps_p"], r["taps_o"], None, tag)
+    compare_taps(r["taps_p"], r["taps_o"], None, tag, tol=("fast", "f16" if dtype == torch.float16 else "bf16"))
     route_o = torch.argmax(r["logits_o"], -1)
     report(f"  [{tag}] logits oracle {r['logits_o'].tolist()} hip {r['logits_p'].tolist()}")
     assert torch.equal(route_o.int(), r["route_p"]) and (route_o == (0 if route_bias > 0 else 1)).all()
@@ -161,7 +175,7 @@ def test_small_without_relative_head_projection(precision):
     and feeds the last fused map straight into relative_head.conv1."""
     cfg_o = dataclasses.replace(small_oracle_cfg(), add_projection=False)
     r = run_case(cfg_o, torch.float16, B=2, H=120, W=160, target_hw=(96, 128), seed=6, precision=precision)
-    compare_taps(r["taps_p"], r["taps_o"], None, f"small no-projection {precision}")
+    compare_taps(r["taps_p"], r["taps_o"], None, f"small no-projection {precision}", tol=(precision, "f16"))
     l1 = (r["dm"] - r["ref"]).abs().mean().item()
     report(f"[small no-projection {precision}] depth L1={l1:.3e}")
     assert torch.equal(torch.argmax(r["logits_o"], -1).int(), r["route_p"])
@@ -194,7 +208,7 @@ def test_small_accurate_mode():
     kw = dict(B=2, H=120, W=160, target_hw=(96, 128), seed=3, route_bias=3.0)
     fast = run_case(small_oracle_cfg(), torch.float16, **kw)
     r = run_case(small_oracle_cfg(), torch.float16, precision="accurate", **kw)
-    compare_taps(r["taps_p"], r["taps_o"], None, "small f16 accurate")
+    compare_taps(r["taps_p"], r["taps_o"], None, "small f16 accurate", tol=("accurate", "f16"))
     l1 = (r["dm"] - r["ref"]).abs().mean().item()
     l1_fast = (fast["dm"] - fast["ref"]).abs().mean().item()
     report(f"[small f16 accurate] depth L1={l1:.3e} (fast mode {l1_fast:.3e})")
@@ -227,7 +241,7 @@ def test_full_size_zoed_nk(dtype):
     from oracle import zoedepth_ref as Z
     r = run_case(Z.ZOED_NK, dtype, B=1, H=480, W=640, target_hw=(384, 512), seed=1)
     tag = f"ZoeD_NK {str(dtype)[6:]}"
-    compare_taps(r["taps_p"], r["taps_o"], None, tag)
+    compare_taps(r["taps_p"], r["taps_o"], None, tag, tol=("fast", "f16" if dtype == torch.float16 else "bf16"))
     report(f"  [{tag}] logits oracle {r['logits_o'].tolist()} hip {r['logits_p'].tolist()}  (oracle forward {r['t_oracle']:.1f}s)")
     l1 = (r["dm"] - r["ref"]).abs().mean().item()
     mx = (r["dm"] - r["ref"]).abs().max().item()
@@ -246,7 +260,8 @@ def test_full_size_zoed_nk_accurate():
     from oracle import zoedepth_ref as Z
     r = run_case(Z.ZOED_NK, torch.float16, B=1, H=480, W=640, target_hw=(384, 512), seed=1, precision="accurate")
     tag = "ZoeD_NK f16 accurate"
-    compare_taps(r["taps_p"], r["taps_o"], None, tag)
+    compare_taps(r["taps_p"], r["taps_o"], None, tag, tol=("accurate", "f16"))
+    report(f"[{tag}] calibration: {r['calibration']}")
     l1 = (r["dm"] - r["ref"]).abs().mean().item()
     mx = (r["dm"] - r["ref"]).abs().max().item()
     report(f"[{tag}] 640x480 depth L1={l1:.3e} m, max={mx:.3e} m, mean signed {(r['dm'] - r['ref']).mean().item():+.3e} m")
@@ -288,7 +303,7 @@ def test_single_head_models_small(name, precision):
     256 / 128 / 80, the relative depth as a 33rd input of the log-binomial MLP -- small backbone, full-size neck and head."""
     cfg_o = dataclasses.replace(small_oracle_cfg(), head_names=(name,))
     r = run_case(cfg_o, torch.float16, B=2, H=120, W=160, target_hw=(96, 128), seed=5, precision=precision)
-    compare_taps(r["taps_p"], r["taps_o"], None, f"small {name} {precision}", heads=(name,))
+    compare_taps(r["taps_p"], r["taps_o"], None, f"small {name} {precision}", heads=(name,), tol=(precision, "f16"))
     l1 = (r["dm"] - r["ref"]).abs().mean().item()
     report(f"[small single-head {name} {precision}] depth L1={l1:.3e} (range {r['ref'].min():.3f}..{r['ref'].max():.3f})")
     assert (r["route_p"] == 0).all()
@@ -302,3 +317,62 @@ def test_full_size_zoed_n_accurate():
     l1 = (r["dm"] - r["ref"]).abs().mean().item()
     report(f"[ZoeD_N f16 accurate] 640x480 depth L1={l1:.3e} m, max={(r['dm'] - r['ref']).abs().max().item():.3e} m")
     assert l1 <= 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# The tolerance against weights that do not look like the seeded ones: trained BEiT-L checkpoints carry a
+# per-channel layer-scale spanning decades, a few outlier channels and heavy-tailed weights.  "auto" (the default) must hold the
+# north star's 1e-4 m on each, whatever it has to switch back on; the fixed cheap mode is reported beside it.
+def _hook_layerscale_wide(w):
+    g = torch.Generator().manual_seed(101)
+    for k in w:
+        if k.endswith("lambda_1") or k.endswith("lambda_2"):          # log-uniform 1e-3 .. 1 per channel (trained BEiT: 1e-5 init, grown unevenly)
+            w[k] = w[k].sign() * torch.pow(10.0, -3.0 * torch.rand(w[k].shape, generator=g)) * 0.3
+
+
+def _hook_outlier_channels(w):
+    g = torch.Generator().manual_seed(102)
+    idx = torch.randperm(1024, generator=g)[:6]
+    for k in w:
+        if k.endswith("layernorm_before.weight") or k.endswith("layernorm_after.weight"):       # 6 channels 50x larger after every LayerNorm
+            w[k] = w[k].clone()
+            w[k][idx] *= 50.0
+        if k.endswith("attention.q_proj.weight") or k.endswith("mlp.fc1.weight"):               # ... and damped again where they are consumed, so
+            w[k] = w[k].clone()                                                                     # the network stays in range
+            w[k][:, idx] /= 25.0
+
+
+def _hook_heavy_tailed(w):
+    g = torch.Generator().manual_seed(103)
+    for k in w:
+        if w[k].dim() >= 2 and w[k].numel() >= 1 << 16 and "position_bias" not in k:
+            t = torch.randn(w[k].shape, generator=g) / torch.randn(w[k].shape, generator=g).abs().clamp_min(0.35)   # ratio of normals: heavy tails
+            w[k] = w[k] * (0.6 + 0.4 * t.abs().clamp_max(12.0) / 1.6)
+
+
+@pytest.mark.parametrize("hook", [_hook_layerscale_wide, _hook_outlier_channels, _hook_heavy_tailed])
+def test_auto_modes_hold_tolerance_on_adversarial_weights(hook):
+    from oracle import zoedepth_ref as Z
+    kw = dict(B=1, H=480, W=640, target_hw=(384, 512), seed=9, precision="accurate", weights_hook=hook)
+    r = run_case(Z.ZOED_NK, torch.float16, **kw)                       # class_modes = "auto" (default)
+    l1 = (r["dm"] - r["ref"]).abs().mean().item()
+    cal = r["calibration"]
+    del r
+    torch.cuda.empty_cache()
+    rw = run_case(Z.ZOED_NK, torch.float16, class_modes="wmean", neck_mode="full", **kw)
+    l1w = (rw["dm"] - rw["ref"]).abs().mean().item()
+    report(f"[adversarial {hook.__name__}] auto: L1={l1:.3e} m with {cal['class_modes']} neck={cal['neck_mode']!r} "
+           f"(vs all-full {cal['l1_total_vs_full_m']:.2e}; per class {({k: round(v, 7) for k, v in cal['l1_vs_full_m'].items()})}); "
+           f"fixed wmean: L1={l1w:.3e} m; depth range {rw['ref'].min():.3f}..{rw['ref'].max():.3f}")
+    assert torch.isfinite(rw["ref"]).all() and rw["ref"].std() > 1e-3, "the adversarial weights must still give a non-trivial depth map"
+    assert cal["l1_total_vs_full_m"] <= cal["tol_total_m"]
+    assert l1 <= l1w + 2e-5                                            # never worse than the fixed cheap mode
+    if hook is _hook_outlier_channels:
+        # 50x outlier channels that K, V and fc2's input see undamped: every cheap mode costs > 1e-4 m against the all-"full" result, so
+        # the guard must switch EVERYTHING back on.  (Even then 1e-4 m against the fp32 oracle is out of reach here -- 2.7e-4 m measured:
+        # Q, K, V and the softmax probabilities are single 16-bit operands and the e4m3 planes have one exponent per tensor --
+        # DESIGN.md "Numerics" lists it as the known limit of accurate mode.)
+        assert all(v == "full" for v in cal["class_modes"].values()) and cal["neck_mode"] == "full"
+        assert l1 < 0.7 * l1w
+    else:
+        assert l1 <= 1e-4
