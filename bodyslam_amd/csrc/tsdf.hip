@@ -81,10 +81,14 @@ __global__ __launch_bounds__(256) void tsdf_touch_kernel(const float* __restrict
     counters[2] = 1;      // table full
 }
 
-// second half: entries stamped by this frame get a block number if they have none, and go on the frame's list
+// second half: entries stamped by this frame get a block number if they have none, and go on the frame's list -- unless the unit lies
+// wholly outside the view frustum.  Units are opened in a +-sdf_trunc box around every sampled point, far wider than the frustum at
+// endoscopic range (round 2, PMC: 90 % of the integrate kernel's threads projected outside the image and left): a unit whose
+// bounding sphere is behind the camera or projects wholly outside the image holds no voxel the integration would update, so it
+// is opened (as in Open3D) but not put on the list.  `view` = world -> camera, W x H the image; conservative bound, see below.
 __global__ __launch_bounds__(256) void tsdf_assign_kernel(const long long* __restrict__ keys, int32_t* slots, const int32_t* __restrict__ stamp,
                                                            unsigned cap, int frame_id, int32_t* unit_index, int max_units, int32_t* counters,
-                                                           int32_t* touched) {
+                                                           int32_t* touched, TsdfCam view, double unit_length, int W, int H, int cull) {
     const unsigned h = blockIdx.x * 256 + threadIdx.x;
     if (h >= cap || keys[h] == TS_EMPTY || stamp[h] != frame_id) return;
     int s = slots[h];
@@ -104,16 +108,32 @@ __global__ __launch_bounds__(256) void tsdf_assign_kernel(const long long* __res
         unit_index[3 * s + 1] = (int)((k >> 21) & ((1 << 21) - 1)) - TS_OFF;
         unit_index[3 * s + 2] = (int)(k & ((1 << 21) - 1)) - TS_OFF;
     }
+    if (cull) {
+        const long long k = keys[h];
+        const double c[3] = {((double)((int)(k >> 42) - TS_OFF) + 0.5) * unit_length, ((double)((int)((k >> 21) & ((1 << 21) - 1)) - TS_OFF) + 0.5) * unit_length,
+                             ((double)((int)(k & ((1 << 21) - 1)) - TS_OFF) + 0.5) * unit_length};
+        const double r = 0.8660254037844387 * unit_length;           // half the cube's diagonal
+        const double qx = view.e[0] * c[0] + view.e[1] * c[1] + view.e[2] * c[2] + view.e[3];
+        const double qy = view.e[4] * c[0] + view.e[5] * c[1] + view.e[6] * c[2] + view.e[7];
+        const double qz = view.e[8] * c[0] + view.e[9] * c[1] + view.e[10] * c[2] + view.e[11];
+        if (qz + r <= 0.0) return;                                   // wholly behind the camera
+        if (qz > r) {                                                // (a sphere that reaches the camera plane is never culled)
+            // a point p = q + d, |d| <= r, projects within  f r / (qz - r) * (1 + |qx| / qz)  pixels of q's projection:
+            // |px / pz - qx / qz| = |dx qz - qx dz| / (pz qz) <= r (qz + |qx|) / ((qz - r) qz)
+            const double inv = 1.0 / (qz - r);
+            const double ru = view.fx * r * inv * (1.0 + fabs(qx) / qz) + 1.0, rv = view.fy * r * inv * (1.0 + fabs(qy) / qz) + 1.0;
+            const double uc = qx * view.fx / qz + view.cx + 0.5, vc = qy * view.fy / qz + view.cy + 0.5;
+            if (uc + ru < 0.0 || uc - ru > (double)W || vc + rv < 0.0 || vc - rv > (double)H) return;
+        }
+    }
     touched[atomicAdd(counters + 1, 1)] = s;
 }
 
 // Open3D UniformTSDFVolume::IntegrateWithDepthToCameraDistanceMultiplier, one thread per voxel.  Grid: blocks_per_unit x an UPPER
 // BOUND of the touched units, folded into blockIdx.x (no 65 535 limit); the number of units this frame really touched is read
 // from device memory (counters[1], written by tsdf_assign_kernel), so the host never has to wait for it.
-// Culling: a block's 256 voxels are one x-slice of 8 rows x 32 (res = 32) -- a box 1 x 8 x 32 voxels.  Units are opened in a +-sdf_trunc
-// box around every sampled point, far wider than the view frustum at endoscopic range (PMC, round 2: 90 % of the threads projected
-// outside the image and left); the box's bounding sphere is projected once per block and the block leaves when the sphere lies
-// behind the camera or wholly outside the image (conservative: a block that might hold one updated voxel is never skipped).
+// (Units wholly outside the view frustum never reach `touched`: tsdf_assign_kernel.  A test per 256-voxel block was tried first and
+// cost what it saved: the block-uniform fp64 test is as many vector instructions as the per-voxel projection it replaces.)
 __device__ __forceinline__ void tsdf_integrate_block(int work, const float* __restrict__ depth, const uint8_t* __restrict__ color, int H, int W,
                                                      const TsdfCam& cam, const int32_t* __restrict__ unit_index, const int32_t* __restrict__ touched,
                                                      int blocks_per_unit, const int64_t* __restrict__ slab_base, int slab_units, int res,
@@ -123,34 +143,6 @@ __device__ __forceinline__ void tsdf_integrate_block(int work, const float* __re
     const int v = bx * 256 + threadIdx.x;
     const int nvox = res * res * res;
     const double unit_len = voxel_length * res, half = voxel_length * 0.5;
-    if (cull) {
-        // bounding sphere of the voxels [bx * 256, bx * 256 + 256) of this unit (whole x-slices / rows: res divides 256 or 256 divides res^2)
-        const int v0 = bx * 256, v1 = (v0 + 255 < nvox - 1 ? v0 + 255 : nvox - 1);
-        const int x0 = v0 / (res * res), x1 = v1 / (res * res);
-        int y0 = (v0 / res) % res, y1 = (v1 / res) % res;
-        if (x1 > x0) { y0 = 0; y1 = res - 1; }
-        const double lo[3] = {(double)x0, (double)y0, 0.0}, hi[3] = {(double)x1 + 1.0, (double)y1 + 1.0, (double)res};
-        double c[3], r2 = 0.0;
-        for (int a = 0; a < 3; ++a) {
-            c[a] = 0.5 * (lo[a] + hi[a]) * voxel_length + unit_len * unit_index[3 * u + a];
-            const double e = 0.5 * (hi[a] - lo[a]) * voxel_length;
-            r2 += e * e;
-        }
-        const double r = sqrt(r2);
-        const double qx = cam.e[0] * c[0] + cam.e[1] * c[1] + cam.e[2] * c[2] + cam.e[3];
-        const double qy = cam.e[4] * c[0] + cam.e[5] * c[1] + cam.e[6] * c[2] + cam.e[7];
-        const double qz = cam.e[8] * c[0] + cam.e[9] * c[1] + cam.e[10] * c[2] + cam.e[11];
-        if (qz + r <= 0.0) return;                                   // wholly behind the camera
-        if (qz > r) {                                                // (a sphere that reaches the camera plane is never culled)
-            // the sphere lies inside the cone of half-angle asin(r / |q|) around q: compare the tangent-cone's pixel footprint with the
-            // image.  |pixel - centre pixel| <= f * r / (qz - r) * (1 + (|qx| + |qy|) / qz) bounds the footprint for the small r here.
-            const double inv = 1.0 / (qz - r);
-            const double spread = 1.0 + (fabs(qx) + fabs(qy)) * inv;
-            const double ru = cam.fx * r * inv * spread + 1.0, rv = cam.fy * r * inv * spread + 1.0;
-            const double uc = qx * cam.fx / qz + cam.cx + 0.5, vc = qy * cam.fy / qz + cam.cy + 0.5;
-            if (uc + ru < 0.0 || uc - ru > (double)W || vc + rv < 0.0 || vc - rv > (double)H) return;
-        }
-    }
     if (v >= nvox) return;
     const int x = v / (res * res), y = (v / res) % res, z = v % res;
     const double px = half + voxel_length * x + unit_len * unit_index[3 * u + 0];
@@ -419,6 +411,11 @@ __global__ __launch_bounds__(256) void tsdf_mesh_kernel(const int32_t* __restric
 
 using namespace bs;
 
+static bool det_ok(const double* m) {
+    const double det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
+    return det > 1e-12 || det < -1e-12;
+}
+
 static void tsdf_cam(TsdfCam& cam, const double* K, const double* m12) {
     cam.fx = K[0]; cam.fy = K[1]; cam.cx = K[2]; cam.cy = K[3];
     for (int i = 0; i < 12; ++i) cam.e[i] = m12[i];
@@ -441,8 +438,23 @@ extern "C" int bs_tsdf_touch(const float* depth, int32_t H, int32_t W, int32_t s
     hipLaunchKernelGGL(tsdf_touch_kernel, dim3((unsigned)cdiv64(threads, 256)), dim3(256), 0, st, depth, H, W, stride, cam, unit_length, sdf_trunc, span,
                        reinterpret_cast<long long*>(table_keys), table_stamp, (unsigned)(table_cap - 1), frame_id, counters);
     BS_CHECK_LAUNCH();
+    // world -> camera for the frustum test of the units: the inverse of the 3x4 `pose` (general affine inverse)
+    TsdfCam view = cam;
+    {
+        const double* m = pose;
+        const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+        const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+        const double id = 1.0 / det;
+        const double inv[9] = {(e * i - f * h) * id, (c * h - b * i) * id, (b * f - c * e) * id, (f * g - d * i) * id, (a * i - c * g) * id,
+                               (c * d - a * f) * id, (d * h - e * g) * id, (b * g - a * h) * id, (a * e - b * d) * id};
+        for (int r = 0; r < 3; ++r) {
+            for (int q = 0; q < 3; ++q) view.e[4 * r + q] = inv[3 * r + q];
+            view.e[4 * r + 3] = -(inv[3 * r] * m[3] + inv[3 * r + 1] * m[7] + inv[3 * r + 2] * m[11]);
+        }
+    }
+    const int cull = getenv("BS_TSDF_NO_CULL") == nullptr && det_ok(pose);
     hipLaunchKernelGGL(tsdf_assign_kernel, dim3(cdiv(table_cap, 256)), dim3(256), 0, st, reinterpret_cast<const long long*>(table_keys), table_slots,
-                       table_stamp, (unsigned)table_cap, frame_id, unit_index, max_units, counters, touched);
+                       table_stamp, (unsigned)table_cap, frame_id, unit_index, max_units, counters, touched, view, unit_length, W, H, cull);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }
@@ -463,8 +475,7 @@ extern "C" int bs_tsdf_integrate(const float* depth, const uint8_t* color, int32
     // passes any generous value (a few blocks per CU walk the work items)
     const long long want = (long long)bpu * n_touched;
     const unsigned grid = (unsigned)(want < 16ll * cu_count() ? want : 16ll * cu_count());
-    // the block culling assumes whole rows per block (res divides 256 or the other way round)
-    const int cull = (256 % res == 0 || res % 256 == 0) && getenv("BS_TSDF_NO_CULL") == nullptr;
+    const int cull = 0;
     hipLaunchKernelGGL(tsdf_integrate_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), depth, color, H, W,
                        cam, unit_index, touched, n_touched_dev, bpu, slab_base, slab_units, res, voxel_length, sdf_trunc, cull);
     BS_CHECK_LAUNCH();

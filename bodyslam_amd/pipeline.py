@@ -244,21 +244,79 @@ class BodySlamPipeline:
                 j1 = min(j0 + self.batch, upto + 1)
                 dm = tsdf_depth(j0, j1)
                 for j in range(j0, j1):
+                    t.discover(RGBDImage(fr_dev[j], dm[j - j0]), intr, poses[j])
+                t.reserve_discovered()
+                for j in range(j0, j1):
                     t.build_3D_map(RGBDImage(fr_dev[j], dm[j - j0]), intr, poses[j], sync=False)
                 t.sync()
             state["tsdf"] = t
+
+        def run_map_actions(actions, b0, dm_map):
+            """the map steps a batch of frames asked for, in order.  Runs of plain integrations are done in two streamed passes: unit
+            discovery of every frame (no voxel work), ONE round trip that allocates exactly the blocks those frames need, then
+            discovery + integration frame by frame -- no guess at how many units a stream opens, no round trip per frame."""
+            k = 0
+            while k < len(actions):
+                if actions[k][0] == "rebuild":
+                    rebuild(actions[k][1], actions[k][2])
+                    k += 1
+                    continue
+                run = []
+                while k < len(actions) and actions[k][0] == "int":
+                    run.append(actions[k])
+                    k += 1
+                t = state["tsdf"]
+                for (_, i, pose) in run:
+                    t.discover(RGBDImage(fr_dev[i], dm_map[i - b0]), intr, pose)
+                t.reserve_discovered()
+                for (_, i, pose) in run:
+                    t.build_3D_map(RGBDImage(fr_dev[i], dm_map[i - b0]), intr, pose, sync=False)
 
         pg = PoseGraph()
         extr, rel_fused = [], []
         cnt_all = torch.empty(N, dtype=torch.int32, device=self.dev)
         points = [] if keep_points else None
-        for b0 in range(0, N, self.batch):
+        # Two streams.  The network stages of batch k + 1 (MDEM + MPEM: ~180 ms of large GEMMs at B = 64) are enqueued on the caller's
+        # stream BEFORE batch k's sequential part runs -- odometry tracking, UKF, chain, pose graph, map steps: small latency-bound
+        # kernels and host arithmetic -- which goes to a side stream that waits only for batch k's network results.  The host work and
+        # the small kernels hide under the next batch's GEMMs (the round-2 loop ran them one after the other: 72 frames/s).
+        main = torch.cuda.current_stream(self.dev)
+        if getattr(self, "_loop_stream", None) is None:
+            self._loop_stream = torch.cuda.Stream(device=self.dev)
+        side = self._loop_stream
+
+        def launch_network(b0):
             b1 = min(b0 + self.batch, N)
-            d_u16, d_m, t_mpem = self.depth_and_pose_block(frames, b0, b1, keep_depth_m, 0, pad_to_batch=N > self.batch)
+            d_u16, d_m, t_dev = self.depth_and_pose_block(frames, b0, b1, keep_depth_m, 0, pad_to_batch=N > self.batch)
             depth_all[b0:b1].copy_(d_u16)
             if keep_depth_m:
                 depth_m_all[b0:b1].copy_(d_m)
-            t_mpem = t_mpem.view(-1, 4, 4).cpu().numpy()                       # the pairs (i - 1, i), i in [max(b0, 1), b1)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            return b0, b1, t_dev, ev
+
+        pending = launch_network(0)
+        while pending is not None:
+            b0, b1, t_dev, ev = pending
+            t_mpem = t_dev.view(-1, 4, 4).cpu().numpy()                         # the pairs (i - 1, i), i in [max(b0, 1), b1); waits for batch k's network
+            pending = launch_network(b1) if b1 < N else None                    # batch k + 1's network: enqueued, not waited for
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                self._slam_batch(b0, b1, t_mpem, vo, odo, stored if vo else None, vo_obj if vo else None, state, fr_dev, depth_all, intr, pg, extr,
+                                 rel_fused, cnt_all, points, keep_points, every, rebuild_every, extract_every_frame, on_frame, tsdf_depth,
+                                 run_map_actions)
+        main.wait_stream(side)
+        self.last_tsdf = state["tsdf"]
+        t_rel = torch.from_numpy(np.stack(rel_fused).astype(np.float32)).to(self.dev) if rel_fused else torch.zeros(0, 4, 4, device=self.dev)
+        g_abs = torch.from_numpy(np.stack(self._extr_final)).to(self.dev)
+        return SequenceResult(0, N, depth_all, t_rel, g_abs, cnt_all, points, depth_m_all)
+
+    def _slam_batch(self, b0, b1, t_mpem, vo, odo, stored, vo_obj, state, fr_dev, depth_all, intr, pg, extr, rel_fused, cnt_all, points,
+                    keep_points, every, rebuild_every, extract_every_frame, on_frame, tsdf_depth, run_map_actions):
+        """the sequential part of run_slam_loop for the frames [b0, b1) (see there); runs on the loop's side stream"""
+        from .posegraph import update_global_extrinsic
+        from .tsdf import RGBDImage
+        if True:
             t_odo = None
             if vo:
                 # the odometry's depth: raw / depth_scale (no truncation); every frame of the batch is tracked on the device
@@ -271,8 +329,7 @@ class BodySlamPipeline:
                     t_odo[:, :3] = t12
                     t_odo = np.linalg.inv(t_odo)                                # what _compute_vo_o3d returns (visual_odometry.py:118)
             dm_map = tsdf_depth(b0, b1) if state["tsdf"] is not None else None
-            if state["tsdf"] is not None:
-                state["tsdf"].reserve_ahead(b1 - b0)
+            actions = []                              # the batch's map steps; executed together unless a point cloud is wanted per frame
             first_pair = max(b0, 1)
             for i in range(b0, b1):
                 pcd = None
@@ -281,7 +338,7 @@ class BodySlamPipeline:
                     extr.append(pose)
                     pg.add_node(pose)
                     if state["tsdf"] is not None:
-                        state["tsdf"].build_3D_map(RGBDImage(fr_dev[0], dm_map[0]), intr, pose, sync=False)
+                        actions.append(("int", 0, pose))
                 else:
                     T = np.array(t_mpem[i - first_pair])
                     if vo:
@@ -298,19 +355,23 @@ class BodySlamPipeline:
                     if every > 0 and i % every == 0:
                         before = [p_.copy() for p_ in extr]
                         pg.optimize()
-                        extr = update_global_extrinsic(pg.pose_graph)
+                        extr[:] = update_global_extrinsic(pg.pose_graph)        # (in place: the caller's list)
                         if state["tsdf"] is not None and not all(np.array_equal(a_, b_) for a_, b_ in zip(before, extr)):
-                            rebuild(i, extr)
+                            actions.append(("rebuild", i, [p_.copy() for p_ in extr]))
                     elif state["tsdf"] is not None:
-                        state["tsdf"].build_3D_map(RGBDImage(fr_dev[i], dm_map[i - b0]), intr, extr[-1], sync=False)
+                        actions.append(("int", i, extr[-1].copy()))
                     if state["tsdf"] is not None and rebuild_every > 0 and i % rebuild_every == 0:
-                        rebuild(i, extr)
+                        actions.append(("rebuild", i, [p_.copy() for p_ in extr]))
                 if extract_every_frame and state["tsdf"] is not None:
+                    run_map_actions(actions, b0, dm_map)                        # the map as it stands after frame i (slam.py:195)
+                    actions = []
+                    state["tsdf"].sync()
                     pcd = state["tsdf"].extract_pcd()
                 if on_frame is not None:
                     on_frame(i, extr[-1], pcd)
             if state["tsdf"] is not None:
-                state["tsdf"].sync()                                            # one round trip per batch: unit counts, overflow check
+                run_map_actions(actions, b0, dm_map)
+                state["tsdf"].sync()                                            # unit counts of the batch, overflow check
             # back-projection of the batch with the poses as they stand (the hot path's D3 output; the reference's loop keeps the map only)
             g_b = torch.from_numpy(np.stack(extr[b0:b1])).to(self.dev)
             xyz, idx, cnt = geom3d.backproject(depth_all[b0:b1], self.K, self.depth_scale, self.depth_trunc, poses=g_b)
@@ -319,10 +380,7 @@ class BodySlamPipeline:
                 c = cnt.cpu().tolist()
                 for j in range(b1 - b0):
                     points.append((xyz[j, :c[j]].clone(), idx[j, :c[j]].clone()))
-        self.last_tsdf = state["tsdf"]
-        t_rel = torch.from_numpy(np.stack(rel_fused).astype(np.float32)).to(self.dev) if rel_fused else torch.zeros(0, 4, 4, device=self.dev)
-        g_abs = torch.from_numpy(np.stack(extr)).to(self.dev)
-        return SequenceResult(0, N, depth_all, t_rel, g_abs, cnt_all, points, depth_m_all)
+        self._extr_final = list(extr)
 
     def fuse_vo(self, frames, depth_u16: torch.Tensor, t_rel: torch.Tensor) -> torch.Tensor:
         """visual_odometry.py:60-93 over the pairs (i-1, i) in order: returns t_rel with each translation replaced by the UKF state"""

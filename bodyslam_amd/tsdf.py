@@ -102,7 +102,8 @@ class TSDF:
         self.unit_index = torch.zeros(self.max_units, 3, dtype=torch.int32, device=d)
         self.counters = torch.zeros(3, dtype=torch.int32, device=d)
         self.touched = torch.zeros(self.max_units, dtype=torch.int32, device=d)
-        self.n_units, self.frame_id = 0, 0
+        self.n_units, self.frame_id = 0, 0                                # frame_id: discovery passes so far (the stamp of the unit table)
+        self.frames_integrated = 0
         self._max_new_per_frame, self._frames_since_sync = 0, 0
 
     # ---- block capacity ------------------------------------------------------------------------------
@@ -119,12 +120,32 @@ class TSDF:
             self.slab_base[len(self.slabs) - 1] = self.slabs[-1].data_ptr()
 
     def reserve_ahead(self, n_frames: int) -> None:
-        """capacity for `n_frames` un-synchronised frames: the known unit count plus, per frame, twice the most units one frame has
-        opened so far (at least 2048, the order a 640x480 endoscopic frame touches)"""
-        self.reserve(self.n_units + n_frames * max(2048, 2 * self._max_new_per_frame))
+        """capacity for `n_frames` un-synchronised frames: the known unit count + 2 048 (a first view of a scene opens ~1 500 units at
+        endoscopic range) + per frame four times what the frames of the last stream opened on average, at least 128 (measured on the
+        bench's synthetic sequence: ~65).  A stream that still runs out is reported by sync() -- 288 GB of HBM is what makes the
+        generous bound affordable (a block is 655 KB)."""
+        self.reserve(self.n_units + 2048 + n_frames * max(128, 4 * self._max_new_per_frame))
 
     def n_units_known(self) -> int:
         return self.n_units
+
+    def discover(self, rgbd: "RGBDImage", intrinsic: "PinholeCameraIntrinsic", extrinsic) -> None:
+        """unit discovery of a frame WITHOUT integrating it (no round trip): the units it needs enter the table and take blocks as far as
+        blocks exist.  ``reserve_discovered()`` then makes the missing blocks -- two cheap passes over a batch of frames replace a guess
+        at how many units a stream will open."""
+        self._touch_integrate(rgbd, intrinsic, extrinsic, integrate=False)
+
+    def reserve_discovered(self, margin: int = 256) -> int:
+        """after a run of discover() calls: one round trip for the unit count and the number of table entries still without a block;
+        allocates what is missing (+ margin) and clears the overflow flag those frames may have raised.  Returns the blocks added."""
+        n_units = int(self.counters[0])
+        missing = int(((self.table_keys != -1) & (self.table_slots < 0)).sum())
+        before = self.alloc_units
+        self.reserve(n_units + missing + margin)
+        self.counters[2] = 0
+        self.n_units = n_units
+        self._frames_since_sync = 0
+        return self.alloc_units - before
 
     def sync(self):
         """the round trip a stream of build_3D_map(sync=False) calls owes: unit counts, and the overflow check"""
@@ -141,6 +162,9 @@ class TSDF:
 
     # ---- the reference's surface -----------------------------------------------------------------
     def build_3D_map(self, rgbd: RGBDImage, intrinsic: PinholeCameraIntrinsic, extrinsic, sync: bool = True) -> None:
+        self._touch_integrate(rgbd, intrinsic, extrinsic, sync=sync)
+
+    def _touch_integrate(self, rgbd: RGBDImage, intrinsic: PinholeCameraIntrinsic, extrinsic, sync: bool = False, integrate: bool = True) -> None:
         """ScalableTSDFVolume.integrate(rgbd, intrinsic, extrinsic).  sync=True (one frame at a time, as the reference calls it): the
         unit count is read back (12 bytes) and slabs are added on demand.  sync=False: nothing is read back -- the frame is enqueued
         against the blocks that exist (reserve / reserve_ahead) and ``sync()`` later collects the counts and the overflow flag."""
@@ -165,6 +189,8 @@ class TSDF:
                                       self.sdf_trunc, L.p(self.table_keys), L.p(self.table_slots), L.p(self.table_stamp), self.table_cap, self.frame_id,
                                       L.p(self.unit_index), self.alloc_units, L.p(self.counters), L.p(self.touched), st), "bs_tsdf_touch")
 
+        integrate_too = integrate
+
         def integrate(n_hint):
             # (K / pose are copied into the kernel arguments at launch: nothing here has to outlive the call)
             L.check(lib.bs_tsdf_integrate(L.p(d_dev), L.p(c_dev), H, W, K.ctypes.data_as(C.c_void_p), e12.ctypes.data_as(C.c_void_p), L.p(self.unit_index),
@@ -172,9 +198,11 @@ class TSDF:
                                           L.p(self.counters[1:]), st), "bs_tsdf_integrate")
 
         self._frames_since_sync += 1
+        self.frames_integrated += int(integrate_too)
         if not sync:
             touch()
-            integrate(self.alloc_units)
+            if integrate_too:
+                integrate(self.alloc_units)
             return
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()

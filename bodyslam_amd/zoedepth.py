@@ -26,7 +26,7 @@ from __future__ import annotations
 import math
 import os
 from dataclasses import dataclass
-from typing import Dict, Optional, Tuple
+from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -105,6 +105,11 @@ AUTO_TOL_CLASS_M = 4.0e-5                        # depth L1 against the all-"ful
 AUTO_TOL_TOTAL_M = 6.0e-5                        # ... and the chosen combination as a whole
 # neck: "full", or the list of weight-key prefixes that keep both products (the rest: weight-rounding correction only).
 NECK_RELHEAD_WONLY = "ro,ra,nc,fu,pj"            # everything but the relative head keeps both
+# What a class's cheap mode saves per bench step (ms, B = 64, measured: profiles/r02_bench_kernels.txt "wmean" against "wcls"; neck:
+# profiles/r03_neck_relhead_wonly.txt).  When the chosen combination misses the total tolerance, the class that pays the most depth
+# error per millisecond saved goes back up first.  The relative head's weight-only mode buys 1 % for ~2e-5 m: not a default candidate.
+AUTO_SAVING_MS = {"fc1": 8.7, "fc2": 8.0, "qkv": 3.7, "o": 1.8, "neck": 2.0}
+AUTO_NECK_CANDIDATES = ("full",)
 ACCURATE_NECK_MODE = "full"
 # Operand format of the neck's two correction products: "f8" = e4m3 planes with one scale per tensor (2 pass-equivalents, neck error
 # ~7e-6 m on its own), "f4" = e2m1 planes with one E8M0 scale per 64 channels at 4x the 16-bit MFMA rate (1.5 pass-equivalents,
@@ -274,7 +279,7 @@ class ZoeDepthEngine:
         self._plans.clear()
 
     def calibrate(self, H: int = 480, W: int = 640, frames_u8: Optional[torch.Tensor] = None, tol_class: float = AUTO_TOL_CLASS_M,
-                  tol_total: float = AUTO_TOL_TOTAL_M) -> dict:
+                  tol_total: float = AUTO_TOL_TOTAL_M, neck_candidates: Optional[Sequence[str]] = None) -> dict:
         """Choose, with THESE weights on THIS device, the cheapest correction mode per backbone GEMM class (and for the neck) that keeps
         the depth map of a calibration frame within `tol_class` metres (L1) of the all-"full" result, then check the combination
         against `tol_total` and step the most expensive offender back up until it holds.  One B = 1 forward per candidate (about a
@@ -286,7 +291,7 @@ class ZoeDepthEngine:
         frames_u8 = frames_u8[:1].contiguous()
         H, W = int(frames_u8.shape[1]), int(frames_u8.shape[2])
         switchable = [k for k in BACKBONE_CLASSES if self.class_modes[k] in ("full", "wcls", "wmean")]
-        neck_cands = ["full"] if (self.neck_f4 or not self.neck_f8) else [NECK_RELHEAD_WONLY, "full"]
+        neck_cands = ["full"] if (self.neck_f4 or not self.neck_f8) else list(neck_candidates or AUTO_NECK_CANDIDATES)
         saved_auto, self.auto_modes = self.auto_modes, False
 
         def depth(modes, neck):
@@ -327,7 +332,10 @@ class ZoeDepthEngine:
             total = (depth(chosen, neck) - ref).abs().mean().item() if (any(v != "full" for v in chosen.values()) or neck != "full") else 0.0
             if total <= tol_total:
                 break
-            worst = max(cost, key=lambda k_: cost[k_])               # step the largest single contribution back up
+            live = [k_ for k_ in cost if cost[k_] > 0.0]
+            if not live:
+                break
+            worst = max(live, key=lambda k_: cost[k_] / AUTO_SAVING_MS.get(k_, 1.0))     # most error per millisecond saved goes first
             if worst == "neck":
                 neck = "full"
             else:

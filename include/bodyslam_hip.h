@@ -349,8 +349,9 @@ int bs_pose_chain_from(const float* t_rel, int32_t N, const double* g0_dev, doub
  *
  * bs_tsdf_touch: ScalableTSDFVolume::Integrate's unit discovery -- every unit that meets the +-sdf_trunc box of a point of the
  *   depth image sampled every `stride` pixels (depth fp32 [H, W] metres, <= 0 invalid; pose = rows 0..2 of the camera->world 4x4,
- *   i.e. extrinsic^-1; K = (fx, fy, cx, cy); both host doubles) is inserted, gets a block number and goes on `touched`
- *   (int32 [max_units]); frame_id must differ from call to call.
+ *   i.e. extrinsic^-1; K = (fx, fy, cx, cy); both host doubles) is inserted, gets a block number and -- unless its bounding sphere
+ *   lies wholly outside the view frustum, where the integration updates nothing -- goes on `touched` (int32 [max_units]);
+ *   frame_id must differ from call to call.
  * bs_tsdf_integrate: UniformTSDFVolume::IntegrateWithDepthToCameraDistanceMultiplier on the units of `touched`
  *   (extrinsic = rows 0..2 of the world->camera 4x4; color u8 [H, W, 3] or NULL).  Their number is read on the device from
  *   n_touched_dev (= counters + 1); the host value n_touched only sizes the grid (any value >= 1 works), so a stream of frames is

@@ -167,4 +167,47 @@ def test_cyclepose_256_pairs(weights, dtype):
     assert torch.equal(one, T[129])
 
 
+def test_config5_size_on_one_gpu(weights):
+    """BASELINE config 5 at its size, as far as one GPU goes: the BATCHED 1280x1024 plan (B = 16; a 416x512 network input, 833 tokens:
+    image blocks straddle GEMM tiles, the per-row bias2 path) against the B = 1 plan that tests/test_zoedepth_gpu.py checks against
+    the oracle, bit for bit; and stage 3 of a rank at the configuration's length -- the fp64 chain over 4 000 poses with the
+    pose-graph step every 500 (3DM/slam.py:54,159-165: odometry edges only, so the chain comes back untouched), then the
+    back-projection of the rank's own 1280x1024 frames with their poses out of the 4 000."""
+    from bodyslam_amd import geom3d
+    from bodyslam_amd.pipeline import BodySlamPipeline
+    from bodyslam_amd.synthetic import make_sequence
+    from oracle import geom3d_ref as G
+    cfg, wz, wp = weights
+    H, W, B = 1024, 1280, 16
+    frames = torch.from_numpy(make_sequence(B, H, W, seed=8))
+    pipe = BodySlamPipeline(wz, wp, cfg, batch=B, precision="accurate")
+    dm, du = pipe.zoe.infer(frames.cuda())
+    dm, du = dm.clone(), du.clone()
+    assert torch.isfinite(dm).all() and (dm > 0).all()
+    for i in (0, 7, 15):
+        d1, u1 = pipe.zoe.infer(frames[i:i + 1].cuda())
+        assert torch.equal(d1[0], dm[i]) and torch.equal(u1[0], du[i]), f"frame {i}: B=16 1280x1024 plan differs from the B=1 plan"
+    # stage 3 at 4 000 poses: this rank owns frames [3984, 4000)
+    N = 4000
+    rng = np.random.default_rng(5)
+    t_rel = np.tile(np.eye(4, dtype=np.float32), (N - 1, 1, 1))
+    ang = rng.normal(0, 2e-3, (N - 1, 3)).astype(np.float32)
+    t_rel[:, 0, 1], t_rel[:, 1, 0], t_rel[:, 0, 2], t_rel[:, 2, 0], t_rel[:, 1, 2], t_rel[:, 2, 1] = -ang[:, 2], ang[:, 2], ang[:, 1], -ang[:, 1], -ang[:, 0], ang[:, 0]
+    t_rel[:, :3, 3] = rng.normal(0, 1e-3, (N - 1, 3)).astype(np.float32)
+    t_all = torch.from_numpy(t_rel).cuda().view(-1, 16)
+    pipe.posegraph_every = 500
+    res = pipe.chain_and_backproject(N, N - B, N, du, None, t_all, keep_points=True)
+    ref = G.pose_chain(t_rel)
+    assert np.abs(res.g_abs.cpu().numpy() - ref).max() < 1e-9               # the pose graph left the chain untouched
+    dun = du.cpu().numpy().view(np.uint16)
+    for j in (0, B - 1):
+        rx, ri = G.backproject(dun[j], pose=ref[N - B + j])
+        xyz, idx = res.points[j]
+        assert np.array_equal(idx.cpu().numpy(), ri) and np.allclose(xyz.cpu().numpy(), rx, atol=1e-5)
+    report(f"config 5 on one GPU: B=16 1280x1024 plan == B=1 plan; 4000-pose chain + pose graph every 500 == oracle chain; "
+           f"points/frame {res.point_counts.float().mean().item():.0f}")
+    del pipe
+    _free()
+
+
 POSE_TOL = 1e-5      # the accurate MPEM path (split-precision convolutions; DESIGN.md, Numerics)

@@ -179,7 +179,7 @@ def test_run_slam_loop_orders_the_steps_like_the_reference():
         T = vo.estimate_relative_pose_between(i - 1, i, rg[i - 1], rg[i], i)
         assert np.array_equal(T.astype(np.float32), tf[i - 1])
     assert np.abs(res.g_abs.cpu().numpy() - G.pose_chain(tf)).max() < 1e-10
-    assert t.n_units > 0 and t.frame_id == 4
+    assert t.n_units > 0 and t.frames_integrated == 4
 
 
 def test_tsdf_streamed_and_culled_equal_the_synchronous_path():
@@ -253,7 +253,7 @@ def test_slam_loop_reference_order_640x480():
     for i in integrated:
         rg = create_rgbd_from_color_and_depth(frames[i], du[i], pipe.depth_scale, pipe.depth_trunc)
         ref.integrate(rg.depth, rg.color, tuple(pipe.K), g[i])
-    assert t.frame_id == len(integrated)
+    assert t.frames_integrated == len(integrated)
     assert set(t.index) == set(ref.units)
     keys = sorted(ref.units, key=lambda k: -float(ref.units[k][..., 1].sum()))[:12] + list(ref.units)[:: max(1, len(ref.units) // 12)]
     for key in keys:
