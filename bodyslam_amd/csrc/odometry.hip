@@ -42,6 +42,8 @@ template <bool DEPTH>
 __global__ __launch_bounds__(256) void odo_pyrdown_kernel(const float* __restrict__ src, int H, int W, float* __restrict__ dst, int h2, int w2, double thr) {
     const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= w2 || y >= h2) return;
+    src += (int64_t)blockIdx.z * H * W;            // image blockIdx.z of a batch of contiguous [H, W] images
+    dst += (int64_t)blockIdx.z * h2 * w2;
     const double k5[5] = {1.0 / 16, 4.0 / 16, 6.0 / 16, 4.0 / 16, 1.0 / 16};
     const double centre = (double)src[(int64_t)clampi(2 * y, 0, H - 1) * W + clampi(2 * x, 0, W - 1)];
     if (DEPTH && centre != centre) {
@@ -69,6 +71,9 @@ __global__ __launch_bounds__(256) void odo_pyrdown_kernel(const float* __restric
 __global__ __launch_bounds__(256) void odo_sobel_kernel(const float* __restrict__ img, int H, int W, float* __restrict__ gx, float* __restrict__ gy) {
     const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= W || y >= H) return;
+    img += (int64_t)blockIdx.z * H * W;
+    gx += (int64_t)blockIdx.z * H * W;
+    gy += (int64_t)blockIdx.z * H * W;
     auto at = [&](int yy, int xx) { return (double)img[(int64_t)clampi(yy, 0, H - 1) * W + clampi(xx, 0, W - 1)]; };
     const double a = at(y - 1, x - 1), b = at(y - 1, x), c = at(y - 1, x + 1), d = at(y, x - 1), f = at(y, x + 1), g = at(y + 1, x - 1), h = at(y + 1, x),
                  i = at(y + 1, x + 1);
@@ -88,9 +93,14 @@ __global__ __launch_bounds__(256) void odo_accumulate_kernel(const float* __rest
                                                               const float* __restrict__ dDx, const float* __restrict__ dDy, int H, int W, OdoPose P,
                                                               const double* __restrict__ T_dev, double outlier, double huber_d, double huber_i,
                                                               double* __restrict__ partial) {
+    {                     // pair blockIdx.y of a batch: source image y and target image y of two [batch, H, W] stacks, its own pose and partials
+        const int64_t o = (int64_t)blockIdx.y * H * W;
+        Is += o; Ds += o; It += o; Dt += o; dIx += o; dIy += o; dDx += o; dDy += o;
+        partial += (int64_t)blockIdx.y * gridDim.x * ODO_TERMS;
+    }
     if (T_dev) {          // the pose lives on the device (bs_odo_step chains steps without a host round trip)
 #pragma unroll
-        for (int i = 0; i < 12; ++i) P.t[i] = T_dev[i];
+        for (int i = 0; i < 12; ++i) P.t[i] = T_dev[(int64_t)blockIdx.y * 12 + i];
     }
     double acc[ODO_TERMS], tot[ODO_TERMS];
 #pragma unroll
@@ -273,6 +283,9 @@ __global__ void odo_solve_kernel(const double* __restrict__ s29, double* __restr
 __global__ __launch_bounds__(1024) void odo_finish_solve_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ out, double* __restrict__ T) {
     __shared__ double s29[ODO_TERMS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    partial += (int64_t)blockIdx.x * nblocks * ODO_TERMS;      // pair blockIdx.x of a batch
+    out += (int64_t)blockIdx.x * ODO_TERMS;
+    T += (int64_t)blockIdx.x * 12;
     for (int k = wave; k < ODO_TERMS; k += 16) {
         double s = 0.0;
         for (int b = lane; b < nblocks; b += 64) s += partial[(int64_t)b * ODO_TERMS + k];
@@ -287,12 +300,12 @@ __global__ __launch_bounds__(1024) void odo_finish_solve_kernel(const double* __
 }
 
 template <int FLAGS>
-static void launch_accumulate(int nblocks, hipStream_t st, const float* a, const float* b, const float* c, const float* d, const float* e, const float* f,
+static void launch_accumulate(dim3 nblocks, hipStream_t st, const float* a, const float* b, const float* c, const float* d, const float* e, const float* f,
                               const float* g, const float* h, int H, int W, const OdoPose& P, const double* T_dev, double o, double hd, double hi,
                               double* partial) {
-    hipLaunchKernelGGL(odo_accumulate_kernel<FLAGS>, dim3(nblocks), dim3(256), 0, st, a, b, c, d, e, f, g, h, H, W, P, T_dev, o, hd, hi, partial);
+    hipLaunchKernelGGL(odo_accumulate_kernel<FLAGS>, nblocks, dim3(256), 0, st, a, b, c, d, e, f, g, h, H, W, P, T_dev, o, hd, hi, partial);
 }
-static void launch_accumulate_flags(int flags, int nblocks, hipStream_t st, const float* a, const float* b, const float* c, const float* d, const float* e,
+static void launch_accumulate_flags(int flags, dim3 nblocks, hipStream_t st, const float* a, const float* b, const float* c, const float* d, const float* e,
                                     const float* f, const float* g, const float* h, int H, int W, const OdoPose& P, const double* T_dev, double o,
                                     double hd, double hi, double* partial) {
     switch (flags & 3) {
@@ -319,22 +332,23 @@ extern "C" int bs_depth_u16_to_m(const uint16_t* depth_u16, int64_t n, double de
     return BS_OK;
 }
 
-extern "C" int bs_odo_prepare(const uint8_t* color, const float* depth, int32_t H, int32_t W, double depth_max, float* intensity, float* depth_out,
-                              void* stream) {
+extern "C" int bs_odo_prepare(const uint8_t* color, const float* depth, int32_t batch, int32_t H, int32_t W, double depth_max, float* intensity,
+                              float* depth_out, void* stream) {
     ODO_ENTRY("bs_odo_prepare");
-    BS_REQUIRE(color && depth && intensity && depth_out && H > 0 && W > 0, "bs_odo_prepare: bad argument");
-    const int64_t n = (int64_t)H * W;
+    BS_REQUIRE(color && depth && intensity && depth_out && H > 0 && W > 0 && batch > 0, "bs_odo_prepare: bad argument");
+    const int64_t n = (int64_t)batch * H * W;
     hipLaunchKernelGGL(odo_prepare_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), color, depth, n,
                        (float)depth_max, intensity, depth_out);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }
 
-extern "C" int bs_odo_pyrdown(const float* src, int32_t H, int32_t W, float* dst, int32_t is_depth, double depth_threshold, void* stream) {
+extern "C" int bs_odo_pyrdown(const float* src, int32_t batch, int32_t H, int32_t W, float* dst, int32_t is_depth, double depth_threshold,
+                              void* stream) {
     ODO_ENTRY("bs_odo_pyrdown");
-    BS_REQUIRE(src && dst && H > 1 && W > 1, "bs_odo_pyrdown: bad argument");
+    BS_REQUIRE(src && dst && H > 1 && W > 1 && batch > 0 && batch <= 65535, "bs_odo_pyrdown: bad argument");
     const int h2 = (H + 1) / 2, w2 = (W + 1) / 2;
-    const dim3 grid(cdiv(w2, 16), cdiv(h2, 16));
+    const dim3 grid(cdiv(w2, 16), cdiv(h2, 16), batch);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (is_depth)
         hipLaunchKernelGGL(odo_pyrdown_kernel<true>, grid, dim3(256), 0, st, src, H, W, dst, h2, w2, depth_threshold);
@@ -344,10 +358,10 @@ extern "C" int bs_odo_pyrdown(const float* src, int32_t H, int32_t W, float* dst
     return BS_OK;
 }
 
-extern "C" int bs_odo_sobel(const float* img, int32_t H, int32_t W, float* gx, float* gy, void* stream) {
+extern "C" int bs_odo_sobel(const float* img, int32_t batch, int32_t H, int32_t W, float* gx, float* gy, void* stream) {
     ODO_ENTRY("bs_odo_sobel");
-    BS_REQUIRE(img && gx && gy && H > 0 && W > 0, "bs_odo_sobel: bad argument");
-    hipLaunchKernelGGL(odo_sobel_kernel, dim3(cdiv(W, 16), cdiv(H, 16)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), img, H, W, gx, gy);
+    BS_REQUIRE(img && gx && gy && H > 0 && W > 0 && batch > 0 && batch <= 65535, "bs_odo_sobel: bad argument");
+    hipLaunchKernelGGL(odo_sobel_kernel, dim3(cdiv(W, 16), cdiv(H, 16), batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), img, H, W, gx, gy);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }
@@ -365,7 +379,7 @@ extern "C" int bs_odo_accumulate(const float* src_intensity, const float* src_de
     P.fx = K[0]; P.fy = K[1]; P.cx = K[2]; P.cy = K[3];
     const int nblocks = (int)(cdiv64((int64_t)H * W, 256) < ODO_GRID ? cdiv64((int64_t)H * W, 256) : ODO_GRID);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    launch_accumulate_flags(flags, nblocks, st, src_intensity, src_depth, tgt_intensity, tgt_depth, tgt_dIx, tgt_dIy, tgt_dDx, tgt_dDy, H, W, P,
+    launch_accumulate_flags(flags, dim3(nblocks), st, src_intensity, src_depth, tgt_intensity, tgt_depth, tgt_dIx, tgt_dIy, tgt_dDx, tgt_dDy, H, W, P,
                             (const double*)nullptr, depth_outlier_trunc, depth_huber, intensity_huber, partial);
     BS_CHECK_LAUNCH();
     hipLaunchKernelGGL(odo_finish_kernel, dim3(ODO_TERMS), dim3(64), 0, st, partial, nblocks, out29);
@@ -374,23 +388,23 @@ extern "C" int bs_odo_accumulate(const float* src_intensity, const float* src_de
 }
 
 extern "C" int bs_odo_step(const float* src_intensity, const float* src_depth, const float* tgt_intensity, const float* tgt_depth,
-                           const float* tgt_dIx, const float* tgt_dIy, const float* tgt_dDx, const float* tgt_dDy, int32_t H, int32_t W,
+                           const float* tgt_dIx, const float* tgt_dIy, const float* tgt_dDx, const float* tgt_dDy, int32_t batch, int32_t H, int32_t W,
                            const double* K, double* T_dev, int32_t iterations, double depth_outlier_trunc, double depth_huber,
                            double intensity_huber, double* partial, double* out29, int32_t flags, void* stream) {
     ODO_ENTRY("bs_odo_step");
     BS_REQUIRE(src_intensity && src_depth && tgt_intensity && tgt_depth && tgt_dIx && tgt_dIy && tgt_dDx && tgt_dDy && K && T_dev && partial && out29,
                "bs_odo_step: null argument");
-    BS_REQUIRE(H > 1 && W > 1 && iterations >= 0, "bs_odo_step: bad geometry");
+    BS_REQUIRE(H > 1 && W > 1 && iterations >= 0 && batch > 0 && batch <= 65535, "bs_odo_step: bad geometry");
     OdoPose P;
     for (int i = 0; i < 12; ++i) P.t[i] = 0.0;
     P.fx = K[0]; P.fy = K[1]; P.cx = K[2]; P.cy = K[3];
     const int nblocks = (int)(cdiv64((int64_t)H * W, 256) < ODO_GRID ? cdiv64((int64_t)H * W, 256) : ODO_GRID);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     for (int it = 0; it < iterations; ++it) {
-        launch_accumulate_flags(flags, nblocks, st, src_intensity, src_depth, tgt_intensity, tgt_depth, tgt_dIx, tgt_dIy, tgt_dDx, tgt_dDy, H, W, P,
-                                (const double*)T_dev, depth_outlier_trunc, depth_huber, intensity_huber, partial);
+        launch_accumulate_flags(flags, dim3(nblocks, batch), st, src_intensity, src_depth, tgt_intensity, tgt_depth, tgt_dIx, tgt_dIy, tgt_dDx, tgt_dDy, H, W,
+                                P, (const double*)T_dev, depth_outlier_trunc, depth_huber, intensity_huber, partial);
         BS_CHECK_LAUNCH();
-        hipLaunchKernelGGL(odo_finish_solve_kernel, dim3(1), dim3(1024), 0, st, partial, nblocks, out29, T_dev);
+        hipLaunchKernelGGL(odo_finish_solve_kernel, dim3(batch), dim3(1024), 0, st, partial, nblocks, out29, T_dev);
         BS_CHECK_LAUNCH();
     }
     return BS_OK;

@@ -282,7 +282,7 @@ class BodySlamPipeline:
         # the small kernels hide under the next batch's GEMMs (the round-2 loop ran them one after the other: 72 frames/s).
         main = torch.cuda.current_stream(self.dev)
         if getattr(self, "_loop_stream", None) is None:
-            self._loop_stream = torch.cuda.Stream(device=self.dev)
+            self._loop_stream = torch.cuda.Stream(device=self.dev, priority=-1)   # its short kernels go ahead of the network's big ones
         side = self._loop_stream
 
         def launch_network(b0):
@@ -291,6 +291,7 @@ class BodySlamPipeline:
             depth_all[b0:b1].copy_(d_u16)
             if keep_depth_m:
                 depth_m_all[b0:b1].copy_(d_m)
+            t_dev.record_stream(side)
             ev = torch.cuda.Event()
             ev.record(main)
             return b0, b1, t_dev, ev
@@ -298,10 +299,10 @@ class BodySlamPipeline:
         pending = launch_network(0)
         while pending is not None:
             b0, b1, t_dev, ev = pending
-            t_mpem = t_dev.view(-1, 4, 4).cpu().numpy()                         # the pairs (i - 1, i), i in [max(b0, 1), b1); waits for batch k's network
-            pending = launch_network(b1) if b1 < N else None                    # batch k + 1's network: enqueued, not waited for
+            pending = launch_network(b1) if b1 < N else None                    # batch k + 1's network: enqueued behind batch k's, not waited for
             side.wait_event(ev)
             with torch.cuda.stream(side):
+                t_mpem = t_dev.view(-1, 4, 4).cpu().numpy()                     # the pairs (i - 1, i), i in [max(b0, 1), b1); waits for batch k's network only
                 self._slam_batch(b0, b1, t_mpem, vo, odo, stored if vo else None, vo_obj if vo else None, state, fr_dev, depth_all, intr, pg, extr,
                                  rel_fused, cnt_all, points, keep_points, every, rebuild_every, extract_every_frame, on_frame, tsdf_depth,
                                  run_map_actions)
@@ -319,18 +320,40 @@ class BodySlamPipeline:
         if True:
             t_odo = None
             if vo:
-                # the odometry's depth: raw / depth_scale (no truncation); every frame of the batch is tracked on the device
+                # the odometry's depth: raw / depth_scale (no truncation); the pairs of a batch do not depend on each other
                 raw = L.depth_u16_to_m(depth_all[b0:b1].contiguous(), self.depth_scale, 3.0e38)
-                got = [odo.track(fr_dev[i], raw[i - b0]) for i in range(b0, b1)]
-                got = [g for g in got if g is not None]
-                if got:
-                    t12 = torch.stack(got).cpu().numpy().reshape(-1, 3, 4)   # ONE readback per batch
+                got = odo.track_block(fr_dev[b0:b1], raw)                      # the block's pairs at once, on the device
+                if got.shape[0]:
+                    t12 = got.cpu().numpy().reshape(-1, 3, 4)                   # ONE readback per batch
                     t_odo = np.tile(np.eye(4), (t12.shape[0], 1, 1))
                     t_odo[:, :3] = t12
                     t_odo = np.linalg.inv(t_odo)                                # what _compute_vo_o3d returns (visual_odometry.py:118)
             dm_map = tsdf_depth(b0, b1) if state["tsdf"] is not None else None
             actions = []                              # the batch's map steps; executed together unless a point cloud is wanted per frame
             first_pair = max(b0, 1)
+            # the fused relatives of the batch: the UKF is sequential over the frames but does not look at the poses
+            fused = {}
+            for i in range(first_pair, b1):
+                T = np.array(t_mpem[i - first_pair])
+                if vo:
+                    stored["mpem"], stored["odo"] = T, t_odo[i - first_pair]
+                    T = vo_obj.estimate_relative_pose_between(i - 1, i, None, None, i)
+                fused[i] = T
+            ahead = {}                                # poses chained ahead on the device, from extr[-1] up to the next frame on which the pose graph may move them
+
+            def chained_pose(i):
+                """slam_utils.py:110-122 for frame i; one device call and one readback per segment of the batch instead of per frame"""
+                if i not in ahead:
+                    j1 = i
+                    while j1 + 1 < b1 and not (every > 0 and j1 % every == 0):
+                        j1 += 1
+                    seg = geom3d.pose_chain(np.stack([fused[j] for j in range(i, j1 + 1)]).astype(np.float32), g0=np.asarray(extr[-1], dtype=np.float64),
+                                            device=self.dev.index or 0).cpu().numpy()
+                    ahead.clear()
+                    for j in range(i, j1 + 1):
+                        ahead[j] = seg[j - i + 1]
+                return ahead.pop(i)
+
             for i in range(b0, b1):
                 pcd = None
                 if i == 0:
@@ -340,12 +363,9 @@ class BodySlamPipeline:
                     if state["tsdf"] is not None:
                         actions.append(("int", 0, pose))
                 else:
-                    T = np.array(t_mpem[i - first_pair])
-                    if vo:
-                        stored["mpem"], stored["odo"] = T, t_odo[i - first_pair]
-                        T = vo_obj.estimate_relative_pose_between(i - 1, i, None, None, i)
+                    T = fused[i]
                     rel_fused.append(T)
-                    pose = geom3d.compute_curr_estimate_global_pose(extr[-1], T)
+                    pose = chained_pose(i)
                     extr.append(pose)
                     pg.add_node(pose)
                     pg.add_edge(T, i, i - 1, False)

@@ -13,11 +13,15 @@ projected source point, and the robust step has Open3D's form (J^T J unweighted,
 ``association="bilinear"`` (round 2's variant, kept as an option): the target is sampled bilinearly and the step is IRLS-weighted --
 a smooth cost, which on sub-pixel motions converges to the micrometre where the nearest-pixel cost is piecewise constant.
 
-Everything runs in the kernels of csrc/odometry.hip.  Two ways to call it:
+Everything runs in the kernels of csrc/odometry.hip.  Three ways to call it:
   * ``RGBDOdometry()(curr_rgbd, prev_rgbd)`` -- what ``_compute_vo_o3d`` returns (the inverse of source -> target), one pair at a time;
   * ``track(color, depth)`` -- a stream of consecutive frames: each frame's pyramid and gradients are built ONCE (it is the source of
     one pair and the target of the next), the 11 + 70 launches of a frame are captured in a HIP graph and replayed, and the pose
-    stays on the device, so a sequence is tracked without a host round trip per pair."""
+    stays on the device, so a sequence is tracked without a host round trip per pair;
+  * ``track_block(colors, depths)`` -- a block of consecutive frames at once.  The pairs of a sequence do not depend on each other
+    (the reference starts every pair from the identity, visual_odometry.py:100), so n frames are n simultaneous pairs: every stage is
+    ONE launch over the whole block (~100 launches per block instead of 81 per frame) and the work is HBM streaming instead of a
+    chain of 10-microsecond launches.  Pair for pair the same sums in the same order as the other two: bit-equal results."""
 from __future__ import annotations
 
 import ctypes as C
@@ -49,7 +53,7 @@ def se3_exp(delta: np.ndarray) -> np.ndarray:
 
 
 class _Level:
-    __slots__ = ("H", "W", "K", "Kc", "I", "D", "gIx", "gIy", "gDx", "gDy")
+    __slots__ = ("H", "W", "K", "Kc", "I", "D", "gIx", "gIy", "gDx", "gDy")     # maps: [H, W], or [slots, H, W] in track_block
 
 
 class RGBDOdometry:
@@ -68,6 +72,7 @@ class RGBDOdometry:
         L.init(device)
         self.last_trace = None
         self._trk = None
+        self._blk = None
 
     # ---- device-side image preparation ---------------------------------------------------------------
     def _alloc_levels(self, H: int, W: int) -> List[_Level]:
@@ -94,14 +99,14 @@ class RGBDOdometry:
     def _build(self, levels: List[_Level], color: torch.Tensor, depth: torch.Tensor, depth_max: float, gradients: bool = True):
         lib, st = L.load_library(), L.stream_ptr()
         l0 = levels[0]
-        L.check(lib.bs_odo_prepare(L.p(color), L.p(depth), l0.H, l0.W, float(depth_max), L.p(l0.I), L.p(l0.D), st), "bs_odo_prepare")
+        L.check(lib.bs_odo_prepare(L.p(color), L.p(depth), 1, l0.H, l0.W, float(depth_max), L.p(l0.I), L.p(l0.D), st), "bs_odo_prepare")
         for p, n in zip(levels[:-1], levels[1:]):
-            L.check(lib.bs_odo_pyrdown(L.p(p.I), p.H, p.W, L.p(n.I), 0, 0.0, st), "bs_odo_pyrdown")
-            L.check(lib.bs_odo_pyrdown(L.p(p.D), p.H, p.W, L.p(n.D), 1, 2.0 * DEPTH_OUTLIER_TRUNC, st), "bs_odo_pyrdown")
+            L.check(lib.bs_odo_pyrdown(L.p(p.I), 1, p.H, p.W, L.p(n.I), 0, 0.0, st), "bs_odo_pyrdown")
+            L.check(lib.bs_odo_pyrdown(L.p(p.D), 1, p.H, p.W, L.p(n.D), 1, 2.0 * DEPTH_OUTLIER_TRUNC, st), "bs_odo_pyrdown")
         if gradients:
             for lv in levels:
-                L.check(lib.bs_odo_sobel(L.p(lv.I), lv.H, lv.W, L.p(lv.gIx), L.p(lv.gIy), st), "bs_odo_sobel")
-                L.check(lib.bs_odo_sobel(L.p(lv.D), lv.H, lv.W, L.p(lv.gDx), L.p(lv.gDy), st), "bs_odo_sobel")
+                L.check(lib.bs_odo_sobel(L.p(lv.I), 1, lv.H, lv.W, L.p(lv.gIx), L.p(lv.gIy), st), "bs_odo_sobel")
+                L.check(lib.bs_odo_sobel(L.p(lv.D), 1, lv.H, lv.W, L.p(lv.gDx), L.p(lv.gDy), st), "bs_odo_sobel")
 
     def _pyramid(self, color_u8, depth_m, depth_max: float, gradients: bool):
         color, depth = self._dev(color_u8, torch.uint8), self._dev(depth_m, torch.float32)      # numpy, host or device tensors
@@ -114,7 +119,7 @@ class RGBDOdometry:
         lib, st = L.load_library(), L.stream_ptr()
         for level, iters in zip(range(len(ps) - 1, -1, -1), self.iterations):
             s, t = ps[level], pt[level]
-            L.check(lib.bs_odo_step(L.p(s.I), L.p(s.D), L.p(t.I), L.p(t.D), L.p(t.gIx), L.p(t.gIy), L.p(t.gDx), L.p(t.gDy), s.H, s.W,
+            L.check(lib.bs_odo_step(L.p(s.I), L.p(s.D), L.p(t.I), L.p(t.D), L.p(t.gIx), L.p(t.gIy), L.p(t.gDx), L.p(t.gDy), 1, s.H, s.W,
                                     s.Kc.ctypes.data_as(C.c_void_p), L.p(T_dev), iters, DEPTH_OUTLIER_TRUNC, DEPTH_HUBER, INTENSITY_HUBER,
                                     L.p(partial), L.p(out), self.flags, st), "bs_odo_step")
 
@@ -165,8 +170,9 @@ class RGBDOdometry:
     # ---- a stream of consecutive frames --------------------------------------------------------------
     def reset(self):
         """forget the previous frame of track()"""
-        if self._trk is not None:
-            self._trk["have_prev"] = False
+        for k in (self._trk, self._blk):
+            if k is not None:
+                k["have_prev"] = False
 
     def track(self, color_u8: torch.Tensor, depth_m: torch.Tensor, graph: bool = True) -> Optional[torch.Tensor]:
         """The next frame of a sequence (device tensors: color uint8 [H, W, 3], depth fp32 metres [H, W]).  Returns None for the first
@@ -220,6 +226,62 @@ class RGBDOdometry:
         else:
             k["graph"].replay()
         return k["T"].clone()
+
+    # ---- a block of consecutive frames at once ---------------------------------------------------------
+    def track_block(self, colors_u8: torch.Tensor, depths_m: torch.Tensor, max_block: int = 64) -> torch.Tensor:
+        """The next n frames of a sequence (device tensors: colors uint8 [n, H, W, 3], depths fp32 metres [n, H, W]).  Returns a device
+        tensor [pairs, 12] (float64): rows 0..2 of T(frame -> the frame before it) for every frame that has a predecessor -- n - 1 pairs
+        for the first block after ``reset()`` / construction, n afterwards (the last frame of a block is kept as the next block's
+        first target).  Nothing is read back to the host.  Pair for pair bit-equal to ``estimate(current, previous)``."""
+        assert colors_u8.is_cuda and depths_m.is_cuda and colors_u8.dtype == torch.uint8 and depths_m.dtype == torch.float32
+        n, H, W = depths_m.shape
+        if n > max_block:                        # bounded scratch: long inputs go through in pieces
+            return torch.cat([self.track_block(colors_u8[a:a + max_block], depths_m[a:a + max_block], max_block) for a in range(0, n, max_block)])
+        k = self._blk
+        if k is None or k["hw"] != (H, W) or k["slots"] < n + 1:
+            slots = max(n, max_block if n > 1 else 1) + 1
+            levels, (h, w, kk) = [], (H, W, self.K)
+            for _ in range(len(self.iterations)):
+                lv = _Level()
+                lv.H, lv.W, lv.K, lv.Kc = h, w, kk, np.array(kk, dtype=np.float64)
+                lv.I, lv.D, lv.gIx, lv.gIy, lv.gDx, lv.gDy = (torch.empty(slots, h, w, device=self.dev, dtype=torch.float32) for _ in range(6))
+                levels.append(lv)
+                h, w, kk = (h + 1) // 2, (w + 1) // 2, tuple(v / 2.0 for v in kk)
+            nblk = min((H * W + 255) // 256, 256)
+            k = self._blk = dict(hw=(H, W), slots=slots, levels=levels, have_prev=False,
+                                 T=torch.empty(slots - 1, 12, dtype=torch.float64, device=self.dev),
+                                 T0=torch.tensor([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=torch.float64, device=self.dev),
+                                 partial=torch.empty(slots - 1, nblk, 29, dtype=torch.float64, device=self.dev),
+                                 out=torch.zeros(slots - 1, 29, dtype=torch.float64, device=self.dev))
+        if n == 0:
+            return torch.empty(0, 12, dtype=torch.float64, device=self.dev)
+        lib, st = L.load_library(), L.stream_ptr()
+        colors_u8, depths_m = colors_u8.contiguous(), depths_m.contiguous()
+        lv = k["levels"]
+        # slot 0 holds the previous block's last frame; the n new frames go to slots 1..n
+        L.check(lib.bs_odo_prepare(L.p(colors_u8), L.p(depths_m), n, H, W, 3.0e38, L.p(lv[0].I[1]), L.p(lv[0].D[1]), st), "bs_odo_prepare")
+        for p_, n_ in zip(lv[:-1], lv[1:]):
+            L.check(lib.bs_odo_pyrdown(L.p(p_.I[1]), n, p_.H, p_.W, L.p(n_.I[1]), 0, 0.0, st), "bs_odo_pyrdown")
+            L.check(lib.bs_odo_pyrdown(L.p(p_.D[1]), n, p_.H, p_.W, L.p(n_.D[1]), 1, 2.0 * DEPTH_OUTLIER_TRUNC, st), "bs_odo_pyrdown")
+        for l_ in lv:                           # every new frame is a target, in this block or (the last one) in the next
+            L.check(lib.bs_odo_sobel(L.p(l_.I[1]), n, l_.H, l_.W, L.p(l_.gIx[1]), L.p(l_.gIy[1]), st), "bs_odo_sobel")
+            L.check(lib.bs_odo_sobel(L.p(l_.D[1]), n, l_.H, l_.W, L.p(l_.gDx[1]), L.p(l_.gDy[1]), st), "bs_odo_sobel")
+        first = 0 if k["have_prev"] else 1       # the first pair's target slot
+        pairs = n - first
+        T = k["T"][:max(pairs, 0)]
+        if pairs > 0:
+            T.copy_(k["T0"].expand(pairs, 12))
+            for level, iters in zip(range(len(lv) - 1, -1, -1), self.iterations):
+                l_ = lv[level]
+                s, t = first + 1, first
+                L.check(lib.bs_odo_step(L.p(l_.I[s]), L.p(l_.D[s]), L.p(l_.I[t]), L.p(l_.D[t]), L.p(l_.gIx[t]), L.p(l_.gIy[t]), L.p(l_.gDx[t]),
+                                        L.p(l_.gDy[t]), pairs, l_.H, l_.W, l_.Kc.ctypes.data_as(C.c_void_p), L.p(T), iters, DEPTH_OUTLIER_TRUNC,
+                                        DEPTH_HUBER, INTENSITY_HUBER, L.p(k["partial"]), L.p(k["out"]), self.flags, st), "bs_odo_step")
+        for l_ in lv:                           # the block's last frame is the next block's first target
+            for m in (l_.I, l_.D, l_.gIx, l_.gIy, l_.gDx, l_.gDy):
+                m[0].copy_(m[n])
+        k["have_prev"] = True
+        return T.clone()
 
     def _dev(self, x, dtype) -> torch.Tensor:
         t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(x)))

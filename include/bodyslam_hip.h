@@ -397,20 +397,25 @@ int bs_tsdf_mesh(const int32_t* unit_index, int32_t units, const void* table_key
  *                      weights, target sampled bilinearly; partial = scratch double [ceil(H*W/256), 29]; deterministic.
  *                      flags bit 0: the target images are read at the NEAREST pixel of the projected point (round half away from zero),
  *                      Open3D's association; bit 1: Open3D's robust step -- sum J^T J unweighted, sum J^T huber'(r) with
- *                      huber'(r) = r clipped to +-delta, cost = sum huber(r) */
+ *                      huber'(r) = r clipped to +-delta, cost = sum huber(r)
+ * `batch` (prepare / pyrdown / sobel / step): the images are `batch` contiguous [H, W] images, processed by ONE launch per stage.  The
+ * frame-to-frame pairs of a sequence are independent of each other (every pair starts from the identity), so a batch of frames
+ * is tracked as `batch` simultaneous pairs: bs_odo_step's pair p reads source image p of the src_* stacks and target image p of the
+ * tgt_* stacks (for consecutive frames held in one [slots, H, W] stack: src = the stack + H*W, tgt = the stack), its pose is
+ * T_dev[12 p ..], its scratch partial[p][.][29], its sums out29[29 p ..].  The sums of a pair do not depend on the batch. */
 /* the pseudo-RGBD depth of the 3DM loop (3DM/slam_utils.py:212-220): out = u16 / depth_scale as fp32 metres, values >= depth_trunc -> 0 */
 int bs_depth_u16_to_m(const uint16_t* depth_u16, int64_t n, double depth_scale, double depth_trunc, float* out, void* stream);
 /* `iterations` Gauss-Newton steps of one pyramid level entirely on the device: bs_odo_accumulate's sums at the pose in T_dev (12
  * doubles in device memory, rows 0..2 of source -> target), delta = -(A + 1e-12 I)^-1 b, T_dev <- exp(delta) T_dev; a step with
  * fewer than 6 inliers leaves T_dev alone.  No host round trip between steps. */
 int bs_odo_step(const float* src_intensity, const float* src_depth, const float* tgt_intensity, const float* tgt_depth,
-                const float* tgt_dIx, const float* tgt_dIy, const float* tgt_dDx, const float* tgt_dDy, int32_t H, int32_t W,
+                const float* tgt_dIx, const float* tgt_dIy, const float* tgt_dDx, const float* tgt_dDy, int32_t batch, int32_t H, int32_t W,
                 const double* K, double* T_dev, int32_t iterations, double depth_outlier_trunc, double depth_huber,
                 double intensity_huber, double* partial, double* out29, int32_t flags, void* stream);
-int bs_odo_prepare(const uint8_t* color, const float* depth, int32_t H, int32_t W, double depth_max, float* intensity, float* depth_out,
-                   void* stream);
-int bs_odo_pyrdown(const float* src, int32_t H, int32_t W, float* dst, int32_t is_depth, double depth_threshold, void* stream);
-int bs_odo_sobel(const float* img, int32_t H, int32_t W, float* gx, float* gy, void* stream);
+int bs_odo_prepare(const uint8_t* color, const float* depth, int32_t batch, int32_t H, int32_t W, double depth_max, float* intensity,
+                   float* depth_out, void* stream);
+int bs_odo_pyrdown(const float* src, int32_t batch, int32_t H, int32_t W, float* dst, int32_t is_depth, double depth_threshold, void* stream);
+int bs_odo_sobel(const float* img, int32_t batch, int32_t H, int32_t W, float* gx, float* gy, void* stream);
 int bs_odo_accumulate(const float* src_intensity, const float* src_depth, const float* tgt_intensity, const float* tgt_depth,
                       const float* tgt_dIx, const float* tgt_dIy, const float* tgt_dDx, const float* tgt_dDy, int32_t H, int32_t W,
                       const double* K, const double* T, double depth_outlier_trunc, double depth_huber, double intensity_huber,

@@ -125,3 +125,47 @@ def test_track_stream_equals_pairwise_and_is_fast(assoc):
         f.write(f"track() {assoc}: {ms:.3f} ms per 640x480 pair (HIP graph replay, pyramids reused, no readback)\n")
     print(f"track() {assoc}: {ms:.3f} ms per pair")
     assert ms < 1.0
+
+
+@pytest.mark.parametrize("assoc", ["nearest", "bilinear"])
+def test_track_block_equals_pairwise_and_is_fast(assoc):
+    """track_block(): the pairs of a block of consecutive frames do not depend on each other (every pair starts from the identity,
+    visual_odometry.py:100), so a block is tracked as simultaneous pairs, one launch per stage.  Pair for pair the same transforms as
+    estimate() (bit for bit: the same sums in the same order), across block borders too; a 64-frame block of 640x480 frames costs
+    well under 0.25 ms per pair"""
+    import os
+    import time
+    import torch
+    from bodyslam_amd.rgbd_odometry import RGBDOdometry
+    Kf = (383.1901395, 383.1901395, 276.4727783203125, 124.3335933685303)
+    poses = [small_pose(0.002 * i, -0.003 * i, 0.001 * i, 0.0015 * i, -0.001 * i, 0.0008 * i) for i in range(6)]
+    fr = [render(p, Kf, 480, 640) for p in poses]
+    dev = torch.device("cuda:0")
+    cols = torch.stack([torch.from_numpy(c) for c, _ in fr]).to(dev)
+    deps = torch.stack([torch.from_numpy(d) for _, d in fr]).to(dev)
+    odo = RGBDOdometry(Kf, association=assoc)
+    a = odo.track_block(cols[:3], deps[:3])                 # frames 0..2: two pairs
+    b = odo.track_block(cols[3:4], deps[3:4])               # frame 3 against the kept frame 2
+    c = odo.track_block(cols[4:], deps[4:], max_block=1)    # pieces of one frame
+    assert a.shape == (2, 12) and b.shape == (1, 12) and c.shape == (2, 12)
+    got = torch.cat([a, b, c]).cpu().numpy()
+    for i in range(1, 6):
+        T = odo.estimate(fr[i][0], fr[i][1], fr[i - 1][0], fr[i - 1][1], 3.0e38)
+        assert np.array_equal(got[i - 1].reshape(3, 4), T[:3]), i
+    odo.reset()
+    assert odo.track_block(cols[:1], deps[:1]).shape == (0, 12) and odo.track_block(cols[:0], deps[:0]).shape == (0, 12)
+    # timing: blocks of 64 frames
+    big_c = cols[torch.arange(64, device=dev) % 6].contiguous()
+    big_d = deps[torch.arange(64, device=dev) % 6].contiguous()
+    odo.track_block(big_c, big_d)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        out = odo.track_block(big_c, big_d)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / (3 * 64) * 1e3
+    assert np.array_equal(out[1].cpu().numpy(), got[0])     # (pair 1 of the big block = frames 0 -> 1 again)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "odometry_track.txt"), "a") as f:
+        f.write(f"track_block() {assoc}: {ms:.3f} ms per 640x480 pair (blocks of 64 frames, one launch per stage, no readback)\n")
+    print(f"track_block() {assoc}: {ms:.3f} ms per pair")
+    assert ms < 0.25

@@ -36,6 +36,16 @@ pipe.run_slam_loop(frames[:B + 2], vo=True, tsdf=TSDF())                        
 torch.cuda.empty_cache()
 tsdf = TSDF()
 tsdf.reserve(4096)
+if os.environ.get("BS_PROFILE"):                                                  # where the host's time goes (python -X importtime is no help here)
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    pipe.run_slam_loop(frames, vo=True, tsdf=TSDF(), posegraph_every=500)
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+    torch.cuda.empty_cache()
 res, t_all = timed(lambda: pipe.run_slam_loop(frames, vo=True, tsdf=tsdf, posegraph_every=500))
 tsdf = pipe.last_tsdf
 print(f"run_slam_loop, {N} frames 640x480, batch {B}, VO fusion + TSDF map (1 mm voxels, 0.1 m truncation, 32^3 units): {t_all * 1e3:.0f} ms = "
