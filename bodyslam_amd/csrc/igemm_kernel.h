@@ -805,32 +805,26 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                         const int j = jp * 2 + h;
                         float* y = y8 + h * 4;
                         if (n0j[j] >= p.N) continue;
-                        if (brow) {
-                            const f32x4 bb = *reinterpret_cast<const f32x4*>(brow + n0j[j]);
+                        // (the same association as a tile that lies in one group, where bias2 is folded into bj: acc + (bias + bias2) --
+                        // a row's result must not depend on which rows share its tile, i.e. on the batch)
+                        f32x4 bsum = brow ? *reinterpret_cast<const f32x4*>(brow + n0j[j]) : bj[j];
+                        if (brow2) bsum += *reinterpret_cast<const f32x4*>(brow2 + n0j[j]);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) y[e] = acc[i][j][e] + bb[e];
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) y[e] = acc[i][j][e] + bj[j][e];
-                        }
-                        if (brow2) {
-                            const f32x4 bb = *reinterpret_cast<const f32x4*>(brow2 + n0j[j]);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) y[e] += bb[e];
-                        }
+                        for (int e = 0; e < 4; ++e) y[e] = acc[i][j][e] + bsum[e];
+                        const bool res32 = p.res && p.res_dtype == BS_F32;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             if (ACT == BS_ACT_RELU) y[e] = fmaxf(y[e], 0.0f);
                             else if (ACT == BS_ACT_GELU) y[e] = gelu_erf(y[e]);
                             else if (ACT == BS_ACT_SOFTPLUS) y[e] = softplus20(y[e]);
-                            y[e] *= sj[j][e];
+                            if (!res32) y[e] *= sj[j][e];
                         }
                         if (p.res) {
                             const int64_t ro = orow * p.ldr + n0j[j];   // residuals live in the OUTPUT row geometry
                             if (p.res_dtype == BS_F32) {
                                 const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + ro);
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) y[e] += rr[e];
+                                for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf(y[e], sj[j][e], rr[e]);     // (one fused step, as the o_proj / fc2 form below)
                             } else {
                                 const typename T16<T>::v4 rr = *reinterpret_cast<const typename T16<T>::v4*>(reinterpret_cast<const T*>(p.res) + ro);
 #pragma unroll
@@ -929,8 +923,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                 f32x4 y0, y1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    y0[e] = (acc[i][2 * jp][e] + bj[2 * jp][e]) * sj[2 * jp][e] + rq[it % DEPTH][0][e];
-                    y1[e] = (acc[i][2 * jp + 1][e] + bj[2 * jp + 1][e]) * sj[2 * jp + 1][e] + rq[it % DEPTH][1][e];
+                    y0[e] = __builtin_fmaf(acc[i][2 * jp][e] + bj[2 * jp][e], sj[2 * jp][e], rq[it % DEPTH][0][e]);
+                    y1[e] = __builtin_fmaf(acc[i][2 * jp + 1][e] + bj[2 * jp + 1][e], sj[2 * jp + 1][e], rq[it % DEPTH][1][e]);
                 }
                 if (it + DEPTH < NP) issue(it + DEPTH, it % DEPTH);
                 if (m < p.M) {

@@ -10,6 +10,8 @@
 // blocks are carved from zero-filled slabs whose base addresses the kernels get as a small device array.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace bs {
@@ -134,6 +136,40 @@ __global__ __launch_bounds__(256) void tsdf_assign_kernel(const long long* __res
 // from device memory (counters[1], written by tsdf_assign_kernel), so the host never has to wait for it.
 // (Units wholly outside the view frustum never reach `touched`: tsdf_assign_kernel.  A test per 256-voxel block was tried first and
 // cost what it saved: the block-uniform fp64 test is as many vector instructions as the per-voxel projection it replaces.)
+// what one frame says about one voxel (world position p): false = the voxel is not updated; otherwise the truncated sdf and the
+// pixel it was read at.  Shared by the frame-at-a-time and the frame-batched kernels: the same instructions, the same bits.
+__device__ __forceinline__ bool tsdf_observe(double px, double py, double pz, const TsdfCam& cam, const float* __restrict__ depth, int H, int W,
+                                             double sdf_trunc, float& tsdf, int64_t& pix) {
+    const double cx_ = cam.e[0] * px + cam.e[1] * py + cam.e[2] * pz + cam.e[3];
+    const double cy_ = cam.e[4] * px + cam.e[5] * py + cam.e[6] * pz + cam.e[7];
+    const double cz_ = cam.e[8] * px + cam.e[9] * py + cam.e[10] * pz + cam.e[11];
+    if (!(cz_ > 0.0)) return false;
+    const double u_f = cx_ * cam.fx / cz_ + cam.cx + 0.5, v_f = cy_ * cam.fy / cz_ + cam.cy + 0.5;
+    if (!(u_f >= 0.0001 && u_f < (double)W - 0.0001 && v_f >= 0.0001 && v_f < (double)H - 0.0001)) return false;
+    const int ui = (int)u_f, vi = (int)v_f;
+    pix = (int64_t)vi * W + ui;
+    const float d = depth[pix];
+    if (!(d > 0.0f)) return false;
+    // depth-to-camera-distance multiplier of the pixel (Open3D keeps it as a float image)
+    const float xx = (float)(((double)ui - cam.cx) / cam.fx), yy = (float)(((double)vi - cam.cy) / cam.fy);
+    const float mult = sqrtf(xx * xx + yy * yy + 1.0f);
+    const float sdf = (float)(((double)d - cz_) * (double)mult);
+    if (!(sdf > -(float)sdf_trunc)) return false;
+    tsdf = fminf(1.0f, sdf * (float)(1.0 / sdf_trunc));
+    return true;
+}
+// the running weighted mean of a voxel (tsdf, weight, r, g, b) takes one observation
+__device__ __forceinline__ void tsdf_blend(float vox[5], float tsdf, const uint8_t* __restrict__ c) {
+    const float w0 = vox[1], w1 = w0 + 1.0f;
+    vox[0] = (vox[0] * w0 + tsdf) / w1;
+    if (c) {
+        vox[2] = (vox[2] * w0 + (float)c[0]) / w1;
+        vox[3] = (vox[3] * w0 + (float)c[1]) / w1;
+        vox[4] = (vox[4] * w0 + (float)c[2]) / w1;
+    }
+    vox[1] = w1;
+}
+
 __device__ __forceinline__ void tsdf_integrate_block(int work, const float* __restrict__ depth, const uint8_t* __restrict__ color, int H, int W,
                                                      const TsdfCam& cam, const int32_t* __restrict__ unit_index, const int32_t* __restrict__ touched,
                                                      int blocks_per_unit, const int64_t* __restrict__ slab_base, int slab_units, int res,
@@ -148,31 +184,20 @@ __device__ __forceinline__ void tsdf_integrate_block(int work, const float* __re
     const double px = half + voxel_length * x + unit_len * unit_index[3 * u + 0];
     const double py = half + voxel_length * y + unit_len * unit_index[3 * u + 1];
     const double pz = half + voxel_length * z + unit_len * unit_index[3 * u + 2];
-    const double cx_ = cam.e[0] * px + cam.e[1] * py + cam.e[2] * pz + cam.e[3];
-    const double cy_ = cam.e[4] * px + cam.e[5] * py + cam.e[6] * pz + cam.e[7];
-    const double cz_ = cam.e[8] * px + cam.e[9] * py + cam.e[10] * pz + cam.e[11];
-    if (!(cz_ > 0.0)) return;
-    const double u_f = cx_ * cam.fx / cz_ + cam.cx + 0.5, v_f = cy_ * cam.fy / cz_ + cam.cy + 0.5;
-    if (!(u_f >= 0.0001 && u_f < (double)W - 0.0001 && v_f >= 0.0001 && v_f < (double)H - 0.0001)) return;
-    const int ui = (int)u_f, vi = (int)v_f;
-    const float d = depth[(int64_t)vi * W + ui];
-    if (!(d > 0.0f)) return;
-    // depth-to-camera-distance multiplier of the pixel (Open3D keeps it as a float image)
-    const float xx = (float)(((double)ui - cam.cx) / cam.fx), yy = (float)(((double)vi - cam.cy) / cam.fy);
-    const float mult = sqrtf(xx * xx + yy * yy + 1.0f);
-    const float sdf = (float)(((double)d - cz_) * (double)mult);
-    if (!(sdf > -(float)sdf_trunc)) return;
-    const float tsdf = fminf(1.0f, sdf * (float)(1.0 / sdf_trunc));
+    float tsdf;
+    int64_t pix;
+    if (!tsdf_observe(px, py, pz, cam, depth, H, W, sdf_trunc, tsdf, pix)) return;
     float* vox = ts_block(slab_base, slab_units, (int64_t)nvox * 20, u) + (int64_t)v * 5;
-    const float w0 = vox[1], w1 = w0 + 1.0f;
-    vox[0] = (vox[0] * w0 + tsdf) / w1;
+    float s[5] = {vox[0], vox[1], 0.0f, 0.0f, 0.0f};
     if (color) {
-        const uint8_t* c = color + ((int64_t)vi * W + ui) * 3;
-        vox[2] = (vox[2] * w0 + (float)c[0]) / w1;
-        vox[3] = (vox[3] * w0 + (float)c[1]) / w1;
-        vox[4] = (vox[4] * w0 + (float)c[2]) / w1;
+        s[2] = vox[2]; s[3] = vox[3]; s[4] = vox[4];
     }
-    vox[1] = w1;
+    tsdf_blend(s, tsdf, color ? color + pix * 3 : nullptr);
+    vox[0] = s[0];
+    vox[1] = s[1];
+    if (color) {
+        vox[2] = s[2]; vox[3] = s[3]; vox[4] = s[4];
+    }
 }
 
 // a fixed grid walks the (touched unit, 256-voxel block) work items; their number comes from device memory
@@ -184,6 +209,162 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float* __rest
     const long long total = (long long)(*n_touched_dev) * blocks_per_unit;
     for (long long w = blockIdx.x; w < total; w += gridDim.x)
         tsdf_integrate_block((int)w, depth, color, H, W, cam, unit_index, touched, blocks_per_unit, slab_base, slab_units, res, voxel_length, sdf_trunc, cull);
+}
+
+// ---- a batch of frames at once ----------------------------------------------------------------------------------------------------
+// A voxel's running mean takes the frames in order, but nothing else orders them: a batch of up to 64 frames is integrated by loading
+// every touched voxel ONCE, applying the frames that touch its unit in ascending order in registers, and storing it once -- the
+// same values bit for bit as 64 frame-at-a-time passes (each of which reads and writes the voxel through HBM), in three launches
+// instead of 192.  Which frames touch a unit is a 64-bit mask: the discovery kernel ORs the frame's bit into the unit's table entry,
+// the assignment kernel hands out blocks, applies the per-frame frustum test and leaves the surviving bits in unit_mask[block].
+struct TsdfFrame {            // one record per frame in device memory (bs_tsdf_frames_upload): 240 bytes
+    const float* depth;
+    const uint8_t* color;
+    double fx, fy, cx, cy;
+    double pose[12];          // camera -> world, rows 0..2 (unit discovery back-projects with it)
+    double view[12];          // world -> camera, rows 0..2: the `extrinsic` of ScalableTSDFVolume::Integrate
+};
+static_assert(sizeof(TsdfFrame) == 240, "TsdfFrame layout is part of the C ABI");
+
+__global__ __launch_bounds__(256) void tsdf_touch_batch_kernel(const TsdfFrame* __restrict__ frames, int H, int W, int stride, double unit_length,
+                                                                double sdf_trunc, int span, long long* keys, unsigned long long* fmask, unsigned mask,
+                                                                int32_t* counters) {
+    const TsdfFrame& F = frames[blockIdx.y];
+    const int cand = span * span * span;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int ws = (W + stride - 1) / stride, hs = (H + stride - 1) / stride;
+    if (t >= (int64_t)ws * hs * cand) return;
+    const int c = (int)(t % cand), pix = (int)(t / cand);
+    const int i = (pix / ws) * stride, j = (pix % ws) * stride;
+    const double z = (double)F.depth[(int64_t)i * W + j];
+    if (!(z > 0.0)) return;
+    const double x = ((double)j - F.cx) * z / F.fx, y = ((double)i - F.cy) * z / F.fy;
+    const double p[3] = {F.pose[0] * x + F.pose[1] * y + F.pose[2] * z + F.pose[3], F.pose[4] * x + F.pose[5] * y + F.pose[6] * z + F.pose[7],
+                         F.pose[8] * x + F.pose[9] * y + F.pose[10] * z + F.pose[11]};
+    const int o[3] = {c / (span * span), (c / span) % span, c % span};
+    int u[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int lo = (int)floor((p[a] - sdf_trunc) / unit_length), hi = (int)floor((p[a] + sdf_trunc) / unit_length);
+        u[a] = lo + o[a];
+        if (u[a] > hi) return;
+    }
+    const long long k = ts_pack(u[0], u[1], u[2]);
+    const unsigned long long bit = 1ull << blockIdx.y;
+    for (unsigned h = ts_hash(k, mask), n = 0; n <= mask; h = (h + 1) & mask, ++n) {
+        long long cur = keys[h];
+        if (cur == TS_EMPTY) cur = (long long)atomicCAS(reinterpret_cast<unsigned long long*>(keys + h), (unsigned long long)TS_EMPTY, (unsigned long long)k);
+        if (cur == TS_EMPTY || cur == k) {
+            if (!(__atomic_load_n(fmask + h, __ATOMIC_RELAXED) & bit)) atomicOr(fmask + h, bit);     // (thousands of candidates name the same unit)
+            return;
+        }
+    }
+    counters[2] = 1;      // table full
+}
+
+__global__ __launch_bounds__(256) void tsdf_assign_batch_kernel(const TsdfFrame* __restrict__ frames, const long long* __restrict__ keys, int32_t* slots,
+                                                                 unsigned long long* fmask, unsigned cap, int32_t* unit_index, int max_units,
+                                                                 int32_t* counters, int32_t* touched, unsigned long long* unit_mask, double unit_length,
+                                                                 int W, int H, int cull) {
+    const unsigned h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= cap || keys[h] == TS_EMPTY) return;
+    const unsigned long long m = fmask[h];
+    if (m == 0ull) return;
+    const long long k = keys[h];
+    const int ix = (int)(k >> 42) - TS_OFF, iy = (int)((k >> 21) & ((1 << 21) - 1)) - TS_OFF, iz = (int)(k & ((1 << 21) - 1)) - TS_OFF;
+    int s = slots[h];
+    if (s < 0) {
+        s = atomicAdd(counters + 0, 1);
+        if (s >= max_units) {          // (the caller reserves what the discovery found before this kernel runs: only a full map gets here)
+            atomicSub(counters + 0, 1);
+            counters[2] = 2;
+            return;
+        }
+        slots[h] = s;
+        unit_index[3 * s + 0] = ix;
+        unit_index[3 * s + 1] = iy;
+        unit_index[3 * s + 2] = iz;
+    }
+    fmask[h] = 0ull;
+    unsigned long long keep = m;
+    if (cull) {
+        const double c[3] = {((double)ix + 0.5) * unit_length, ((double)iy + 0.5) * unit_length, ((double)iz + 0.5) * unit_length};
+        const double r = 0.8660254037844387 * unit_length;
+        for (unsigned long long rest = m; rest; rest &= rest - 1) {          // the per-frame frustum test of tsdf_assign_kernel
+            const int f = __builtin_ctzll(rest);
+            const TsdfFrame& F = frames[f];
+            const double qx = F.view[0] * c[0] + F.view[1] * c[1] + F.view[2] * c[2] + F.view[3];
+            const double qy = F.view[4] * c[0] + F.view[5] * c[1] + F.view[6] * c[2] + F.view[7];
+            const double qz = F.view[8] * c[0] + F.view[9] * c[1] + F.view[10] * c[2] + F.view[11];
+            bool out = qz + r <= 0.0;
+            if (!out && qz > r) {
+                const double inv = 1.0 / (qz - r);
+                const double ru = F.fx * r * inv * (1.0 + fabs(qx) / qz) + 1.0, rv = F.fy * r * inv * (1.0 + fabs(qy) / qz) + 1.0;
+                const double uc = qx * F.fx / qz + F.cx + 0.5, vc = qy * F.fy / qz + F.cy + 0.5;
+                out = uc + ru < 0.0 || uc - ru > (double)W || vc + rv < 0.0 || vc - rv > (double)H;
+            }
+            if (out) keep &= ~(1ull << f);
+        }
+    }
+    if (keep == 0ull) return;
+    unit_mask[s] = keep;
+    touched[atomicAdd(counters + 1, 1)] = s;
+}
+
+__global__ __launch_bounds__(256) void tsdf_integrate_batch_kernel(const TsdfFrame* __restrict__ frames, int H, int W, const int32_t* __restrict__ unit_index,
+                                                                    const int32_t* __restrict__ touched, const int32_t* __restrict__ n_touched_dev,
+                                                                    const unsigned long long* __restrict__ unit_mask, int blocks_per_unit,
+                                                                    const int64_t* __restrict__ slab_base, int slab_units, int res, double voxel_length,
+                                                                    double sdf_trunc) {
+    const long long total = (long long)(*n_touched_dev) * blocks_per_unit;
+    const int nvox = res * res * res;
+    const double unit_len = voxel_length * res, half = voxel_length * 0.5;
+    for (long long w = blockIdx.x; w < total; w += gridDim.x) {
+        const int ti = (int)(w / blocks_per_unit), bx = (int)(w - (long long)ti * blocks_per_unit);
+        const int u = touched[ti];
+        const int v = bx * 256 + threadIdx.x;
+        if (v >= nvox) continue;
+        const unsigned long long m = unit_mask[u];
+        // the frame loop is uniform over the block: the mask goes to scalar registers, a frame's record is read with scalar loads
+        unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)m), hi = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
+        const int x = v / (res * res), y = (v / res) % res, z = v % res;
+        const double px = half + voxel_length * x + unit_len * unit_index[3 * u + 0];
+        const double py = half + voxel_length * y + unit_len * unit_index[3 * u + 1];
+        const double pz = half + voxel_length * z + unit_len * unit_index[3 * u + 2];
+        float* vox = ts_block(slab_base, slab_units, (int64_t)nvox * 20, u) + (int64_t)v * 5;
+        float s[5];
+        bool have = false;
+        for (int half_ = 0; half_ < 2; ++half_) {
+            unsigned bits = half_ ? hi : lo;
+            while (bits) {
+                const int f = __builtin_ctz(bits) + 32 * half_;
+                bits &= bits - 1;
+                const TsdfFrame& F = frames[f];
+                TsdfCam cam;
+                cam.fx = F.fx; cam.fy = F.fy; cam.cx = F.cx; cam.cy = F.cy;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) cam.e[i] = F.view[i];
+                float tsdf;
+                int64_t pix;
+                if (!tsdf_observe(px, py, pz, cam, F.depth, H, W, sdf_trunc, tsdf, pix)) continue;
+                if (!have) {
+                    s[0] = vox[0]; s[1] = vox[1];
+                    if (F.color) {
+                        s[2] = vox[2]; s[3] = vox[3]; s[4] = vox[4];
+                    }
+                    have = true;
+                }
+                tsdf_blend(s, tsdf, F.color ? F.color + pix * 3 : nullptr);
+            }
+        }
+        if (have) {
+            vox[0] = s[0];
+            vox[1] = s[1];
+            if (frames[0].color) {
+                vox[2] = s[2]; vox[3] = s[3]; vox[4] = s[4];
+            }
+        }
+    }
 }
 
 // ScalableTSDFVolume::GetTSDFAt: trilinear interpolation of the tsdf over the 8 voxel centres around p (a corner in a unit that does
@@ -478,6 +659,112 @@ extern "C" int bs_tsdf_integrate(const float* depth, const uint8_t* color, int32
     const int cull = 0;
     hipLaunchKernelGGL(tsdf_integrate_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), depth, color, H, W,
                        cam, unit_index, touched, n_touched_dev, bpu, slab_base, slab_units, res, voxel_length, sdf_trunc, cull);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+// ---- the frame-batched path ---------------------------------------------------------------------------------------------------------
+static bool affine_inverse(const double* m, double* out12) {      // rows 0..2 of the inverse of the affine 4x4 whose rows 0..2 are m
+    const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    if (!(det > 1e-12 || det < -1e-12)) return false;
+    const double id = 1.0 / det;
+    const double inv[9] = {(e * i - f * h) * id, (c * h - b * i) * id, (b * f - c * e) * id, (f * g - d * i) * id, (a * i - c * g) * id,
+                           (c * d - a * f) * id, (d * h - e * g) * id, (b * g - a * h) * id, (a * e - b * d) * id};
+    for (int r = 0; r < 3; ++r) {
+        for (int q = 0; q < 3; ++q) out12[4 * r + q] = inv[3 * r + q];
+        out12[4 * r + 3] = -(inv[3 * r] * m[3] + inv[3 * r + 1] * m[7] + inv[3 * r + 2] * m[11]);
+    }
+    return true;
+}
+
+// pinned staging for the frame records: two slots, each guarded by the event of its last copy (the host never waits for the stream
+// unless a third batch is uploaded before the first one's copy has run)
+namespace {
+struct FrameStage {
+    TsdfFrame* host[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int next = 0;
+};
+FrameStage g_stage;
+std::mutex g_stage_mu;
+}  // namespace
+
+extern "C" int bs_tsdf_frames_upload(const float* const* depth, const uint8_t* const* color, const double* K, const double* extrinsics, const double* poses,
+                                     int32_t n_frames, void* frames_dev, void* stream) {
+    if (!initialized()) { set_error("bs_tsdf_frames_upload: call bs_init first"); return BS_ERR_NOT_INIT; }
+    BS_REQUIRE(depth && K && extrinsics && poses && frames_dev, "bs_tsdf_frames_upload: null argument");
+    BS_REQUIRE(n_frames > 0 && n_frames <= BS_TSDF_BATCH_MAX, "bs_tsdf_frames_upload: n_frames=%d outside 1..%d", n_frames, BS_TSDF_BATCH_MAX);
+    for (int f = 0; f < n_frames; ++f) {
+        BS_REQUIRE(depth[f], "bs_tsdf_frames_upload: frame %d has no depth image", f);
+        BS_REQUIRE(!color || (color[f] != nullptr) == (color[0] != nullptr), "bs_tsdf_frames_upload: either every frame of a batch has a colour image or none");
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    std::lock_guard<std::mutex> lock(g_stage_mu);
+    const int slot = g_stage.next;
+    g_stage.next ^= 1;
+    if (!g_stage.host[slot]) {
+        BS_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&g_stage.host[slot]), sizeof(TsdfFrame) * BS_TSDF_BATCH_MAX, hipHostMallocDefault));
+        BS_CHECK_HIP(hipEventCreateWithFlags(&g_stage.done[slot], hipEventDisableTiming));
+    } else {
+        BS_CHECK_HIP(hipEventSynchronize(g_stage.done[slot]));
+    }
+    TsdfFrame* h = g_stage.host[slot];
+    for (int f = 0; f < n_frames; ++f) {
+        h[f].depth = depth[f];
+        h[f].color = color ? color[f] : nullptr;
+        h[f].fx = K[0]; h[f].fy = K[1]; h[f].cx = K[2]; h[f].cy = K[3];
+        for (int i = 0; i < 12; ++i) {
+            h[f].view[i] = extrinsics[16 * f + i];
+            h[f].pose[i] = poses[16 * f + i];
+        }
+    }
+    BS_CHECK_HIP(hipMemcpyAsync(frames_dev, h, sizeof(TsdfFrame) * n_frames, hipMemcpyHostToDevice, st));
+    BS_CHECK_HIP(hipEventRecord(g_stage.done[slot], st));
+    return BS_OK;
+}
+
+extern "C" int bs_tsdf_touch_batch(const void* frames_dev, int32_t n_frames, int32_t H, int32_t W, int32_t stride, double unit_length, double sdf_trunc,
+                                   void* table_keys, void* table_fmask, int32_t table_cap, int32_t* counters, void* stream) {
+    if (!initialized()) { set_error("bs_tsdf_touch_batch: call bs_init first"); return BS_ERR_NOT_INIT; }
+    BS_REQUIRE(frames_dev && table_keys && table_fmask && counters, "bs_tsdf_touch_batch: null argument");
+    BS_REQUIRE(n_frames > 0 && n_frames <= BS_TSDF_BATCH_MAX && H > 0 && W > 0 && stride > 0 && unit_length > 0.0 && sdf_trunc > 0.0,
+               "bs_tsdf_touch_batch: bad geometry");
+    BS_REQUIRE(table_cap >= 256 && (table_cap & (table_cap - 1)) == 0, "bs_tsdf_touch_batch: table_cap=%d must be a power of two >= 256", table_cap);
+    const int span = (int)floor(2.0 * sdf_trunc / unit_length) + 2;
+    BS_REQUIRE(span <= 64, "bs_tsdf_touch_batch: sdf_trunc / unit_length too large");
+    const int64_t threads = (int64_t)cdiv(W, stride) * cdiv(H, stride) * span * span * span;
+    hipLaunchKernelGGL(tsdf_touch_batch_kernel, dim3((unsigned)cdiv64(threads, 256), n_frames), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       static_cast<const TsdfFrame*>(frames_dev), H, W, stride, unit_length, sdf_trunc, span, reinterpret_cast<long long*>(table_keys),
+                       reinterpret_cast<unsigned long long*>(table_fmask), (unsigned)(table_cap - 1), counters);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+extern "C" int bs_tsdf_integrate_batch(const void* frames_dev, int32_t n_frames, int32_t H, int32_t W, const void* table_keys, int32_t* table_slots,
+                                       void* table_fmask, int32_t table_cap, int32_t* unit_index, int32_t max_units, int32_t* counters, int32_t* touched,
+                                       void* unit_mask, const int64_t* slab_base, int32_t slab_units, int32_t res, double voxel_length, double sdf_trunc,
+                                       void* stream) {
+    if (!initialized()) { set_error("bs_tsdf_integrate_batch: call bs_init first"); return BS_ERR_NOT_INIT; }
+    BS_REQUIRE(frames_dev && table_keys && table_slots && table_fmask && unit_index && counters && touched && unit_mask && slab_base,
+               "bs_tsdf_integrate_batch: null argument");
+    BS_REQUIRE(n_frames > 0 && n_frames <= BS_TSDF_BATCH_MAX && H > 0 && W > 0 && res > 0 && res <= 64 && slab_units > 0 && voxel_length > 0.0 &&
+                   sdf_trunc > 0.0 && max_units > 0,
+               "bs_tsdf_integrate_batch: bad geometry");
+    BS_REQUIRE(table_cap >= 256 && (table_cap & (table_cap - 1)) == 0, "bs_tsdf_integrate_batch: table_cap=%d must be a power of two >= 256", table_cap);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const TsdfFrame* frames = static_cast<const TsdfFrame*>(frames_dev);
+    BS_CHECK_HIP(hipMemsetAsync(counters + 1, 0, sizeof(int32_t), st));
+    const int cull = getenv("BS_TSDF_NO_CULL") == nullptr;
+    hipLaunchKernelGGL(tsdf_assign_batch_kernel, dim3(cdiv(table_cap, 256)), dim3(256), 0, st, frames, reinterpret_cast<const long long*>(table_keys),
+                       table_slots, reinterpret_cast<unsigned long long*>(table_fmask), (unsigned)table_cap, unit_index, max_units, counters, touched,
+                       reinterpret_cast<unsigned long long*>(unit_mask), voxel_length * res, W, H, cull);
+    BS_CHECK_LAUNCH();
+    const int nvox = res * res * res, bpu = cdiv(nvox, 256);
+    const long long want = (long long)bpu * max_units;
+    const unsigned grid = (unsigned)(want < 16ll * cu_count() ? want : 16ll * cu_count());
+    hipLaunchKernelGGL(tsdf_integrate_batch_kernel, dim3(grid), dim3(256), 0, st, frames, H, W, unit_index, touched, counters + 1,
+                       reinterpret_cast<const unsigned long long*>(unit_mask), bpu, slab_base, slab_units, res, voxel_length, sdf_trunc);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }

@@ -243,18 +243,14 @@ class BodySlamPipeline:
             for j0 in range(0, upto + 1, self.batch):
                 j1 = min(j0 + self.batch, upto + 1)
                 dm = tsdf_depth(j0, j1)
-                for j in range(j0, j1):
-                    t.discover(RGBDImage(fr_dev[j], dm[j - j0]), intr, poses[j])
-                t.reserve_discovered()
-                for j in range(j0, j1):
-                    t.build_3D_map(RGBDImage(fr_dev[j], dm[j - j0]), intr, poses[j], sync=False)
-                t.sync()
+                t.build_3D_map_batch([RGBDImage(fr_dev[j], dm[j - j0]) for j in range(j0, j1)], intr, poses[j0:j1])
+            t.sync()
             state["tsdf"] = t
 
         def run_map_actions(actions, b0, dm_map):
-            """the map steps a batch of frames asked for, in order.  Runs of plain integrations are done in two streamed passes: unit
-            discovery of every frame (no voxel work), ONE round trip that allocates exactly the blocks those frames need, then
-            discovery + integration frame by frame -- no guess at how many units a stream opens, no round trip per frame."""
+            """the map steps a batch of frames asked for, in order.  A run of plain integrations is ONE pass over the map
+            (``TSDF.build_3D_map_batch``: unit discovery of all its frames, one round trip that makes exactly the blocks they need, every
+            touched voxel loaded once and updated with its frames in order) -- bit for bit the frame-by-frame result."""
             k = 0
             while k < len(actions):
                 if actions[k][0] == "rebuild":
@@ -265,12 +261,7 @@ class BodySlamPipeline:
                 while k < len(actions) and actions[k][0] == "int":
                     run.append(actions[k])
                     k += 1
-                t = state["tsdf"]
-                for (_, i, pose) in run:
-                    t.discover(RGBDImage(fr_dev[i], dm_map[i - b0]), intr, pose)
-                t.reserve_discovered()
-                for (_, i, pose) in run:
-                    t.build_3D_map(RGBDImage(fr_dev[i], dm_map[i - b0]), intr, pose, sync=False)
+                state["tsdf"].build_3D_map_batch([RGBDImage(fr_dev[i], dm_map[i - b0]) for (_, i, _) in run], intr, [pose for (_, _, pose) in run])
 
         pg = PoseGraph()
         extr, rel_fused = [], []

@@ -19,7 +19,7 @@ from __future__ import annotations
 import copy
 import ctypes as C
 from dataclasses import dataclass
-from typing import Optional
+from typing import Optional, Sequence
 
 import numpy as np
 import torch
@@ -71,6 +71,7 @@ class TriangleMesh:
     triangles: np.ndarray                   # [T, 3] int32, wound so that the normal points from tsdf < 0 to tsdf > 0
 
 
+BATCH_MAX = 64              # frames per pass of build_3D_map_batch (BS_TSDF_BATCH_MAX: one bit per frame in a unit's mask)
 _OFF = 1 << 20              # unit indices are packed as three 21-bit fields (csrc/tsdf.hip ts_pack)
 
 
@@ -229,6 +230,55 @@ class TSDF:
         ev[3].record()
         ev[3].synchronize()
         self.last_touch_ms, self.last_kernel_ms = ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3])      # diagnostics
+
+    def build_3D_map_batch(self, rgbds: Sequence["RGBDImage"], intrinsic: "PinholeCameraIntrinsic", extrinsics) -> None:
+        """``build_3D_map`` for a run of frames, in order, as ONE pass over the map (csrc/tsdf.hip, "a batch of frames at once"): every
+        voxel the run touches is loaded once, takes its frames in ascending order in registers and is stored once.  The blocks end
+        up bit for bit as the frame-by-frame calls leave them; the cost is three launches and one 12-byte round trip (the block
+        reservation) per 64 frames instead of three launches per frame.  Device images (torch tensors) are used in place."""
+        n = len(rgbds)
+        assert len(extrinsics) == n
+        if n == 0:
+            return
+        lib, st = L.load_library(), L.stream_ptr()
+        if not self.slabs:
+            self.reserve(1)
+        if getattr(self, "table_fmask", None) is None:
+            self.table_fmask = torch.zeros(self.table_cap, dtype=torch.int64, device=self.dev)
+            self.unit_mask = torch.zeros(self.max_units, dtype=torch.int64, device=self.dev)
+            self.frames_dev = torch.zeros(BATCH_MAX * 240, dtype=torch.uint8, device=self.dev)
+        K = np.array([intrinsic.fx, intrinsic.fy, intrinsic.cx, intrinsic.cy], dtype=np.float64)
+        for a in range(0, n, BATCH_MAX):
+            chunk = rgbds[a:a + BATCH_MAX]
+            m = len(chunk)
+            depth = [self._image(r.depth, torch.float32) for r in chunk]
+            has_color = chunk[0].color is not None
+            assert all((r.color is not None) == has_color for r in chunk), "either every frame of a batch has a colour image or none"
+            color = [self._image(r.color, torch.uint8) for r in chunk] if has_color else None
+            H, W = depth[0].shape
+            assert all(d.shape == (H, W) for d in depth)
+            E = np.ascontiguousarray(np.stack([np.asarray(self._np(e), dtype=np.float64) for e in extrinsics[a:a + m]]).reshape(m, 16))
+            P = np.ascontiguousarray(np.linalg.inv(E.reshape(m, 4, 4)).reshape(m, 16))
+            dptr = np.array([d.data_ptr() for d in depth], dtype=np.uint64)
+            cptr = np.array([c.data_ptr() for c in color], dtype=np.uint64) if has_color else None
+            L.check(lib.bs_tsdf_frames_upload(dptr.ctypes.data_as(C.c_void_p), cptr.ctypes.data_as(C.c_void_p) if has_color else None,
+                                              K.ctypes.data_as(C.c_void_p), E.ctypes.data_as(C.c_void_p), P.ctypes.data_as(C.c_void_p), m,
+                                              L.p(self.frames_dev), st), "bs_tsdf_frames_upload")
+            L.check(lib.bs_tsdf_touch_batch(L.p(self.frames_dev), m, H, W, self.stride, self.unit_length, self.sdf_trunc, L.p(self.table_keys),
+                                            L.p(self.table_fmask), self.table_cap, L.p(self.counters), st), "bs_tsdf_touch_batch")
+            # the one round trip of the batch: how many blocks the discovered units need
+            need = torch.stack([self.counters[0].to(torch.int64), ((self.table_keys != -1) & (self.table_slots < 0)).sum()]).cpu()
+            self.reserve(int(need[0]) + int(need[1]))
+            L.check(lib.bs_tsdf_integrate_batch(L.p(self.frames_dev), m, H, W, L.p(self.table_keys), L.p(self.table_slots), L.p(self.table_fmask),
+                                                self.table_cap, L.p(self.unit_index), self.alloc_units, L.p(self.counters), L.p(self.touched),
+                                                L.p(self.unit_mask), L.p(self.slab_base), self.slab_units, self.res, self.voxel_length, self.sdf_trunc,
+                                                st), "bs_tsdf_integrate_batch")
+            self.frames_integrated += m
+            self._frames_since_sync += m
+
+    def _image(self, x, dtype) -> torch.Tensor:
+        t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+        return t.to(device=self.dev, dtype=dtype).contiguous()
 
     def build_copy_3D_map(self, rgbd, intrinsic, extrinsic) -> "TSDF":
         other = copy.copy(self)

@@ -367,6 +367,28 @@ int bs_tsdf_touch(const float* depth, int32_t H, int32_t W, int32_t stride, cons
 int bs_tsdf_integrate(const float* depth, const uint8_t* color, int32_t H, int32_t W, const double* K, const double* extrinsic,
                       const int32_t* unit_index, const int32_t* touched, int32_t n_touched, const int64_t* slab_base, int32_t slab_units,
                       int32_t res, double voxel_length, double sdf_trunc, const int32_t* n_touched_dev, void* stream);
+/* A batch of frames at once (the reference integrates frame by frame, 3DM/slam.py:179; a voxel's running mean takes the frames in
+ * order and nothing else orders them, so up to BS_TSDF_BATCH_MAX frames are integrated by loading every touched voxel once, applying
+ * the frames that touch its unit in ascending order in registers and storing it once -- bit for bit what that many
+ * bs_tsdf_touch + bs_tsdf_integrate calls leave in the blocks, in three launches).
+ *   bs_tsdf_frames_upload    writes the batch's frame records (240 bytes each) to frames_dev: depth[f] / color[f] = the frames' device
+ *                            images (color NULL or all entries NULL: no colours), K = (fx, fy, cx, cy), extrinsics / poses = host
+ *                            doubles [n_frames, 16]: the world->camera 4x4 of every frame and its inverse
+ *   bs_tsdf_touch_batch      unit discovery of all frames: inserts the units and ORs bit f into table_fmask (uint64 [table_cap], zero
+ *                            between batches) of every unit frame f touches.  No blocks are handed out: the caller reads counters[0]
+ *                            and counts the entries with a key but no slot, makes the missing blocks, then calls
+ *   bs_tsdf_integrate_batch  block assignment (max_units = the blocks that exist; overflow flag 2 otherwise), the per-frame frustum
+ *                            test, unit_mask (uint64 [max_units]) and `touched`, then the integration; counters[1] = the units updated;
+ *                            table_fmask is zero again afterwards */
+#define BS_TSDF_BATCH_MAX 64
+int bs_tsdf_frames_upload(const float* const* depth, const uint8_t* const* color, const double* K, const double* extrinsics, const double* poses,
+                          int32_t n_frames, void* frames_dev, void* stream);
+int bs_tsdf_touch_batch(const void* frames_dev, int32_t n_frames, int32_t H, int32_t W, int32_t stride, double unit_length, double sdf_trunc,
+                        void* table_keys, void* table_fmask, int32_t table_cap, int32_t* counters, void* stream);
+int bs_tsdf_integrate_batch(const void* frames_dev, int32_t n_frames, int32_t H, int32_t W, const void* table_keys, int32_t* table_slots,
+                            void* table_fmask, int32_t table_cap, int32_t* unit_index, int32_t max_units, int32_t* counters, int32_t* touched,
+                            void* unit_mask, const int64_t* slab_base, int32_t slab_units, int32_t res, double voxel_length, double sdf_trunc,
+                            void* stream);
 int bs_tsdf_extract(const int32_t* unit_index, int32_t units, const void* table_keys, const int32_t* table_slots, int32_t table_cap,
                     const int64_t* slab_base, int32_t slab_units, int32_t res, double voxel_length, int32_t* unit_count,
                     const int64_t* unit_offset, float* points, float* colors, float* normals, void* stream);

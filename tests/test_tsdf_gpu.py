@@ -220,6 +220,55 @@ def test_tsdf_streamed_and_culled_equal_the_synchronous_path():
         t.sync()
 
 
+def test_tsdf_frame_batch_equals_frame_by_frame():
+    """build_3D_map_batch: a run of frames integrated in one pass over the map (every touched voxel loaded once, its frames applied in
+    order in registers) leaves the same units and the same voxels, bit for bit, as build_3D_map frame by frame -- with colours and
+    without, across a chunk border (65 frames > the 64-frame mask), into a map that already holds frames, and with culling off"""
+    import os
+    from bodyslam_amd.tsdf import TSDF, PinholeCameraIntrinsic, RGBDImage
+    vl, trunc = 0.01, 0.04
+    intr = PinholeCameraIntrinsic(W, H, *K)
+    scenes = [scene(seed) for seed in range(5)]
+
+    def frames(n, with_color):
+        return [(RGBDImage(scenes[i % 5][1] if with_color else None, scenes[i % 5][0]), scenes[i % 5][2]) for i in range(n)]
+
+    def check(n, with_color, pre=0, cull=True):
+        if not cull:
+            os.environ["BS_TSDF_NO_CULL"] = "1"
+        try:
+            a = TSDF(vl, trunc, volume_unit_resolution=8, depth_sampling_stride=4, slab_bytes=1 << 16)
+            b = TSDF(vl, trunc, volume_unit_resolution=8, depth_sampling_stride=4, slab_bytes=1 << 16)
+            fr = frames(pre + n, with_color)
+            for r, E in fr:
+                a.build_3D_map(r, intr, E)
+            for r, E in fr[:pre]:
+                b.build_3D_map(r, intr, E)
+            b.build_3D_map_batch([r for r, _ in fr[pre:]], intr, [E for _, E in fr[pre:]])
+            nb, _ = b.sync()
+            assert nb == a.n_units > 0 and b.frames_integrated == a.frames_integrated == pre + n
+            assert set(a.index) == set(b.index)
+            for key in a.index:
+                assert np.array_equal(a.unit(key), b.unit(key)), (n, with_color, pre, key)
+            assert int(b.table_fmask.abs().sum()) == 0                 # the discovery masks are clean for the next batch
+            return a, b
+        finally:
+            os.environ.pop("BS_TSDF_NO_CULL", None)
+
+    check(4, True)
+    check(3, False, pre=2)
+    check(65, True)
+    a, b = check(4, True, cull=False)
+    pa, pb = a.extract_pcd(), b.extract_pcd()
+    assert pa.points.shape == pb.points.shape and np.array_equal(np.sort(pa.points.view("f4,f4,f4"), axis=0), np.sort(pb.points.view("f4,f4,f4"), axis=0))
+    # a full map is reported, not overrun
+    t = TSDF(vl, trunc, volume_unit_resolution=8, depth_sampling_stride=4, slab_bytes=1 << 16, max_units=64)
+    fr = frames(2, True)
+    t.build_3D_map_batch([r for r, _ in fr], intr, [E for _, E in fr])
+    with pytest.raises(Exception, match="blocks|max_units"):
+        t.sync()
+
+
 def test_slam_loop_reference_order_640x480():
     """run_slam_loop at the bench's frame size with the reference's own TSDF parameters (1 mm voxels, 0.1 m truncation, 32^3 units, stride
     8), VO fusion on, pose graph every 2 frames: the per-frame order of SLAM._sequential_loop (3DM/slam.py:131-205) -- frames 2 and 4 take

@@ -58,6 +58,9 @@ raw = L.depth_u16_to_m(depth.contiguous(), pipe.depth_scale, 3.0e38)
 for i in range(3):
     odo.track(frames[i], raw[i])
 _, t_vo = timed(lambda: [odo.track(frames[i], raw[i]) for i in range(3, N)])
+odo_b = RGBDOdometry(tuple(pipe.K))
+odo_b.track_block(frames[:B], raw[:B])
+_, t_vob = timed(lambda: [odo_b.track_block(frames[a:a + B], raw[a:a + B]) for a in range(B, N, B)])
 t2 = TSDF()
 t2.reserve(tsdf.n_units + 4096)
 dm = L.depth_u16_to_m(depth.contiguous(), pipe.depth_scale, pipe.depth_trunc)
@@ -72,8 +75,19 @@ def build():
 
 
 _, t_map = timed(build)
+t3 = TSDF()
+t3.reserve(tsdf.n_units + 4096)
+
+
+def build_batched():
+    for a in range(0, N, B):
+        t3.build_3D_map_batch([RGBDImage(frames[i], dm[i]) for i in range(a, min(a + B, N))], intr, g[a:a + B])
+    return t3.sync()
+
+
+_, t_mapb = timed(build_batched)
 pcd, t_ext = timed(t2.extract_pcd)
 mesh, t_mesh = timed(t2.extract_mesh)
-print(f"parts: depth + MPEM (batched) {t_net / N * 1e3:.2f} ms/frame; RGB-D odometry track() {t_vo / (N - 3) * 1e3:.3f} ms/pair; TSDF touch + integrate "
-      f"(streamed) {t_map / N * 1e3:.3f} ms/frame; extract_pcd {t_ext * 1e3:.0f} ms -> {pcd.points.shape[0]} points; extract_mesh {t_mesh * 1e3:.0f} ms -> "
+print(f"parts: depth + MPEM (batched) {t_net / N * 1e3:.2f} ms/frame; RGB-D odometry track_block() {t_vob / max(N - B, 1) * 1e3:.3f} ms/pair (track(): "
+      f"{t_vo / (N - 3) * 1e3:.3f}); TSDF build_3D_map_batch {t_mapb / N * 1e3:.3f} ms/frame (frame by frame, streamed: {t_map / N * 1e3:.3f}); extract_pcd {t_ext * 1e3:.0f} ms -> {pcd.points.shape[0]} points; extract_mesh {t_mesh * 1e3:.0f} ms -> "
       f"{mesh.vertices.shape[0]} vertices, {mesh.triangles.shape[0]} triangles; allocated {torch.cuda.max_memory_allocated() / 1e9:.1f} GB")
