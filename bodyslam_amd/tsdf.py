@@ -339,10 +339,11 @@ class TSDF:
         if int(err.cpu()):
             raise L.BodySlamHipError("TSDF.extract_mesh: the map spans more than 2^20 voxels along an axis (vertex identity overflow)")
         # equal edge identities are one vertex (every cube that shares the edge computed the same position)
-        uniq, first, inverse = np.unique(keys.cpu().numpy(), return_index=True, return_inverse=True)
-        v = verts.cpu().numpy()[first]
-        c = cols.cpu().numpy()[first]
-        return TriangleMesh(v, c, inverse.reshape(-1, 3).astype(np.int32))
+        # (merged on the device: a radix sort of the keys; on the host np.unique took 1 s for 17 M corners -- longer than a 256-frame loop)
+        uniq, inverse = torch.unique(keys, sorted=True, return_inverse=True)
+        first = torch.full((uniq.shape[0],), keys.shape[0], dtype=torch.int64, device=self.dev)
+        first.scatter_reduce_(0, inverse, torch.arange(keys.shape[0], device=self.dev), reduce="amin")      # the first corner of every vertex
+        return TriangleMesh(verts[first].cpu().numpy(), cols[first].cpu().numpy(), inverse.view(-1, 3).to(torch.int32).cpu().numpy())
 
     def save_mesh(self, saving_path: str) -> None:
         write_ply_mesh(saving_path, self.extract_mesh())
