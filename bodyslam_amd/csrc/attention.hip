@@ -153,15 +153,19 @@ __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict_
             mloc = fmaxf(mloc, sacc[15]);
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
             if (first || __any(mloc > THR)) {   // wave-uniform: move the running max (always on the first sub-tile)
-                const float alpha = __builtin_amdgcn_exp2f(-mloc);
+                // the branch is wave-uniform but the shift is the lane's own: a query whose tile maximum lies BELOW its running max keeps it
+                // (shift 0) -- exp2(-mloc) of a maximum 128 below the running one overflowed to inf (a key that out-scores the rest by
+                // 2^128 earlier in the sequence; found by the spiked-key test).  On the first sub-tile the accumulators are zero: no scaling.
+                const float sh = first ? mloc : fmaxf(mloc, 0.0f);
+                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-sh);
                 l_run *= alpha;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     oacc[0][i] *= alpha;
                     oacc[1][i] *= alpha;
-                    sacc[i] -= mloc;
+                    sacc[i] -= sh;
                 }
-                m_run += mloc;
+                m_run += sh;
                 first = false;
             }
             float p[16];
@@ -473,15 +477,19 @@ __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restr
             mloc = fmaxf(mloc, sacc[15]);
             mloc = half_swap_max(mloc);      // the other lane half holds the other 16 keys of this query
             if (first || __any(mloc > THR)) {
-                const float alpha = __builtin_amdgcn_exp2f(-mloc);
+                // the branch is wave-uniform but the shift is the lane's own: a query whose tile maximum lies BELOW its running max keeps it
+                // (shift 0) -- exp2(-mloc) of a maximum 128 below the running one overflowed to inf (a key that out-scores the rest by
+                // 2^128 earlier in the sequence; found by the spiked-key test).  On the first sub-tile the accumulators are zero: no scaling.
+                const float sh = first ? mloc : fmaxf(mloc, 0.0f);
+                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-sh);
                 l_run *= alpha;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     oacc[0][i] *= alpha;
                     oacc[1][i] *= alpha;
-                    sacc[i] -= mloc;
+                    sacc[i] -= sh;
                 }
-                m_run += mloc;
+                m_run += sh;
                 first = false;
             }
             float p[16];
@@ -640,16 +648,20 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
         mloc = fmaxf(mloc, sacc[15]);
         mloc = half_swap_max(mloc);          // the other lane half holds the other 16 keys of this query
         if (first || __any(mloc > THR)) {
-            const float alpha = __builtin_amdgcn_exp2f(-mloc);
+            // the branch is wave-uniform but the shift is the lane's own: a query whose tile maximum lies BELOW its running max keeps it
+                // (shift 0) -- exp2(-mloc) of a maximum 128 below the running one overflowed to inf (a key that out-scores the rest by
+                // 2^128 earlier in the sequence; found by the spiked-key test).  On the first sub-tile the accumulators are zero: no scaling.
+                const float sh = first ? mloc : fmaxf(mloc, 0.0f);
+                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-sh);
             l_run *= alpha;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 oacc[0][i] *= alpha;
                 oacc[1][i] *= alpha;
-                sacc[i] -= mloc;
-                if (OTHER) other[i] -= mloc;
+                sacc[i] -= sh;
+                if (OTHER) other[i] -= sh;
             }
-            m_run += mloc;
+            m_run += sh;
             first = false;
         }
         float psum = 0.f;

@@ -657,7 +657,8 @@ def test_attention_table(L, dtype, B, hp, nh, split, grouped):
 def test_attention_table_running_max_moves_in_both_lane_halves(L, hp):
     """A rare data-dependent branch needs its own test: the deferred running max must move when ONE key far out-scores the rest, in
     whichever lane half holds it (the two halves of a wave hold keys kx & 8 == 0 / != 0 of a 32-key row).  Before round 3 the
-    compiler had folded the cross-half maximum away and a spike among the upper half's keys overflowed exp2 to inf."""
+    compiler had folded the cross-half maximum away and a spike among the upper half's keys overflowed exp2 to inf; and the shift
+    applied in the (wave-uniform) branch must never be negative for a lane that did not ask for it."""
     dtype = torch.float16
     B, nh, wp = 1, 2, 32
     S = hp * wp + 1
@@ -672,7 +673,9 @@ def test_attention_table_running_max_moves_in_both_lane_halves(L, hp):
     vf = torch.randn(B, nh, S, 64, generator=g)
     # spikes: keys at positions with kx = 8 .. 15 and 24 .. 31 (upper lane half) and one in the lower half, late in the key sequence,
     # aligned with a few queries so that their scores jump by > 40 (log2 domain) over everything before
-    for pos, qpos in ((S - 1 - 64 + 9, 5), (S - 1 - 32 + 27, 40), (S - 1 - 32 + 2, 70)):
+    # ... and one EARLY in the sequence (key 109 for query 200): every later tile's maximum then lies ~190 below that query's running max,
+    # and when another query of the wave moves its max the branch must leave this one alone (exp2(+190) overflowed before the fix)
+    for pos, qpos in ((S - 1 - 64 + 9, 5), (S - 1 - 32 + 27, 40), (S - 1 - 32 + 2, 70), (109, 200)):
         if pos < 0 or qpos >= S - 1:
             continue
         kf[0, :, pos] = qf[0, :, qpos] / qf[0, :, qpos].norm(dim=-1, keepdim=True) * 60.0
