@@ -885,21 +885,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                 }
             }
         };
-        // ---- 16-bit rows through LDS.  A lane's fragment pair is 16 bytes of a row and four lanes make 64 bytes: HALF a cache line per
-        // row and store instruction -- and the memory system takes half-line writes at half the rate (measured: the 16-bit epilogues
-        // moved 2.4 TB/s where the fp32 one, whose lanes cover whole lines, moves 5.2).  So the wave parks its TM x 64 tile in its own
-        // slice of the ring (idle now: one barrier), 128-byte rows with the 16-byte chunks XOR-swizzled, and reads it back eight lanes
-        // to a row: every store instruction writes 8 whole 128-byte lines.
-        constexpr bool ROWS16 = TN == 64 && WM * WN * TM * 128 <= LDS_BYTES;
-        char* wl = smem + (wm * WN + wn) * (TM * 128);
-        auto park = [&](int i, int jp, const typename T16<T>::v8& h) {
-            const int row = i * 16 + frow, chunk = jp * 4 + fq;
-            *reinterpret_cast<typename T16<T>::v8*>(wl + row * 128 + ((chunk ^ (row & 7)) << 4)) = h;
-        };
-        auto unpark = [&](int s) {          // row s * 8 + (lane >> 3) of the wave's tile, 16-byte chunk lane & 7
-            const int row = s * 8 + (lane >> 3), chunk = lane & 7;
-            return *reinterpret_cast<const typename T16<T>::v8*>(wl + row * 128 + ((chunk ^ (row & 7)) << 4));
-        };
         // ---- two specialised forms of the same arithmetic for the backbone's hot shapes (wave-uniform selection) -----------------
         const bool plain_full = p.out_mode == BS_OUT_PLAIN && !p.out_group_rows && p.bias && !p.bias_group_rows && p.N % BN == 0 &&
                                 p.ldo % 8 == 0 && !b2_rows && !(p.ablate & 16);
@@ -963,33 +948,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                     bj[j] = *reinterpret_cast<const f32x4*>(p.bias + n0);
                     if (g2 >= 0) bj[j] += *reinterpret_cast<const f32x4*>(p.bias2 + (int64_t)g2 * p.N + n0);
                 }
-                if constexpr (ROWS16) {
-                    if (!planes && !(p.ablate & 128)) {       // patch tiles: the 16-bit plane alone, as whole lines
-                        __builtin_amdgcn_s_barrier();         // every wave is done with the ring
-#pragma unroll
-                        for (int i = 0; i < FM; ++i)
-#pragma unroll
-                            for (int jp = 0; jp < FN / 2; ++jp) {
-                                typename T16<T>::v8 h;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    h[e] = T16<T>::from_f32(gelu_erf(acc[i][2 * jp][e] + bj[2 * jp][e]));
-                                    h[4 + e] = T16<T>::from_f32(gelu_erf(acc[i][2 * jp + 1][e] + bj[2 * jp + 1][e]));
-                                }
-                                park(i, jp, h);
-                            }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        T* ob16 = reinterpret_cast<T*>(p.out) + n_wave + (lane & 7) * 8;
-#pragma unroll
-                        for (int s8 = 0; s8 < TM / 8; ++s8) {
-                            const int m = m0 + wm * TM + s8 * 8 + (lane >> 3);
-                            const typename T16<T>::v8 h = unpark(s8);
-                            if (m < p.M) *reinterpret_cast<typename T16<T>::v8*>(ob16 + (int64_t)m * p.ldo) = h;
-                        }
-                        return;
-                    }
-                }
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     const int m = m0 + wm * TM + i * 16 + frow;
@@ -1040,47 +998,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                 }
             }
             const int nhead = p.qkv_hidden >> 6;
-            if constexpr (ROWS16) {
-                if (!(p.ablate & 128)) {
-                    __builtin_amdgcn_s_barrier();             // every wave is done with the ring
-#pragma unroll
-                    for (int i = 0; i < FM; ++i)
-#pragma unroll
-                        for (int jp = 0; jp < FN / 2; ++jp) {
-                            typename T16<T>::v8 v;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                v[e] = T16<T>::from_f32((acc[i][2 * jp][e] + bj[2 * jp][e]) * sj[2 * jp][e]);
-                                v[4 + e] = T16<T>::from_f32((acc[i][2 * jp + 1][e] + bj[2 * jp + 1][e]) * sj[2 * jp + 1][e]);
-                            }
-                            park(i, jp, v);
-                        }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    // the wave's 64 columns are one head: a row of the tile is the 128 contiguous bytes [image, head, position, 0..63]
-                    const int rem0 = n_wave - part * p.qkv_hidden;
-                    T* hd = dst + (int64_t)(rem0 >> 6) * p.qkv_sp * 64 + (lane & 7) * 8;
-#pragma unroll
-                    for (int s8 = 0; s8 < TM / 8; ++s8) {
-                        const int m = m0 + wm * TM + s8 * 8 + (lane >> 3);
-                        const typename T16<T>::v8 v = unpark(s8);
-                        if (m >= p.M) continue;
-                        int ob, otok;
-                        if (p.qkv_cls_rows > 0) {
-                            if (m >= p.qkv_cls_rows && m < p.qkv_patch_row0) continue;
-                            const int mp = m - p.qkv_patch_row0;
-                            ob = mp < 0 ? m : mp / (p.qkv_tokens - 1);
-                            otok = mp < 0 ? p.qkv_tokens - 1 : mp - ob * (p.qkv_tokens - 1);
-                        } else {
-                            ob = m / p.qkv_tokens;
-                            otok = m - ob * p.qkv_tokens;
-                            if (p.qkv_cls_last) otok = otok == 0 ? p.qkv_tokens - 1 : otok - 1;
-                        }
-                        *reinterpret_cast<typename T16<T>::v8*>(hd + ((int64_t)ob * nhead * p.qkv_sp + otok) * 64) = v;
-                    }
-                    return;
-                }
-            }
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int m = m0 + wm * TM + i * 16 + frow;
