@@ -739,60 +739,57 @@ extern "C" int bs_col_mean(const void* A, int64_t lda, int32_t row0, int32_t row
 
 // ---------------------------------------------------------------------------------------------
 // bs_rank1_bias: out[g, n] += sum_k abar[g, k] dW[n, k] -- a [G, K] x [K, N] product with G ~ 128 rows.  As a tile GEMM it is 8-32
-// blocks walking a long K (latency-bound, ~100 us); here a block owns 32 columns x HALF of K for all G rows, fragments go straight
-// from L2 to registers (both operands are a few MB and re-read by few blocks), 16x16x32 bf16 MFMA, and the two K halves meet by
-// fp32 atomics on a zeroed target (two addends: the sum does not depend on their order, results stay run-to-run identical).
+// blocks walking a long K (latency-bound, ~100 us).  Round 2: a block owned 32 columns x half of K, the halves met by atomics (21 us:
+// 16-64 dependent fragment loads per wave).  Round 3: a block owns 16 columns x 64 rows x ALL of K, its four waves each take a
+// QUARTER of K (8-32 steps, four in flight), fragments go straight from L2 to registers (both operands are a few MB), 16x16x32 bf16
+// MFMA, and the four partial tiles meet in LDS in wave order: no atomics, the sum has a fixed order.
 __global__ __launch_bounds__(256) void rank1_bias_kernel(const bf16* abar, const bf16* dW, float* out, int G, int N, int K) {
     typedef T16<bf16>::v8 v8;
+    __shared__ float red[4][64][17];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int frow = lane & 15, fq = lane >> 4;
-    const int n0 = blockIdx.x * 32, kh = K >> 1, k0 = blockIdx.y * kh;
-    for (int g0 = wave * 32; g0 < G; g0 += 128) {
-        f32x4 acc[2][2];
+    const int n0 = blockIdx.x * 16, g0 = blockIdx.y * 64;
+    // k range of this wave: whole 32-element steps, the last wave takes the remainder
+    const int steps = K / 32, per = steps / 4, s0 = wave * per, s1 = wave == 3 ? steps : s0 + per;
+    f32x4 acc[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16* ap[4];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const bf16* ap[2];
-        const bf16* bp[2];
+    for (int i = 0; i < 4; ++i) {
+        int g = g0 + i * 16 + frow;
+        g = g < G ? g : G - 1;
+        ap[i] = abar + (int64_t)g * K + fq * 8;
+    }
+    int n = n0 + frow;
+    n = n < N ? n : N - 1;
+    const bf16* bp = dW + (int64_t)n * K + fq * 8;
+    auto step = [&](int k) {
+        v8 af[4];
+        const v8 bf = *reinterpret_cast<const v8*>(bp + k);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int g = g0 + i * 16 + frow;
-            g = g < G ? g : G - 1;
-            ap[i] = abar + (int64_t)g * K + k0 + fq * 8;
-            int n = n0 + i * 16 + frow;
-            n = n < N ? n : N - 1;
-            bp[i] = dW + (int64_t)n * K + k0 + fq * 8;
-        }
-        auto step = [&](int k) {
-            v8 af[2], bf[2];
+        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(ap[i] + k);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = *reinterpret_cast<const v8*>(ap[i] + k);
-                bf[i] = *reinterpret_cast<const v8*>(bp[i] + k);
-            }
+        for (int i = 0; i < 4; ++i) acc[i] = T16<bf16>::mfma16(bf, af[i], acc[i]);
+    };
+    int st = s0;
+    for (; st + 4 <= s1; st += 4) {            // four steps' loads in flight
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int u = 0; u < 4; ++u) step((st + u) * 32);
+    }
+    for (; st < s1; ++st) step(st * 32);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = T16<bf16>::mfma16(bf[j], af[i], acc[i][j]);
-        };
-        int k = 0;
-        for (; k + 128 <= kh; k += 128) {      // four steps' loads in flight
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) step(k + 32 * u);
-        }
-        for (; k < kh; k += 32) step(k);
+        for (int e = 0; e < 4; ++e) red[wave][i * 16 + frow][fq * 4 + e] = acc[i][e];
+    __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int g = g0 + i * 16 + frow;
-            if (g >= G) continue;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int n = n0 + j * 16 + fq * 4 + e;
-                    if (n < N) unsafeAtomicAdd(out + (int64_t)g * N + n, acc[i][j][e]);
-                }
+    for (int r = 0; r < 4; ++r) {
+        const int idx = r * 256 + threadIdx.x, gl = idx >> 4, c = idx & 15;
+        const int g = g0 + gl, nn = n0 + c;
+        if (g < G && nn < N) {
+            float* o = out + (int64_t)g * N + nn;
+            *o += ((red[0][gl][c] + red[1][gl][c]) + red[2][gl][c]) + red[3][gl][c];
         }
     }
 }
@@ -801,7 +798,7 @@ extern "C" int bs_rank1_bias(const void* abar_bf16, const void* dw_bf16, float* 
     BS_ENTRY("bs_rank1_bias");
     BS_REQUIRE(abar_bf16 && dw_bf16 && out, "bs_rank1_bias: null operand");
     BS_REQUIRE(G > 0 && N > 0 && K > 0 && K % 64 == 0, "bs_rank1_bias: K=%d must be a multiple of 64", K);
-    hipLaunchKernelGGL(rank1_bias_kernel, dim3(cdiv(N, 32), 2), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const bf16*)abar_bf16,
+    hipLaunchKernelGGL(rank1_bias_kernel, dim3(cdiv(N, 16), cdiv(G, 64)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const bf16*)abar_bf16,
                        (const bf16*)dw_bf16, out, G, N, K);
     BS_CHECK_LAUNCH();
     return BS_OK;
