@@ -73,6 +73,15 @@ _SIGS = {
     "bs_col_mean": [C.c_void_p, C.c_int64] + [C.c_int32] * 5 + [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p],
     "bs_rank1_bias": [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p],
     "bs_depth_u16_to_m": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p],
+    "bs_engine_load": [C.c_char_p, C.c_void_p],
+    "bs_engine_destroy": [C.c_void_p],
+    "bs_engine_io": [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p],
+    "bs_engine_device_bytes": [C.c_void_p],
+    "bs_engine_run": [C.c_void_p, C.c_void_p],
+    "bs_engine_upload": [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64],
+    "bs_engine_download": [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64],
+    "bs_zoedepth_forward": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+    "bs_cyclepose_forward": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p],
     "bs_tsdf_frames_upload": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p],
     "bs_tsdf_touch_batch": [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                             C.c_void_p],
@@ -128,6 +137,7 @@ def load_library() -> C.CDLL:
         fn.restype = C.c_int
     lib.bs_last_error.restype = C.c_char_p
     lib.bs_last_error.argtypes = []
+    lib.bs_engine_device_bytes.restype = C.c_int64
     _lib = lib
     return lib
 
@@ -282,6 +292,7 @@ class Plan:
         self.calls = []      # (cfunc, args) ; args exclude the trailing stream
         self.names = []
         self.keep = []       # keeps descriptors / tensors alive
+        self.keep_descs = [] # the bs_gemm descriptors in call order (engine export)
         self.marks = {}      # call index -> [(name, tensor)]
         self.gemm_info = {}  # call index -> dict(tile, conv, flops, bytes)
         self.lane = 0        # lane of the calls being added: 0 = the caller's stream, 1 = the plan's side stream
@@ -328,6 +339,7 @@ class Plan:
         d = make_gemm_desc(A, W, out, **kw)
         kw["precision_passes"] = passes
         self.keep.append((d, A, W, out, kw))
+        self.keep_descs.append(d)
         self.calls.append((load_library().bs_gemm, (C.byref(d),)))
         self.names.append(name)
         self.lanes.append(self.lane)

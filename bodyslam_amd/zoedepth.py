@@ -605,6 +605,7 @@ class _Pool:
     def __init__(self, dev):
         self.dev = dev
         self.free_blocks = []        # uint8 tensors
+        self.blocks = []             # every block ever made (engine export: pooled intermediates carry no data)
         self.owner = {}              # data_ptr -> block
         self.hold = False
         self.bytes_new = 0
@@ -623,6 +624,7 @@ class _Pool:
         if blk is None:
             blk = torch.empty((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=self.dev)
             self.bytes_new += blk.numel()
+            self.blocks.append(blk)
         t = blk[:nbytes].view(dtype).view(*shape)
         self.owner[t.data_ptr()] = blk
         return t

@@ -443,6 +443,32 @@ int bs_odo_accumulate(const float* src_intensity, const float* src_depth, const 
                       const double* K, const double* T, double depth_outlier_trunc, double depth_huber, double intensity_huber,
                       double* partial, double* out29, int32_t flags, void* stream);
 
+/* ---- engine files: the forward of a whole model for a host without Python ------------------------------------
+ * The reference's hosts are DepthEstimator.infer_depth_map (BodySLAM_Refactored/src/depth_estimation/interface.py:39-45) and
+ * MPEMInterface.infer_relative_pose_between (BodySLAM_not_refactored/MPEM/mpem_interface.py:61-99), both Python.  A plan -- the launch
+ * sequence of one (model, batch, frame size, precision, dtype) over static device buffers -- is compiled once by the Python builder and
+ * written to an engine file (python -m bodyslam_amd.engine_export); any host then runs it with the calls below.  bs_engine_load
+ * allocates every buffer and uploads the constants (weights in their packed device form); nothing is allocated per call.
+ *   bs_engine_io          the device address / size of a named static input or output ("frames", "depth_m", "depth_u16"; "pairs", "T")
+ *   bs_engine_run         issues the launches on `stream` (and the engine's own side stream, forked from and joined to it)
+ *   bs_engine_upload / _download   host <-> named buffer, synchronous: for hosts that do not link the HIP runtime themselves
+ *   bs_zoedepth_forward   frames u8 [B,H,W,3] (device) -> depth metres fp32 [B,H,W] and / or uint16 metres*256 [B,H,W] (either may be
+ *                         NULL); flip augmentation, routing, post-processing as the engine was exported
+ *   bs_cyclepose_forward  frames u8 [n_frames,H,W,3], pairs int32 [P,2] (indices into frames) -> T fp32 [P,16] (row-major 4x4)
+ * Shapes must be the ones the engine was exported for (checked). */
+typedef struct bs_engine bs_engine;
+int bs_engine_load(const char* path, bs_engine** out);
+int bs_engine_destroy(bs_engine* e);
+int bs_engine_io(const bs_engine* e, const char* name, void** dev_ptr, int64_t* nbytes);
+int64_t bs_engine_device_bytes(const bs_engine* e);
+int bs_engine_run(bs_engine* e, void* stream);
+int bs_engine_upload(bs_engine* e, const char* name, const void* host, int64_t nbytes);
+int bs_engine_download(bs_engine* e, const char* name, void* host, int64_t nbytes);
+int bs_zoedepth_forward(bs_engine* e, const uint8_t* frames_dev, int32_t B, int32_t H, int32_t W, float* depth_m_dev, uint16_t* depth_u16_dev,
+                        void* stream);
+int bs_cyclepose_forward(bs_engine* e, const uint8_t* frames_dev, int32_t n_frames, int32_t H, int32_t W, const int32_t* pairs_dev, int32_t P,
+                         float* T_rel_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
