@@ -10,6 +10,7 @@ relative head is replaced by one of:
   w8          single + the weight-rounding correction only
   a8_wmean    a8 + the weight-rounding term of the per-image mean activation (conv of the constant mean image with dw, borders exact)
   a8_wmeanI   as a8_wmean, the mean term as a per-image bias (interior value used at the borders too)
+  a8_wlocK / a8_wstripK   a8 + the weight-rounding term of the activation map averaged over K x K blocks / 1 x K strips (piecewise constant)
   mx6 / mx4   both corrections with e2m3 / e2m1 operands and one E8M0 scale per 32 channels (OCP MX blocks)
   amx6_wmean, amx4_wmean, mx4a_8w ...  mixtures (see MODES)
 Prints depth L1 / max / mean signed error vs exact, in metres.
@@ -115,6 +116,18 @@ class Proxy:
                 B, C, H, Wd = a16.shape
                 g = a16.view(B, C, 4, H // 4, 4, Wd // 4).mean(dim=(3, 5), keepdim=True).expand(B, C, 4, H // 4, 4, Wd // 4).reshape(B, C, H, Wd)
                 y = y + cv(g, dW)
+            elif p.startswith("wloc") or p.startswith("wstrip"):
+                # the weight-rounding term of a LOCALLY averaged activation map: K x K blocks ("wlocK") or 1 x K strips ("wstripK"),
+                # piecewise constant; what is left out is conv(a16 - local mean, dW) -- small where the feature maps are smooth
+                strip = p.startswith("wstrip")
+                K_ = int(p[6:] if strip else p[4:])
+                B, C, H, Wd = a16.shape
+                kh, kw_ = (1, K_) if strip else (K_, K_)
+                ph, pw = (-H) % kh, (-Wd) % kw_
+                ap = TF.pad(a16, (0, pw, 0, ph), mode="replicate")
+                g = TF.avg_pool2d(ap, (kh, kw_))
+                g = g.repeat_interleave(kh, 2).repeat_interleave(kw_, 3)[:, :, :H, :Wd]
+                y = y + cv(r16(g), dW)
             else:
                 raise ValueError(p)
         return y
