@@ -117,6 +117,41 @@ def test_sharded_sequence_equals_unsharded_256_frames(weights):
     _free()
 
 
+def test_config4_size_eight_ranks_emulated(weights):
+    """BASELINE config 4 at its size: a 1 000-frame sequence cut into the 8 blocks of 125 frames that 8 ranks own (one 64-frame batch +
+    a 61-frame ragged one through the padded plan, each rank reading the frame before its block as its halo), run rank by rank on
+    one GPU with the all-gather replaced by the stitched relatives: depth, relatives, absolute poses and point counts bit-equal to
+    the unsharded run.  (The collective itself is covered by tests/test_sharding_cpu.py, world 2 over gloo; no 8-GPU node was
+    available to measure the scaling.)"""
+    from bodyslam_amd.pipeline import BodySlamPipeline, local_pairs, shard_bounds
+    from bodyslam_amd.synthetic import make_sequence
+    cfg, wz, wp = weights
+    N, H, W, world = 1000, 480, 640, 8
+    frames = torch.from_numpy(make_sequence(N, H, W, seed=6))
+    pipe = BodySlamPipeline(wz, wp, cfg, batch=64, precision="accurate")
+    whole = pipe.run_sequence(frames)
+    assert whole.depth_u16.shape == (N, H, W) and whole.g_abs.shape == (N, 4, 4)
+    blocks = []
+    for r in range(world):
+        s, e = shard_bounds(N, world, r)
+        assert e - s == 125
+        depth, _, t_loc = pipe.depth_and_pose_block(frames, s, e)
+        assert t_loc.shape[0] == local_pairs(s, e).shape[0]
+        assert torch.equal(depth, whole.depth_u16[s:e]), f"rank {r}: depth of block [{s},{e}) differs from the unsharded run"
+        blocks.append((s, e, t_loc))
+        del depth
+    t_all = torch.cat([b[2] for b in blocks], 0)
+    assert torch.equal(t_all.view(-1, 4, 4), whole.t_rel)
+    for r in (0, 3, 7):
+        s, e = blocks[r][0], blocks[r][1]
+        res = pipe.run_sequence(frames, rank=r, world=world, gather=lambda t_loc, counts: t_all)
+        assert torch.equal(res.g_abs, whole.g_abs) and torch.equal(res.depth_u16, whole.depth_u16[s:e])
+        assert torch.equal(res.point_counts, whole.point_counts[s:e])
+    report(f"1000-frame sequence: 8 emulated ranks of 125 frames == unsharded (depth, t_rel, g_abs, counts)")
+    del pipe, whole
+    _free()
+
+
 def test_ragged_block_through_padded_plan(weights):
     """A 70-frame block on batch 64: the 6-frame tail runs through the 64-frame plan (pad_ragged) and equals the result of a
     pipeline that builds a 6-frame plan."""
