@@ -812,10 +812,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
 #pragma unroll
                         for (int e = 0; e < 4; ++e) y[e] = acc[i][j][e] + bsum[e];
                         const bool res32 = p.res && p.res_dtype == BS_F32;
+                        if (ACT == BS_ACT_GELU) {                 // two values per instruction (bit-identical to gelu_erf per element)
+                            const f32x2_ g0 = gelu_erf2(f32x2_{y[0], y[1]}), g1 = gelu_erf2(f32x2_{y[2], y[3]});
+                            y[0] = g0[0]; y[1] = g0[1]; y[2] = g1[0]; y[3] = g1[1];
+                        }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             if (ACT == BS_ACT_RELU) y[e] = fmaxf(y[e], 0.0f);
-                            else if (ACT == BS_ACT_GELU) y[e] = gelu_erf(y[e]);
                             else if (ACT == BS_ACT_SOFTPLUS) y[e] = softplus20(y[e]);
                             if (!res32) y[e] *= sj[j][e];
                         }
@@ -956,9 +959,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                     for (int jp = 0; jp < FN / 2; ++jp) {
                         float y8[8];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            y8[e] = gelu_erf(acc[i][2 * jp][e] + bj[2 * jp][e]);
-                            y8[4 + e] = gelu_erf(acc[i][2 * jp + 1][e] + bj[2 * jp + 1][e]);
+                        for (int h = 0; h < 2; ++h) {             // (two values per instruction: gelu_erf2)
+                            const f32x4 v = acc[i][2 * jp + h] + bj[2 * jp + h];
+                            const f32x2_ g0 = gelu_erf2(f32x2_{v[0], v[1]}), g1 = gelu_erf2(f32x2_{v[2], v[3]});
+                            y8[4 * h] = g0[0]; y8[4 * h + 1] = g0[1]; y8[4 * h + 2] = g1[0]; y8[4 * h + 3] = g1[1];
                         }
                         if (planes) {
                             store8_f8<T>(p.out, (int64_t)m * p.ldo, n_wave + jp * 32 + fq * 8, p.split_off, y8, p.out_f8 & 0xff, (p.out_f8 >> 8) & 0xff, lo);

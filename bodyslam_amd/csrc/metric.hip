@@ -61,13 +61,18 @@ __global__ __launch_bounds__(256) void attractor_kernel(const float* A, const fl
     const float* pa = A + pix * CA + g * na;
     for (int a4 = 0; a4 < na; a4 += 4) {
         const f32x4 av = *reinterpret_cast<const f32x4*>(pa + a4);
+        // inv_attractor defaults alpha=300, gamma=2: dx / (1 + 300 dx^2) with v_rcp (1 ulp) instead of the IEEE division sequence; two bins
+        // per instruction (v_pk_*_f32), the products fused into their adds -- 6 issue slots per term instead of 9
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float dx = av[k] - c[e];
-                // inv_attractor defaults alpha=300, gamma=2; v_rcp-based division (1 ulp) instead of the IEEE sequence
-                dsum[e] += __fdividef(dx, 1.0f + 300.0f * (dx * dx));
+            for (int h = 0; h < 2; ++h) {
+                const f32x2_ dx = f32x2_{av[k], av[k]} - f32x2_{c[2 * h], c[2 * h + 1]};
+                const f32x2_ den = __builtin_elementwise_fma(dx * f32x2_{300.0f, 300.0f}, dx, f32x2_{1.0f, 1.0f});
+                const f32x2_ r = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+                const f32x2_ d2 = __builtin_elementwise_fma(dx, r, f32x2_{dsum[2 * h], dsum[2 * h + 1]});
+                dsum[2 * h] = d2[0];
+                dsum[2 * h + 1] = d2[1];
             }
     }
     f32x4 o;
@@ -176,17 +181,26 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
         for (int c = 0; c < LB_IN; ++c) rd += grel[LB_HID + c] * xin[c];
         rd = fmaxf(rd, 0.0f);
     }
-#pragma unroll 4
-    for (int h = 0; h < LB_HID; ++h) {
-        // same bilinear operation order as torch: hy*(hx*p00 + lx*p01) + ly*(hx*p10 + lx*p11)
-        float a = l.hy * (l.hx * s_eh[c00 * LB_HID + h] + l.lx * s_eh[c01 * LB_HID + h]) +
-                  l.ly * (l.hx * s_eh[c10 * LB_HID + h] + l.lx * s_eh[c11 * LB_HID + h]);
+    // two hidden units per pass: the 32-term dot products run on v_pk_fma_f32 (both halves read the same input, the weights of units h and
+    // h + 1 sit in scalar registers) -- the build has -ffp-contract=off, so without the explicit fused form every term was a multiply
+    // AND an add (2 560 issue slots per pixel for this loop; now 640)
+    static_assert(LB_HID % 2 == 0, "hidden width");
+#pragma unroll 2
+    for (int h = 0; h < LB_HID; h += 2) {
+        f32x2_ a2;
 #pragma unroll
-        for (int c = 0; c < LB_IN; ++c) a += gw0[h * LB_IN + c] * xin[c];
-        if (grel) a += grel[h] * rd;
-        a = gelu_erf_as(a);
+        for (int u = 0; u < 2; ++u)     // same bilinear operation order as torch: hy*(hx*p00 + lx*p01) + ly*(hx*p10 + lx*p11)
+            a2[u] = l.hy * (l.hx * s_eh[c00 * LB_HID + h + u] + l.lx * s_eh[c01 * LB_HID + h + u]) +
+                    l.ly * (l.hx * s_eh[c10 * LB_HID + h + u] + l.lx * s_eh[c11 * LB_HID + h + u]);
 #pragma unroll
-        for (int o = 0; o < 4; ++o) pt[o] += gw2[o * LB_HID + h] * a;
+        for (int c = 0; c < LB_IN; ++c)
+            a2 = __builtin_elementwise_fma(f32x2_{gw0[h * LB_IN + c], gw0[(h + 1) * LB_IN + c]}, f32x2_{xin[c], xin[c]}, a2);
+        if (grel) a2 = __builtin_elementwise_fma(f32x2_{grel[h], grel[h + 1]}, f32x2_{rd, rd}, a2);
+        const f32x2_ ga = gelu_erf_as2(a2);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) pt[o] = fmaf(gw2[o * LB_HID + h + u], ga[u], pt[o]);
     }
 #pragma unroll
     for (int o = 0; o < 4; ++o) pt[o] = softplus20(pt[o]);
@@ -202,11 +216,22 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
     // halved the occupancy): they are three FMAs each and are evaluated twice, once for the max and once for the exponentials;
     // the division by T is one reciprocal (T > 0), applied after the max.
     const float rt = 1.0f / t;
-    auto logit = [&](int k) { return s_lb[k] + (float)k * lp_ + (float)(LB_BINS - 1 - k) * lomp; };
+    // two bins per instruction (v_pk_fma_f32 / v_pk_mul_f32): (lb_k + k log p) + (63 - k) log(1 - p), each product fused into its add
+    const f32x2_ lp2 = {lp_, lp_}, lo2 = {lomp, lomp};
+    auto logit2 = [&](int k) {      // bins k, k + 1 (k even)
+        const f32x2_ kk = {(float)k, (float)(k + 1)}, nk = {(float)(LB_BINS - 1 - k), (float)(LB_BINS - 2 - k)};
+        const f32x2_ lb = *reinterpret_cast<const f32x2_*>(s_lb + k);
+        return __builtin_elementwise_fma(nk, lo2, __builtin_elementwise_fma(kk, lp2, lb));
+    };
     float vmx = -3.0e38f;
 #pragma unroll
-    for (int k = 0; k < LB_BINS; ++k) vmx = fmaxf(vmx, logit(k));
-    float den = 0.f, num = 0.f;
+    for (int k = 0; k < LB_BINS; k += 2) {
+        const f32x2_ v = logit2(k);
+        vmx = fmaxf(fmaxf(vmx, v[0]), v[1]);
+    }
+    const f32x2_ vm2 = {vmx, vmx}, rt2 = {rt, rt};
+    const f32x2_ hx2 = {l.hx, l.hx}, lx2 = {l.lx, l.lx}, hy2 = {l.hy, l.hy}, ly2 = {l.ly, l.ly};
+    f32x2_ den2 = {0.f, 0.f}, num2 = {0.f, 0.f};
 #pragma unroll
     for (int k4 = 0; k4 < LB_BINS / 4; ++k4) {
         const f32x4 b00 = *reinterpret_cast<const f32x4*>(s_bins + c00 * LB_BINS + k4 * 4);
@@ -214,13 +239,19 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
         const f32x4 b10 = *reinterpret_cast<const f32x4*>(s_bins + c10 * LB_BINS + k4 * 4);
         const f32x4 b11 = *reinterpret_cast<const f32x4*>(s_bins + c11 * LB_BINS + k4 * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float w = __expf((logit(k4 * 4 + e) - vmx) * rt);
-            const float c = l.hy * (l.hx * b00[e] + l.lx * b01[e]) + l.ly * (l.hx * b10[e] + l.lx * b11[e]);
-            den += w;
-            num += w * c;
+        for (int h = 0; h < 2; ++h) {
+            const f32x2_ a = (logit2(k4 * 4 + 2 * h) - vm2) * rt2;
+            const f32x2_ w = {__expf(a[0]), __expf(a[1])};
+            const f32x2_ p00 = {b00[2 * h], b00[2 * h + 1]}, p01 = {b01[2 * h], b01[2 * h + 1]};
+            const f32x2_ p10 = {b10[2 * h], b10[2 * h + 1]}, p11 = {b11[2 * h], b11[2 * h + 1]};
+            // torch's bilinear order hy*(hx*p00 + lx*p01) + ly*(hx*p10 + lx*p11), products fused into the adds
+            const f32x2_ top = __builtin_elementwise_fma(lx2, p01, hx2 * p00), bot = __builtin_elementwise_fma(lx2, p11, hx2 * p10);
+            const f32x2_ c = __builtin_elementwise_fma(ly2, bot, hy2 * top);
+            den2 += w;
+            num2 = __builtin_elementwise_fma(w, c, num2);
         }
     }
+    const float den = den2[0] + den2[1], num = num2[0] + num2[1];
     depth[gid] = num / den;
 }
 
