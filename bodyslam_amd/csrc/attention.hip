@@ -626,8 +626,16 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
     };
     // scores of one sub-tile: (bias - running max) + K Q^T, four MFMAs left in flight
     auto qk = [&](f32x16& sacc, const char* sk, int sub) {
+        {   // (as eight v_pk_add_f32: the softmax bookkeeping of this kernel is VALU-bound)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 m2 = {-m_run, -m_run};     // (an add of the negated value: a v2f32 subtraction is split into two v_sub_f32)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sacc[i] -= m_run;
+            for (int i = 0; i < 16; i += 2) {
+                const f32x2 v = f32x2{sacc[i], sacc[i + 1]} + m2;
+                sacc[i] = v[0];
+                sacc[i + 1] = v[1];
+            }
+        }
         const int krow = sub * 32 + kap;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -664,17 +672,19 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
             m_run += sh;
             first = false;
         }
-        float psum = 0.f;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 ps2 = {0.f, 0.f};
         v8 pf[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float pv = __builtin_amdgcn_exp2f(sacc[8 * s2 + e]);
-                psum += pv;
-                pf[s2][e] = T16<T>::from_f32(pv);
+            for (int e = 0; e < 8; e += 2) {
+                const f32x2 pv = {__builtin_amdgcn_exp2f(sacc[8 * s2 + e]), __builtin_amdgcn_exp2f(sacc[8 * s2 + e + 1])};
+                ps2 += pv;                      // (v_pk_add_f32)
+                pf[s2][e] = T16<T>::from_f32(pv[0]);
+                pf[s2][e + 1] = T16<T>::from_f32(pv[1]);
             }
-        l_run += psum;
+        l_run += ps2[0] + ps2[1];
         if (NEXT) load_bias(sacc, next_ky);
 #pragma unroll
         for (int dh = 0; dh < 2; ++dh) {
