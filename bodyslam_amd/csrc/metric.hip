@@ -265,43 +265,49 @@ __global__ __launch_bounds__(256) void small_attention_kernel(const float* qkv, 
     const int b = blockIdx.x / nheads, h = blockIdx.x % nheads;
     const int D = nheads * HD;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* ks = reinterpret_cast<float*>(smem_raw);  // [S][HD+1]
-    float* vs = ks + S * (HD + 1);
+    // K and V rows of this (image, head) in LDS, 32 floats = 128 bytes each: every thread of the block reads the SAME row at the same
+    // time (a broadcast: no bank conflicts whatever the stride), so the rows are left unpadded and go out as eight ds_read_b128
+    // instead of 32 ds_read_b32 -- the kernel was bound by LDS instruction issue, and by a multiply AND an add per term (the build
+    // has -ffp-contract=off): both loops now run fused multiply-adds on whole float4s.
+    float* ks = reinterpret_cast<float*>(smem_raw);  // [S][HD]
+    float* vs = ks + S * HD;
     for (int i = threadIdx.x; i < S * HD; i += blockDim.x) {
         const int t = i / HD, d = i % HD;
         const float* row = qkv + ((int64_t)b * S + t) * 3 * D + h * HD + d;
-        ks[t * (HD + 1) + d] = row[D];
-        vs[t * (HD + 1) + d] = row[2 * D];
+        ks[i] = row[D];
+        vs[i] = row[2 * D];
     }
     __syncthreads();
     for (int t = threadIdx.x; t < S; t += blockDim.x) {
-        float q[HD], o[HD];
+        f32x4 q[HD / 4], o[HD / 4];
         const float* qr = qkv + ((int64_t)b * S + t) * 3 * D + h * HD;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) {
-            q[d] = qr[d];
-            o[d] = 0.f;
+        for (int d = 0; d < HD / 4; ++d) {
+            q[d] = *reinterpret_cast<const f32x4*>(qr + 4 * d);
+            o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        float mx = -3.0e38f;
-        for (int j = 0; j < S; ++j) {
-            float s = 0.f;
+        auto score = [&](int j) {
+            f32x4 acc = q[0] * *reinterpret_cast<const f32x4*>(ks + j * HD);
 #pragma unroll
-            for (int d = 0; d < HD; ++d) s += q[d] * ks[j * (HD + 1) + d];
-            mx = fmaxf(mx, s * scale);
-        }
+            for (int d = 1; d < HD / 4; ++d) acc = __builtin_elementwise_fma(q[d], *reinterpret_cast<const f32x4*>(ks + j * HD + 4 * d), acc);
+            return ((acc[0] + acc[1]) + (acc[2] + acc[3])) * scale;
+        };
+        float mx = -3.0e38f;
+        for (int j = 0; j < S; ++j) mx = fmaxf(mx, score(j));
         float den = 0.f;
         for (int j = 0; j < S; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int d = 0; d < HD; ++d) s += q[d] * ks[j * (HD + 1) + d];
-            const float w = expf(s * scale - mx);
+            const float w = expf(score(j) - mx);
             den += w;
+            const f32x4 w4 = {w, w, w, w};
 #pragma unroll
-            for (int d = 0; d < HD; ++d) o[d] += w * vs[j * (HD + 1) + d];
+            for (int d = 0; d < HD / 4; ++d) o[d] = __builtin_elementwise_fma(w4, *reinterpret_cast<const f32x4*>(vs + j * HD + 4 * d), o[d]);
         }
         T* orow = out + ((int64_t)b * S + t) * D + h * HD;
+        const float inv = 1.0f / den;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) orow[d] = T16<T>::from_f32(o[d] / den);
+        for (int d = 0; d < HD / 4; ++d)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) orow[4 * d + e] = T16<T>::from_f32(o[d][e] * inv);
     }
 }
 
