@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbodyslam_hip.so")
+LIB_PATH = os.environ.get("BODYSLAM_HIP_LIB") or os.path.join(_HERE, "libbodyslam_hip.so")      # (the override: A/B runs of two builds in one call)
 
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SOFTPLUS = 0, 1, 2, 3

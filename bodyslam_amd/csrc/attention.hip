@@ -626,16 +626,11 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
     };
     // scores of one sub-tile: (bias - running max) + K Q^T, four MFMAs left in flight
     auto qk = [&](f32x16& sacc, const char* sk, int sub) {
-        {   // (as eight v_pk_add_f32: the softmax bookkeeping of this kernel is VALU-bound)
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
-            const f32x2 m2 = {-m_run, -m_run};     // (an add of the negated value: a v2f32 subtraction is split into two v_sub_f32)
+        // (kept as sixteen v_sub_f32 on purpose: written as v_pk_add_f32 pairs these registers -- the accumulator operand of the MFMAs
+        // that follow at once -- came out wrong now and then under load at B = 128, run to run: a write-to-MFMA-SrcC hazard the
+        // compiler does not pad for packed writes; tools/probes/attn_batch_invariance.py, test_attention_table_is_deterministic_at_scale)
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                const f32x2 v = f32x2{sacc[i], sacc[i + 1]} + m2;
-                sacc[i] = v[0];
-                sacc[i + 1] = v[1];
-            }
-        }
+        for (int i = 0; i < 16; ++i) sacc[i] -= m_run;
         const int krow = sub * 32 + kap;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {

@@ -157,32 +157,39 @@ template <typename T>
 __device__ __forceinline__ void store8_f8(void* base, int64_t row_off, int n, int plane_off, const float (&y)[8], int ea, int el, bool lo = true) {
     typedef typename T16<T>::v8 v8;
     typedef int i32x2 __attribute__((ext_vector_type(2)));
+    // (two values per instruction for the scalings, one v_med3_f32 for each clamp: the epilogues that emit planes are VALU-bound)
     v8 h;
-    float yh[8];
+    f32x2_ yh[4];
     const float sa = __builtin_ldexpf(1.0f, ea), sl = __builtin_ldexpf(1.0f, el);
+    const f32x2_ sa2 = {sa, sa}, sl2 = {sl, sl};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < 8; e += 2) {
         h[e] = T16<T>::from_f32(y[e]);
-        yh[e] = fminf(fmaxf(y[e] * sa, -448.0f), 448.0f);
+        h[e + 1] = T16<T>::from_f32(y[e + 1]);
+        const f32x2_ v = f32x2_{y[e], y[e + 1]} * sa2;
+        yh[e >> 1] = f32x2_{__builtin_amdgcn_fmed3f(v[0], -448.0f, 448.0f), __builtin_amdgcn_fmed3f(v[1], -448.0f, 448.0f)};
     }
     T* rowp = reinterpret_cast<T*>(base) + row_off;
     *reinterpret_cast<v8*>(rowp + n) = h;
     int ph0 = 0, ph1 = 0;
-    ph0 = __builtin_amdgcn_cvt_pk_fp8_f32(yh[0], yh[1], ph0, false);
-    ph0 = __builtin_amdgcn_cvt_pk_fp8_f32(yh[2], yh[3], ph0, true);
-    ph1 = __builtin_amdgcn_cvt_pk_fp8_f32(yh[4], yh[5], ph1, false);
-    ph1 = __builtin_amdgcn_cvt_pk_fp8_f32(yh[6], yh[7], ph1, true);
+    ph0 = __builtin_amdgcn_cvt_pk_fp8_f32(yh[0][0], yh[0][1], ph0, false);
+    ph0 = __builtin_amdgcn_cvt_pk_fp8_f32(yh[1][0], yh[1][1], ph0, true);
+    ph1 = __builtin_amdgcn_cvt_pk_fp8_f32(yh[2][0], yh[2][1], ph1, false);
+    ph1 = __builtin_amdgcn_cvt_pk_fp8_f32(yh[3][0], yh[3][1], ph1, true);
     char* bytes = reinterpret_cast<char*>(rowp + plane_off);
     *reinterpret_cast<i32x2*>(bytes + n) = i32x2{ph0, ph1};
     if (lo) {       // (wave-uniform) the plane of the rounding residuals: only where the consumer evaluates A_lo8 W_hi8
-        float yl[8];
+        f32x2_ yl[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) yl[e] = fminf(fmaxf((y[e] - T16<T>::to_f32(h[e])) * sl, -448.0f), 448.0f);
+        for (int e = 0; e < 8; e += 2) {
+            const f32x2_ r = (f32x2_{y[e], y[e + 1]} + f32x2_{-T16<T>::to_f32(h[e]), -T16<T>::to_f32(h[e + 1])}) * sl2;
+            yl[e >> 1] = f32x2_{__builtin_amdgcn_fmed3f(r[0], -448.0f, 448.0f), __builtin_amdgcn_fmed3f(r[1], -448.0f, 448.0f)};
+        }
         int pl0 = 0, pl1 = 0;
-        pl0 = __builtin_amdgcn_cvt_pk_fp8_f32(yl[0], yl[1], pl0, false);
-        pl0 = __builtin_amdgcn_cvt_pk_fp8_f32(yl[2], yl[3], pl0, true);
-        pl1 = __builtin_amdgcn_cvt_pk_fp8_f32(yl[4], yl[5], pl1, false);
-        pl1 = __builtin_amdgcn_cvt_pk_fp8_f32(yl[6], yl[7], pl1, true);
+        pl0 = __builtin_amdgcn_cvt_pk_fp8_f32(yl[0][0], yl[0][1], pl0, false);
+        pl0 = __builtin_amdgcn_cvt_pk_fp8_f32(yl[1][0], yl[1][1], pl0, true);
+        pl1 = __builtin_amdgcn_cvt_pk_fp8_f32(yl[2][0], yl[2][1], pl1, false);
+        pl1 = __builtin_amdgcn_cvt_pk_fp8_f32(yl[3][0], yl[3][1], pl1, true);
         *reinterpret_cast<i32x2*>(bytes + plane_off + n) = i32x2{pl0, pl1};
     }
 }

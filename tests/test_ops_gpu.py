@@ -1068,3 +1068,36 @@ def test_pose_chain(L, golden_dir):
     out3 = torch.empty(2, 16, dtype=torch.float64, device=dev())
     L.pose_chain(torch.from_numpy(T.reshape(1, 16)).to(dev()), 1, None, out3)
     assert np.abs(out3.cpu().numpy()[1].reshape(4, 4) - G.pose_chain(T[None])[1]).max() < 1e-12
+
+
+def test_attention_table_is_deterministic_at_scale(L):
+    """The bench's attention launch (128 images, 16 heads, 24 x 32 windows) twice on the same input, and three of its images one at a time:
+    the same bits.  (A packed-math variant of the kernel passed every accuracy test at small batches and was wrong now and then at
+    this size -- a register hazard that shows only when the chip is full; the B = 64 plan then differed from the B = 1 plan.)"""
+    dtype = torch.float16
+    hp, wp, nh, B = 24, 32, 16, 128
+    S = hp * wp + 1
+    Sp = (S + 63) // 64 * 64
+    ntab = (2 * hp - 1) * (2 * wp - 1) + 3
+    g = torch.Generator().manual_seed(3)
+    q = torch.zeros(B, nh, Sp, 64, device=dev(), dtype=dtype)
+    k = torch.zeros_like(q)
+    vt = torch.zeros(B, nh, 64, Sp, device=dev(), dtype=dtype)
+    q[:, :, :S] = (torch.randn(B, nh, S, 64, generator=g) * 0.3).to(dtype).to(dev())
+    k[:, :, :S] = torch.randn(B, nh, S, 64, generator=g).to(dtype).to(dev())
+    vt[:, :, :, :S] = torch.randn(B, nh, 64, S, generator=g).to(dtype).to(dev())
+    tab = torch.randn(nh, ntab, generator=g).to(dev())
+    for split in (0, 32):
+        width = nh * 64 * (2 if split else 1)
+        lib = L.load_library()
+
+        def run(qq, kk, vv, b):
+            out = torch.zeros(b * S, width, device=dev(), dtype=dtype)
+            L.check(lib.bs_attention_table(L.p(qq), L.p(kk), L.p(vv), L.p(tab), L.p(out), b, nh, hp, wp, Sp, 0, L.dt(qq) | split, L.stream_ptr()), "attn")
+            return out
+        a = run(q, k, vt, B)
+        for _ in range(3):
+            assert torch.equal(run(q, k, vt, B), a), "bs_attention_table is not deterministic at B = 128"
+        for b in (0, 63, B - 1):
+            one = run(q[b:b + 1].contiguous(), k[b:b + 1].contiguous(), vt[b:b + 1].contiguous(), 1)
+            assert torch.equal(one, a[b * S:(b + 1) * S]), f"image {b} of the batch differs from the same image alone"
