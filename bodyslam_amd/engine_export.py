@@ -81,7 +81,6 @@ def _pack_name(s: str, n: int) -> bytes:
 def export_plan(plan: L.Plan, path: str, io: Dict[str, torch.Tensor], workspace: Iterable[torch.Tensor] = ()) -> dict:
     """write `plan` as an engine file.  io: name -> tensor (a view of one of the plan's static buffers).  workspace: tensors whose
     storages hold nothing the launches rely on (the plan's pooled intermediates): only their size is written."""
-    lib = L.load_library()
     ts: List[torch.Tensor] = []
     _tensors(plan.keep, ts)
     _tensors(list(io.values()), ts)
@@ -189,7 +188,7 @@ def export_cyclepose(engine, n_frames: int, n_pairs: int, H: int, W: int, path: 
 
 def main(argv=None):
     import argparse
-    from .weights import load_cyclepose_weights, load_zoedepth_weights
+    from .weights import load_cyclepose_checkpoint, load_zoedepth_weights
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("model", choices=["zoedepth", "cyclepose"])
     ap.add_argument("weights")
@@ -204,7 +203,7 @@ def main(argv=None):
         info = export_zoedepth(ZoeDepthEngine(load_zoedepth_weights(a.weights), precision=a.precision), a.batch, a.height, a.width, a.out)
     else:
         from .cyclepose import CyclePoseEngine
-        info = export_cyclepose(CyclePoseEngine(load_cyclepose_weights(a.weights), precision=a.precision), a.batch + 1, a.batch, a.height, a.width,
+        info = export_cyclepose(CyclePoseEngine(load_cyclepose_checkpoint(a.weights), precision=a.precision), a.batch + 1, a.batch, a.height, a.width,
                                 a.out)
     print(info)
 
