@@ -344,10 +344,14 @@ template <typename T, int SPLIT>
 __global__ __launch_bounds__(256) void upconv_tapsum_kernel(const float* y, const float* bias, T* out, int B, int Hin, int Win, int Co, int Hout,
                                                              int Wout, float sy, float sx, int align, int relu) {
     const int groups = Co >> 2;
-    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (unsigned)Wout * groups) return;
-    const int g = idx % groups, ox = idx / groups;
-    const int b = blockIdx.y / Hout, oy = blockIdx.y - b * Hout;
+    // a block is a TW x TH patch of output pixels (x fastest) times the channel groups: vertical neighbours share their low-resolution
+    // rows in L1 (a 32 x 1 strip re-fetched every corner row from L2 for each output row)
+    const int per = 256 / groups, TW = per >= 8 ? 8 : per, TH = per / TW;
+    const int g = threadIdx.x % groups, px = threadIdx.x / groups;
+    const int ox = blockIdx.x * TW + px % TW;
+    const int nty = (Hout + TH - 1) / TH;
+    const int b = blockIdx.y / nty, oy = (blockIdx.y - b * nty) * TH + px / TW;
+    if (px >= per || ox >= Wout || oy >= Hout) return;
     const int ld = 9 * Co;
     const float* yb = y + (int64_t)b * Hin * Win * ld + 4 * g;
     typedef float f32x4_ __attribute__((ext_vector_type(4)));
@@ -824,7 +828,8 @@ static int launch_tapsum(const float* y, const float* bias, void* out, int B, in
         sy = (float)Hin / (float)Hout;
         sx = (float)Win / (float)Wout;
     }
-    const dim3 blocks(cdiv(Wout * (Co / 4), 256), B * Hout);
+    const int groups = Co / 4, per = 256 / groups, TW = per >= 8 ? 8 : per, TH = per / TW;
+    const dim3 blocks(cdiv(Wout, TW), B * cdiv(Hout, TH));
     if (split == 2)
         hipLaunchKernelGGL((upconv_tapsum_kernel<T, 2>), blocks, dim3(256), 0, st, y, bias, (T*)out, B, Hin, Win, Co, Hout, Wout, sy, sx, align, relu);
     else if (split == 1)
@@ -842,6 +847,7 @@ extern "C" int bs_upconv_tapsum(const float* y, const float* bias, void* out, in
     BS_REQUIRE(B > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "bs_upconv_tapsum: empty problem");
     BS_REQUIRE(Cout > 0 && Cout % 4 == 0, "bs_upconv_tapsum: Cout=%d must be a multiple of 4", Cout);
     BS_REQUIRE((int64_t)B * Hout <= 0x7fffffffll && (int64_t)Wout * (Cout / 4) <= 0x7fffffffll, "bs_upconv_tapsum: grid too large");
+    BS_REQUIRE(Cout / 4 <= 256 && 256 % (Cout / 4) == 0, "bs_upconv_tapsum: Cout / 4 = %d must divide 256", Cout / 4);
     const int split = (align_corners & 4) ? 2 : ((align_corners & 2) ? 1 : 0);
     const int align = align_corners & 1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
