@@ -104,6 +104,12 @@ __device__ __forceinline__ f32x2_ gelu_erf2(f32x2_ x) {
     const f32x2_ s = {x[0] < 0.0f ? e[0] : om[0], x[1] < 0.0f ? e[1] : om[1]};
     return x * s;
 }
+// bilinear interpolation of two values at once, torch's association hy*(hx*p00 + lx*p01) + ly*(hx*p10 + lx*p11) with the second
+// product of every sum fused into the add (v_pk_mul_f32 + v_pk_fma_f32: 3 issue slots per value instead of 9 with -ffp-contract=off)
+__device__ __forceinline__ f32x2_ bilerp2(f32x2_ p00, f32x2_ p01, f32x2_ p10, f32x2_ p11, f32x2_ hx, f32x2_ lx, f32x2_ hy, f32x2_ ly) {
+    const f32x2_ top = __builtin_elementwise_fma(lx, p01, hx * p00), bot = __builtin_elementwise_fma(lx, p11, hx * p10);
+    return __builtin_elementwise_fma(ly, bot, hy * top);
+}
 // exact-erf GELU (torch's default "none" approximation).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7,
 // far below the fp32 round-off that reaches a 16-bit output): 1 rcp + 1 exp + 5 FMA instead of libm's ~40 ops
 // Kept for the log-binomial head (metric.hip), whose temperature-sharpened softmax amplifies a 1e-6 change of the hidden
@@ -146,7 +152,7 @@ __device__ __forceinline__ float apply_act(float y, int act) {
 
 // four floats -> four OCP e4m3 bytes (round to nearest even, saturating at +-448), element 0 in the low byte
 __device__ __forceinline__ int f8_pack4(float a, float b, float c, float d) {
-    auto cl = [](float v) { return fminf(fmaxf(v, -448.0f), 448.0f); };
+    auto cl = [](float v) { return __builtin_amdgcn_fmed3f(v, -448.0f, 448.0f); };     // (one v_med3_f32 instead of max + min)
     int r = 0;
     r = __builtin_amdgcn_cvt_pk_fp8_f32(cl(a), cl(b), r, false);
     r = __builtin_amdgcn_cvt_pk_fp8_f32(cl(c), cl(d), r, true);

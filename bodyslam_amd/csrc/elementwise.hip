@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void resize_nhwc_f8_kernel(const T* x, T* out,
             float lo[4];
             f8_unpack4(l[g], lo);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) q[4 * g + e] += lo[e] * sc;
+            for (int e = 0; e < 4; ++e) q[4 * g + e] = fmaf(lo[e], sc, q[4 * g + e]);      // (sc is a power of two: the product is exact)
         }
     };
     ld(y0, x0, q00);
@@ -310,13 +310,18 @@ __global__ __launch_bounds__(256) void resize_nhwc_f8_kernel(const T* x, T* out,
     ld(y1, x1, q11);
     v8 o0, o1;
     float vv[16], rl[16];
+    const f32x2_ hx2 = {hx, hx}, lx2 = {lx, lx}, hy2 = {hy, hy}, ly2 = {ly, ly};
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const float v = hy * (hx * q00[e] + lx * q01[e]) + ly * (hx * q10[e] + lx * q11[e]);
-        vv[e] = v;
-        const T h = T16<T>::from_f32(v);
-        if (e < 8) o0[e] = h; else o1[e - 8] = h;
-        rl[e] = v - (float)h;
+    for (int e = 0; e < 16; e += 2) {
+        const f32x2_ v2 = bilerp2(f32x2_{q00[e], q00[e + 1]}, f32x2_{q01[e], q01[e + 1]}, f32x2_{q10[e], q10[e + 1]}, f32x2_{q11[e], q11[e + 1]}, hx2, lx2, hy2, ly2);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float v = v2[u];
+            vv[e + u] = v;
+            const T h = T16<T>::from_f32(v);
+            if (e + u < 8) o0[e + u] = h; else o1[e + u - 8] = h;
+            rl[e + u] = v - (float)h;
+        }
     }
     T* op = out + pix * C * 2;
     *reinterpret_cast<v8*>(op + c16 * 16) = o0;
@@ -470,8 +475,8 @@ __global__ __launch_bounds__(256) void resize_nhwc_kernel(const T* x, const T* a
             const float sc = __builtin_ldexpf(1.0f, -F8_ACT_LO_EXP);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                dst[e] += l0[e] * sc;
-                dst[4 + e] += l1[e] * sc;
+                dst[e] = fmaf(l0[e], sc, dst[e]);                 // (sc is a power of two: the product is exact)
+                dst[4 + e] = fmaf(l1[e], sc, dst[4 + e]);
             }
         }
     };
@@ -482,13 +487,17 @@ __global__ __launch_bounds__(256) void resize_nhwc_kernel(const T* x, const T* a
     if (ADD) ld(addend + pix * C * PS + c8 * 8, av);
     v8 o, ol;
     float vv[8];
+    const f32x2_ hx2 = {hx, hx}, lx2 = {lx, lx}, hy2 = {hy, hy}, ly2 = {ly, ly};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float v = hy * (hx * q00[e] + lx * q01[e]) + ly * (hx * q10[e] + lx * q11[e]);
-        if (ADD) v += av[e];
-        vv[e] = v;
-        o[e] = T16<T>::from_f32(v);
-        if (SPLIT == 1) ol[e] = T16<T>::from_f32(v - (float)o[e]);
+    for (int e = 0; e < 8; e += 2) {
+        f32x2_ v = bilerp2(f32x2_{q00[e], q00[e + 1]}, f32x2_{q01[e], q01[e + 1]}, f32x2_{q10[e], q10[e + 1]}, f32x2_{q11[e], q11[e + 1]}, hx2, lx2, hy2, ly2);
+        if (ADD) v += f32x2_{av[e], av[e + 1]};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            vv[e + u] = v[u];
+            o[e + u] = T16<T>::from_f32(v[u]);
+            if (SPLIT == 1) ol[e + u] = T16<T>::from_f32(v[u] - (float)o[e + u]);
+        }
     }
     *reinterpret_cast<v8*>(out + pix * C * PS + c8 * 8) = o;
     if (SPLIT == 1) *reinterpret_cast<v8*>(out + pix * C * PS + C + c8 * 8) = ol;
