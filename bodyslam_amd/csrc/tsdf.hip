@@ -19,6 +19,7 @@ namespace bs {
 struct TsdfCam {
     double fx, fy, cx, cy;
     double e[12];            // extrinsic, rows 0..2 of the 4x4 (world -> camera)
+    double ifx, ify;         // 1 / fx, 1 / fy (host-computed: the per-voxel code multiplies instead of dividing)
 };
 
 // ---- the table of volume units: an open-addressing hash table in HBM (Open3D: std::unordered_map<Vector3i, VolumeUnit>) ----------
@@ -154,7 +155,7 @@ __device__ __forceinline__ bool tsdf_observe(double px, double py, double pz, co
     const float d = depth[pix];
     if (!(d > 0.0f)) return false;
     // depth-to-camera-distance multiplier of the pixel (Open3D keeps it as a float image)
-    const float xx = (float)(((double)ui - cam.cx) / cam.fx), yy = (float)(((double)vi - cam.cy) / cam.fy);
+    const float xx = (float)(((double)ui - cam.cx) * cam.ifx), yy = (float)(((double)vi - cam.cy) * cam.ify);
     const float mult = sqrtf(xx * xx + yy * yy + 1.0f);
     const float sdf = (float)(((double)d - cz_) * (double)mult);
     if (!(sdf > -(float)sdf_trunc)) return false;
@@ -163,12 +164,13 @@ __device__ __forceinline__ bool tsdf_observe(double px, double py, double pz, co
 }
 // the running weighted mean of a voxel (tsdf, weight, r, g, b) takes one observation
 __device__ __forceinline__ void tsdf_blend(float vox[5], float tsdf, const uint8_t* __restrict__ c) {
-    const float w0 = vox[1], w1 = w0 + 1.0f;
-    vox[0] = (vox[0] * w0 + tsdf) / w1;
+    // (one division, by the weight -- a small integer -- and four multiplies: the four IEEE divisions were a third of the per-voxel work)
+    const float w0 = vox[1], w1 = w0 + 1.0f, rw = 1.0f / w1;
+    vox[0] = fmaf(vox[0], w0, tsdf) * rw;
     if (c) {
-        vox[2] = (vox[2] * w0 + (float)c[0]) / w1;
-        vox[3] = (vox[3] * w0 + (float)c[1]) / w1;
-        vox[4] = (vox[4] * w0 + (float)c[2]) / w1;
+        vox[2] = fmaf(vox[2], w0, (float)c[0]) * rw;
+        vox[3] = fmaf(vox[3], w0, (float)c[1]) * rw;
+        vox[4] = fmaf(vox[4], w0, (float)c[2]) * rw;
     }
     vox[1] = w1;
 }
@@ -220,14 +222,15 @@ __global__ __launch_bounds__(256) void tsdf_integrate_kernel(const float* __rest
 // same values bit for bit as 64 frame-at-a-time passes (each of which reads and writes the voxel through HBM), in three launches
 // instead of 192.  Which frames touch a unit is a 64-bit mask: the discovery kernel ORs the frame's bit into the unit's table entry,
 // the assignment kernel hands out blocks, applies the per-frame frustum test and leaves the surviving bits in unit_mask[block].
-struct TsdfFrame {            // one record per frame in device memory (bs_tsdf_frames_upload): 240 bytes
+struct TsdfFrame {            // one record per frame in device memory (bs_tsdf_frames_upload): BS_TSDF_FRAME_BYTES
     const float* depth;
     const uint8_t* color;
     double fx, fy, cx, cy;
     double pose[12];          // camera -> world, rows 0..2 (unit discovery back-projects with it)
     double view[12];          // world -> camera, rows 0..2: the `extrinsic` of ScalableTSDFVolume::Integrate
+    double ifx, ify;          // 1 / fx, 1 / fy
 };
-static_assert(sizeof(TsdfFrame) == 240, "TsdfFrame layout is part of the C ABI");
+static_assert(sizeof(TsdfFrame) == BS_TSDF_FRAME_BYTES, "TsdfFrame layout is part of the C ABI");
 
 __global__ __launch_bounds__(256) void tsdf_touch_batch_kernel(const TsdfFrame* __restrict__ frames, int H, int W, int stride, double unit_length,
                                                                 double sdf_trunc, int span, long long* keys, unsigned long long* fmask, unsigned mask,
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(256) void tsdf_integrate_batch_kernel(const TsdfFra
                 bits &= bits - 1;
                 const TsdfFrame& F = frames[f];
                 TsdfCam cam;
-                cam.fx = F.fx; cam.fy = F.fy; cam.cx = F.cx; cam.cy = F.cy;
+                cam.fx = F.fx; cam.fy = F.fy; cam.cx = F.cx; cam.cy = F.cy; cam.ifx = F.ifx; cam.ify = F.ify;
 #pragma unroll
                 for (int i = 0; i < 12; ++i) cam.e[i] = F.view[i];
                 float tsdf;
@@ -602,6 +605,7 @@ static bool det_ok(const double* m) {
 
 static void tsdf_cam(TsdfCam& cam, const double* K, const double* m12) {
     cam.fx = K[0]; cam.fy = K[1]; cam.cx = K[2]; cam.cy = K[3];
+    cam.ifx = 1.0 / K[0]; cam.ify = 1.0 / K[1];
     for (int i = 0; i < 12; ++i) cam.e[i] = m12[i];
 }
 
@@ -717,6 +721,7 @@ extern "C" int bs_tsdf_frames_upload(const float* const* depth, const uint8_t* c
         h[f].depth = depth[f];
         h[f].color = color ? color[f] : nullptr;
         h[f].fx = K[0]; h[f].fy = K[1]; h[f].cx = K[2]; h[f].cy = K[3];
+        h[f].ifx = 1.0 / K[0]; h[f].ify = 1.0 / K[1];
         for (int i = 0; i < 12; ++i) {
             h[f].view[i] = extrinsics[16 * f + i];
             h[f].pose[i] = poses[16 * f + i];

@@ -246,7 +246,7 @@ class TSDF:
         if getattr(self, "table_fmask", None) is None:
             self.table_fmask = torch.zeros(self.table_cap, dtype=torch.int64, device=self.dev)
             self.unit_mask = torch.zeros(self.max_units, dtype=torch.int64, device=self.dev)
-            self.frames_dev = torch.zeros(BATCH_MAX * 240, dtype=torch.uint8, device=self.dev)
+            self.frames_dev = torch.zeros(BATCH_MAX * 256, dtype=torch.uint8, device=self.dev)      # BS_TSDF_FRAME_BYTES per frame
         K = np.array([intrinsic.fx, intrinsic.fy, intrinsic.cx, intrinsic.cy], dtype=np.float64)
         for a in range(0, n, BATCH_MAX):
             chunk = rgbds[a:a + BATCH_MAX]

@@ -371,7 +371,7 @@ int bs_tsdf_integrate(const float* depth, const uint8_t* color, int32_t H, int32
  * order and nothing else orders them, so up to BS_TSDF_BATCH_MAX frames are integrated by loading every touched voxel once, applying
  * the frames that touch its unit in ascending order in registers and storing it once -- bit for bit what that many
  * bs_tsdf_touch + bs_tsdf_integrate calls leave in the blocks, in three launches).
- *   bs_tsdf_frames_upload    writes the batch's frame records (240 bytes each) to frames_dev: depth[f] / color[f] = the frames' device
+ *   bs_tsdf_frames_upload    writes the batch's frame records (BS_TSDF_FRAME_BYTES each) to frames_dev: depth[f] / color[f] = the frames' device
  *                            images (color NULL or all entries NULL: no colours), K = (fx, fy, cx, cy), extrinsics / poses = host
  *                            doubles [n_frames, 16]: the world->camera 4x4 of every frame and its inverse
  *   bs_tsdf_touch_batch      unit discovery of all frames: inserts the units and ORs bit f into table_fmask (uint64 [table_cap], zero
@@ -381,6 +381,7 @@ int bs_tsdf_integrate(const float* depth, const uint8_t* color, int32_t H, int32
  *                            test, unit_mask (uint64 [max_units]) and `touched`, then the integration; counters[1] = the units updated;
  *                            table_fmask is zero again afterwards */
 #define BS_TSDF_BATCH_MAX 64
+#define BS_TSDF_FRAME_BYTES 256
 int bs_tsdf_frames_upload(const float* const* depth, const uint8_t* const* color, const double* K, const double* extrinsics, const double* poses,
                           int32_t n_frames, void* frames_dev, void* stream);
 int bs_tsdf_touch_batch(const void* frames_dev, int32_t n_frames, int32_t H, int32_t W, int32_t stride, double unit_length, double sdf_trunc,
