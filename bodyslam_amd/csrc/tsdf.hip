@@ -147,7 +147,10 @@ __device__ __forceinline__ bool tsdf_observe(double px, double py, double pz, co
     if (!(cz_ > 0.0)) return false;
     const double cx_ = fma(cam.e[0], px, fma(cam.e[1], py, fma(cam.e[2], pz, cam.e[3])));
     const double cy_ = fma(cam.e[4], px, fma(cam.e[5], py, fma(cam.e[6], pz, cam.e[7])));
-    const double iz = 1.0 / cz_;
+    // 1 / cz: v_rcp_f64 and two Newton steps (five instructions, <= 1 ulp) instead of the fifteen-instruction IEEE division
+    double iz = __builtin_amdgcn_rcp(cz_);
+    iz = fma(iz, fma(-cz_, iz, 1.0), iz);
+    iz = fma(iz, fma(-cz_, iz, 1.0), iz);
     const double u_f = fma(cx_ * cam.fx, iz, cam.cx + 0.5), v_f = fma(cy_ * cam.fy, iz, cam.cy + 0.5);
     if (!(u_f >= 0.0001 && u_f < (double)W - 0.0001 && v_f >= 0.0001 && v_f < (double)H - 0.0001)) return false;
     const int ui = (int)u_f, vi = (int)v_f;
