@@ -278,7 +278,7 @@ class BodySlamPipeline:
 
         def launch_network(b0):
             b1 = min(b0 + self.batch, N)
-            d_u16, d_m, t_dev = self.depth_and_pose_block(frames, b0, b1, keep_depth_m, 0, pad_to_batch=N > self.batch)
+            d_u16, d_m, t_dev = self.depth_and_pose_block(fr_dev, b0, b1, keep_depth_m, 0, pad_to_batch=N > self.batch)      # (the device copy: no re-upload per batch)
             depth_all[b0:b1].copy_(d_u16)
             if keep_depth_m:
                 depth_m_all[b0:b1].copy_(d_m)
