@@ -64,7 +64,7 @@ def measure_pmc_traffic(args):
             cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", counter, "--",
                    "python3", os.path.join(ROOT, "bench.py"), "--single-mode", "--precision", args.precision, "--steps", "1", "--warmup", "0",
                    "--batch", str(args.batch), "--dtype", args.dtype, "--height", str(args.height), "--width", str(args.width),
-                   "--no-cpu-baseline", "--no-kernel-timing", "--no-pmc-traffic"]
+                   "--no-cpu-baseline", "--no-kernel-timing", "--no-pmc-traffic", "--no-slam-loop"]
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             path = None
             for dp, _, fns in os.walk(tmp):
@@ -103,6 +103,7 @@ def main():
                          "fast: one 16-bit MFMA pass per product (L1 ~3e-4 m).  The other mode is measured too and reported beside it.")
     ap.add_argument("--single-mode", action="store_true", help="measure only --precision")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-slam-loop", action="store_true", help="skip the extra `slam_loop` figure (the reference's whole per-frame loop around the hot path)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (pure throughput run)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank runs its own sequence, --batch frames per step; strong: one --frames sequence cut across the ranks")
@@ -293,6 +294,29 @@ def main():
         other_name = "fast" if args.precision == "accurate" else "accurate"
         other = measure(other_name)
 
+    # ---- the reference's whole per-frame loop around the hot path (BodySlamPipeline.run_slam_loop: + RGB-D odometry and UKF fusion, pose
+    # graph every 500 frames, TSDF map at the reference's parameters), reported beside the metric, never as `value`: rank 0 at N = 1
+    slam = None
+    if rank == 0 and world == 1 and not strong and not args.no_slam_loop and args.precision == "accurate":
+        from bodyslam_amd.tsdf import TSDF
+        nloop = min(int(frames.shape[0]), 4 * B)
+        pipe.run_slam_loop(frames[:min(B + 2, nloop)], vo=True, tsdf=TSDF(device=local_rank))       # plans, odometry buffers (not timed)
+        torch.cuda.empty_cache()
+        tsdf = TSDF(device=local_rank)
+        tsdf.reserve(4096)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pipe.run_slam_loop(frames[:nloop], vo=True, tsdf=tsdf, posegraph_every=500)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        slam = {"what": "SLAM._sequential_loop order (3DM/slam.py:131-205): MDEM + MPEM + RGB-D odometry / UKF fusion + chain + pose graph "
+                        "every 500 + TSDF map (1 mm voxels, 0.1 m truncation, 32^3 units) + back-projection, one GPU",
+                "value": round(nloop / dt, 1), "unit": "frames/s", "frames": nloop, "batch": B, "ms_per_frame": round(1e3 * dt / nloop, 3),
+                "map_units": int(pipe.last_tsdf.n_units)}
+        del tsdf
+        pipe.last_tsdf = None
+        torch.cuda.empty_cache()
+
     # ---- CPU baseline (rank 0): the oracle on one frame of the same sequence, all host cores
     cpu = None
     l1 = None
@@ -347,6 +371,7 @@ def main():
                                 "calibration": pipe.zoe.calibration} if pipe.zoe.acc else None),
             "depth_l1_vs_oracle_m": l1, "depth_l1_frame": "frame 0 of the last timed step's batch, from the timed plan's output",
             "kernels": kern_table,
+            "slam_loop": slam,
             "hbm_allocated_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
         }
         if other:

@@ -275,6 +275,9 @@ class TSDF:
                                                 st), "bs_tsdf_integrate_batch")
             self.frames_integrated += m
             self._frames_since_sync += m
+            # every discovered unit has a block now (unless the map is full: sync() reports that), so the count is known without
+            # another round trip -- extract_pcd / extract_mesh right after a batch see the whole map
+            self.n_units = min(int(need[0]) + int(need[1]), self.alloc_units)
 
     def _image(self, x, dtype) -> torch.Tensor:
         t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(x)))

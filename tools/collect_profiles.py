@@ -19,7 +19,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
-COMMON = ["--single-mode", "--no-cpu-baseline", "--no-kernel-timing", "--no-pmc-traffic"]
+COMMON = ["--single-mode", "--no-cpu-baseline", "--no-kernel-timing", "--no-pmc-traffic", "--no-slam-loop"]
 
 
 def run(cmd, log):
