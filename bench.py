@@ -13,8 +13,11 @@ A step = one pass of the full loop over one batch of B consecutive frames per ra
   3DM   back-projection + compaction of the rank's B depth maps with their absolute poses
 Inputs are resident in HBM before the timed region.  K steps are timed between barrier +
 torch.cuda.synchronize() pairs; the value is (ranks x K x B frames) / max-over-ranks time.
-Weights are random-init (no checkpoint is reachable offline); data is synthetic.  The chain of a rank's sequence continues
-from step to step (bs_pose_chain_from: the last absolute pose of a step is the next step's g0, on the device).
+Weights are random-init (no checkpoint is reachable offline); data is synthetic.  The chain continues from step to step
+(bs_pose_chain_from: the last absolute pose of a step is the next step's g0, on the device).  At N > 1 (weak scaling: B frames per
+rank and step) the ranks process ONE sequence: step k hands rank r the B frames that follow rank r - 1's block, with that block's
+last frame as its halo, so the gathered world x B relatives of a step are consecutive poses of the same sequence (BASELINE config
+4's semantics at a fixed per-GPU load); every rank synthesises only the frames it owns (synthetic.make_sequence_at).
 
 --scaling strong: ONE sequence of --frames frames (default 1000: BASELINE config 4) is cut into contiguous blocks by
 shard_bounds (ragged: 125 frames per rank at 8 GPUs); a step = BodySlamPipeline.run_sequence over the whole sequence
@@ -165,7 +168,16 @@ def main():
         n_frames = Nseq
     else:
         n_frames = (K + Wm) * B + 1
-        frames = torch.from_numpy(make_sequence(n_frames, H, W, seed=rank)).to(dev)     # resident in HBM
+        if world == 1:
+            frames = torch.from_numpy(make_sequence(n_frames, H, W, seed=0)).to(dev)     # resident in HBM
+        else:
+            # ONE sequence of world x (K + Wm) x B frames (+ the frame before it): step k hands rank r the block of B frames that
+            # follows rank r - 1's (its one-frame halo is that block's last frame), so the gathered relatives of a step chain into
+            # world x B consecutive poses of the same sequence -- config 4's semantics, weak-scaled.  A rank makes only its own frames.
+            from bodyslam_amd.synthetic import make_sequence_at
+            total = (K + Wm) * world * B + 1
+            idx = [(k * world + rank) * B + j for k in range(K + Wm) for j in range(B + 1)]
+            frames = torch.from_numpy(make_sequence_at(idx, total, H, W, seed=0)).to(dev)
     pairs = torch.tensor([[i, i + 1] for i in range(B)], dtype=torch.int32, device=dev)
     counts = [B] * world
 
@@ -188,7 +200,7 @@ def main():
             if strong:      # the whole sequence: this rank's block through run_sequence (all-gather + chain + back-projection inside)
                 res = pipe.run_sequence(frames, rank, world, frame_offset=foff, n_frames=Nseq)
                 return res.point_counts
-            chunk = frames[k * B: (k + 1) * B + 1]                                       # halo frame + B frames
+            chunk = frames[k * B: (k + 1) * B + 1] if world == 1 else frames[k * (B + 1): (k + 1) * (B + 1)]     # halo frame + B frames
             zplan.frames.copy_(chunk[1:])
             zplan.plan.run()
             pplan.frames.copy_(chunk)
@@ -363,7 +375,7 @@ def main():
                        if strong else
                        {"workload": f"full MDEM(ZoeD_NK, flip-aug)+MPEM(CyclePose)+3DM loop, {K * B} synthetic {W}x{H} frames per GPU, "
                                     f"batch {B} frames/step", "frames_per_step_per_gpu": B, "net_input": list(zplan.geom[k] for k in ("nh", "nw")),
-                        "sharding": "contiguous frame blocks per rank, one RCCL all-gather of relative poses per step" if world > 1 else "single GPU"}),
+                        "sharding": "ONE sequence: per step, rank r owns the B frames after rank r-1's (1-frame halo); one RCCL all-gather of the relative poses per step" if world > 1 else "single GPU"}),
             "roofline": roof, "roofline_conv_stack": roof_conv, "cpu_baseline": cpu,
             "precision": args.precision,
             # which correction products the engine evaluates per GEMM class: chosen at load time on the device (ZoeDepthEngine.calibrate)

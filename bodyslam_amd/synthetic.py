@@ -25,6 +25,31 @@ def make_sequence(n: int, h: int = 480, w: int = 640, seed: int = 0) -> np.ndarr
     return out
 
 
+def make_sequence_at(indices, total: int, h: int = 480, w: int = 640, seed: int = 0) -> np.ndarray:
+    """frames `indices` of ONE synthetic sequence of `total` frames (the same construction as make_sequence, with the noise of frame i
+    drawn from its own generator, so any rank can make exactly the frames it owns): what a multi-GPU run needs to process ONE
+    sequence cut into blocks instead of one unrelated sequence per rank"""
+    rng = np.random.default_rng(seed)
+    n = int(total)
+    yy, xx = np.meshgrid(np.arange(h + n, dtype=np.float32), np.arange(w + n, dtype=np.float32), indexing="ij")
+    base = np.zeros((h + n, w + n, 3), np.float32)
+    for c in range(3):
+        f = np.full((h + n, w + n), 106.0, np.float32)
+        for _ in range(8):
+            fy, fx = rng.uniform(0.002, 0.02, size=2)
+            ph = rng.uniform(0, 2 * np.pi)
+            amp = rng.uniform(5, 20)
+            f += amp * np.sin(2 * np.pi * (fy * yy + fx * xx) + ph).astype(np.float32)
+        base[..., c] = f
+    indices = [int(i) for i in indices]
+    out = np.empty((len(indices), h, w, 3), np.uint8)
+    for k, i in enumerate(indices):
+        assert 0 <= i < n, (i, n)
+        noise = np.random.default_rng([seed, i]).normal(0.0, 8.0, size=(h, w, 3)).astype(np.float32)
+        out[k] = np.clip(np.rint(base[i:i + h, i:i + w] + noise), 0, 255).astype(np.uint8)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------
 # random-init weights of the two networks' architectures (no checkpoint is reachable offline)
 # ---------------------------------------------------------------------------------------------------

@@ -64,3 +64,24 @@ def test_all_gather_stitches_the_chain(tmp_path, golden_dir, n_frames):
         assert open(tmp_path / f"ok_{r}").read() == "1"
         # every rank evaluates the identical chain: bit-equal to the single-process reference result
         assert np.array_equal(np.load(tmp_path / f"g_{r}.npy"), ref)
+
+
+def test_make_sequence_at_is_one_sequence_whatever_the_subset():
+    """bench.py at N > 1: every rank synthesises only its own frames of ONE sequence -- frame i must not depend on which other frames
+    are asked for, and the blocks (B frames + the one-frame halo) of consecutive ranks must overlap in exactly that halo frame"""
+    import numpy as np
+    from bodyslam_amd.synthetic import make_sequence_at
+    total, h, w, B, world = 41, 24, 32, 4, 2
+    whole = make_sequence_at(range(total), total, h, w, seed=3)
+    some = make_sequence_at([7, 0, 40, 8], total, h, w, seed=3)
+    assert np.array_equal(some, whole[[7, 0, 40, 8]])
+    assert not np.array_equal(whole[7], whole[8])
+    blocks = {}
+    for rank in range(world):
+        idx = [(k * world + rank) * B + j for k in range(5) for j in range(B + 1)]
+        blocks[rank] = (idx, make_sequence_at(idx, total, h, w, seed=3))
+    i0, f0 = blocks[0]
+    i1, f1 = blocks[1]
+    assert i1[0] == i0[B] and np.array_equal(f1[0], f0[B])                 # rank 1's halo = rank 0's last frame of the same step
+    assert i0[B + 1] == i1[B] and np.array_equal(f0[B + 1], f1[B])         # next step: rank 0's halo = rank 1's last frame
+    assert sorted(set(i0) | set(i1)) == list(range(total))
