@@ -187,14 +187,23 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
     static_assert(LB_HID % 2 == 0, "hidden width");
 #pragma unroll 2
     for (int h = 0; h < LB_HID; h += 2) {
-        f32x2_ a2;
+        // each unit's dot product as an (even inputs, odd inputs) pair: the weight pairs are adjacent in memory -- they arrive as aligned
+        // scalar register pairs, no s_mov to pair up weights of two rows -- and so are the input pairs in the vector registers
+        f32x2_ sv[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)     // same bilinear operation order as torch: hy*(hx*p00 + lx*p01) + ly*(hx*p10 + lx*p11)
-            a2[u] = l.hy * (l.hx * s_eh[c00 * LB_HID + h + u] + l.lx * s_eh[c01 * LB_HID + h + u]) +
-                    l.ly * (l.hx * s_eh[c10 * LB_HID + h + u] + l.lx * s_eh[c11 * LB_HID + h + u]);
+        for (int u = 0; u < 2; ++u) {   // same bilinear operation order as torch: hy*(hx*p00 + lx*p01) + ly*(hx*p10 + lx*p11)
+            sv[u][0] = l.hy * (l.hx * s_eh[c00 * LB_HID + h + u] + l.lx * s_eh[c01 * LB_HID + h + u]) +
+                       l.ly * (l.hx * s_eh[c10 * LB_HID + h + u] + l.lx * s_eh[c11 * LB_HID + h + u]);
+            sv[u][1] = 0.0f;
+        }
 #pragma unroll
-        for (int c = 0; c < LB_IN; ++c)
-            a2 = __builtin_elementwise_fma(f32x2_{gw0[h * LB_IN + c], gw0[(h + 1) * LB_IN + c]}, f32x2_{xin[c], xin[c]}, a2);
+        for (int c = 0; c < LB_IN; c += 2) {
+            const f32x2_ x2 = {xin[c], xin[c + 1]};
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                sv[u] = __builtin_elementwise_fma(*reinterpret_cast<const f32x2_*>(gw0 + (h + u) * LB_IN + c), x2, sv[u]);
+        }
+        f32x2_ a2 = {sv[0][0] + sv[0][1], sv[1][0] + sv[1][1]};
         if (grel) a2 = __builtin_elementwise_fma(f32x2_{grel[h], grel[h + 1]}, f32x2_{rd, rd}, a2);
         const f32x2_ ga = gelu_erf_as2(a2);
 #pragma unroll
