@@ -92,6 +92,18 @@ def measure_pmc_traffic(args):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def weak_frame_indices(steps: int, B: int, world: int, rank: int):
+    """N > 1, weak scaling: (frames of the ONE sequence, the indices rank `rank` holds).  Step k gives rank r the B frames
+    (k * world + r) * B + 1 .. + B and, in front of them, the frame before (its halo = the last frame of rank r - 1's block of the same
+    step, or of the last rank's block of step k - 1): `steps` x (B + 1) frames per rank, step k's at weak_chunk(k, B)"""
+    total = steps * world * B + 1
+    return total, [(k * world + rank) * B + j for k in range(steps) for j in range(B + 1)]
+
+
+def weak_chunk(k: int, B: int) -> slice:
+    return slice(k * (B + 1), (k + 1) * (B + 1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,8 +187,7 @@ def main():
             # follows rank r - 1's (its one-frame halo is that block's last frame), so the gathered relatives of a step chain into
             # world x B consecutive poses of the same sequence -- config 4's semantics, weak-scaled.  A rank makes only its own frames.
             from bodyslam_amd.synthetic import make_sequence_at
-            total = (K + Wm) * world * B + 1
-            idx = [(k * world + rank) * B + j for k in range(K + Wm) for j in range(B + 1)]
+            total, idx = weak_frame_indices(K + Wm, B, world, rank)
             frames = torch.from_numpy(make_sequence_at(idx, total, H, W, seed=0)).to(dev)
     pairs = torch.tensor([[i, i + 1] for i in range(B)], dtype=torch.int32, device=dev)
     counts = [B] * world
@@ -200,7 +211,7 @@ def main():
             if strong:      # the whole sequence: this rank's block through run_sequence (all-gather + chain + back-projection inside)
                 res = pipe.run_sequence(frames, rank, world, frame_offset=foff, n_frames=Nseq)
                 return res.point_counts
-            chunk = frames[k * B: (k + 1) * B + 1] if world == 1 else frames[k * (B + 1): (k + 1) * (B + 1)]     # halo frame + B frames
+            chunk = frames[k * B: (k + 1) * B + 1] if world == 1 else frames[weak_chunk(k, B)]     # halo frame + B frames
             zplan.frames.copy_(chunk[1:])
             zplan.plan.run()
             pplan.frames.copy_(chunk)

@@ -76,10 +76,19 @@ def test_make_sequence_at_is_one_sequence_whatever_the_subset():
     some = make_sequence_at([7, 0, 40, 8], total, h, w, seed=3)
     assert np.array_equal(some, whole[[7, 0, 40, 8]])
     assert not np.array_equal(whole[7], whole[8])
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench                                            # (bench.py's own index helpers: what a rank of the driver's N > 1 run uses)
     blocks = {}
     for rank in range(world):
-        idx = [(k * world + rank) * B + j for k in range(5) for j in range(B + 1)]
+        tot, idx = bench.weak_frame_indices(5, B, world, rank)
+        assert tot == total and len(idx) == 5 * (B + 1)
         blocks[rank] = (idx, make_sequence_at(idx, total, h, w, seed=3))
+    # step k of rank r: its chunk is the halo + B consecutive frames, and the ranks' blocks of a step are consecutive in the sequence
+    for k in range(5):
+        for rank in range(world):
+            ch = blocks[rank][0][bench.weak_chunk(k, B)]
+            assert ch == list(range((k * world + rank) * B, (k * world + rank) * B + B + 1))
     i0, f0 = blocks[0]
     i1, f1 = blocks[1]
     assert i1[0] == i0[B] and np.array_equal(f1[0], f0[B])                 # rank 1's halo = rank 0's last frame of the same step
