@@ -312,3 +312,48 @@ def test_slam_loop_reference_order_640x480():
     assert 2.0 <= max(float(v[..., 1].max()) for v in ref.units.values()) <= float(len(integrated))
     pcd = t.extract_pcd()
     assert pcd.points.shape[0] > 1000
+
+
+def test_run_slam_loop_edge_cases():
+    """one frame, two frames, no VO, no map, a point cloud per frame (slam.py:195), points kept: the loop's options on a small configuration"""
+    import dataclasses
+    from bodyslam_amd.pipeline import BodySlamPipeline
+    from bodyslam_amd.synthetic import make_sequence
+    from bodyslam_amd.tsdf import TSDF
+    from bodyslam_amd.zoedepth import ZoeConfig
+    from oracle import cyclepose_ref as CP
+    from oracle import zoedepth_ref as Z
+    cfg_o = Z.ZoeConfig(hidden=128, layers=4, heads=2, intermediate=256, taps=(1, 2, 3, 4), image_size=64)
+    names = {f.name for f in dataclasses.fields(ZoeConfig)}
+    cfg_p = ZoeConfig(**{k: v for k, v in dataclasses.asdict(cfg_o).items() if k in names})
+    frames = make_sequence(5, 160, 192, seed=6)
+    pipe = BodySlamPipeline(Z.synth_weights(cfg_o, seed=2), CP.synth_weights(seed=2), cfg_p, batch=2, target_hw=(64, 96))
+
+    def volume():
+        return TSDF(voxel_length=0.02, sdf_trunc=0.06, volume_unit_resolution=8, depth_sampling_stride=8)
+
+    whole = pipe.run_slam_loop(frames, vo=True, tsdf=volume(), keep_points=True)
+    assert whole.g_abs.shape == (5, 4, 4) and whole.t_rel.shape == (4, 4, 4) and len(whole.points) == 5
+    c = whole.point_counts.cpu().tolist()
+    assert all(whole.points[i][0].shape == (c[i], 3) and c[i] > 0 for i in range(5))
+    # one frame: the identity pose, nothing to chain, the frame is in the map
+    t1 = volume()
+    one = pipe.run_slam_loop(frames[:1], vo=True, tsdf=t1)
+    assert one.t_rel.shape[0] == 0 and np.array_equal(one.g_abs[0].cpu().numpy(), np.eye(4)) and t1.frames_integrated == 1 and t1.n_units > 0
+    assert torch.equal(one.depth_u16[0], whole.depth_u16[0])
+    # two frames = the first pair of the long run
+    two = pipe.run_slam_loop(frames[:2], vo=True, tsdf=volume())
+    assert np.array_equal(two.t_rel.cpu().numpy(), whole.t_rel[:1].cpu().numpy()) and torch.equal(two.g_abs, whole.g_abs[:2])
+    # no VO: the relatives are MPEM's own; no map: nothing else changes
+    plain = pipe.run_sequence(frames)
+    novo = pipe.run_slam_loop(frames, vo=False, tsdf=None)
+    assert np.array_equal(novo.t_rel.cpu().numpy(), plain.t_rel.cpu().numpy()) and np.abs((novo.g_abs - plain.g_abs).cpu().numpy()).max() < 1e-12
+    assert torch.equal(novo.depth_u16, whole.depth_u16) and pipe.last_tsdf is None
+    # a point cloud per frame, as the reference extracts it: it grows with the map and ends as the batched run's
+    clouds = []
+    t2 = volume()
+    per = pipe.run_slam_loop(frames, vo=True, tsdf=t2, extract_every_frame=True, on_frame=lambda i, pose, pcd: clouds.append(pcd.points.shape[0]))
+    assert len(clouds) == 5 and clouds[0] > 0 and clouds[-1] >= clouds[0] and torch.equal(per.g_abs, whole.g_abs)
+    ref_map = volume()
+    pipe.run_slam_loop(frames, vo=True, tsdf=ref_map)
+    assert t2.extract_pcd().points.shape[0] == ref_map.extract_pcd().points.shape[0] == clouds[-1]
