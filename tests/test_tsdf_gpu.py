@@ -357,3 +357,27 @@ def test_run_slam_loop_edge_cases():
     ref_map = volume()
     pipe.run_slam_loop(frames, vo=True, tsdf=ref_map)
     assert t2.extract_pcd().points.shape[0] == ref_map.extract_pcd().points.shape[0] == clouds[-1]
+
+
+def test_empty_observations_do_nothing():
+    """frames without a single valid depth: the map stays empty (frame by frame and batched), the odometry leaves the identity"""
+    from bodyslam_amd.rgbd_odometry import RGBDOdometry
+    from bodyslam_amd.tsdf import TSDF, PinholeCameraIntrinsic, RGBDImage
+    intr = PinholeCameraIntrinsic(W, H, *K)
+    depth0 = np.zeros((H, W), np.float32)
+    color = np.zeros((H, W, 3), np.uint8)
+    t = TSDF(0.01, 0.04, volume_unit_resolution=8, depth_sampling_stride=4, slab_bytes=1 << 16)
+    t.build_3D_map(RGBDImage(color, depth0), intr, np.eye(4))
+    t.build_3D_map_batch([RGBDImage(color, depth0)] * 3, intr, [np.eye(4)] * 3)
+    n, touched = t.sync()
+    assert n == 0 and touched == 0 and t.frames_integrated == 4
+    assert t.extract_pcd().points.shape == (0, 3) and t.extract_mesh().triangles.shape == (0, 3)
+    # one real frame after the empty ones still lands
+    d, c, E = scene(0)
+    t.build_3D_map_batch([RGBDImage(color, depth0), RGBDImage(c, d)], intr, [np.eye(4), E])
+    assert t.sync()[0] > 0 and t.extract_pcd().points.shape[0] > 0
+    odo = RGBDOdometry(K)
+    cols = torch.zeros(3, H, W, 3, dtype=torch.uint8, device="cuda")
+    deps = torch.zeros(3, H, W, device="cuda")
+    T = odo.track_block(cols, deps).cpu().numpy().reshape(-1, 3, 4)
+    assert T.shape[0] == 2 and np.array_equal(T[0], np.eye(4)[:3]) and np.array_equal(T[1], np.eye(4)[:3])
