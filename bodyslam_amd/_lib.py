@@ -48,6 +48,7 @@ class GemmDesc(C.Structure):
         ("f8_skip_from", C.c_int32), ("bias2_row0", C.c_int32), ("bias2_group_rows", C.c_int32), ("out_planes_rows", C.c_int32),
         ("bias2", C.c_void_p),
         ("f4_seg", C.c_int32), ("f4_a_scale_off", C.c_int32), ("f4_w_scale_off", C.c_int32), ("w_pitch", C.c_int32), ("out_f4", C.c_int32),
+        ("qkv_lo_off", C.c_int32),
     ]
 
 
@@ -60,6 +61,7 @@ _SIGS = {
     "bs_gemm_tile": [C.POINTER(GemmDesc)],
     "bs_attention": [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p],
     "bs_attention_table": [C.c_void_p] * 5 + [C.c_int32] * 7 + [C.c_void_p],
+    "bs_attention_table_corr": [C.c_void_p] * 8 + [C.c_int32] * 7 + [C.c_void_p],
     "bs_layernorm": [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p],
     "bs_cast": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p],
     "bs_copy_f32": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
@@ -189,7 +191,8 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
                    f4=None, out_f4: bool = False) -> GemmDesc:
     """Fill a bs_gemm_desc.  conv = (Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_h, pad_w) or None;
     out_group = (rows, stride, offset); shuffle = (s, Cout, Hgrid, Wgrid);
-    qkv = (hidden, tokens, Sp, q_scale, out_k, out_vt[, cls_last[, cls_rows[, patch_row0]]]); a_offset in elements;
+    qkv = (hidden, tokens, Sp, q_scale, out_k, out_vt[, cls_last[, cls_rows[, patch_row0[, lo_off]]]]); a_offset in elements;
+    (lo_off > 0: out / out_k / out_vt are allocated twice over and the rounding residuals go lo_off elements behind the values)
     bias2 = (fp32 [groups, N], row0, group_rows); f4 = (f4_seg, a_scale_off, w_scale_off, w_pitch) (see f4_weight / f4_conv_weight)."""
     d = GemmDesc()
     d.A = A.data_ptr() + a_offset * A.element_size()
@@ -230,6 +233,7 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
         d.qkv_cls_last = int(bool(qkv[6])) if len(qkv) > 6 else 0
         d.qkv_cls_rows = int(qkv[7]) if len(qkv) > 7 else 0
         d.qkv_patch_row0 = int(qkv[8]) if len(qkv) > 8 else d.qkv_cls_rows
+        d.qkv_lo_off = int(qkv[9]) if len(qkv) > 9 else 0
         d.qkv_hidden, d.qkv_tokens, d.qkv_sp, d.q_scale = hidden, tokens, sp, q_scale
         d.out2 = out_k.data_ptr()
         d.out3 = out_vt.data_ptr()
@@ -651,6 +655,12 @@ def attention(q, k, vt, bias, out, B, nh, S, Sp):
 def attention_table(q, k, vt, table, out, B, nh, hp, wp, Sp, split=0, grouped=0):
     check(load_library().bs_attention_table(p(q), p(k), p(vt), p(table), p(out), B, nh, hp, wp, Sp, int(grouped), dt(q) | split, stream_ptr()),
           "bs_attention_table")
+
+
+def attention_table_corr(q, k, vt, q_lo, k_lo, vt_lo, table, out, B, nh, hp, wp, Sp, split=0, grouped=0):
+    """split-precision operands: x = x16 + x_lo (bs_attention_table_corr)"""
+    check(load_library().bs_attention_table_corr(p(q), p(k), p(vt), p(q_lo), p(k_lo), p(vt_lo), p(table), p(out), B, nh, hp, wp, Sp, int(grouped),
+                                                 dt(q) | split, stream_ptr()), "bs_attention_table_corr")
 
 
 def layernorm(x, gamma, beta, out16, out32, rows, cols, eps, dtype=F16):

@@ -35,6 +35,18 @@ __device__ __forceinline__ float half_swap_max(float v) {
     return __builtin_bit_cast(float, m);
 }
 
+// Barrier of the K / V^T ring.  A tile is written to LDS by `global_load_lds` pieces issued by ALL waves of the block and read by
+// all of them, so the order is: every wave waits for ITS OWN pieces (vmcnt counts LDS-DMA), then the workgroup barrier, then the
+// reads.  `__syncthreads()` alone is NOT that: inside the tile loops hipcc (ROCm 7.2) compiles it to `s_waitcnt lgkmcnt(0);
+// s_barrier` -- no vmcnt -- although an LDS-DMA is in flight (ISA of attention_tab2_kernel, round 4: the only vmcnt(0) of the loop
+// belonged to a spill reload behind the stage; the register-leaner rewrites of round 3 lost that accident and read tiles that
+// had not landed -- the "nondeterminism at NB = 128").  The wait is written out, as the LDS-DMA rules demand (counted vmcnt, then
+// the barrier, then the ds_read).
+__device__ __forceinline__ void dma_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 
 template <typename T, int QW>
 __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ Vt,
@@ -121,7 +133,7 @@ __global__ __launch_bounds__(QW * 64) void attention_kernel(const T* __restrict_
     load_bias(0);
     stage(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();
+        dma_barrier();
         if (kt + 1 < nkt && !(ablate & 2)) stage(kt + 1, (kt + 1) & 1);
         const char* sk = smem + (kt & 1) * STAGE;
         const char* sv = sk + 8 * 1024;
@@ -444,13 +456,13 @@ __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restr
 
     bool first = true;
     stage(0, 0);
-    __syncthreads();                    // tile 0 and the table have landed
+    dma_barrier();                    // tile 0 and the table have landed
     if (1 < nkt) stage(1, 1);
     load_bias(0);
     for (int kt = 0; kt < nkt; ++kt) {
         if (ablate & 32) break;
         if (kt > 0) {
-            __syncthreads();
+            dma_barrier();
             if (kt + 1 < nkt && !(ablate & 16)) stage(kt + 1, (kt + 1) & 1);
         }
         const char* sk = smem + (kt & 1) * STAGE;
@@ -543,14 +555,24 @@ __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restr
 //     VALU stream of the same wave, and PV of the first half overlaps the softmax of the second.  A rescale of the running max
 //     also shifts the accumulator still in flight.
 // Table operand: `table` holds per head [(2hp-1)*63 body entries in REVERSED order | cls->patch, patch->cls, cls->cls].
-template <typename T, int QW, int WPE>
+//
+// CORR (bs_attention_table_corr): the split-precision product.  Q, K, V^T each come with a second 16-bit tensor holding the rounding
+// residual (x - round16(x), unscaled; written by the QKV epilogue, bs_gemm_desc.qkv_lo_off), and the probabilities are split the
+// same way in registers:  S = Q_hi K_hi + Q_lo K_hi + Q_hi K_lo,  O = V_hi P_hi + V_hi P_lo + V_lo P_hi  -- three MFMA passes
+// accumulating into the same fp32 registers, ~22 significant bits per operand.  With outlier channels after the LayerNorms (trained
+// BEiT checkpoints) the single 16-bit Q / K / V / P of the plain kernel cost 0.9-2.4e-4 m of depth EACH
+// (tools/probes/outlier_rounding_study.py); all four corrected: 1.7e-6 m.  The K / V^T ring holds the lo tiles behind the hi tiles
+// (32 KiB per stage, two blocks per CU).
+template <typename T, int QW, int WPE, bool CORR>
 __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ Vt,
+                                                                  const T* __restrict__ Ql, const T* __restrict__ Kl, const T* __restrict__ Vtl,
                                                                   const float* __restrict__ table, T* __restrict__ out, int split, int B, int nh,
                                                                   int hp, int Sp, int nqb, int ntab, int grouped) {
     const bool cls_planes = (split & 4) != 0;   // FP8 planes for the cls query's row only (bs_attention_table, dtype bit 6)
     split &= 3;
     typedef typename T16<T>::v8 v8;
-    constexpr int STAGE = 16 * 1024;  // K tile 8 KiB + V^T tile 8 KiB
+    constexpr int HALF = 16 * 1024;             // K tile 8 KiB + V^T tile 8 KiB
+    constexpr int STAGE = CORR ? 2 * HALF : HALF;   // CORR: [K_hi | V^T_hi | K_lo | V^T_lo]
     constexpr int WP = 32, RW = 2 * WP - 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tab = reinterpret_cast<float*>(smem + 2 * STAGE);
@@ -580,21 +602,30 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
     const T* Qg = Q + bh * Sp * 64;
     const T* Kg = K + bh * Sp * 64;
     const T* Vg = Vt + bh * 64 * Sp;
+    const T* Klg = CORR ? Kl + bh * Sp * 64 : nullptr;
+    const T* Vlg = CORR ? Vtl + bh * 64 * Sp : nullptr;
 
     load_table<QW * 64>(tab, table, head, ntab, tid, wave, lane);
     if (tid < 64) creg[tid] = table[(int64_t)head * ntab + ntab - 3];
 
-    v8 qf[4];
+    v8 qf[4], qlf[CORR ? 4 : 1];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const v8*>(Qg + (int64_t)(q0 + r) * 64 + ks * 16 + h2 * 8);
+    if constexpr (CORR) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qlf[ks] = *reinterpret_cast<const v8*>(Ql + bh * Sp * 64 + (int64_t)(q0 + r) * 64 + ks * 16 + h2 * 8);
+    }
 
     const int srow = lane >> 3;
     auto stage = [&](int kt, int buf) {
         char* sb = smem + buf * STAGE;
-        for (int i = wave; i < 16; i += QW) {
-            const int row = (i & 7) * 8 + srow;
+        for (int i = wave; i < (CORR ? 32 : 16); i += QW) {
+            const int j = i & 15;                         // piece of the hi (i < 16) or lo half of the stage
+            const int row = (j & 7) * 8 + srow;
             const int cs8 = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
-            const T* src = i < 8 ? Kg + (int64_t)(kt * 64 + row) * 64 + cs8 : Vg + (int64_t)row * Sp + kt * 64 + cs8;
+            const T* kb = (CORR && i >= 16) ? Klg : Kg;
+            const T* vb = (CORR && i >= 16) ? Vlg : Vg;
+            const T* src = j < 8 ? kb + (int64_t)(kt * 64 + row) * 64 + cs8 : vb + (int64_t)row * Sp + kt * 64 + cs8;
             glds16(src, sb + i * 1024);
         }
     };
@@ -637,8 +668,14 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int chunk = 2 * ks + h2;
-            const v8 kf = *reinterpret_cast<const v8*>(sk + krow * 128 + ((chunk ^ ((krow >> 1) & 7)) << 4));
+            const int off = krow * 128 + ((chunk ^ ((krow >> 1) & 7)) << 4);
+            const v8 kf = *reinterpret_cast<const v8*>(sk + off);
             sacc = T16<T>::mfma32(kf, qf[ks], sacc);
+            if constexpr (CORR) {
+                sacc = T16<T>::mfma32(kf, qlf[ks], sacc);
+                const v8 kfl = *reinterpret_cast<const v8*>(sk + HALF + off);
+                sacc = T16<T>::mfma32(kfl, qf[ks], sacc);
+            }
         }
     };
     // softmax of one sub-tile's scores + O^T += V^T P^T.  OTHER: `other` is the accumulator of the next sub-tile, already shifted
@@ -670,7 +707,7 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
             first = false;
         }
         float psum = 0.f;
-        v8 pf[2];
+        v8 pf[2], pfl[CORR ? 2 : 1];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -678,6 +715,7 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
                 const float pv = __builtin_amdgcn_exp2f(sacc[8 * s2 + e]);
                 psum += pv;
                 pf[s2][e] = T16<T>::from_f32(pv);
+                if constexpr (CORR) pfl[s2][e] = T16<T>::from_f32(pv - T16<T>::to_f32(pf[s2][e]));
             }
         l_run += psum;
         if (NEXT) load_bias(sacc, next_ky);
@@ -687,8 +725,14 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int chunk = sub * 4 + 2 * s2 + h2;
-                const v8 vf = *reinterpret_cast<const v8*>(sv + drow * 128 + ((chunk ^ ((drow >> 1) & 7)) << 4));
+                const int off = drow * 128 + ((chunk ^ ((drow >> 1) & 7)) << 4);
+                const v8 vf = *reinterpret_cast<const v8*>(sv + off);
                 oacc[dh] = T16<T>::mfma32(vf, pf[s2], oacc[dh]);
+                if constexpr (CORR) {
+                    oacc[dh] = T16<T>::mfma32(vf, pfl[s2], oacc[dh]);
+                    const v8 vfl = *reinterpret_cast<const v8*>(sv + HALF + off);
+                    oacc[dh] = T16<T>::mfma32(vfl, pf[s2], oacc[dh]);
+                }
             }
         }
     };
@@ -698,11 +742,11 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
     typedef std::true_type Yes;
     typedef std::false_type No;
     stage(0, 0);
-    __syncthreads();                      // tile 0 and the table have landed
+    dma_barrier();                      // tile 0 and the table have landed
     load_bias(sa, 0);
     load_bias(sb2, 1);
     for (int kt = 0; kt < NT - 1; ++kt) {
-        if (kt > 0) __syncthreads();      // tile kt has landed; everyone is done with tile kt - 1
+        if (kt > 0) dma_barrier();      // tile kt has landed; everyone is done with tile kt - 1
         stage(kt + 1, (kt + 1) & 1);
         const char* sk = smem + (kt & 1) * STAGE;
         qk(sa, sk, 0);
@@ -711,7 +755,7 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
         softmax_pv(sb2, sa, sk + 8 * 1024, 1, 2 * kt + 3, No{}, Yes{});
     }
     {   // last full tile; then the cls key (sub-tile 0 of tile NT: one valid key, the rest padding)
-        if (NT > 1) __syncthreads();
+        if (NT > 1) dma_barrier();
         stage(NT, NT & 1);
         const char* sk = smem + ((NT - 1) & 1) * STAGE;
         qk(sa, sk, 0);
@@ -721,7 +765,7 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
         for (int i = 0; i < 16; ++i) sa[i] = -1.0e30f;
         if (h2 == 0) sa[0] = cls_tile ? tab[ntab - 1] : tab[ntab - 2];
         softmax_pv(sb2, sa, sk + 8 * 1024, 1, 0, No{}, No{});
-        __syncthreads();
+        dma_barrier();
         const char* sk2 = smem + (NT & 1) * STAGE;
         qk(sa, sk2, 0);
         softmax_pv(sa, sb2, sk2 + 8 * 1024, 0, 0, No{}, No{});
@@ -734,10 +778,23 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
 }
 
 template <typename T>
-static int launch_attn_tab(const void* q, const void* k, const void* vt, const float* table, void* out, int split, int B, int nh, int hp, int Sp,
-                           int grouped, hipStream_t st) {
+static int launch_attn_tab(const void* q, const void* k, const void* vt, const void* ql, const void* kl, const void* vtl, const float* table, void* out,
+                           int split, int B, int nh, int hp, int Sp, int grouped, hipStream_t st) {
     constexpr int QW = 5;
     const int nqt = hp + 1, nqb = cdiv(nqt, QW), ntab = (2 * hp - 1) * 63 + 3;
+    const int tab_bytes = (((ntab + 255) & ~255) + 64) * 4;
+    if (ql) {     // split-precision operands (bs_attention_table_corr): 64 KiB ring, two blocks per CU, the 256-register budget
+        auto kc = attention_tab2_kernel<T, QW, 2, true>;
+        static bool attrc = false;
+        if (!attrc) {
+            BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            attrc = true;
+        }
+        hipLaunchKernelGGL(kc, dim3(B * nh * nqb), dim3(QW * 64), 64 * 1024 + tab_bytes, st, (const T*)q, (const T*)k, (const T*)vt, (const T*)ql,
+                           (const T*)kl, (const T*)vtl, table, (T*)out, split, B, nh, hp, Sp, nqb, ntab, grouped);
+        BS_CHECK_LAUNCH();
+        return BS_OK;
+    }
     int smem = 32 * 1024 + ((ntab * 4 + 1023) & ~1023);
     smem = smem < QW * 8192 ? QW * 8192 : smem;                    // the epilogue stages 8 KiB per wave
     auto kern = attention_tab_kernel<T, QW>;
@@ -748,16 +805,18 @@ static int launch_attn_tab(const void* q, const void* k, const void* vt, const f
     }
     static const bool pipelined_ok = getenv("BS_ATTN_NO_PIPE") == nullptr;       // diagnostics: the unpipelined loop
     if (hp % 2 == 0 && pipelined_ok) {
-        static const bool wpe3 = getenv("BS_ATTN_WPE3") != nullptr;       // diagnostics: 3 waves / SIMD, no spill
-        auto kern2 = wpe3 ? attention_tab2_kernel<T, QW, 3> : attention_tab2_kernel<T, QW, 4>;
+        // 3 waves per SIMD (168 registers): no spill.  At 4 (128 registers) the kernel spills three address registers whose reloads
+        // put an `s_waitcnt vmcnt(0)` right behind the stage -- the next tile's DMA is then waited for at once instead of under the
+        // tile's arithmetic.  BS_ATTN_WPE4 keeps the round-3 configuration for A/B runs.
+        static const bool wpe4 = getenv("BS_ATTN_WPE4") != nullptr;
+        auto kern2 = wpe4 ? attention_tab2_kernel<T, QW, 4, false> : attention_tab2_kernel<T, QW, 3, false>;
         static bool attr2 = false;
         if (!attr2) {
             BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
             attr2 = true;
         }
-        const int smem2 = 32 * 1024 + (((ntab + 255) & ~255) + 64) * 4;
-        hipLaunchKernelGGL(kern2, dim3(B * nh * nqb), dim3(QW * 64), smem2, st, (const T*)q, (const T*)k, (const T*)vt, table, (T*)out,
-                           split, B, nh, hp, Sp, nqb, ntab, grouped);
+        hipLaunchKernelGGL(kern2, dim3(B * nh * nqb), dim3(QW * 64), 32 * 1024 + tab_bytes, st, (const T*)q, (const T*)k, (const T*)vt, (const T*)nullptr,
+                           (const T*)nullptr, (const T*)nullptr, table, (T*)out, split, B, nh, hp, Sp, nqb, ntab, grouped);
         BS_CHECK_LAUNCH();
         return BS_OK;
     }
@@ -806,22 +865,36 @@ extern "C" int bs_attention(const void* q, const void* k, const void* vt, const 
                            : dispatch_attn<bf16>(q, k, vt, bias, out, split, B, nh, S, Sp, st);
 }
 
-extern "C" int bs_attention_table(const void* q, const void* k, const void* vt, const float* table, void* out, int32_t B, int32_t nh,
-                                  int32_t hp, int32_t wp, int32_t Sp, int32_t grouped, int32_t dtype, void* stream) {
+static int attention_table_entry(const char* who, const void* q, const void* k, const void* vt, const void* ql, const void* kl, const void* vtl,
+                                 const float* table, void* out, int32_t B, int32_t nh, int32_t hp, int32_t wp, int32_t Sp, int32_t grouped,
+                                 int32_t dtype, void* stream) {
     using namespace bs;
-    if (!initialized()) { set_error("bs_attention_table: call bs_init first"); return BS_ERR_NOT_INIT; }
-    BS_REQUIRE(q && k && vt && table && out && B >= 0 && nh > 0 && hp > 0, "bs_attention_table: bad argument");
-    BS_REQUIRE(wp == 32, "bs_attention_table: built for windows of 32 patches per row (wp=%d): use bs_attention", wp);
-    BS_REQUIRE(hp <= 40, "bs_attention_table: hp=%d: the table must fit 32 KiB of LDS", hp);
-    BS_REQUIRE(grouped == 0 || grouped >= B, "bs_attention_table: grouped=%d is the first patch row, >= B", grouped);
+    if (!initialized()) { set_error("%s: call bs_init first", who); return BS_ERR_NOT_INIT; }
+    BS_REQUIRE(q && k && vt && table && out && B >= 0 && nh > 0 && hp > 0, "%s: bad argument", who);
+    BS_REQUIRE(wp == 32, "%s: built for windows of 32 patches per row (wp=%d): use bs_attention", who, wp);
+    BS_REQUIRE(hp <= 40, "%s: hp=%d: the table must fit 32 KiB of LDS", who, hp);
+    BS_REQUIRE(grouped == 0 || grouped >= B, "%s: grouped=%d is the first patch row, >= B", who, grouped);
+    BS_REQUIRE(!ql || hp % 2 == 0, "%s: the split-precision kernel is built for an even number of patch rows (hp=%d)", who, hp);
     const int S = hp * wp + 1;
-    BS_REQUIRE(Sp % 64 == 0 && Sp >= S, "bs_attention_table: Sp=%d must be a multiple of 64 and >= S=%d", Sp, S);
+    BS_REQUIRE(Sp % 64 == 0 && Sp >= S, "%s: Sp=%d must be a multiple of 64 and >= S=%d", who, Sp, S);
     int split = (dtype & 32) ? 2 : ((dtype & 16) ? 1 : 0);
     if ((dtype & 64) && split == 2) split |= 4;     // bit 6: only the cls rows of `out` need their FP8 planes
     dtype &= 15;
-    BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_attention_table: dtype");
+    BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "%s: dtype", who);
     if (B == 0) return BS_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    return dtype == BS_F16 ? launch_attn_tab<f16>(q, k, vt, table, out, split, B, nh, hp, Sp, grouped, st)
-                           : launch_attn_tab<bf16>(q, k, vt, table, out, split, B, nh, hp, Sp, grouped, st);
+    return dtype == BS_F16 ? launch_attn_tab<f16>(q, k, vt, ql, kl, vtl, table, out, split, B, nh, hp, Sp, grouped, st)
+                           : launch_attn_tab<bf16>(q, k, vt, ql, kl, vtl, table, out, split, B, nh, hp, Sp, grouped, st);
+}
+
+extern "C" int bs_attention_table(const void* q, const void* k, const void* vt, const float* table, void* out, int32_t B, int32_t nh,
+                                  int32_t hp, int32_t wp, int32_t Sp, int32_t grouped, int32_t dtype, void* stream) {
+    return attention_table_entry("bs_attention_table", q, k, vt, nullptr, nullptr, nullptr, table, out, B, nh, hp, wp, Sp, grouped, dtype, stream);
+}
+
+extern "C" int bs_attention_table_corr(const void* q, const void* k, const void* vt, const void* q_lo, const void* k_lo, const void* vt_lo,
+                                       const float* table, void* out, int32_t B, int32_t nh, int32_t hp, int32_t wp, int32_t Sp, int32_t grouped,
+                                       int32_t dtype, void* stream) {
+    if (!q_lo || !k_lo || !vt_lo) { bs::set_error("bs_attention_table_corr: null residual tensor"); return BS_ERR_INVALID; }
+    return attention_table_entry("bs_attention_table_corr", q, k, vt, q_lo, k_lo, vt_lo, table, out, B, nh, hp, wp, Sp, grouped, dtype, stream);
 }

@@ -61,6 +61,7 @@ const std::map<std::string, Entry>& entries() {
     // every entry point a plan of zoedepth.py / cyclepose.py issues (all take the stream last)
     static const std::map<std::string, Entry> m = {
         BS_ENGINE_ENTRY(bs_gemm),           BS_ENGINE_ENTRY(bs_attention),          BS_ENGINE_ENTRY(bs_attention_table),
+        BS_ENGINE_ENTRY(bs_attention_table_corr),
         BS_ENGINE_ENTRY(bs_layernorm),      BS_ENGINE_ENTRY(bs_cast),               BS_ENGINE_ENTRY(bs_copy_f32),
         BS_ENGINE_ENTRY(bs_cast_split),     BS_ENGINE_ENTRY(bs_relu_split),         BS_ENGINE_ENTRY(bs_preprocess_patches),
         BS_ENGINE_ENTRY(bs_fill_rows),      BS_ENGINE_ENTRY(bs_upconv_tapsum),      BS_ENGINE_ENTRY(bs_small_attention),

@@ -247,6 +247,9 @@ extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
     p.qkv_cls_last = d->qkv_cls_last;
     p.qkv_cls_rows = d->qkv_cls_rows;
     p.qkv_patch_row0 = d->qkv_patch_row0;
+    p.qkv_lo_off = d->qkv_lo_off;
+    BS_REQUIRE(d->qkv_lo_off == 0 || (d->out_mode == BS_OUT_QKV && d->qkv_lo_off > 0 && d->qkv_lo_off % 8 == 0),
+               "bs_gemm: qkv_lo_off needs BS_OUT_QKV and a multiple of 8 elements");
     p.f8_wonly_from = d->f8_wonly_from;
     p.out_lo8_rows = d->out_lo8_rows;
     p.f8_skip_from = d->f8_skip_from;

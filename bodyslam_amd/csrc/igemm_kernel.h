@@ -60,6 +60,7 @@ struct IgemmParams {
     int qkv_cls_last;    // Q / K / V^T hold an image's tokens patches first, cls (token 0) last
     int qkv_cls_rows;    // > 0: grouped rows -- the first qkv_cls_rows rows are the images' cls tokens, patches from qkv_patch_row0 on
     int qkv_patch_row0;
+    int qkv_lo_off;      // > 0 (BS_OUT_QKV): also store y - round16(y) of Q / K / V^T, this many elements behind the value
     int f8_wonly_from;   // tiles starting at a row >= this (> 0; -1: every tile) skip the second FP8 half (activation-rounding correction)
     float q_scale;
     int ntm, ntn;
@@ -876,7 +877,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                     const int j0 = jp * 2, j1 = j0 + 1;
                     if (n0j[j0] >= p.N) continue;
                     void* dst = (p.out_mode == BS_OUT_QKV && which[j0] == 1) ? p.out2 : p.out;
-                    const int so = p.out_mode != BS_OUT_QKV ? p.split_off : 0;
+                    const int so = p.out_mode != BS_OUT_QKV ? p.split_off : p.qkv_lo_off;   // (QKV: the residual tensors of the split-precision attention)
                     // the pair is one 8-wide store when both halves exist, are adjacent in the output and 16-byte aligned
                     if (F8 && p.out_f8) {     // PLAIN / SHUFFLE, channels % 8 == 0 (checked on the host): (hi16 | hi8 | lo8) planes per row / pixel
                         const int nloc = p.out_mode == BS_OUT_SHUFFLE ? n0j[j0] % p.shuffle_cout : n0j[j0];
@@ -1028,12 +1029,21 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
 #pragma unroll
                 for (int jp = 0; jp < FN / 2; ++jp) {
                     typename T16<T>::v8 v;
+                    float yq[8];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = T16<T>::from_f32((acc[i][2 * jp][e] + bj[2 * jp][e]) * sj[2 * jp][e]);
-                        v[4 + e] = T16<T>::from_f32((acc[i][2 * jp + 1][e] + bj[2 * jp + 1][e]) * sj[2 * jp + 1][e]);
+                        yq[e] = (acc[i][2 * jp][e] + bj[2 * jp][e]) * sj[2 * jp][e];
+                        yq[4 + e] = (acc[i][2 * jp + 1][e] + bj[2 * jp + 1][e]) * sj[2 * jp + 1][e];
+                        v[e] = T16<T>::from_f32(yq[e]);
+                        v[4 + e] = T16<T>::from_f32(yq[4 + e]);
                     }
                     *reinterpret_cast<typename T16<T>::v8*>(rowp + coff[jp]) = v;
+                    if (p.qkv_lo_off) {       // (wave-uniform) the rounding residuals, for bs_attention_table_corr
+                        typename T16<T>::v8 vl;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) vl[e] = T16<T>::from_f32(yq[e] - T16<T>::to_f32(v[e]));
+                        *reinterpret_cast<typename T16<T>::v8*>(rowp + coff[jp] + p.qkv_lo_off) = vl;
+                    }
                 }
             }
             return;
@@ -1093,7 +1103,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                     if (p.bias) y += p.bias[n];
                     if (b2) y += b2[n];
                     const int rem = n - 2 * p.qkv_hidden;
-                    vt[(((int64_t)ob * nh + (rem >> 6)) * 64 + (rem & 63)) * p.qkv_sp + otok] = T16<T>::from_f32(y);
+                    const int64_t vo = (((int64_t)ob * nh + (rem >> 6)) * 64 + (rem & 63)) * p.qkv_sp + otok;
+                    const T vh = T16<T>::from_f32(y);
+                    vt[vo] = vh;
+                    if (p.qkv_lo_off) vt[vo + p.qkv_lo_off] = T16<T>::from_f32(y - T16<T>::to_f32(vh));
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

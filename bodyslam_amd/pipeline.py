@@ -60,6 +60,21 @@ def gather_relative_poses(t_local: torch.Tensor, counts: Sequence[int], group=No
     return torch.cat([out[r * pmax: r * pmax + counts[r]] for r in range(world)], dim=0)
 
 
+def share_calibration(make_report: Callable[[], dict], group=None, device=None) -> dict:
+    """Every rank of a sharded run must evaluate the same arithmetic: rank 0 calibrates (``make_report()``, e.g.
+    ``ZoeDepthEngine.calibrate``) and broadcasts its report; the other ranks return it without calibrating themselves (ranks
+    calibrating on their own could fall on different sides of a tolerance).  Not on the data path: once per engine, a few hundred
+    bytes.  Without an initialised process group (one GPU) the report is simply made."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return make_report()
+    rank = dist.get_rank(group)
+    box = [make_report() if rank == 0 else None]
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast_object_list(box, src=src, group=group, device=device)
+    return box[0]
+
+
 @dataclass
 class SequenceResult:
     start: int
@@ -94,6 +109,19 @@ class BodySlamPipeline:
         self.zoe = ZoeDepthEngine(zoe_weights, zoe_cfg, dtype=dtype, device=device, target_hw=target_hw, precision=precision)
         self.precision = precision
         self.pose = CyclePoseEngine(pose_weights, dtype=dtype, device=device, precision=precision)
+
+    def calibrate(self, H: int, W: int, group=None) -> Optional[dict]:
+        """the depth engine's load-time calibration (ZoeDepthEngine.calibrate), made once by rank 0 and shared (share_calibration)"""
+        z = self.zoe
+        if not (z.acc and z.auto_modes):
+            return z.calibration
+        if z.calibration is None:
+            import torch.distributed as dist
+            first = not dist.is_initialized() or dist.get_rank(group) == 0
+            rep = share_calibration(lambda: z.calibrate(H, W), group, self.dev)
+            if not first:
+                z.apply_calibration(rep)
+        return z.calibration
 
     # -- stage 1+2 for one block of frames ----------------------------------------------------------
     def depth_and_pose_block(self, frames: torch.Tensor, start: int, end: int, keep_depth_m: bool = False, frame_offset: int = 0,
@@ -173,6 +201,8 @@ class BodySlamPipeline:
         assert frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[-1] == 3
         N = frames.shape[0] if n_frames is None else n_frames
         start, end = shard_bounds(N, world, rank)
+        if world > 1 and gather is None:
+            self.calibrate(int(frames.shape[1]), int(frames.shape[2]), group)
         depth, depth_m, t_local = self.depth_and_pose_block(frames, start, end, keep_depth_m, frame_offset)
         counts = [local_pairs(*shard_bounds(N, world, r)).shape[0] for r in range(world)]
         if gather is not None:

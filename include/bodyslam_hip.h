@@ -153,6 +153,9 @@ typedef struct bs_gemm_desc {
     int32_t f4_w_scale_off;
     int32_t w_pitch;
     int32_t out_f4;
+    int32_t qkv_lo_off;            /* BS_OUT_QKV, > 0: the rounding residuals of Q, K and V^T (y - round16(y) as a second 16-bit value, unscaled)
+                                    * are stored too, this many ELEMENTS behind the respective value in out / out2 / out3 (each tensor
+                                    * allocated twice over): the operands of bs_attention_table_corr */
 } bs_gemm_desc;
 /* The F4 activation format (pixel / row of C channels, C % 256 == 0, pitch >= 4C + C/32 bytes; BS_F4_PITCH_ELEMS(C) 16-bit elements
  * keeps 128-byte alignment):  [0, 2C) round16(y) | [2C, 2.5C) e2m1(y / s_hi), even channel in the low nibble | [2.5C, 3C)
@@ -195,6 +198,14 @@ int bs_attention(const void* q, const void* k, const void* vt, const float* bias
  * grouped + b*hp*wp on (bs_gemm_desc.qkv_cls_rows / qkv_patch_row0).  Built for wp == 32 (every 512-wide network input). */
 int bs_attention_table(const void* q, const void* k, const void* vt, const float* table, void* out,
                        int32_t B, int32_t nh, int32_t hp, int32_t wp, int32_t Sp, int32_t grouped, int32_t dtype, void* stream);
+/* The same with SPLIT-PRECISION operands: q_lo / k_lo / vt_lo hold x - round16(x) of the respective tensor (same shapes; written by
+ * bs_gemm with qkv_lo_off), and the kernel evaluates  S = Q K^T + Q_lo K^T + Q K_lo^T,  O = V P + V P_lo + V_lo P  on the 16-bit MFMA
+ * (three passes into the same fp32 accumulators; P split in registers).  For weights whose LayerNorm outputs carry outlier channels
+ * -- trained BEiT checkpoints -- the single 16-bit Q / K / V / P of bs_attention_table cost 1-3e-4 m of depth
+ * (tools/probes/outlier_rounding_study.py); ZoeDepthEngine.calibrate chooses between the two per weight set.  hp must be even. */
+int bs_attention_table_corr(const void* q, const void* k, const void* vt, const void* q_lo, const void* k_lo, const void* vt_lo,
+                            const float* table, void* out, int32_t B, int32_t nh, int32_t hp, int32_t wp, int32_t Sp, int32_t grouped,
+                            int32_t dtype, void* stream);
 
 /* LayerNorm over the last dim, fp32 in; out16 (fp16/bf16, nullable) and out32 (fp32, nullable, may
  * alias x) -- HF modeling_beit.py:418,432; post-norm of the router HF modeling_zoedepth.py:876-881

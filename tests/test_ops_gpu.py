@@ -653,6 +653,89 @@ def test_attention_table(L, dtype, B, hp, nh, split, grouped):
     assert err < (4e-3 if dtype == torch.float16 else 3e-2)
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,hp,nh,split,grouped,spike", [(2, 24, 4, 0, 0, False), (1, 26, 2, 32, 0, False), (3, 24, 2, 32, 256, False), (2, 4, 2, 0, 2, False),
+                                                         (1, 24, 2, 16, 0, True)])
+def test_attention_table_corr(L, dtype, B, hp, nh, split, grouped, spike):
+    """bs_attention_table_corr: the QKV product with qkv_lo_off leaves the rounding residuals of Q / K / V^T behind the values, and the
+    split-precision kernel (S = Q K^T + Q_lo K^T + Q K_lo^T, O = V P + V P_lo + V_lo P) reproduces fp64 softmax attention on the
+    UNROUNDED q / k / v to ~1e-5 -- two orders below the single-operand kernel on the same inputs.  K carries a few outlier channels
+    (what trained BEiT checkpoints put behind their LayerNorms), `spike` adds keys that move the running max."""
+    from bodyslam_amd.zoedepth import _relative_position_index
+    wp = 32
+    S = hp * wp + 1
+    Sp = (S + 63) // 64 * 64
+    hidden = nh * 64
+    ntab = (2 * hp - 1) * (2 * wp - 1) + 3
+    LOG2E = 1.4426950408889634
+    x = rnd(B * S, hidden, seed=11, dtype=dtype)
+    wq = rnd(3 * hidden, hidden, seed=12, scale=1 / math.sqrt(hidden))
+    wq[hidden:2 * hidden, :3] *= 12.0                                # K: three input channels weigh 12x (a low-rank outlier part)
+    if spike:
+        wq[hidden:2 * hidden] *= 3.0
+    wqkv = wq.to(dtype)
+    bqkv = rnd(3 * hidden, seed=13, scale=0.1)
+    QN = B * nh * Sp * 64
+    q = torch.zeros(2 * B, nh, Sp, 64, device=dev(), dtype=dtype)
+    k = torch.zeros(2 * B, nh, Sp, 64, device=dev(), dtype=dtype)
+    vt = torch.zeros(2 * B, nh, 64, Sp, device=dev(), dtype=dtype)
+    if grouped:
+        MT = grouped + B * (S - 1)
+        xg = torch.zeros(MT, hidden, device=dev(), dtype=dtype)
+        xv = x.view(B, S, hidden)
+        xg[:B] = xv[:, 0]
+        xg[grouped:] = xv[:, 1:].reshape(-1, hidden)
+        L.gemm(xg, wqkv, q, M=MT, N=3 * hidden, K=hidden, lda=hidden, bias=bqkv, qkv=(hidden, S, Sp, 0.125 * LOG2E, k, vt, True, B, grouped, QN))
+    else:
+        L.gemm(x, wqkv, q, M=B * S, N=3 * hidden, K=hidden, lda=hidden, bias=bqkv, qkv=(hidden, S, Sp, 0.125 * LOG2E, k, vt, True, 0, 0, QN))
+    # hi + lo reproduces the fp32 product far below one 16-bit rounding
+    y = (x.double() @ wqkv.double().t() + bqkv.double()).view(B, S, 3, nh, 64)
+    perm = torch.cat([torch.arange(1, S), torch.zeros(1, dtype=torch.long)]).to(dev())
+    qr = (y[:, :, 0] * (0.125 * LOG2E)).permute(0, 2, 1, 3)[:, :, perm]
+    kr = y[:, :, 1].permute(0, 2, 1, 3)[:, :, perm]
+    vr = y[:, :, 2].permute(0, 2, 1, 3)[:, :, perm]
+    q2, k2, v2 = (q[:B].double() + q[B:].double())[:, :, :S], (k[:B].double() + k[B:].double())[:, :, :S], (vt[:B].double() + vt[B:].double())[:, :, :, :S]
+    acc_tol = 4e-6 * max(1.0, kr.abs().max().item()) if dtype == torch.float16 else 1.5e-4 * max(1.0, kr.abs().max().item())
+    assert (q2 - qr).abs().max().item() < acc_tol and (k2 - kr).abs().max().item() < acc_tol and (v2 - vr.transpose(2, 3)).abs().max().item() < acc_tol
+    assert q[B:, :, S:].abs().max().item() == 0 and vt[B:, :, :, S:].abs().max().item() == 0      # the padding of the residual tensors stays zero
+    table = rnd(nh, ntab, seed=14)
+    tab2 = (torch.cat([torch.flip(table[:, :ntab - 3], dims=[1]), table[:, ntab - 3:]], 1) * LOG2E).contiguous()
+    mult = 2 if split else 1
+    rows = (grouped + B * (S - 1)) if grouped else B * S
+
+    def decode(out):
+        if grouped:
+            out = torch.cat([out[:B].view(B, 1, -1), out[grouped:].view(B, S - 1, -1)], 1).reshape(B * S, -1)
+        if split == 16:
+            return out[:, :hidden].double() + out[:, hidden:].double()
+        if split == 32:
+            planes = out[:, hidden:].contiguous().view(torch.uint8).view(B * S, 2 * hidden)
+            return out[:, :hidden].double() + planes[:, hidden:].contiguous().view(torch.float8_e4m3fn).double() * 2.0 ** -L.F8_ACT_LO_EXP
+        return out.double()
+    out_c = torch.zeros(rows, hidden * mult, device=dev(), dtype=dtype)
+    L.attention_table_corr(q[:B], k[:B], vt[:B], q[B:], k[B:], vt[B:], tab2, out_c, B, nh, hp, wp, Sp, split=split, grouped=grouped)
+    out_s = torch.zeros(rows, hidden * mult, device=dev(), dtype=dtype)
+    L.attention_table(q[:B], k[:B], vt[:B], tab2, out_s, B, nh, hp, wp, Sp, split=split, grouped=grouped)
+    idx = _relative_position_index(hp, wp).to(dev())
+    bias = table[:, idx.view(-1)].view(nh, S, S).double()
+    inv = torch.empty(S, dtype=torch.long, device=dev())
+    inv[perm] = torch.arange(S, device=dev())
+    a = torch.softmax((qr[:, :, inv] / LOG2E) @ kr[:, :, inv].transpose(2, 3) + bias[None], dim=-1)      # the UNROUNDED operands, fp64
+    ref = (a @ vr[:, :, inv]).permute(0, 2, 1, 3).reshape(B * S, hidden)
+    err_c, err_s = (decode(out_c) - ref).abs().max().item(), (decode(out_s) - ref).abs().max().item()
+    out_res = {0: 2.0 ** -11, 16: 2.0 ** -21, 32: 2.0 ** -15}[split] * (1.0 if dtype == torch.float16 else 8.0) * max(ref.abs().max().item(), 1.0)
+    report(f"attention_table_corr {dtype} B{B} hp{hp} nh{nh} split{split} spike{spike}: max|err| corr {err_c:.3e}, single {err_s:.3e} "
+           f"(output resolution {out_res:.1e}, ref max {ref.abs().max().item():.2f}, |k| max {kr.abs().max().item():.1f})")
+    assert torch.isfinite(decode(out_c)).all()
+    # the corrected kernel is limited by its output format (and, bf16, by 16 bits per operand pair), not by the operands' rounding
+    assert err_c < 2.5 * out_res + (2e-5 if dtype == torch.float16 else 2e-3)
+    if split:
+        assert err_c < 0.2 * err_s, "the split-precision operands must beat the single 16-bit ones by far"
+    out_c2 = torch.zeros_like(out_c)
+    L.attention_table_corr(q[:B], k[:B], vt[:B], q[B:], k[B:], vt[B:], tab2, out_c2, B, nh, hp, wp, Sp, split=split, grouped=grouped)
+    assert torch.equal(out_c, out_c2)
+
+
 @pytest.mark.parametrize("hp", [24, 3])
 def test_attention_table_running_max_moves_in_both_lane_halves(L, hp):
     """A rare data-dependent branch needs its own test: the deferred running max must move when ONE key far out-scores the rest, in

@@ -94,3 +94,38 @@ def test_make_sequence_at_is_one_sequence_whatever_the_subset():
     assert i1[0] == i0[B] and np.array_equal(f1[0], f0[B])                 # rank 1's halo = rank 0's last frame of the same step
     assert i0[B + 1] == i1[B] and np.array_equal(f0[B + 1], f1[B])         # next step: rank 0's halo = rank 1's last frame
     assert sorted(set(i0) | set(i1)) == list(range(total))
+
+
+def _calib_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bodyslam_amd.pipeline import share_calibration
+    calls = []
+
+    def make():
+        calls.append(rank)
+        # a rank calibrating on its own could land on the other side of a tolerance: model it with a rank-dependent report
+        return {"class_modes": {"qkv": "wmean" if rank == 0 else "full"}, "neck_mode": "full", "attn_mode": "single", "by": rank}
+    rep = share_calibration(make)
+    with open(os.path.join(out_dir, f"cal_{rank}"), "w") as f:
+        f.write(repr((rep, calls)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_calibration_is_made_by_rank0_and_shared(tmp_path):
+    """ZoeDepthEngine.calibrate picks the correction modes from measurements; in a sharded run every rank must run the SAME arithmetic
+    (rank r's depth maps join rank r+1's in one sequence), so rank 0's report is broadcast and nobody else calibrates."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 2
+    mp.spawn(_calib_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    reps = [eval(open(tmp_path / f"cal_{r}").read()) for r in range(world)]
+    assert reps[0][0] == reps[1][0] and reps[0][0]["by"] == 0
+    assert reps[0][1] == [0] and reps[1][1] == []          # only rank 0 made a report
+    # without a process group: the report is simply made
+    from bodyslam_amd.pipeline import share_calibration
+    assert share_calibration(lambda: {"x": 1}) == {"x": 1}
