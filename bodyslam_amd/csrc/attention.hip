@@ -563,7 +563,7 @@ __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restr
 // BEiT checkpoints) the single 16-bit Q / K / V / P of the plain kernel cost 0.9-2.4e-4 m of depth EACH
 // (tools/probes/outlier_rounding_study.py); all four corrected: 1.7e-6 m.  The K / V^T ring holds the lo tiles behind the hi tiles
 // (32 KiB per stage, two blocks per CU).
-template <typename T, int QW, int WPE, bool CORR>
+template <typename T, int QW, int WPE, bool CORR, bool PK = false>
 __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ Vt,
                                                                   const T* __restrict__ Ql, const T* __restrict__ Kl, const T* __restrict__ Vtl,
                                                                   const float* __restrict__ table, T* __restrict__ out, int split, int B, int nh,
@@ -657,13 +657,22 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
     };
     // scores of one sub-tile: (bias - running max) + K Q^T, four MFMAs left in flight
     auto qk = [&](f32x16& sacc, const char* sk, int sub) {
-        // (Do not "optimise" this pre-shift.  Round 3 tried it as v_pk_add_f32 pairs, and tried dropping it in favour of a subtraction after
-        // the product: both ran 12 % faster and both gave wrong rows now and then at B = 128, differently from run to run, while
-        // passing every accuracy test at small batches -- without these sixteen VALU reads of the freshly loaded bias the MFMAs below
-        // start on accumulator registers that are not settled.  tools/probes/attn_batch_invariance.py and
-        // test_attention_table_is_deterministic_at_scale guard it; the B = 64 vs B = 1 plan test is what found it.)
+        // The pre-shift by the running max.  (Round 3 found packed / dropped forms of it "nondeterministic at NB = 128" and concluded the
+        // MFMAs needed these sixteen VALU reads of the freshly loaded bias.  They do not: those forms had lost a spill reload whose
+        // `s_waitcnt vmcnt(0)` was the only thing ordering the tile DMA before the barrier -- dma_barrier() above.  PK: the same
+        // subtraction as eight v_pk_add_f32 of the negated max, bit-identical.)
+        if constexpr (PK) {
+            const f32x2_ nm = {-m_run, -m_run};
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sacc[i] -= m_run;
+            for (int i = 0; i < 16; i += 2) {
+                const f32x2_ v = f32x2_{sacc[i], sacc[i + 1]} + nm;
+                sacc[i] = v[0];
+                sacc[i + 1] = v[1];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[i] -= m_run;
+        }
         const int krow = sub * 32 + kap;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -805,11 +814,14 @@ static int launch_attn_tab(const void* q, const void* k, const void* vt, const v
     }
     static const bool pipelined_ok = getenv("BS_ATTN_NO_PIPE") == nullptr;       // diagnostics: the unpipelined loop
     if (hp % 2 == 0 && pipelined_ok) {
-        // 3 waves per SIMD (168 registers): no spill.  At 4 (128 registers) the kernel spills three address registers whose reloads
-        // put an `s_waitcnt vmcnt(0)` right behind the stage -- the next tile's DMA is then waited for at once instead of under the
-        // tile's arithmetic.  BS_ATTN_WPE4 keeps the round-3 configuration for A/B runs.
-        static const bool wpe4 = getenv("BS_ATTN_WPE4") != nullptr;
-        auto kern2 = wpe4 ? attention_tab2_kernel<T, QW, 4, false> : attention_tab2_kernel<T, QW, 3, false>;
+        // 4 waves per SIMD (128 registers, three blocks per CU) with the packed pre-shift: one spilled register, 628 us per NB = 128 launch.
+        // With the scalar pre-shift (BS_ATTN_NO_PK, the round-3 kernel) ten registers spill and their reloads put an `s_waitcnt vmcnt(0)`
+        // right behind the stage -- the next tile's DMA is waited for at once instead of under the tile's arithmetic: 700 us.  The spill-free
+        // 3-waves-per-SIMD build (BS_ATTN_WPE3) overlaps the DMA too and is still slower (811 us): occupancy hides more than the
+        // prefetch does (profiles/r04_attention_variants.txt).
+        static const bool wpe3 = getenv("BS_ATTN_WPE3") != nullptr, pk = getenv("BS_ATTN_NO_PK") == nullptr;
+        auto kern2 = wpe3 ? (pk ? attention_tab2_kernel<T, QW, 3, false, true> : attention_tab2_kernel<T, QW, 3, false>)
+                          : (pk ? attention_tab2_kernel<T, QW, 4, false, true> : attention_tab2_kernel<T, QW, 4, false>);
         static bool attr2 = false;
         if (!attr2) {
             BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));

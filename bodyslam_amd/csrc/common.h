@@ -44,6 +44,14 @@ int cu_count();                   // compute units of the device bs_init bound (
 #define BS_CHECK_LAUNCH() BS_CHECK_HIP(hipGetLastError())
 
 // 16-bit storage traits -----------------------------------------------------------------------
+// The library is built with the target feature `fma-mix-insts` OFF (Makefile).  Reason (round 4, found in the ISA of the attention
+// epilogue): with it hipcc folds `(f16)(a * b)` into ONE v_fma_mixlo_f16 -- the exact product rounded once to 16 bits -- while another
+// use of the same fp32 product is converted from the fp32-ROUNDED product (v_cvt_pk_f16_f32).  Where that fp32 value is an exact
+// 16-bit tie the two roundings pick different neighbours, so a (hi, lo) pair producer -- hi = round16(y), lo = y - hi -- stored the hi
+// of one and the residual of the other: the pair was off by a whole ulp of hi on 2^-13 of all elements, in every split format
+// (16-bit pairs, (hi16 | hi8 | lo8), F4).  That floor is 3 % of the single-precision error: invisible behind e4m3 correction planes,
+// dominant for the 22-bit pairs of the reference precision (9.6e-5 m on the outlier-channel weights).  (An opaque-asm operand in
+// from_f32 cures it too, but costs the 256x256 igemm instantiations their register allocation: 241 -> 256 VGPRs + scratch.)
 template <typename T> struct T16;
 template <> struct T16<f16> {
     typedef f16x8 v8;

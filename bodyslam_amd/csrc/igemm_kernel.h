@@ -85,7 +85,7 @@ struct IgemmParams {
     int a_sc_off, w_sc_off;
     int w_pitch;         // bytes between consecutive W rows (0: K * 2)
     int out_f4;          // != 0: the output row / pixel is written in the F4 activation format (store_f4)
-    int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue, 8 = no tail split (host side),
+    int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue, 8 = no tail split (host side), 128 = the Q / K epilogue without its stores,
                   // 32 = no FP4 scale fetch, 64 = constant FP4 scales (no LDS scale reads)
 };
 
@@ -1037,6 +1037,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                         v[e] = T16<T>::from_f32(yq[e]);
                         v[4 + e] = T16<T>::from_f32(yq[4 + e]);
                     }
+                    if (p.ablate & 128) {                 // diagnostics: everything but the store
+                        asm volatile("" ::"v"(v));
+                        continue;
+                    }
                     *reinterpret_cast<typename T16<T>::v8*>(rowp + coff[jp]) = v;
                     if (p.qkv_lo_off) {       // (wave-uniform) the rounding residuals, for bs_attention_table_corr
                         typename T16<T>::v8 vl;
@@ -1105,6 +1109,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                     const int rem = n - 2 * p.qkv_hidden;
                     const int64_t vo = (((int64_t)ob * nh + (rem >> 6)) * 64 + (rem & 63)) * p.qkv_sp + otok;
                     const T vh = T16<T>::from_f32(y);
+                    if (p.ablate & 128) {                 // diagnostics: everything but the store
+                        asm volatile("" ::"v"(y));
+                        continue;
+                    }
                     vt[vo] = vh;
                     if (p.qkv_lo_off) vt[vo + p.qkv_lo_off] = T16<T>::from_f32(y - T16<T>::to_f32(vh));
                 }

@@ -542,7 +542,10 @@ class ZoeDepthEngine:
         # ---- metric head
         mh = "metric_head."
         B_, E = c.bottleneck, c.bin_dim
-        w["mh.conv2.w"] = self._h(g(mh + "conv2.weight").reshape(B_, B_))
+        # conv2 and the seed regressors work at the bottleneck resolution (12 x 16 pixels per image: no time at all) and decide where every
+        # bin STARTS: as single 16-bit products they cost 4.3e-5 + 7.1e-5 m of depth on outlier-channel weights
+        # (tools/probes/outlier_rounding_study.py mh16) -- in accurate mode they are split-precision products like the neck.
+        w["mh.conv2.w"] = self._wp("mh.conv2.w", g(mh + "conv2.weight").reshape(B_, B_))
         w["mh.conv2.b"] = self._f(g(mh + "conv2.bias"))
         # Two head slots are carried side by side (buffers, block-diagonal weights) and an image is routed to one of them.  A
         # single-head model (ZoeD_N / ZoeD_K) fills slot 0 and leaves slot 1 as zeros with every image routed to slot 0.
@@ -572,11 +575,12 @@ class ZoeDepthEngine:
             return t0, (t1.repeat_interleave(rep, 0) if rep > 1 else t1)
 
         s0, s1 = two("seed", "conv1.weight")
-        w["seed.c1.w"] = self._h(torch.cat([s0, s1, sq(mh + "seed_projector.conv1.weight")], 0))            # [2*SM + PM, 256]
-        b0, b1 = two("seed", "conv1.bias")
-        w["seed.c1.b"] = self._f(torch.cat([b0, b1, g(mh + "seed_projector.conv1.bias")], 0))
+        w["seed.c1.w"] = self._wn(torch.cat([s0, s1], 0))                                                     # [2*SM, 256]
+        w["seed.c1.b"] = self._f(torch.cat(two("seed", "conv1.bias")))
+        w["seedproj.c1.w"] = self._h(sq(mh + "seed_projector.conv1.weight"))                                 # [PM, 256]
+        w["seedproj.c1.b"] = self._f(g(mh + "seed_projector.conv1.bias"))
         s0, s1 = two("seed", "conv2.weight")
-        w["seed.c2.w"] = self._h(torch.block_diag(s0, s1))                                                    # [2*nb, 2*SM]
+        w["seed.c2.w"] = self._wn(torch.block_diag(s0, s1))                                                   # [2*nb, 2*SM]
         w["seed.c2.b"] = self._f(torch.cat(two("seed", "conv2.bias")))
         w["seedproj.c2.w"] = self._h(sq(mh + "seed_projector.conv2.weight"))                                 # [E, PM]
         w["seedproj.c2.b"] = self._f(g(mh + "seed_projector.conv2.bias"))
@@ -1025,8 +1029,8 @@ class _ZoePlan:
         pool.hold = True
         # ---- Z7: metric-bins head
         Mb = NB * bh_ * bw_
-        xb = e16(Mb, c.bottleneck)
-        P.gemm("mh.conv2", bott, w["mh.conv2.w"], xb, M=Mb, N=c.bottleneck, K=c.bottleneck, lda=PE(c.bottleneck), bias=w["mh.conv2.b"])   # hi half of a split map
+        xb = e16(Mb, c.bottleneck * m2)                                   # (hi | lo) pairs in accurate mode
+        nplain("mh.conv2", bott, "mh.conv2.w", xb, Mb, c.bottleneck, c.bottleneck, bias=w["mh.conv2.b"], out8=False)
         self.logits = e32(NB, 4)
         self.route = torch.zeros(NB, dtype=torch.int32, device=dev)       # single-head models: every image stays on slot 0
         if not c.single_head:
@@ -1041,7 +1045,7 @@ class _ZoePlan:
             self._router_init = (e32b, self._pe_src)
             # e = pos_enc (token 0 is the zero "cls" pad) ; tokens 1.. += embedding conv
             P.add("rt.init", "bs_copy_f32", self._pe_src, e32b, e32b.numel())
-            P.gemm("rt.emb", xb, w["rt.emb.w"], e32b, M=Mb, N=D, K=c.bottleneck, lda=c.bottleneck, bias=w["rt.emb.b"], res=e32b, ldr=D,
+            P.gemm("rt.emb", xb, w["rt.emb.w"], e32b, M=Mb, N=D, K=c.bottleneck, lda=c.bottleneck * m2, bias=w["rt.emb.b"], res=e32b, ldr=D,
                    out_group=(bh_ * bw_, St, 1))
             P.add("rt.cast", "bs_cast", e32b, e16b, e32b.numel(), L.dt(e16b))
             qkv32 = e32(NB * St, 3 * D)
@@ -1064,13 +1068,19 @@ class _ZoePlan:
         # seeds + seed projector
         E, nb = c.bin_dim, c.n_bins
         SM, PM, HID = c.seed_mlp, c.proj_mlp, c.clb_hidden          # hidden widths: 64 / 64 / 40 (NK head), 256 / 128 / 80 (single head)
-        sh = e16(Mb, 2 * SM + PM)                                  # [seed regressor slot 0 | slot 1 | seed projector] hidden units
-        P.gemm("seed.c1", xb, w["seed.c1.w"], sh, M=Mb, N=2 * SM + PM, K=c.bottleneck, lda=c.bottleneck, bias=w["seed.c1.b"], act=L.ACT_RELU)
+        KB = c.bottleneck
+        sh = e16(Mb, 2 * SM * m2)                                  # [seed regressor slot 0 | slot 1] hidden units, pairs in accurate mode
+        P.gemm("seed.c1", xb, w["seed.c1.w"], sh, M=Mb, N=2 * SM, K=KB * np3, lda=KB * m2, seg1=KB if acc else 0, bias=w["seed.c1.b"], act=L.ACT_RELU,
+               ldo=2 * SM * m2, out_split_off=2 * SM if acc else 0, precision_passes=np3)
         bins_prev = e32(NB, bh_, bw_, 2 * nb)
-        P.gemm("seed.c2", sh, w["seed.c2.w"], bins_prev, M=Mb, N=2 * nb, K=2 * SM, lda=2 * SM + PM, bias=w["seed.c2.b"], act=L.ACT_SOFTPLUS)
-        # projector embeddings feed the last 1x1 convs of the head almost directly, so accurate mode keeps them as (hi | lo) pairs too
+        P.gemm("seed.c2", sh, w["seed.c2.w"], bins_prev, M=Mb, N=2 * nb, K=2 * SM * np3, lda=2 * SM * m2, seg1=2 * SM if acc else 0, bias=w["seed.c2.b"],
+               act=L.ACT_SOFTPLUS, precision_passes=np3)
+        # seed projector: its own small GEMM pair (1.3e-6 m as single products: stays single); the projector embeddings feed the last
+        # 1x1 convs of the head almost directly, so accurate mode keeps them as (hi | lo) pairs
+        shp = e16(Mb, PM)
+        P.gemm("seedproj.c1", xb, w["seedproj.c1.w"], shp, M=Mb, N=PM, K=KB, lda=KB * m2, bias=w["seedproj.c1.b"], act=L.ACT_RELU)
         emb_prev = e16(Mb, E * m2)
-        P.gemm("seedproj.c2", sh, w["seedproj.c2.w"], emb_prev, M=Mb, N=E, K=PM, lda=2 * SM + PM, a_offset=2 * SM, bias=w["seedproj.c2.b"],
+        P.gemm("seedproj.c2", shp, w["seedproj.c2.w"], emb_prev, M=Mb, N=E, K=PM, lda=PM, bias=w["seedproj.c2.b"],
                ldo=E * m2, out_split_off=E if acc else 0)
         P.signal(1)
         P.lane = 0

@@ -8,6 +8,8 @@ and prints the depth L1 against the exact oracle, in metres:
   qk16, qkvp16                combinations
   qcorr, kcorr, vcorr, pcorr  the operand as hi16 + fp16(residual), unscaled (the corrected attention's operand pair)
   act_f8                      every backbone GEMM's A operand as hi16 + e4m3((x - hi16) * 2^11)   (the "full" product's A side)
+  pe_f8 / pe_16               the patch embedding's operands as hi16 + e4m3 residuals / as single 16-bit values
+  mh16                        the bins head's single-pass 1x1 convs (conv2, seed regressors, seed projector, attractor MLPs) on 16-bit operands
   w_f8                        every backbone weight as W16 + e4m3((W - W16) * 2^b), b per matrix   (the "full" product's W side)
 Usage: python tools/probes/outlier_rounding_study.py [variant ...]      (about 20 s per variant on 8 cores)"""
 import os
@@ -24,6 +26,7 @@ from oracle import zoedepth_ref as Z                  # noqa: E402
 from bodyslam_amd.synthetic import make_sequence      # noqa: E402
 import test_zoedepth_gpu as T                         # noqa: E402
 
+MH_PTRS = set()
 HOOKS = {"outlier": T._hook_outlier_channels, "layerscale": T._hook_layerscale_wide, "heavy": T._hook_heavy_tailed, "none": None}
 
 
@@ -89,6 +92,20 @@ class FProxy:
     def __getattr__(self, name):
         return getattr(TF, name)
 
+    def conv2d(self, x, W, b=None, **kw):
+        m = self.mode
+        if "mh16" in m and W.data_ptr() in MH_PTRS:               # the bins head's single-precision 1x1 convs (16-bit operands)
+            return TF.conv2d(r16(x), r16(W), b, **kw)
+        if W.shape[-1] == 16 and kw.get("stride") == 16:           # the patch embedding
+            if "pe_f8" in m:        # A = hi16 + e4m3 residual, W = W16 + e4m3 residual (the "full" product's operands)
+                W16 = r16(W)
+                d = W - W16
+                bexp = torch.floor(torch.log2(448.0 / d.abs().max().clamp_min(1e-30)))
+                return TF.conv2d(hi_lo8(x), W16 + e4m3(d * 2.0 ** bexp) * 2.0 ** -bexp, b, **kw)
+            if "pe_16" in m:
+                return TF.conv2d(r16(x), r16(W), b, **kw)
+        return TF.conv2d(x, W, b, **kw)
+
     def linear(self, x, W, b=None):
         m = self.mode
         big = x.dim() == 3 and x.shape[1] > 700 and W.shape[0] >= 1024 and W.shape[1] >= 1024
@@ -124,6 +141,12 @@ def main(argv):
     if HOOKS[hook_name] is not None:
         HOOKS[hook_name](w)
     frames = torch.from_numpy(make_sequence(1, 480, 640, seed=seed))
+    # single 16-bit GEMMs of the bins head in every engine mode: conv2, seed regressors / projector conv1+conv2, attractor MLPs
+    sel = os.environ.get("MH_SEL", "")             # substring filter on the weight key (e.g. "attractors", "seed_bin", "conv2")
+    for k_, v_ in w.items():
+        if k_.startswith("metric_head.") and v_.dim() == 4 and ("projectors" not in k_) and ("conditional_log_binomial" not in k_) and sel in k_:
+            MH_PTRS.add(v_.data_ptr())
+    print("mh16 applies to", len(MH_PTRS), "weights", flush=True)
     out = open(os.path.join(ROOT, "gpurun_out", "outlier_rounding_study.txt"), "a")
     with torch.no_grad():
         t0 = time.time()
