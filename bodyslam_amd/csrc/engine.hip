@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <exception>
 #include <map>
 #include <string>
 #include <tuple>
@@ -127,7 +128,7 @@ void engine_free(bs_engine* e) {
 
 using namespace bs;
 
-extern "C" int bs_engine_load(const char* path, bs_engine** out) {
+static int engine_load_impl(const char* path, bs_engine** out) {
     if (!initialized()) { set_error("bs_engine_load: call bs_init first"); return BS_ERR_NOT_INIT; }
     BS_REQUIRE(path && out, "bs_engine_load: null argument");
     *out = nullptr;
@@ -138,6 +139,19 @@ extern "C" int bs_engine_load(const char* path, bs_engine** out) {
     r.bytes(magic, 8);
     const uint32_t n_buf = r.get<uint32_t>(), n_ops = r.get<uint32_t>(), n_io = r.get<uint32_t>(), desc_size = r.get<uint32_t>();
     const int64_t calls_bytes = r.get<int64_t>();
+    // the file is untrusted input of a public C entry point: every count is bounded by the file's size before anything is allocated
+    long file_size = 0;
+    {
+        const long pos = ftell(f);
+        if (fseek(f, 0, SEEK_END) == 0) file_size = ftell(f);
+        (void)fseek(f, pos, SEEK_SET);
+    }
+    if (r.ok && memcmp(magic, kMagic, 8) == 0 &&
+        ((long)n_buf * 20 > file_size || (long)n_io * 52 > file_size || (long)n_ops * 56 > file_size || calls_bytes < 0 || calls_bytes > file_size)) {
+        fclose(f);
+        set_error("bs_engine_load: %s: record counts exceed the file size (corrupt or truncated)", path);
+        return BS_ERR_INVALID;
+    }
     if (!r.ok || memcmp(magic, kMagic, 8) != 0) {
         fclose(f);
         set_error("bs_engine_load: %s is not an engine file of this version", path);
@@ -173,6 +187,10 @@ extern "C" int bs_engine_load(const char* path, bs_engine** out) {
         i.nbytes = r.get<int64_t>();
     }
     if (!r.ok) return fail("truncated header");
+    for (auto& b : recs)
+        if (b.nbytes < 0 || (b.kind == KIND_DATA && (b.off < 0 || b.off + b.nbytes > file_size))) return fail("bad buffer record");
+    for (auto& i : ios)
+        if (i.buf >= n_buf || i.nbytes < 0 || i.off < 0 || i.off + i.nbytes > recs[i.buf].nbytes) return fail("io record outside its buffer");
     // buffers
     e->bufs.assign(n_buf, nullptr);
     for (uint32_t i = 0; i < n_buf; ++i) {
@@ -261,6 +279,12 @@ extern "C" int bs_engine_load(const char* path, bs_engine** out) {
         if (hipMemcpy(e->bufs[i], host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
     }
     fclose(f);
+    // the zero-fills and uploads above ran on the null stream; bs_engine_run may be given a non-blocking stream that does not wait for it
+    if (hipDeviceSynchronize() != hipSuccess) {
+        engine_free(e);
+        set_error("bs_engine_load: device synchronisation failed");
+        return BS_ERR_HIP;
+    }
     if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) {
         engine_free(e);
         set_error("bs_engine_load: cannot create the side stream");
@@ -278,6 +302,16 @@ extern "C" int bs_engine_load(const char* path, bs_engine** out) {
         }
     *out = e;
     return BS_OK;
+}
+
+extern "C" int bs_engine_load(const char* path, bs_engine** out) {
+    try {          // (std::vector / new on a corrupt count must not unwind through the C boundary)
+        return engine_load_impl(path, out);
+    } catch (const std::exception& ex) {
+        if (out) *out = nullptr;
+        set_error("bs_engine_load: %s (%s)", ex.what(), path ? path : "");
+        return BS_ERR_INVALID;
+    }
 }
 
 extern "C" int bs_engine_destroy(bs_engine* e) {
@@ -319,6 +353,9 @@ extern "C" int64_t bs_engine_device_bytes(const bs_engine* e) { return e ? e->de
 extern "C" int bs_engine_run(bs_engine* e, void* stream) {
     if (!initialized()) { set_error("bs_engine_run: call bs_init first"); return BS_ERR_NOT_INIT; }
     BS_REQUIRE(e, "bs_engine_run: null engine");
+    int dev_now = -1;
+    BS_CHECK_HIP(hipGetDevice(&dev_now));
+    BS_REQUIRE(dev_now == e->device, "bs_engine_run: the engine was loaded on device %d, the current device is %d", e->device, dev_now);
     hipStream_t lanes[2] = {reinterpret_cast<hipStream_t>(stream), e->side};
     for (const Op& op : e->ops) {
         hipStream_t st = lanes[op.lane ? 1 : 0];

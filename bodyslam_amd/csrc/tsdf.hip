@@ -287,6 +287,7 @@ __global__ __launch_bounds__(256) void tsdf_assign_batch_kernel(const TsdfFrame*
         if (s >= max_units) {          // (the caller reserves what the discovery found before this kernel runs: only a full map gets here)
             atomicSub(counters + 0, 1);
             counters[2] = 2;
+            fmask[h] = 0ull;           // the table's frame masks are zero between batches: a stale bit would name another frame next time
             return;
         }
         slots[h] = s;

@@ -70,22 +70,29 @@ class CyclePoseEngine:
                            "(architecture_v3.py:208-209); pass it explicitly")
         # skip_linear is sized by the network input (architecture_v3.py:205-209): one weight per input window, keyed by the
         # number of pixels of the stride-4 map (32*32 for the 128x128 crop)
-        self._skip = {}
-        self.add_skip(g("skip_linear.weight"), g("skip_linear.bias"))
+        self._skip, self._skip_shape = {}, {}
+        n_skip = (g("skip_linear.weight").shape[1] - 512) // 256
+        # (the checkpoint's own layer belongs to the reference's 128 x 128 crop: a 32 x 32 map)
+        self.add_skip(g("skip_linear.weight"), g("skip_linear.bias"), map_hw=(32, 32) if n_skip == 1024 else None)
         w["d1.w"], w["d1.b"] = f(g("pose_dense.1.weight")), f(g("pose_dense.1.bias"))
         w["d2.w"], w["d2.b"] = f(g("pose_dense.3.weight")), f(g("pose_dense.3.bias"))
 
     # (keyed by the number of map positions h' * w', as the reference's lazily created Linear(512 + 256 h' w', 7) is: the flattened NCHW
     # feature index c * h'w' + p only knows the row-major position p, which is the row of the [7][h'w'][C] layout for every (h', w')
     # of that product)
-    def add_skip(self, weight: torch.Tensor, bias: torch.Tensor) -> int:
-        """Register a skip_linear weight [7, 512 + 256*h*w] (h x w = the stride-4 map of the network input); returns h*w."""
+    def add_skip(self, weight: torch.Tensor, bias: torch.Tensor, map_hw=None) -> int:
+        """Register a skip_linear weight [7, 512 + 256*h*w] (h x w = the stride-4 map of the network input); returns h*w.
+        map_hw = (h, w) the weight was trained for, when known: a plan whose map has the same number of positions but another shape
+        (32 x 43 against 43 x 32) then warns -- the arithmetic is what the reference's Linear would do with it (it only sees the
+        flattened index), the result is meaningless."""
         ws = weight.detach().float()
         assert ws.dim() == 2 and ws.shape[0] == 7 and (ws.shape[1] - 512) % 256 == 0 and ws.shape[1] > 512, ws.shape
         hw = (ws.shape[1] - 512) // 256
+        assert map_hw is None or map_hw[0] * map_hw[1] == hw, (map_hw, hw)
         f = lambda t: t.to(self.dev, dtype=torch.float32).contiguous()
         self._skip[hw] = (f(ws[:, :512]), f(ws[:, 512:].view(7, 256, hw).permute(0, 2, 1)),      # NCHW flatten -> [7][HW][C]
                           f(bias.detach().float()))
+        self._skip_shape[hw] = tuple(map_hw) if map_hw is not None else None
         return hw
 
     @staticmethod
@@ -126,6 +133,10 @@ class _PosePlan:
         if h2 * w2 not in eng._skip:
             raise KeyError(f"no skip_linear weight for a {CH}x{CW} network input ({512 + 256 * h2 * w2} features): "
                            "register one with CyclePoseEngine.add_skip (the reference would create a random layer, architecture_v3.py:208-209)")
+        if eng._skip_shape.get(h2 * w2) not in (None, (h2, w2)):
+            import warnings
+            warnings.warn(f"CyclePose: the skip_linear weight of {h2 * w2} map positions was registered for a {eng._skip_shape[h2 * w2]} map and is "
+                          f"being applied to a {(h2, w2)} one: same flattened size, other geometry (the reference's Linear would do the same)")
         skip_pool, skip_x2, skip_b = eng._skip[h2 * w2]
         H1, W1 = (CH - 1) // 2 + 1, (CW - 1) // 2 + 1
         H3, W3 = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1

@@ -85,6 +85,8 @@ class SequenceResult:
     point_counts: torch.Tensor         # int32 [n_local]
     points: Optional[list] = None      # optional [(xyz [M,3] fp32, idx [M] int32)] per local frame
     depth_m: Optional[torch.Tensor] = None
+    tsdf: Optional[object] = None      # run_slam_loop: the map as the loop left it -- NOT necessarily the volume the caller passed in: a rebuild
+                                       # (pose graph moved the poses, or frame 2000) starts a fresh one, as slam.py:159-185 does
 
 
 class BodySlamPipeline:
@@ -331,7 +333,10 @@ class BodySlamPipeline:
         self.last_tsdf = state["tsdf"]
         t_rel = torch.from_numpy(np.stack(rel_fused).astype(np.float32)).to(self.dev) if rel_fused else torch.zeros(0, 4, 4, device=self.dev)
         g_abs = torch.from_numpy(np.stack(self._extr_final)).to(self.dev)
-        return SequenceResult(0, N, depth_all, t_rel, g_abs, cnt_all, points, depth_m_all)
+        # (points / point_counts were back-projected batch by batch with the poses as they stood then; g_abs holds the poses after the last
+        # pose-graph step -- the reference's per-frame point clouds have the same property, slam.py:195.  The fused relatives are fp32 as in
+        # the reference: visual_odometry.py:90 writes the filter state into MPEM's float32 matrix.)
+        return SequenceResult(0, N, depth_all, t_rel, g_abs, cnt_all, points, depth_m_all, state["tsdf"])
 
     def _slam_batch(self, b0, b1, t_mpem, vo, odo, stored, vo_obj, state, fr_dev, depth_all, intr, pg, extr, rel_fused, cnt_all, points,
                     keep_points, every, rebuild_every, extract_every_frame, on_frame, tsdf_depth, run_map_actions):

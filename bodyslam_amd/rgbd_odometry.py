@@ -239,6 +239,7 @@ class RGBDOdometry:
             return torch.cat([self.track_block(colors_u8[a:a + max_block], depths_m[a:a + max_block], max_block) for a in range(0, n, max_block)])
         k = self._blk
         if k is None or k["hw"] != (H, W) or k["slots"] < n + 1:
+            old = k if (k is not None and k["hw"] == (H, W) and k["have_prev"]) else None      # a larger block than before: keep the previous frame
             slots = max(n, max_block if n > 1 else 1) + 1
             levels, (h, w, kk) = [], (H, W, self.K)
             for _ in range(len(self.iterations)):
@@ -253,6 +254,11 @@ class RGBDOdometry:
                                  T0=torch.tensor([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=torch.float64, device=self.dev),
                                  partial=torch.empty(slots - 1, nblk, 29, dtype=torch.float64, device=self.dev),
                                  out=torch.zeros(slots - 1, 29, dtype=torch.float64, device=self.dev))
+            if old is not None:      # (a first call with one frame allocates two slots; the next, larger block must still pair with that frame)
+                for l_new, l_old in zip(levels, old["levels"]):
+                    for name in ("I", "D", "gIx", "gIy", "gDx", "gDy"):
+                        getattr(l_new, name)[0].copy_(getattr(l_old, name)[0])
+                k["have_prev"] = True
         if n == 0:
             return torch.empty(0, 12, dtype=torch.float64, device=self.dev)
         lib, st = L.load_library(), L.stream_ptr()

@@ -267,7 +267,16 @@ class TSDF:
             L.check(lib.bs_tsdf_touch_batch(L.p(self.frames_dev), m, H, W, self.stride, self.unit_length, self.sdf_trunc, L.p(self.table_keys),
                                             L.p(self.table_fmask), self.table_cap, L.p(self.counters), st), "bs_tsdf_touch_batch")
             # the one round trip of the batch: how many blocks the discovered units need
-            need = torch.stack([self.counters[0].to(torch.int64), ((self.table_keys != -1) & (self.table_slots < 0)).sum()]).cpu()
+            # (+ the overflow flag the discovery may have raised: 1 = unit table full)
+            need = torch.stack([self.counters[0].to(torch.int64), ((self.table_keys != -1) & (self.table_slots < 0)).sum(),
+                                self.counters[2].to(torch.int64)]).cpu()
+            if int(need[2]) == 1 or int(need[0]) + int(need[1]) > self.max_units:
+                # nothing of this batch has been integrated yet: clear the flag and the batch's frame bits, then refuse
+                self.counters[2] = 0
+                self.table_fmask.zero_()
+                raise L.BodySlamHipError("TSDF: " + ("unit table full" if int(need[2]) == 1 else
+                                                     f"the batch needs {int(need[0]) + int(need[1])} volume units, more than max_units={self.max_units}")
+                                         + "; construct TSDF with a larger max_units")
             self.reserve(int(need[0]) + int(need[1]))
             L.check(lib.bs_tsdf_integrate_batch(L.p(self.frames_dev), m, H, W, L.p(self.table_keys), L.p(self.table_slots), L.p(self.table_fmask),
                                                 self.table_cap, L.p(self.unit_index), self.alloc_units, L.p(self.counters), L.p(self.touched),
@@ -275,6 +284,7 @@ class TSDF:
                                                 st), "bs_tsdf_integrate_batch")
             self.frames_integrated += m
             self._frames_since_sync += m
+            # (the assignment cannot run out of blocks after the reserve above; its flag is still collected by sync())
             # every discovered unit has a block now (unless the map is full: sync() reports that), so the count is known without
             # another round trip -- extract_pcd / extract_mesh right after a batch see the whole map
             self.n_units = min(int(need[0]) + int(need[1]), self.alloc_units)

@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import math
 import os
+import warnings
 from dataclasses import dataclass
 from typing import Dict, Optional, Sequence, Tuple
 
@@ -438,6 +439,7 @@ class ZoeDepthEngine:
         if l1_abs is not None and l1_abs > TOLERANCE_M:
             report["warning"] = (f"depth L1 of the calibration frame against the reference-precision engine is {l1_abs:.2e} m with every "
                                  f"correction on: above the {TOLERANCE_M:.0e} m tolerance for these weights")
+            warnings.warn("ZoeDepthEngine.calibrate: " + report["warning"])
         elif truth is None:
             report["note"] = "no absolute reference (the engine holds no source weights): l1_total_vs_full_m is relative to the best mode only"
         self.set_class_modes(chosen, neck, attn)

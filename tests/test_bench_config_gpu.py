@@ -245,4 +245,45 @@ def test_config5_size_on_one_gpu(weights):
     _free()
 
 
+def test_config5_sequence_on_one_gpu(weights):
+    """BASELINE config 5 as a SEQUENCE on one GPU: 64 consecutive 1280x1024 frames through run_sequence (MDEM B = 16 per step, MPEM on the
+    reference's CenterCrop(128) of a 1280x1024 frame -- top 448, left 576, mpem_interface.py:40-44 --, chain, pose-graph step every 500,
+    back-projection): MPEM against the oracle at that size, the chain against the oracle chain, depth of sampled frames bit-equal to
+    the B = 1 plan, points against the C oracle.  (The 8-GPU sharding of this configuration is config 4's mechanism at another frame
+    size: tests/test_sharding_cpu.py, test_config4_size_eight_ranks_emulated.)"""
+    from bodyslam_amd.pipeline import BodySlamPipeline
+    from bodyslam_amd.synthetic import make_sequence
+    from oracle import cyclepose_ref as CP
+    from oracle import geom3d_ref as G
+    cfg, wz, wp = weights
+    H, W, B, N = 1024, 1280, 16, 64
+    frames = torch.from_numpy(make_sequence(N, H, W, seed=12))
+    pipe = BodySlamPipeline(wz, wp, cfg, batch=B, precision="accurate")
+    pipe.posegraph_every = 500
+    res = pipe.run_sequence(frames, keep_points=True, keep_depth_m=True)
+    assert res.t_rel.shape == (N - 1, 4, 4) and res.g_abs.shape == (N, 4, 4) and res.depth_u16.shape == (N, H, W)
+    # MPEM at 1280x1024 against the oracle (pairs across batch borders included)
+    sample = [0, 14, 15, 16, 40, 62]
+    with torch.no_grad():
+        Tref = CP.forward_pose(wp, CP.center_crop_pair(frames, torch.tensor([[i, i + 1] for i in sample])))
+    perr = (res.t_rel.cpu()[sample] - Tref).abs().max().item()
+    # the chain (float64, SO(3) projection per step) against the oracle's chain of the SAME relatives; the pose-graph step leaves it alone
+    ref_g = G.pose_chain(res.t_rel.cpu().numpy())
+    gerr = np.abs(res.g_abs.cpu().numpy() - ref_g).max()
+    # depth: the batched plan against the B = 1 plan (which tests/test_zoedepth_gpu.py::test_other_frame_geometries holds to the oracle)
+    for i in (0, 17, 63):
+        d1, u1 = pipe.zoe.infer(frames[i:i + 1].cuda())
+        assert torch.equal(d1[0], res.depth_m[i]) and torch.equal(u1[0], res.depth_u16[i]), f"frame {i}: sequence depth differs from the B=1 plan"
+    du = res.depth_u16.cpu().numpy().view(np.uint16)
+    for j in (0, 31, 63):
+        rx, ri = G.backproject(du[j], pose=ref_g[j])
+        xyz, idx = res.points[j]
+        assert np.array_equal(idx.cpu().numpy(), ri) and np.allclose(xyz.cpu().numpy(), rx, atol=1e-5)
+    report(f"config 5 sequence on one GPU: 64 frames 1280x1024, MPEM max|T - T_oracle| = {perr:.3e}, chain max err {gerr:.1e}, "
+           f"points/frame {res.point_counts.float().mean().item():.0f}")
+    assert perr < POSE_TOL and gerr < 1e-9
+    del pipe
+    _free()
+
+
 POSE_TOL = 1e-5      # the accurate MPEM path (split-precision convolutions; DESIGN.md, Numerics)

@@ -154,6 +154,11 @@ def test_track_block_equals_pairwise_and_is_fast(assoc):
         assert np.array_equal(got[i - 1].reshape(3, 4), T[:3]), i
     odo.reset()
     assert odo.track_block(cols[:1], deps[:1]).shape == (0, 12) and odo.track_block(cols[:0], deps[:0]).shape == (0, 12)
+    # a first call with ONE frame sizes the buffers for one frame; the larger block that follows reallocates them and must still pair its
+    # first frame with the one kept (round-3 advisor: the reallocation used to drop it and return n - 1 pairs)
+    d = odo.track_block(cols[1:4], deps[1:4])
+    assert d.shape == (3, 12) and np.array_equal(d.cpu().numpy(), got[:3])
+    odo.reset()
     # timing: blocks of 64 frames
     big_c = cols[torch.arange(64, device=dev) % 6].contiguous()
     big_d = deps[torch.arange(64, device=dev) % 6].contiguous()

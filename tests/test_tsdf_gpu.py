@@ -262,11 +262,13 @@ def test_tsdf_frame_batch_equals_frame_by_frame():
     pa, pb = a.extract_pcd(), b.extract_pcd()
     assert pa.points.shape == pb.points.shape and np.array_equal(np.sort(pa.points.view("f4,f4,f4"), axis=0), np.sort(pb.points.view("f4,f4,f4"), axis=0))
     # a full map is reported, not overrun
+    # ... and by the batch call itself, before anything of the batch is integrated: a direct caller that never calls sync() must not
+    # lose frames silently (round-3 advisor), and the discovery masks must be clean again for the next batch
     t = TSDF(vl, trunc, volume_unit_resolution=8, depth_sampling_stride=4, slab_bytes=1 << 16, max_units=64)
     fr = frames(2, True)
-    t.build_3D_map_batch([r for r, _ in fr], intr, [E for _, E in fr])
-    with pytest.raises(Exception, match="blocks|max_units"):
-        t.sync()
+    with pytest.raises(Exception, match="max_units|unit table full"):
+        t.build_3D_map_batch([r for r, _ in fr], intr, [E for _, E in fr])
+    assert t.frames_integrated == 0 and int(t.table_fmask.abs().sum()) == 0 and int(t.counters[2]) == 0
 
 
 def test_slam_loop_reference_order_640x480():
