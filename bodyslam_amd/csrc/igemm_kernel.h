@@ -85,7 +85,7 @@ struct IgemmParams {
     int a_sc_off, w_sc_off;
     int w_pitch;         // bytes between consecutive W rows (0: K * 2)
     int out_f4;          // != 0: the output row / pixel is written in the F4 activation format (store_f4)
-    int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue, 8 = no tail split (host side), 128 = the Q / K epilogue without its stores,
+    int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue, 8 = no tail split (host side), 128 = the Q / K epilogue without its stores, 256 = no fast Q / K patch-tile path,
                   // 32 = no FP4 scale fetch, 64 = constant FP4 scales (no LDS scale reads)
 };
 
@@ -1010,6 +1010,48 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                 }
             }
             const int nhead = p.qkv_hidden >> 6;
+            // Patch tiles of the grouped layout (all but the first M-tile of a backbone launch): the rows of a lane are 16 apart, so
+            // (image, token) is decoded by ONE division and then advanced; the stores go through a buffer descriptor with 32-bit
+            // offsets.  The loop below re-derives both per row with 64-bit addresses: 17 integer divisions and ~1 700 instructions per
+            // wave, 6 us of a 46 us tile at two waves per SIMD (profiles/r04_gemm_experiments.txt).  Same values, same bits.
+            const long long q_bytes = (long long)p.qkv_cls_rows * nhead * p.qkv_sp * 128;
+            if (p.qkv_cls_rows > 0 && m0 >= p.qkv_patch_row0 && p.qkv_lo_off == 0 && !(p.ablate & (128 | 256)) && q_bytes < 0x7FFFFFF0ll) {
+                typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)q_bytes, 0x00020000);
+                const int Tk = p.qkv_tokens - 1;
+                int m = m0 + wm * TM + frow;
+                const int mp0 = m - p.qkv_patch_row0;
+                const int ob0 = mp0 / Tk;
+                int otok = mp0 - ob0 * Tk;
+                const unsigned img_bytes = (unsigned)(nhead * p.qkv_sp) * 128u;
+                unsigned roff = (unsigned)ob0 * img_bytes + (unsigned)otok * 128u;
+                unsigned cb[FN / 2];
+#pragma unroll
+                for (int jp = 0; jp < FN / 2; ++jp) cb[jp] = (unsigned)coff[jp] * 2u;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    if (m < p.M) {
+#pragma unroll
+                        for (int jp = 0; jp < FN / 2; ++jp) {
+                            typename T16<T>::v8 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v[e] = T16<T>::from_f32((acc[i][2 * jp][e] + bj[2 * jp][e]) * sj[2 * jp][e]);
+                                v[4 + e] = T16<T>::from_f32((acc[i][2 * jp + 1][e] + bj[2 * jp + 1][e]) * sj[2 * jp + 1][e]);
+                            }
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), orsrc, roff + cb[jp], 0, 0);
+                        }
+                    }
+                    m += 16;
+                    otok += 16;
+                    roff += 16u * 128u;
+                    if (otok >= Tk) {          // next image: its block of [head, position, 64] starts img_bytes further on
+                        otok -= Tk;
+                        roff += img_bytes - (unsigned)Tk * 128u;
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int m = m0 + wm * TM + i * 16 + frow;

@@ -115,12 +115,17 @@ TOLERANCE_M = 1.0e-4                             # BASELINE.json north_star: dep
 # (tools/probes/outlier_rounding_study.py) -- so the choice is calibrated per weight set like the GEMM classes ("auto").
 ACCURATE_ATTN_MODE = "auto"
 # neck: "full", or the list of weight-key prefixes that keep both products (the rest: weight-rounding correction only).
-NECK_RELHEAD_WONLY = "ro,ra,nc,fu,pj"            # everything but the relative head keeps both
+NECK_RELHEAD_WONLY = "ro,ra,nc,fu,pj,mh"         # everything but the relative head keeps both (mh: the bins head's bottleneck conv)
 # What a class's cheap mode saves per bench step (ms, B = 64, measured: profiles/r02_bench_kernels.txt "wmean" against "wcls"; neck:
 # profiles/r03_neck_relhead_wonly.txt).  When the chosen combination misses the total tolerance, the class that pays the most depth
 # error per millisecond saved goes back up first.  The relative head's weight-only mode buys 1 % for ~2e-5 m: not a default candidate.
 AUTO_SAVING_MS = {"fc1": 8.7, "fc2": 8.0, "qkv": 3.7, "o": 1.8, "neck": 2.0, "attn": 25.0}
-AUTO_NECK_CANDIDATES = ("full",)
+# The relative head (rh.projection, rh.conv1: 40 % of the conv stack's time) with the weight-rounding correction only is +1.1 % frames/s for
+# +0.7-1.8e-5 m (profiles/r03_neck_relhead_wonly.txt): a candidate since round 4, when calibrate() got an ABSOLUTE reference -- it is kept
+# only while the chosen combination stays under AUTO_TOL_NECK_ABS_M against the reference-precision engine (half the tolerance: the
+# calibration frame is one frame).  Without that reference (no source weights) the neck stays "full".
+AUTO_NECK_CANDIDATES = (NECK_RELHEAD_WONLY, "full")
+AUTO_TOL_NECK_ABS_M = 5.0e-5
 ACCURATE_NECK_MODE = "full"
 # Operand format of the neck's two correction products: "f8" = e4m3 planes with one scale per tensor (2 pass-equivalents, neck error
 # ~7e-6 m on its own), "f4" = e2m1 planes with one E8M0 scale per 64 channels at 4x the 16-bit MFMA rate (1.5 pass-equivalents,
@@ -356,7 +361,8 @@ class ZoeDepthEngine:
         frames_u8 = frames_u8[:1].contiguous()
         H, W = int(frames_u8.shape[1]), int(frames_u8.shape[2])
         switchable = [k for k in BACKBONE_CLASSES if self.class_modes[k] in ("full", "wcls", "wmean")] if self.auto_classes else []
-        neck_cands = ["full"] if (self.neck_f4 or not self.neck_f8 or not self.auto_classes) else list(neck_candidates or AUTO_NECK_CANDIDATES)
+        neck_cands = ["full"] if (self.neck_f4 or not self.neck_f8 or not self.auto_classes or (neck_candidates is None and (not reference or self._sd is None))) \
+            else list(neck_candidates or AUTO_NECK_CANDIDATES)
         nh_, nw_ = net_size(H, W, self.target_hw)
         corr_ok = nw_ // self.cfg.patch == 32 and (nh_ // self.cfg.patch) % 2 == 0 and nh_ // self.cfg.patch <= 40
         attn_best = ("corr" if corr_ok else "single") if self.auto_attn else self.attn_mode
@@ -430,6 +436,9 @@ class ZoeDepthEngine:
             d_c = depth(chosen, neck, attn) if cheap else ref
             total = (d_c - ref).abs().mean().item() if cheap else 0.0
             l1_abs = (d_c - truth).abs().mean().item() if truth is not None else None
+            if neck != neck_full and neck_candidates is None and l1_abs is not None and l1_abs > AUTO_TOL_NECK_ABS_M:
+                neck, cost["neck"] = neck_full, 0.0           # the cheaper neck is only worth half the tolerance (see AUTO_TOL_NECK_ABS_M)
+                continue
             if total <= tol_total and (l1_abs is None or l1_abs <= tol_abs):
                 break
             if not step_up():
