@@ -96,7 +96,8 @@ class BodySlamPipeline:
                  depth_trunc: float = geom3d.REF_DEPTH_TRUNC, flip_aug: bool = True,
                  target_hw: Tuple[int, int] = (384, 512), precision: str = "accurate", pad_ragged: bool = True):
         """precision: ZoeDepthEngine's -- "accurate" keeps depth within 1e-4 m (L1) of the fp32 reference, "fast" is one
-        16-bit MFMA pass per product (L1 ~3e-4 m at fp16).  pad_ragged: run a ragged last batch of a block through the
+        16-bit MFMA pass per product (L1 ~3e-4 m at fp16), "reference" three 16-bit passes on (hi | lo) pairs for every product
+        (~1e-5 m; the precision calibrate() measures the others against, and the one bf16 storage needs to meet the tolerance).  pad_ragged: run a ragged last batch of a block through the
         full-size plan instead of building a second plan for its size."""
         L.init(device)
         self.dev = torch.device("cuda", device)
@@ -110,7 +111,7 @@ class BodySlamPipeline:
         self.K, self.depth_scale, self.depth_trunc, self.flip = tuple(K), depth_scale, depth_trunc, flip_aug
         self.zoe = ZoeDepthEngine(zoe_weights, zoe_cfg, dtype=dtype, device=device, target_hw=target_hw, precision=precision)
         self.precision = precision
-        self.pose = CyclePoseEngine(pose_weights, dtype=dtype, device=device, precision=precision)
+        self.pose = CyclePoseEngine(pose_weights, dtype=dtype, device=device, precision="accurate" if precision == "reference" else precision)
 
     def calibrate(self, H: int, W: int, group=None) -> Optional[dict]:
         """the depth engine's load-time calibration (ZoeDepthEngine.calibrate), made once by rank 0 and shared (share_calibration)"""

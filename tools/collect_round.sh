@@ -9,6 +9,10 @@ python3 $REPO/tools/collect_profiles.py $TAG > $OUT/collect.log 2>&1
 cd $REPO
 python3 bench.py --dtype bf16 --precision fast --single-mode --no-pmc-traffic > $OUT/${TAG}_bench_bf16_fast.json 2> $OUT/bf16.err
 python3 bench.py --dtype bf16 --precision accurate --single-mode --no-pmc-traffic > $OUT/bf16_accurate_refusal.txt 2>&1
+python3 bench.py --dtype bf16 --precision reference --no-pmc-traffic --no-slam-loop > $OUT/${TAG}_bench_bf16_reference.json 2> $OUT/bf16_ref.err
+# BASELINE config 5's frame size on one GPU (1280x1024 -> a 416x512 network input, 833 tokens), 16 frames per step
+python3 bench.py --height 1024 --width 1280 --batch 16 --no-pmc-traffic --no-slam-loop > $OUT/${TAG}_bench_1280x1024_n1.json 2> $OUT/cfg5.err
+python3 tools/probes/plan_call_times.py > $OUT/${TAG}_plan_call_times.txt 2>/dev/null
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 2 --warmup 1 --no-pmc-traffic 2> $OUT/torchrun.err | grep "^{" > $OUT/${TAG}_bench_torchrun_n1.json   # (RCCL prints a version banner on stdout)
 python3 tools/bench_kernels.py --nb 128 2>/dev/null > $OUT/${TAG}_bench_kernels.txt
 ls -la $OUT
