@@ -328,7 +328,10 @@ def main():
     slam = None
     if rank == 0 and world == 1 and not strong and not args.no_slam_loop and args.precision == "accurate":
         from bodyslam_amd.tsdf import TSDF
-        nloop = min(int(frames.shape[0]), 4 * B)
+        # whole batches only (a ragged last batch runs through the full-size plan and would be timed as B frames: --steps 2 gave 193 frames =
+        # 3 batches + 1 frame and read 250 frames/s where 256 frames read 318)
+        nloop = max(min(int(frames.shape[0]), 4 * B) // B, 1) * B
+        nloop = min(nloop, int(frames.shape[0]))
         pipe.run_slam_loop(frames[:min(B + 2, nloop)], vo=True, tsdf=TSDF(device=local_rank))       # plans, odometry buffers (not timed)
         torch.cuda.empty_cache()
         # three passes, each into a fresh map (reserved outside the timed region); `value` is the MEDIAN, every pass is listed: the
