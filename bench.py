@@ -409,7 +409,6 @@ def main():
             # ... and, new in round 4, the ABSOLUTE check: the chosen modes against a reference-precision engine (three 16-bit passes per
             # product, split-precision attention) built from the same weights on the device; `warning` is set when that exceeds 1e-4 m
             "accurate_modes": ({"class_modes": pipe.zoe.class_modes, "attn_mode": pipe.zoe.attn_mode, "neck_mode": pipe.zoe.neck_mode,
-                                "neck_corr": pipe.zoe.neck_corr,
                                 "l1_abs_vs_reference_m": (pipe.zoe.calibration or {}).get("l1_abs_vs_reference_m"),
                                 "warning": (pipe.zoe.calibration or {}).get("warning"),
                                 "calibration": pipe.zoe.calibration} if pipe.zoe.acc else None),

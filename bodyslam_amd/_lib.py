@@ -47,7 +47,6 @@ class GemmDesc(C.Structure):
         ("qkv_cls_last", C.c_int32), ("qkv_cls_rows", C.c_int32), ("qkv_patch_row0", C.c_int32), ("f8_wonly_from", C.c_int32), ("out_lo8_rows", C.c_int32),
         ("f8_skip_from", C.c_int32), ("bias2_row0", C.c_int32), ("bias2_group_rows", C.c_int32), ("out_planes_rows", C.c_int32),
         ("bias2", C.c_void_p),
-        ("f4_seg", C.c_int32), ("f4_a_scale_off", C.c_int32), ("f4_w_scale_off", C.c_int32), ("w_pitch", C.c_int32), ("out_f4", C.c_int32),
         ("qkv_lo_off", C.c_int32),
     ]
 
@@ -188,12 +187,12 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
                    shuffle=None, qkv=None, a_offset: int = 0, tile: int = 0, seg1: int = 0, out_split_off: int = 0,
                    res_split_off: int = 0, f8_seg: int = 0, f8_scales=(127, 127, 127, 127), out_f8=None, res_f8: bool = False,
                    f8_wonly_from: int = 0, out_lo8_rows: int = 0, f8_skip_from: int = 0, bias2=None, out_planes_rows: int = 0,
-                   f4=None, out_f4: bool = False) -> GemmDesc:
+                   ) -> GemmDesc:
     """Fill a bs_gemm_desc.  conv = (Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_h, pad_w) or None;
     out_group = (rows, stride, offset); shuffle = (s, Cout, Hgrid, Wgrid);
     qkv = (hidden, tokens, Sp, q_scale, out_k, out_vt[, cls_last[, cls_rows[, patch_row0[, lo_off]]]]); a_offset in elements;
     (lo_off > 0: out / out_k / out_vt are allocated twice over and the rounding residuals go lo_off elements behind the values)
-    bias2 = (fp32 [groups, N], row0, group_rows); f4 = (f4_seg, a_scale_off, w_scale_off, w_pitch) (see f4_weight / f4_conv_weight)."""
+    bias2 = (fp32 [groups, N], row0, group_rows)."""
     d = GemmDesc()
     d.A = A.data_ptr() + a_offset * A.element_size()
     d.W = W.data_ptr()
@@ -247,9 +246,6 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
     d.out_lo8_rows = out_lo8_rows
     d.f8_skip_from = f8_skip_from
     d.out_planes_rows = out_planes_rows
-    if f4 is not None:
-        d.f4_seg, d.f4_a_scale_off, d.f4_w_scale_off, d.w_pitch = f4
-    d.out_f4 = int(out_f4)
     if bias2 is not None:
         b2, row0, grows = bias2
         assert b2.dtype == torch.float32 and b2.shape[-1] == N
@@ -266,12 +262,10 @@ def _gemm_bytes(d) -> float:
     rows_in = float(d.M if not d.conv else d.M / max(d.stride * d.stride, 1))
     rows_f8 = rows_in if (d.conv or not d.f8_skip_from) else float(min(d.f8_skip_from, d.M))
     taps = d.KH * d.KW if d.conv else 1
-    a = rows_in * (d.Cin if d.conv else d.K) * 2 + rows_f8 * d.f8_seg + rows_in * d.f4_seg * (1.0 + 1.0 / 32)
-    w = float(d.N) * (d.K * 2 + taps * (d.f8_seg + d.f4_seg * (1.0 + 1.0 / 32)))
+    a = rows_in * (d.Cin if d.conv else d.K) * 2 + rows_f8 * d.f8_seg
+    w = float(d.N) * (d.K * 2 + taps * d.f8_seg)
     if d.out_dtype == F32:
         per_row = [4.0, 4.0, 4.0]
-    elif d.out_f4:              # F4 format: hi16 + two e2m1 planes + e4m3 residual plane + scale bytes
-        per_row = [4.0 + 1.0 / 32] * 3
     elif d.out_f8:              # (hi16 | hi8 | lo8): 4 B; without the lo8 plane 3 B; hi16 alone 2 B
         per_row = [4.0, 3.0, 2.0]
     else:
@@ -353,9 +347,8 @@ class Plan:
             # executed work in 16-bit-MFMA-equivalents: an FP8 correction stage covers 128 k in the time of 64
             # (tiles past f8_wonly_from run only the first FP8 half)
             # (tiles past f8_skip_from run none)
-            # (an FP4 stage covers 256 k in the time of 64: f4_seg bytes of e2m1 planes per row / tap count as f4_seg / 2)
             flops=2.0 * d.N * (d.M * d.K + (min(d.f8_skip_from, d.M) if d.f8_skip_from else d.M) * (d.KH * d.KW if d.conv else 1) * d.f8_seg
-                               / (4 if d.f8_wonly_from else 2) + d.M * (d.KH * d.KW if d.conv else 1) * d.f4_seg / 2.0),
+                               / (4 if d.f8_wonly_from else 2)),
             # algorithmic FLOPs exclude the extra passes of a split-precision product
             alg_flops=2.0 * d.M * d.N * (d.K / kw.get("precision_passes", 1)),
             # algorithmic HBM bytes: A once (16-bit values + the FP8 planes of the rows that run FP8 stages), W once, the output
@@ -501,140 +494,6 @@ F8_ACT_HI_EXP, F8_ACT_LO_EXP = 0, 11          # include/bodyslam_hip.h BS_F8_ACT
 
 
 # ---------------------------------------------------------------------------------------------
-# F4 format (include/bodyslam_hip.h): e2m1 correction planes with one E8M0 scale per 64 values
-# ---------------------------------------------------------------------------------------------
-_E2M1 = (0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0)
-
-
-def f4_pitch(C: int) -> int:
-    """16-bit elements between consecutive pixels / rows of an F4-format tensor with C channels (BS_F4_PITCH_ELEMS)"""
-    return 2 * C + 64
-
-
-def f4_quant(x: torch.Tensor):
-    """fp32 [..., K] (K % 64 == 0) -> (codes uint8 [..., K] (sign << 3 | e2m1 magnitude code), E8M0 bytes uint8 [..., K/64], the
-    dequantised values fp32).  Scale 2^(floor(log2 amax) - 2) per 64 values, round to nearest even, saturation at 6: what
-    v_cvt_scalef32_pk_fp4_f32 computes (tools/probes/mfma_f4_scale.hip)."""
-    x = x.detach().float().cpu()
-    sh = x.shape
-    xb = x.reshape(*sh[:-1], sh[-1] // 64, 64)
-    amax = xb.abs().amax(-1, keepdim=True)
-    e = ((amax.contiguous().view(torch.int32) >> 23) & 0xff) - 2
-    e = e.clamp(min=1)
-    scale = (e << 23).view(torch.float32)
-    v = (xb / scale).abs()
-    code = ((v > 0.25).to(torch.uint8) + (v >= 0.75).to(torch.uint8) + (v > 1.25).to(torch.uint8) + (v >= 1.75).to(torch.uint8)
-            + (v > 2.5).to(torch.uint8) + (v >= 3.5).to(torch.uint8) + (v > 5.0).to(torch.uint8))
-    mag = torch.tensor(_E2M1)[code.long()]
-    sign = torch.signbit(xb)
-    deq = torch.where(sign, -mag, mag) * scale
-    code = code | (sign.to(torch.uint8) << 3)
-    return code.reshape(sh), e.to(torch.uint8).reshape(*sh[:-1], sh[-1] // 64), deq.reshape(sh)
-
-
-def f4_pack_units(code: torch.Tensor) -> torch.Tensor:
-    """codes uint8 [..., K] (K % 256 == 0) -> bytes uint8 [..., K/2] in the chunk order of the F4 planes: inside every unit of 256
-    values, the halves of 64-value group g go to the 16-byte chunks g and g + 4; two values per byte, the even one in the low nibble"""
-    sh = code.shape
-    c = code.reshape(*sh[:-1], sh[-1] // 256, 4, 2, 16, 2)              # [unit][g][half][byte][nibble]
-    b = (c[..., 0] | (c[..., 1] << 4))                                   # [unit][g][half][16]
-    b = b.transpose(-3, -2)                                              # [unit][half][g][16]: chunk position = half * 4 + g
-    return b.reshape(*sh[:-1], sh[-1] // 2).contiguous()
-
-
-def f4_rows(x: torch.Tensor, dtype) -> torch.Tensor:
-    """fp32 [rows, C] (C % 256 == 0) -> F4-format rows as a `dtype`-typed tensor [rows, f4_pitch(C)]: what an F4 producer writes
-    (tests: the host statement of the format; the product's producers are the HIP kernels)."""
-    x = x.detach().float().cpu()
-    R, Cc = x.shape
-    assert Cc % 256 == 0
-    hi = x.to(dtype)
-    lo = x - hi.float()
-    ch, eh, _ = f4_quant(x)
-    cl, el, _ = f4_quant(lo)
-    lo8 = (lo * 2.0 ** F8_ACT_LO_EXP).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
-    row = torch.zeros(R, f4_pitch(Cc) * 2, dtype=torch.uint8)
-    row[:, :2 * Cc] = hi.contiguous().view(torch.uint8).view(R, -1)
-    row[:, 2 * Cc:2 * Cc + Cc // 2] = f4_pack_units(ch)
-    row[:, 2 * Cc + Cc // 2:3 * Cc] = f4_pack_units(cl)
-    row[:, 3 * Cc:4 * Cc] = lo8
-    row[:, 4 * Cc:4 * Cc + Cc // 64] = eh
-    row[:, 4 * Cc + Cc // 64:4 * Cc + Cc // 32] = el
-    return row.view(dtype)
-
-
-def f4_decode_rows(rows: torch.Tensor, C: int):
-    """F4-format rows (any leading shape, last dim f4_pitch(C) 16-bit elements) -> (value = hi16 + lo8 fp32 [..., C], dequantised
-    e2m1 hi plane, dequantised e2m1 lo plane) -- test helper"""
-    raw = rows.detach().cpu().contiguous()
-    lead = raw.shape[:-1]
-    b = raw.view(torch.uint8).reshape(-1, f4_pitch(C) * 2)
-    R = b.shape[0]
-    hi = b[:, :2 * C].contiguous().view(rows.dtype).float()
-    lo8 = b[:, 3 * C:4 * C].contiguous().view(torch.float8_e4m3fn).float() * 2.0 ** -F8_ACT_LO_EXP
-
-    def plane(pb, eb):
-        u = pb.reshape(R, C // 256, 2, 4, 16)                            # [unit][half][g][byte]
-        u = u.transpose(2, 3)                                            # [unit][g][half][byte]
-        codes = torch.stack([u & 15, u >> 4], -1).reshape(R, C)
-        mag = torch.tensor(_E2M1)[(codes & 7).long()]
-        val = torch.where((codes & 8) != 0, -mag, mag)
-        sc = (eb.to(torch.int32) << 23).view(torch.float32)              # [R, C/64]
-        return (val.reshape(R, C // 64, 64) * sc[:, :, None]).reshape(R, C)
-
-    h4 = plane(b[:, 2 * C:2 * C + C // 2], b[:, 4 * C:4 * C + C // 64])
-    l4 = plane(b[:, 2 * C + C // 2:3 * C], b[:, 4 * C + C // 64:4 * C + C // 32])
-    return (hi + lo8).reshape(*lead, C), h4.reshape(*lead, C), l4.reshape(*lead, C)
-
-
-def f4_weight(w: torch.Tensor, dtype):
-    """fp32 [N, K] (K % 256 == 0) -> (rows [N, pitch/2] `dtype`-typed, f4 = (f4_seg, a_scale_off, w_scale_off, w_pitch)) for bs_gemm's
-    FP4 correction segment: [W_hi16 x K | e2m1(W - W_hi16) | e2m1(W_hi16) | E8M0 bytes in stage order | pad]."""
-    w = w.detach().float().cpu()
-    N, K = w.shape
-    assert K % 256 == 0, K
-    hi = w.to(dtype)
-    lo = w - hi.float()
-    cl, el, _ = f4_quant(lo)
-    ch, eh, _ = f4_quant(hi.float())
-    sc_off = 3 * K
-    pitch = (sc_off + K // 32 + 15) // 16 * 16
-    row = torch.zeros(N, pitch, dtype=torch.uint8)
-    row[:, :2 * K] = hi.contiguous().view(torch.uint8).view(N, -1)
-    row[:, 2 * K:2 * K + K // 2] = f4_pack_units(cl)
-    row[:, 2 * K + K // 2:3 * K] = f4_pack_units(ch)
-    row[:, sc_off:sc_off + K // 64] = el
-    row[:, sc_off + K // 64:sc_off + K // 32] = eh
-    return row.view(dtype), (K, 4 * K, sc_off, pitch)
-
-
-def f4_conv_weight(w_ohwi: torch.Tensor, dtype):
-    """fp32 [O, kh, kw, I] (I % 256 == 0) -> the conv-mode counterpart of f4_weight: [W_hi16: chunk64, tap, 64][e2m1(W_lo): unit256, tap,
-    128 bytes][e2m1(W_hi16): unit256, tap, 128 bytes][E8M0: the same (plane, unit, tap) order, 4 bytes each]."""
-    w = w_ohwi.detach().float().cpu()
-    O, kh, kw, I = w.shape
-    assert I % 256 == 0, I
-    T = kh * kw
-    hi = w.to(dtype)
-    lo = w - hi.float()
-
-    def plane(t):
-        c, e, _ = f4_quant(t)                                            # [O, kh, kw, I], [O, kh, kw, I/64]
-        b = f4_pack_units(c).reshape(O, T, I // 256, 128).permute(0, 2, 1, 3).reshape(O, -1)       # [unit][tap][128]
-        s = e.reshape(O, T, I // 256, 4).permute(0, 2, 1, 3).reshape(O, -1)                          # [unit][tap][4]
-        return b, s
-
-    bl, sl = plane(lo)
-    bh, sh_ = plane(hi.float())
-    hi16 = conv_weight(hi).view(torch.uint8).view(O, -1)
-    sc_off = hi16.shape[1] + bl.shape[1] + bh.shape[1]                   # 3 * T * I
-    pitch = (sc_off + sl.shape[1] + sh_.shape[1] + 15) // 16 * 16
-    row = torch.zeros(O, pitch, dtype=torch.uint8)
-    row[:, :sc_off] = torch.cat([hi16, bl, bh], 1)
-    row[:, sc_off:sc_off + sl.shape[1] + sh_.shape[1]] = torch.cat([sl, sh_], 1)
-    return row.view(dtype), (I, 4 * I, sc_off, pitch)
-
-
 def conv_weight(w_ohwi: torch.Tensor) -> torch.Tensor:
     """[O, kh, kw, I] -> the K order bs_gemm's conv mode walks: [O][I/64 chunks][kh][kw][64] flattened to [O, kh*kw*I]."""
     O, kh, kw, I = w_ohwi.shape

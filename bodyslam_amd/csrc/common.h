@@ -49,7 +49,7 @@ int cu_count();                   // compute units of the device bs_init bound (
 // use of the same fp32 product is converted from the fp32-ROUNDED product (v_cvt_pk_f16_f32).  Where that fp32 value is an exact
 // 16-bit tie the two roundings pick different neighbours, so a (hi, lo) pair producer -- hi = round16(y), lo = y - hi -- stored the hi
 // of one and the residual of the other: the pair was off by a whole ulp of hi on 2^-13 of all elements, in every split format
-// (16-bit pairs, (hi16 | hi8 | lo8), F4).  That floor is 3 % of the single-precision error: invisible behind e4m3 correction planes,
+// (16-bit pairs, (hi16 | hi8 | lo8)).  That floor is 3 % of the single-precision error: invisible behind e4m3 correction planes,
 // dominant for the 22-bit pairs of the reference precision (9.6e-5 m on the outlier-channel weights).  (An opaque-asm operand in
 // from_f32 cures it too, but costs the 256x256 igemm instantiations their register allocation: 241 -> 256 VGPRs + scratch.)
 template <typename T> struct T16;
@@ -180,11 +180,6 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
-
-// F4-format pointwise producers (f4_pointwise.hip), reached through bs_cast_split / bs_relu_split / bs_resize_bilinear_nhwc
-int f4_cast(const float* x, void* out, int64_t rows, int C, int dtype, hipStream_t st);
-int f4_relu(const void* x, void* out, int64_t rows, int C, int dtype, hipStream_t st);
-int f4_resize(const void* x, void* out, int B, int Hin, int Win, int C, int Hout, int Wout, int align, int dtype, hipStream_t st);
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

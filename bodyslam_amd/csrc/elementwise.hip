@@ -874,7 +874,6 @@ extern "C" int bs_resize_bilinear_nhwc(const void* x, void* out, int32_t B, int3
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int split = (align_corners & 4) ? 2 : ((align_corners & 2) ? 1 : 0);   // bit 1: (hi | lo) 16-bit pairs; bit 2: (hi16 | hi8 | lo8)
     const int ac = align_corners & 1;
-    if (align_corners & 8) return f4_resize(x, out, B, Hin, Win, C, Hout, Wout, ac, dtype, st);     // bit 3: F4 format (pitch BS_F4_PITCH_ELEMS(C))
     BS_REQUIRE(split != 2 || C % 16 == 0, "bs_resize_bilinear_nhwc: the FP8 pair format needs C %% 16 == 0");
     return dtype == BS_F16 ? launch_resize<f16>(x, nullptr, out, B, Hin, Win, C, Hout, Wout, ac, st, split)
                            : launch_resize<bf16>(x, nullptr, out, B, Hin, Win, C, Hout, Wout, ac, st, split);
@@ -912,12 +911,10 @@ extern "C" int bs_cast_split(const float* x, void* out, int64_t rows, int32_t co
     BS_ENTRY("bs_cast_split");
     BS_REQUIRE(x && out && rows >= 0 && cols > 0 && cols % 4 == 0, "bs_cast_split: cols must be a multiple of 4");
     const int f8 = (out_dtype & 32) ? 1 : 0;          // bit 5: (hi16 | hi8 | lo8) instead of (hi | lo) 16-bit pairs
-    const int f4 = (out_dtype & 64) ? 1 : 0;          // bit 6: F4 format (rows of BS_F4_PITCH_ELEMS(cols) elements)
     out_dtype &= 15;
     BS_REQUIRE(out_dtype == BS_F16 || out_dtype == BS_BF16, "bs_cast_split: dtype");
     if (rows == 0) return BS_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (f4) return f4_cast(x, out, rows, cols, out_dtype, st);
     const int64_t n = rows * (cols / 4);
     const unsigned blocks = (unsigned)(cdiv64(n, 256) < 8192 ? cdiv64(n, 256) : 8192);
     if (out_dtype == BS_F16)
@@ -932,12 +929,10 @@ extern "C" int bs_relu_split(const void* x, void* out, int64_t rows, int32_t col
     BS_ENTRY("bs_relu_split");
     BS_REQUIRE(x && out && rows >= 0 && cols > 0 && cols % 8 == 0, "bs_relu_split: cols must be a multiple of 8");
     const int f8 = (dtype & 32) ? 1 : 0;              // bit 5: (hi16 | hi8 | lo8) rows
-    const int f4 = (dtype & 64) ? 1 : 0;              // bit 6: F4 format (rows of BS_F4_PITCH_ELEMS(cols) elements)
     dtype &= 15;
     BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_relu_split: dtype");
     if (rows == 0) return BS_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (f4) return f4_relu(x, out, rows, cols, dtype, st);
     const int64_t n = rows * (cols / 8);
     const unsigned blocks = (unsigned)(cdiv64(n, 256) < 16384 ? cdiv64(n, 256) : 16384);
     if (dtype == BS_F16)

@@ -13,10 +13,10 @@ namespace bs {
 #define BS_DECL_TILE(t, cm)                                                  \
     int igemm_launch_tile##t##_f16_cm##cm(const IgemmParams&, bool, hipStream_t); \
     int igemm_launch_tile##t##_bf16_cm##cm(const IgemmParams&, bool, hipStream_t);
-BS_DECL_TILE(1, 0) BS_DECL_TILE(1, 1) BS_DECL_TILE(1, 2)
-BS_DECL_TILE(2, 0) BS_DECL_TILE(2, 1) BS_DECL_TILE(2, 2)
+BS_DECL_TILE(1, 0) BS_DECL_TILE(1, 1)
+BS_DECL_TILE(2, 0) BS_DECL_TILE(2, 1)
 BS_DECL_TILE(3, 0) BS_DECL_TILE(3, 1)
-BS_DECL_TILE(9, 0) BS_DECL_TILE(9, 1) BS_DECL_TILE(9, 2)
+BS_DECL_TILE(9, 0) BS_DECL_TILE(9, 1)
 BS_DECL_TILE(10, 0) BS_DECL_TILE(11, 0)
 #undef BS_DECL_TILE
 
@@ -48,22 +48,19 @@ static int launch_tile(IgemmParams& p, int dtype, bool conv, int tile, hipStream
     tile_dims(tile, BM, BN);
     p.ntm = cdiv(p.M - p.m_begin, BM);
     p.ntn = cdiv(p.N, BN);
-    // correction mode of the instantiation: 2 = FP4 stages / F4 output, 1 = FP8 stages / (hi16 | hi8 | lo8) formats, 0 = plain
-    const int cm = (p.f4_stages > 0 || p.out_f4) ? 2 : ((p.f8_stages > 0 || p.out_f8 || p.res_f8) ? 1 : 0);
+    // correction mode of the instantiation: 1 = FP8 stages / (hi16 | hi8 | lo8) formats, 0 = plain
+    const int cm = (p.f8_stages > 0 || p.out_f8 || p.res_f8) ? 1 : 0;
     const bool h = dtype == BS_F16;
 #define BS_TILE(t, c) (h ? igemm_launch_tile##t##_f16_cm##c(p, conv, st) : igemm_launch_tile##t##_bf16_cm##c(p, conv, st))
     switch (tile * 10 + cm) {
         case 10: return BS_TILE(1, 0);
         case 11: return BS_TILE(1, 1);
-        case 12: return BS_TILE(1, 2);
         case 20: return BS_TILE(2, 0);
         case 21: return BS_TILE(2, 1);
-        case 22: return BS_TILE(2, 2);
         case 30: return BS_TILE(3, 0);
         case 31: return BS_TILE(3, 1);
         case 90: return BS_TILE(9, 0);
         case 91: return BS_TILE(9, 1);
-        case 92: return BS_TILE(9, 2);
         case 100: return BS_TILE(10, 0);
         case 110: return BS_TILE(11, 0);
 #undef BS_TILE
@@ -102,8 +99,7 @@ static int tail_lane(hipStream_t caller, hipStream_t& side, hipEvent_t& ev_fork,
 // on the same stream (same kernel family; IgemmParams::m_begin offsets its rows).
 static int dispatch(IgemmParams& p, int dtype, bool conv, int tile, hipStream_t st) {
     tile = auto_tile(p.M, p.N, p.K, tile, conv);
-    if ((p.f8_seg > 0 || p.out_f8 || p.res_f8 || p.f4_stages > 0 || p.out_f4) && (tile == 10 || tile == 11)) tile = 9;    // the FP8 / FP4 paths are built for the BK = 64 ring tiles
-    if ((p.f4_stages > 0 || p.out_f4) && tile == 3) tile = 2;      // (the scale fetch needs BN % 64 == 0)
+    if ((p.f8_seg > 0 || p.out_f8 || p.res_f8) && (tile == 10 || tile == 11)) tile = 9;    // the FP8 path is built for the BK = 64 ring tiles
     int BM, BN;
     tile_dims(tile, BM, BN);
     const int rem = p.M % BM, full = p.M / BM, ntn = cdiv(p.N, BN), cus = cu_count();
@@ -148,9 +144,8 @@ static int dispatch(IgemmParams& p, int dtype, bool conv, int tile, hipStream_t 
 
 extern "C" int bs_gemm_tile(const bs_gemm_desc* d) {
     if (!d) return BS_ERR_INVALID;
-    int tile = bs::auto_tile(d->M, d->N, d->K + d->f8_seg / 2 + d->f4_seg / 2, d->tile % 100, d->conv != 0);
-    if ((d->f4_seg > 0 || d->out_f4) && tile == 3) tile = 2;
-    return ((d->f8_seg > 0 || d->out_f8 || d->res_f8 || d->f4_seg > 0 || d->out_f4) && (tile == 10 || tile == 11)) ? 9 : tile;
+    const int tile = bs::auto_tile(d->M, d->N, d->K + d->f8_seg / 2, d->tile % 100, d->conv != 0);
+    return ((d->f8_seg > 0 || d->out_f8 || d->res_f8) && (tile == 10 || tile == 11)) ? 9 : tile;
 }
 
 extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
@@ -200,32 +195,6 @@ extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
             p.f8_stages = d->KH * d->KW * (d->f8_seg / 128);
             BS_REQUIRE((long long)d->N * p.K * 2 < 0x7FFFFFF0ll, "bs_gemm: weight matrix too large for one descriptor");
         }
-    }
-    if (d->f4_seg > 0) {
-        BS_REQUIRE(d->f4_seg % 256 == 0 && d->f8_seg == 0 && d->seg1 == 0 && !d->relu_a, "bs_gemm: f4_seg=%d must be a multiple of 256 and excludes f8_seg, seg1, relu_a", d->f4_seg);
-        BS_REQUIRE(d->f4_a_scale_off > 0 && d->f4_a_scale_off % 4 == 0 && d->f4_w_scale_off % 4 == 0, "bs_gemm: f4 scale offsets must be multiples of 4");
-        if (d->conv) {
-            BS_REQUIRE(d->f4_seg == d->Cin && (long long)d->lda * 2 >= d->f4_a_scale_off + d->Cin / 32, "bs_gemm: conv FP4 segment needs f4_seg = Cin (%% 256 == 0) and the scale bytes inside the pixel pitch");
-            p.Cin = d->Cin + d->Cin / 2;                      // 2C bytes of 16-bit values + C bytes of e2m1 planes per tap
-            p.K = d->KH * d->KW * p.Cin;
-            p.f4_stages = d->KH * d->KW * (d->f4_seg / 128);
-        } else {
-            BS_REQUIRE(d->f4_seg == d->K && (long long)d->lda * 2 >= d->f4_a_scale_off + d->K / 32, "bs_gemm: FP4 segment needs f4_seg = K (%% 256 == 0) and the scale bytes inside the row pitch");
-            p.K = d->K + d->f4_seg / 2;
-            p.f4_stages = d->f4_seg / 128;
-            p.a_bytes = (long long)d->M * d->lda * 2;
-        }
-        p.a_sc_off = d->f4_a_scale_off; p.w_sc_off = d->f4_w_scale_off; p.w_pitch = d->w_pitch;
-        BS_REQUIRE(d->w_pitch % 16 == 0 && d->w_pitch >= p.K * 2 && d->f4_w_scale_off >= p.K * 2 && d->f4_w_scale_off + p.f4_stages * 4 <= d->w_pitch,
-                   "bs_gemm: w_pitch=%d / f4_w_scale_off=%d do not hold %d stages of K and their scale bytes", d->w_pitch, d->f4_w_scale_off, p.f4_stages);
-        BS_REQUIRE((long long)d->N * d->w_pitch < 0x7FFFFFF0ll, "bs_gemm: weight matrix too large for one descriptor");
-    }
-    p.out_f4 = d->out_f4;
-    if (d->out_f4) {
-        const int Cc = d->out_mode == BS_OUT_SHUFFLE ? d->shuffle_cout : d->N;
-        BS_REQUIRE(d->out_dtype == d->dtype && d->out_mode != BS_OUT_QKV && d->out_split_off == Cc && Cc % 256 == 0 && !d->out_f8 &&
-                       (long long)d->ldo * 2 >= 4ll * Cc + Cc / 32 && d->ldo % 8 == 0 && d->N >= 128,
-                   "bs_gemm: out_f4 needs a plain / shuffle 16-bit output with out_split_off = channels (%% 256 == 0), ldo * 2 >= 4C + C/32");
     }
     p.relu_a = d->relu_a;
     p.cin1 = d->seg1;

@@ -78,15 +78,7 @@ struct IgemmParams {
     int out_planes_rows; // > 0: tiles that start at a row >= this store hi16 only (no FP8 plane; fc1 -> fc2 with f8_skip_from)
     const float* bias2;  // optional fp32 [groups, N] added to rows >= bias2_row0, group = (m - bias2_row0) / bias2_group_rows
     int bias2_row0, bias2_group_rows;
-    // ---- FP4 correction stages (CM == 2 instantiations; DESIGN.md "F4 format").  The last f4_stages 128-byte K stages of every A / W row hold
-    // 256 e2m1 values each, multiplied on the block-scaled MFMA at 4x the 16-bit rate with one E8M0 scale per (row, 64 values):
-    // the scale bytes of a stage (4 per row) are fetched beside it from a_sc_off / w_sc_off (bytes from the row / pixel start).
-    int f4_stages;
-    int a_sc_off, w_sc_off;
-    int w_pitch;         // bytes between consecutive W rows (0: K * 2)
-    int out_f4;          // != 0: the output row / pixel is written in the F4 activation format (store_f4)
     int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue, 8 = no tail split (host side), 128 = the Q / K epilogue without its stores, 256 = no fast Q / K patch-tile path,
-                  // 32 = no FP4 scale fetch, 64 = constant FP4 scales (no LDS scale reads)
 };
 
 template <typename T>
@@ -206,83 +198,6 @@ __device__ __forceinline__ void add_lo8(float* y, const void* base, int64_t row_
     y[0] += a[0] * sc; y[1] += a[1] * sc; y[2] += b[0] * sc; y[3] += b[1] * sc;
 }
 
-
-// F4 activation format of a pixel / row of C channels (C % 256 == 0), pitch >= 4C + C/32 bytes (DESIGN.md "F4 format"):
-//   [0, 2C)            round16(y)
-//   [2C, 2C + C/2)     e2m1(y / s_hi)           two values per byte, even channel in the low nibble
-//   [2C + C/2, 3C)     e2m1((y - round16(y)) / s_lo)
-//   [3C, 4C)           e4m3((y - round16(y)) * 2^BS_F8_ACT_LO_EXP)   (the value hi16 + lo8 for residual adds and pointwise consumers)
-//   [4C, 4C + C/64)    E8M0 exponent of s_hi per 64 channels;  [4C + C/64, 4C + C/32): of s_lo
-// s = 2^(floor(log2 amax) - 2) over the 64 channels (amax / s in [4, 8); e2m1 saturates at 6).  Inside each 128-byte unit of an
-// e2m1 plane (256 channels) the 16-byte chunk of channels [64g, 64g + 32) sits at chunk position g and that of [64g + 32, 64g + 64)
-// at position g + 4: a consumer lane's two MFMA operands (chunks fq and fq + 4 of the stage row) then share one scale byte.
-// This lane holds, of one row, the 2 x 8 channels  n64 + jp * 32 + fq * 8 + 0..7  (jp = 0, 1); the three other lanes of the row
-// (lane ^ 16, ^ 32, ^ 48) hold the rest of the 64-channel group.
-template <typename T>
-__device__ __forceinline__ void store_f4_row(void* base, int64_t pix_off, int n64, int C, int fq, const float (&y)[2][8]) {
-    typedef typename T16<T>::v8 v8;
-    typedef int i32x2 __attribute__((ext_vector_type(2)));
-    T* rowp = reinterpret_cast<T*>(base) + pix_off;
-    float r[2][8];
-    float mh = 0.0f, ml = 0.0f;
-#pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
-        v8 h;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            h[e] = T16<T>::from_f32(y[jp][e]);
-            r[jp][e] = y[jp][e] - T16<T>::to_f32(h[e]);
-            mh = fmaxf(mh, fabsf(y[jp][e]));
-            ml = fmaxf(ml, fabsf(r[jp][e]));
-        }
-        *reinterpret_cast<v8*>(rowp + n64 + jp * 32 + fq * 8) = h;
-    }
-    // (the maxima are non-negative floats: their bit patterns order like unsigned integers -- and hipcc drops an fmaxf of the two
-    // halves of a swap whose operands are one value, see the ISA; the integer form is kept)
-    auto group_max = [](float v) {
-        const unsigned u = __builtin_bit_cast(unsigned, v);
-        const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-        const unsigned w = a[0] > a[1] ? a[0] : a[1];
-        const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
-        return __builtin_bit_cast(float, b[0] > b[1] ? b[0] : b[1]);
-    };
-    mh = group_max(mh);
-    ml = group_max(ml);
-    int eh = (int)(__builtin_bit_cast(unsigned, mh) >> 23) - 2, el = (int)(__builtin_bit_cast(unsigned, ml) >> 23) - 2;
-    eh = eh < 1 ? 1 : eh;
-    el = el < 1 ? 1 : el;
-    const float sh = __builtin_bit_cast(float, (unsigned)eh << 23), sl = __builtin_bit_cast(float, (unsigned)el << 23);
-    char* bytes = reinterpret_cast<char*>(rowp);
-    const int u = n64 >> 8, g = (n64 >> 6) & 3;
-    const float s8 = __builtin_ldexpf(1.0f, BS_F8_ACT_LO_EXP);
-#pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
-        unsigned ph = 0, pl = 0;
-        ph = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ph, y[jp][0], y[jp][1], sh, 0);
-        ph = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ph, y[jp][2], y[jp][3], sh, 1);
-        ph = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ph, y[jp][4], y[jp][5], sh, 2);
-        ph = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(ph, y[jp][6], y[jp][7], sh, 3);
-        pl = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pl, r[jp][0], r[jp][1], sl, 0);
-        pl = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pl, r[jp][2], r[jp][3], sl, 1);
-        pl = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pl, r[jp][4], r[jp][5], sl, 2);
-        pl = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(pl, r[jp][6], r[jp][7], sl, 3);
-        const int pos = u * 128 + (g + 4 * jp) * 16 + fq * 4;
-        *reinterpret_cast<unsigned*>(bytes + 2 * C + pos) = ph;
-        *reinterpret_cast<unsigned*>(bytes + 2 * C + (C >> 1) + pos) = pl;
-        int l0 = 0, l1 = 0;
-        auto cl = [&](float v) { return fminf(fmaxf(v * s8, -448.0f), 448.0f); };
-        l0 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(r[jp][0]), cl(r[jp][1]), l0, false);
-        l0 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(r[jp][2]), cl(r[jp][3]), l0, true);
-        l1 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(r[jp][4]), cl(r[jp][5]), l1, false);
-        l1 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(r[jp][6]), cl(r[jp][7]), l1, true);
-        *reinterpret_cast<i32x2*>(bytes + 3 * C + n64 + jp * 32 + fq * 8) = i32x2{l0, l1};
-    }
-    if (fq == 0) {
-        bytes[4 * C + (n64 >> 6)] = (char)eh;
-        bytes[4 * C + (C >> 6) + (n64 >> 6)] = (char)el;
-    }
-}
-
 constexpr int NW_CHECK(int a, int b) { return a * b; }
 
 template <int N>
@@ -294,16 +209,15 @@ __device__ __forceinline__ void wait_vmcnt() {
 // of the LDS ring: STAGES-1 tiles are in flight (global_load_lds) while one is multiplied.
 // MODE: 0 plain GEMM rows, 1 implicit conv, 2 implicit conv with ReLU applied to A on load
 // CM (correction mode): 1 = the instantiation that knows the FP8 correction stages and the (hi16 | hi8 | lo8) epilogue formats
-// (accurate mode), 2 = the FP4 correction stages with per-block scales and the F4 activation format (which also reads / writes the
-// FP8-era formats where a consumer needs them); 0 = the plain instantiation, which carries none of that code, so fast-mode
-// launches are not affected by its register pressure.
+// (accurate mode); 0 = the plain instantiation, which carries none of that code, so fast-mode launches are not affected by its
+// register pressure.  (CM = 2, FP4 correction stages with per-block scales, existed in round 3: +1.4 % frames/s for 1.5x the depth error --
+// removed in round 4, profiles/r03_fp4_corrections.txt keeps the measurements.)
 template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int MODE, bool PP = false, int CM = 0>
 __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins exist in the device pass only; the host pass needs just the stub
     constexpr bool CONV = MODE != 0;
     constexpr bool RELU_A = MODE == 2;
-    constexpr bool F8 = CM != 0;          // the FP8-era epilogue formats are known to both correction instantiations
-    constexpr bool F4 = CM == 2;
+    constexpr bool F8 = CM != 0;
     constexpr int NT = WM * WN * 64;
     constexpr int ROWB = BK * 2;        // bytes per LDS row
     constexpr int LPR = ROWB / 16;      // lanes (16-byte chunks) per row: 8 (BK 64) or 4 (BK 32)
@@ -357,7 +271,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
     a_left = a_left > 0x7FFFFFF0ll ? 0x7FFFFFF0ll : a_left;
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T*>(reinterpret_cast<const T*>(p.A)) + a_base_el, 0, (int)a_left, 0x00020000);
-    const int w_pitch = (F4 && p.w_pitch) ? p.w_pitch : p.K * 2;     // bytes per W row (F4: the scale bytes follow the planes)
+    const int w_pitch = p.K * 2;     // bytes per W row
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(p.W), 0, (int)((long long)p.N * w_pitch), 0x00020000);
 
@@ -399,41 +313,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
         n = n < p.N ? n : p.N - 1;
         w_off[j] = (unsigned)(n * w_pitch + cs16);
     }
-    // F4: the row whose 4 scale bytes this lane fetches beside every FP4 stage (one 4-byte LDS-DMA per row): waves [0, BM/64) take the
-    // A rows wave * 64 + lane, the next BN/64 waves the W rows
-    constexpr int SC_A = BM * 4, SC_STAGE = (BM + BN) * 4;      // LDS bytes of the scale region of one stage
-    unsigned sc_off = 0, sc_mask = 1u;
-    int sc_role = 0;                                            // 1 = A rows, 2 = W rows, 0 = none
-    if constexpr (F4) {
-        if (wave < BM / 64) {
-            sc_role = 1;
-            int m = m0 + wave * 64 + lane;
-            m = m < p.M ? m : p.M - 1;
-            if (CONV) {
-                const int hw = p.Hout * p.Wout;
-                const int b = m / hw, rem = m - b * hw;
-                const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-                const int iy0 = oy * p.stride - p.pad_h, ix0 = ox * p.stride - p.pad_w;
-                sc_off = (unsigned)((((b - img0) * p.Hin + iy0) * p.Win + ix0) * p.lda * 2);
-                unsigned mk = 0;
-                for (int ky = 0; ky < p.KH; ++ky)
-                    for (int kx = 0; kx < p.KW; ++kx) {
-                        const bool ok = (unsigned)(iy0 + ky) < (unsigned)p.Hin && (unsigned)(ix0 + kx) < (unsigned)p.Win;
-                        mk |= (ok ? 1u : 0u) << (ky * p.KW + kx);
-                    }
-                sc_mask = mk;
-            } else {
-                sc_off = (unsigned)((m - m0) * p.lda * 2);
-            }
-        } else if (wave < BM / 64 + BN / 64) {
-            sc_role = 2;
-            const int r = (wave - BM / 64) * 64 + lane;
-            int n = tn * BN + ((r & ~31) | ((r & 12) << 1) | ((r & 16) >> 2) | (r & 3));
-            n = n < p.N ? n : p.N - 1;
-            sc_off = (unsigned)(n * w_pitch);
-        }
-    }
-
     // running state of the NEXT tile to stage.  W side: s_k (byte offset along K, runs straight through).  A side: the
     // K axis is up to two SEGMENTS that both walk the same rows of A -- segment 0 with seg0 bytes per tap, then segment 1
     // with seg1 bytes per tap (taps restart).  This is how split-precision products are expressed without a second
@@ -447,28 +326,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
     const int seg0 = (CONV ? p.Cin : p.K - p.cin1) * 2, seg1 = p.cin1 * 2;
     const int ntaps = CONV ? p.KH * p.KW : 1;
     int s_tap = 0, s_kx = 0, s_tapoff = 0, s_cb = 0, s_sub = 0, s_k = 0, s_seg = seg0;
-    int s_idx = 0;                                              // (F4) index of the next stage to issue
-    const int f4_first = F4 ? p.K / BK - p.f4_stages : 0x7fffffff;       // first FP4 stage
-    const int f4_cb0 = F4 ? seg0 - (CONV ? p.f4_stages / ntaps : p.f4_stages) * 128 : 0;   // byte offset of the FP4 planes in the row / pixel vector
 
     auto stage = [&](int buf) {
         char* sa = smem + buf * STAGE;
         char* sb = sa + A_BYTES;
         const int s_c0 = s_cb + s_sub;
-        if constexpr (F4) {
-            if (s_idx >= f4_first && sc_role && !(p.ablate & 32)) {     // this stage's scale bytes: unit u of the FP4 part of the row -> 4 bytes at sc_off + 4u
-                char* ss = smem + STAGES * STAGE + buf * SC_STAGE;
-                if (sc_role == 1) {
-                    const unsigned vo = (!CONV || ((sc_mask >> s_tap) & 1u)) ? sc_off + (unsigned)s_tapoff : OOB;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(ss + wave * 256), 4, vo,
-                                                             p.a_sc_off + ((s_cb - f4_cb0) >> 7) * 4, 0, 0);
-                } else {
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(ss + SC_A + (wave - BM / 64) * 256), 4,
-                                                             sc_off, p.w_sc_off + (s_idx - f4_first) * 4, 0, 0);
-                }
-            }
-            ++s_idx;
-        }
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             unsigned vo;
@@ -522,7 +384,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
     const int a_base = (wm * TM + frow) * ROWB, b_base = (wn * TN + frow) * ROWB;
 
     const int nt_all = p.K / BK;
-    const int ncorr = F4 ? p.f4_stages : p.f8_stages;
+    const int ncorr = p.f8_stages;
     const int nt16 = F8 ? nt_all - ncorr : nt_all;   // stages multiplied as 16-bit data; the rest are FP8 / FP4 correction stages (BK = 64 tiles)
     // the second half of the FP8 stages (A_lo8 W_hi8) is dropped for tiles past f8_wonly_from: they stop after the first half
     const bool wonly = F8 && p.f8_wonly_from != 0 && (p.f8_wonly_from < 0 || m0 >= p.f8_wonly_from);
@@ -538,7 +400,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
         // made the register allocator spill the accumulators)
         auto iteration = [&](int t, auto f8_tag) {
             constexpr bool F8S = decltype(f8_tag)::value == 1;
-            constexpr bool F4S = decltype(f8_tag)::value == 2;
             // my own DMA for tile t has landed once at most (tiles issued after t) x GL operations are outstanding
             const int younger = nt - 1 - t;
             if (STAGES >= 4 && younger >= 2) wait_vmcnt<(STAGES >= 4 ? 2 : 0) * GL>();
@@ -549,40 +410,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
             if (t + STAGES - 1 < nt && !(p.ablate & 1)) stage(sbuf);
             const char* sa = smem + cbuf * STAGE;
             const char* sb = sa + A_BYTES;
-            if constexpr (F4S) {
-                // ---- FP4 correction stage: the 128-byte LDS rows hold 256 e2m1 values; a lane supplies the same two 16-byte chunks
-                // (fq and 4 + fq) as two operands of 32 values each.  Both chunks belong to ONE 64-value scale group (the producers
-                // place the two halves of channel group g at chunk positions g and g + 4), so the lane reads a single scale byte per
-                // row: byte fq of the row's 4-byte scale word.
-                typedef int i32x4 __attribute__((ext_vector_type(4)));
-                typedef int i32x8 __attribute__((ext_vector_type(8)));
-                const unsigned char* ssa = reinterpret_cast<const unsigned char*>(smem + STAGES * STAGE + cbuf * SC_STAGE);
-                const unsigned char* ssb = ssa + SC_A;
-                auto ld4 = [&](const char* base, int ko) {
-                    const i32x4 v = *reinterpret_cast<const i32x4*>(base + ko);
-                    return __builtin_shufflevector(v, v, 0, 1, 2, 3, 0, 1, 2, 3);     // (the upper half is not read for e2m1 operands)
-                };
-                i32x8 b4[FN][2];
-                int sbj[FN];
-#pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    b4[j][0] = ld4(sb + b_base + j * 16 * ROWB, koff0);
-                    b4[j][1] = ld4(sb + b_base + j * 16 * ROWB, koff1);
-                    sbj[j] = (p.ablate & 64) ? 127 : ssb[(wn * TN + j * 16 + frow) * 4 + fq];
-                }
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < FM; ++i) {
-                    const i32x8 a0 = ld4(sa + a_base + i * 16 * ROWB, koff0), a1 = ld4(sa + a_base + i * 16 * ROWB, koff1);
-                    const int sai = (p.ablate & 64) ? 127 : ssa[(wm * TM + i * 16 + frow) * 4 + fq];
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b4[j][0], a0, acc[i][j], 4, 4, 0, sbj[j], 0, sai);
-                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b4[j][1], a1, acc[i][j], 4, 4, 0, sbj[j], 0, sai);
-                    }
-                }
-                __builtin_amdgcn_s_setprio(0);
-            } else if constexpr (F8S) {
+            if constexpr (F8S) {
                 // ---- FP8 correction stage: the 128-byte LDS rows hold 128 e4m3 values.  A lane supplies 32 of them per
                 // row: the same two 16-byte chunks (fq and 4 + fq) the 16-bit path reads -- A and W use the same
                 // permutation of k, so the product is unchanged -- as one 8-register operand of the 16x16x128 MFMA.
@@ -634,7 +462,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
         int t = 0;
         for (; t < nt16; ++t) iteration(t, std::integral_constant<int, 0>{});
         if constexpr (F8 && BK == 64 && !RELU_A) {
-            for (; t < nt; ++t) iteration(t, std::integral_constant<int, F4 ? 2 : 1>{});
+            for (; t < nt; ++t) iteration(t, std::integral_constant<int, 1>{});
         }
     } else {
         // ---- ping-pong schedule (BK = 32, 4-stage ring, 8 waves = two groups of four, one wave of each group per
@@ -861,14 +689,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                                 }
                             }
                         }
-                    }
-                }
-                if constexpr (F4 && FN == 4) {
-                    if (p.out_f4) {     // PLAIN / SHUFFLE, the wave's 64 columns are one 64-channel group of a pixel vector (host-checked)
-                        const int nloc = p.out_mode == BS_OUT_SHUFFLE ? n0j[0] % p.shuffle_cout : n0j[0];
-                        const int n64 = nloc - fq * 8;
-                        store_f4_row<T>(p.out, roff + coff[0] - nloc, n64, p.split_off, fq, yall);
-                        continue;
                     }
                 }
 #pragma unroll
@@ -1168,7 +988,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
 
 template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int MODE, bool PP = false, int CM = 0>
 inline int launch_mode(const IgemmParams& p, hipStream_t st) {
-    constexpr int smem = STAGES * (BM + BN) * BK * 2 + (CM == 2 ? STAGES * (BM + BN) * 4 : 0);
+    constexpr int smem = STAGES * (BM + BN) * BK * 2;
     dim3 grid(p.ntm * p.ntn), block(WM * WN * 64);
     auto k = igemm_kernel<T, BM, BN, WM, WN, BK, STAGES, MODE, PP, CM>;
     static bool attr = false;
@@ -1190,7 +1010,6 @@ inline int launch_cm(const IgemmParams& p, bool conv, hipStream_t st) {
         return launch_mode<T, BM, BN, WM, WN, BK, STAGES, 1, PP, 0>(p, st);
     } else {
         static_assert(BK == 64 && !PP, "the correction instantiations are built for the BK = 64 ring tiles");
-        static_assert(CM != 2 || ((BM + BN) / 64 <= WM * WN && BN % 64 == 0), "FP4: one wave per 64 rows fetches the scale bytes");
         if (!conv) return launch_mode<T, BM, BN, WM, WN, BK, STAGES, 0, PP, CM>(p, st);
         return launch_mode<T, BM, BN, WM, WN, BK, STAGES, 1, PP, CM>(p, st);
     }

@@ -127,11 +127,8 @@ AUTO_SAVING_MS = {"fc1": 8.7, "fc2": 8.0, "qkv": 3.7, "o": 1.8, "neck": 2.0, "at
 AUTO_NECK_CANDIDATES = (NECK_RELHEAD_WONLY, "full")
 AUTO_TOL_NECK_ABS_M = 5.0e-5
 ACCURATE_NECK_MODE = "full"
-# Operand format of the neck's two correction products: "f8" = e4m3 planes with one scale per tensor (2 pass-equivalents, neck error
-# ~7e-6 m on its own), "f4" = e2m1 planes with one E8M0 scale per 64 channels at 4x the 16-bit MFMA rate (1.5 pass-equivalents,
-# 2.5-4e-5 m: tools/probes/neck_precision_study.py, profiles/r03_neck_precision_study.txt).  "f4" needs every K / Cin of the neck to
-# be whole 256-value units and the grouped token layout (512-wide network inputs); the engine falls back to "f8" otherwise.
-ACCURATE_NECK_CORR = "f8"
+# (Round 3 also had neck_corr="f4": e2m1 correction planes with E8M0 block scales on the FP4 MFMA -- +1.4 % frames/s for 1.5x the depth error,
+# profiles/r03_fp4_corrections.txt.  It never paid and was removed in round 4; the correction products run on the block-scaled FP8 MFMA.)
 
 ZOED_NK = ZoeConfig()
 ZOED_N = ZoeConfig(head_names=("nyu",))
@@ -182,8 +179,7 @@ class ZoeDepthEngine:
 
     def __init__(self, weights: Dict[str, torch.Tensor], cfg: Optional[ZoeConfig] = None, dtype=torch.float16,
                  device: int = 0, target_hw: Tuple[int, int] = (384, 512), precision: str = "fast",
-                 class_modes: Optional[Dict[str, str]] = None, neck_mode: Optional[str] = None, neck_corr: Optional[str] = None,
-                 attn_mode: Optional[str] = None):
+                 class_modes: Optional[Dict[str, str]] = None, neck_mode: Optional[str] = None, attn_mode: Optional[str] = None):
         """precision: "fast" = one MFMA pass per product (16-bit operands, fp32 accumulate);
         "accurate" = split-precision products (Numerics): every GEMM / conv operand of the backbone, the DPT neck,
         the relative head and the projector path of the bins head is a (hi, lo) pair of 16-bit values; one launch evaluates
@@ -240,13 +236,6 @@ class ZoeDepthEngine:
         c_ = self.cfg
         # the neck switches to the (hi16 | hi8 | lo8) operand format as a whole: every K / Cin on it must be whole 128-byte FP8 stages
         self.neck_f8 = self.acc and self.neck_mode != "pairs" and all(v % 128 == 0 for v in (c_.hidden, c_.fusion, c_.fusion // 2, *c_.neck_hidden))
-        # ... and to the F4 format (e2m1 correction planes, 1.5 pass-equivalents) where every K / Cin but the relative head's
-        # 128-channel map is whole 256-value units
-        self.neck_corr = neck_corr or os.environ.get("BS_NECK_CORR") or ACCURATE_NECK_CORR
-        assert self.neck_corr in ("f8", "f4"), self.neck_corr
-        self.neck_f4 = (self.neck_f8 and self.neck_corr == "f4" and self.neck_mode == "full" and
-                        all(v % 256 == 0 for v in (c_.hidden, c_.fusion, *c_.neck_hidden)))
-        self.f4s: Dict[str, Tuple[int, int, int, int]] = {}
         with torch.no_grad():
             self._ingest(weights)
 
@@ -308,7 +297,6 @@ class ZoeDepthEngine:
             assert self.class_modes[k] in ("full", "wcls", "wmean"), f"class {k} was ingested as {self.class_modes[k]!r}: not switchable"
         self.class_modes.update(modes)
         if neck_mode is not None:
-            assert not self.neck_f4 or neck_mode == "full"
             assert (neck_mode == "pairs") == (self.neck_mode == "pairs"), "the neck's operand format is fixed at ingestion"
             self.neck_mode = neck_mode
         if attn_mode is not None:
@@ -361,7 +349,7 @@ class ZoeDepthEngine:
         frames_u8 = frames_u8[:1].contiguous()
         H, W = int(frames_u8.shape[1]), int(frames_u8.shape[2])
         switchable = [k for k in BACKBONE_CLASSES if self.class_modes[k] in ("full", "wcls", "wmean")] if self.auto_classes else []
-        neck_cands = ["full"] if (self.neck_f4 or not self.neck_f8 or not self.auto_classes or (neck_candidates is None and (not reference or self._sd is None))) \
+        neck_cands = ["full"] if (not self.neck_f8 or not self.auto_classes or (neck_candidates is None and (not reference or self._sd is None))) \
             else list(neck_candidates or AUTO_NECK_CANDIDATES)
         nh_, nw_ = net_size(H, W, self.target_hw)
         corr_ok = nw_ // self.cfg.patch == 32 and (nh_ // self.cfg.patch) % 2 == 0 and nh_ // self.cfg.patch <= 40
@@ -464,16 +452,10 @@ class ZoeDepthEngine:
         return w8.to(self.dev)
 
     def _wp(self, key: str, t: torch.Tensor) -> torch.Tensor:
-        """plain neck / head weight: FP4- or FP8-correction packing when the whole neck runs that format, else three 16-bit passes"""
-        if self.neck_f4 and t.shape[1] % 256 == 0:
-            w4, self.f4s[key] = L.f4_weight(t, self.dtype)
-            return w4.to(self.dev)
+        """plain neck / head weight: FP8-correction packing when the whole neck runs that format, else three 16-bit passes"""
         return self._w8(key, t) if self.neck_f8 else self._wn(t)
 
     def _wc(self, key: str, t: torch.Tensor) -> torch.Tensor:
-        if self.neck_f4 and t.shape[1] % 256 == 0:
-            w4, self.f4s[key] = L.f4_conv_weight(t.permute(0, 2, 3, 1), self.dtype)
-            return w4.to(self.dev)
         return self._w8conv(key, t) if self.neck_f8 else self._wn_conv(t)
 
     def _wn(self, t: torch.Tensor) -> torch.Tensor:
@@ -803,13 +785,9 @@ class _ZoePlan:
         q, k, vt = z16((2 if corr else 1) * NB, c.heads, Sp, 64), z16((2 if corr else 1) * NB, c.heads, Sp, 64), z16((2 if corr else 1) * NB, c.heads, 64, Sp)
         ao = z16(MT, Hd * m2)
         hid = z16(MT, c.intermediate * m2)
-        nf4 = eng.neck_f4 and grouped                       # F4 neck format (e2m1 correction planes); needs the grouped token rows
-        if eng.neck_f4 and not grouped:
-            raise L.BodySlamHipError("neck_corr='f4' needs a 512-wide network input (grouped token rows); build the engine with neck_corr='f8'")
-
         def PE(C):
             """elements between consecutive pixels / rows of a neck activation with C channels"""
-            return L.f4_pitch(C) if (nf4 and C % 256 == 0) else C * m2
+            return C * m2
 
         taps16 = [z16(MT, PE(Hd)) for _ in c.taps]
 
@@ -908,28 +886,22 @@ class _ZoePlan:
             P.mark(f"layer{l + 1}", x, TOK)
             if (l + 1) in c.taps:
                 if acc:
-                    P.add(f"tap{ti}", "bs_cast_split", x, taps16[ti], MT, Hd, L.dt(xn) | (64 if nf4 else (32 if eng.neck_f8 else 0)))
+                    P.add(f"tap{ti}", "bs_cast_split", x, taps16[ti], MT, Hd, L.dt(xn) | (32 if eng.neck_f8 else 0))
                 else:
                     P.add(f"tap{ti}", "bs_cast", x, taps16[ti], x.numel(), L.dt(xn))
                 ti += 1
 
-        # ---- neck helpers.  Activations are NHWC 16-bit; in accurate mode every tensor is a pair per pixel: the F4 format (hi16, two
-        # e2m1 planes with block scales, an e4m3 residual plane; pitch PE(C)) with the correction products on the FP4 MFMA, or
+        # ---- neck helpers.  Activations are NHWC 16-bit; in accurate mode every tensor is a pair per pixel:
         # (hi16 | hi8 | lo8) with them on the FP8 MFMA (nf8: the whole neck, when every K is whole FP8 stages), or (hi | lo) 16-bit
         # pairs with the product as three K segments.
         nf8 = eng.neck_f8
-        f4s = eng.f4s
         NSP = (32 if nf8 else 16) if acc else 0          # format flag of the pointwise producers whose output stays (hi16 | hi8 | lo8)
         RZ = 1 | ((4 if nf8 else 2) if acc else 0)       # bs_resize_bilinear_nhwc flag: align_corners | pair format
-        RZ4 = 1 | 8                                      # ... F4 maps
         F8O = (L.F8_ACT_HI_EXP, L.F8_ACT_LO_EXP)
 
-        def is4(C):
-            return nf4 and C % 256 == 0
-
         def mfmt(C):
-            """format code of a marked neck tensor (tests/test_zoedepth_gpu.py to_nchw): 3 = F4, 2 = (hi16 | hi8 | lo8), 1 = (hi | lo)"""
-            return (3 if is4(C) else (2 if nf8 else 1)) if acc else 0
+            """format code of a marked neck tensor (tests/test_zoedepth_gpu.py to_nchw): 2 = (hi16 | hi8 | lo8), 1 = (hi | lo)"""
+            return (2 if nf8 else 1) if acc else 0
 
         def f8kw(wkey):
             sb0, sb1 = f8s[wkey]
@@ -944,8 +916,6 @@ class _ZoePlan:
             """output-format arguments of a neck GEMM writing Cout channels per row / pixel"""
             if not (acc and out_pairs):
                 return dict(ldo=Cout, out_split_off=0)
-            if is4(Cout) and out8:
-                return dict(ldo=PE(Cout), out_split_off=Cout, out_f4=True)
             return dict(ldo=Cout * m2, out_split_off=Cout, out_f8=F8O if (nf8 and out8) else None)
 
         def nplain(name, A, wkey, out, M, N, K, shuffle=None, out_pairs=True, **kw):
@@ -958,9 +928,7 @@ class _ZoePlan:
                 ok["out_split_off"] = kw.pop("split_off")
             if not out_pairs:
                 ok = dict(ldo=ok["ldo"], out_split_off=0)
-            if acc and wkey in f4s:
-                P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=kw.pop("lda", PE(K)), f4=f4s[wkey], shuffle=shuffle, precision_passes=1, **ok, **kw)
-            elif acc and wkey in f8s:
+            if acc and wkey in f8s:
                 P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=kw.pop("lda", 2 * K), f8_seg=2 * K, shuffle=shuffle,
                        precision_passes=1, **ok, **f8kw(wkey), **kw)
             else:
@@ -969,15 +937,11 @@ class _ZoePlan:
                        shuffle=shuffle, precision_passes=np3, **ok, **kw)
 
         def nconv(name, A, wkey, out, hh, ww, Ci, Co, stride=1, **kw):
-            use4 = acc and wkey in f4s
             use8 = acc and wkey in f8s
-            g_ = L.conv_geom(hh, ww, Ci if (use8 or use4) else Ci * m2, 3, 3, stride, 1)
+            g_ = L.conv_geom(hh, ww, Ci if use8 else Ci * m2, 3, 3, stride, 1)
             ho, wo = g_[3], g_[4]
             has_res = "res" in kw
-            if use4:
-                P.gemm(name, A, w[wkey], out, M=NB * ho * wo, N=Co, K=9 * Ci, lda=PE(Ci), conv=g_, f4=f4s[wkey],
-                       ldr=PE(Co) if has_res else 0, res_f8=has_res, precision_passes=1, **okw(Co, True, True), **kw)
-            elif use8:
+            if use8:
                 P.gemm(name, A, w[wkey], out, M=NB * ho * wo, N=Co, K=9 * Ci, lda=2 * Ci, conv=g_, f8_seg=2 * Ci, ldo=2 * Co,
                        ldr=2 * Co if has_res else 0, res_f8=has_res, out_split_off=Co, out_f8=F8O, precision_passes=1, **f8kw(wkey), **kw)
             else:
@@ -1105,7 +1069,7 @@ class _ZoePlan:
             y = e16(NB, hh, ww, PE(Fc))
             if acc:
                 xr = e16(NB, hh, ww, PE(Fc))
-                P.add(name + ".relu", "bs_relu_split", xin, xr, NB * hh * ww, Fc, L.dt(xr) | (64 if is4(Fc) else (32 if nf8 else 0)))
+                P.add(name + ".relu", "bs_relu_split", xin, xr, NB * hh * ww, Fc, L.dt(xr) | (32 if nf8 else 0))
                 nconv(name + ".c1", xr, name + ".c1.w", t, hh, ww, Fc, Fc, bias=w[name + ".c1.b"], act=L.ACT_RELU)
                 free(xr)
             else:
@@ -1137,7 +1101,7 @@ class _ZoePlan:
             nplain(f"fu{li}.proj", cur, f"fu{li}.proj.w", lowp, NB * fh * fw, Fc, Fc, bias=w[f"fu{li}.proj.b"])
             free(cur)
             fused = e16(NB, 2 * fh, 2 * fw, PE(Fc))
-            P.add(f"fu{li}.up", "bs_resize_bilinear_nhwc", lowp, fused, NB, fh, fw, Fc, 2 * fh, 2 * fw, RZ4 if is4(Fc) else RZ, L.dt(fused))
+            P.add(f"fu{li}.up", "bs_resize_bilinear_nhwc", lowp, fused, NB, fh, fw, Fc, 2 * fh, 2 * fw, RZ, L.dt(fused))
             free(lowp)
             P.mark(f"fused{li}", fused, ("nhwc", NB, 2 * fh, 2 * fw, Fc, mfmt(Fc)))
             fused_list.append((fused, 2 * fh, 2 * fw))

@@ -138,32 +138,10 @@ typedef struct bs_gemm_desc {
     const float* bias2;            /* optional fp32 [groups, N], added like the bias: y = acc + bias[n] + bias2[group, n].  The backbone
                                     * uses it for the rank-1 part of the weight-rounding error of a single-pass product:
                                     * A dW^T ~ 1 (mean_tokens(A) dW^T) per image (Numerics); excludes bias_group_rows */
-    /* FP4 correction segment: the same two correction products as f8_seg, on e2m1 operands with OCP-MX style block scales at 4x
-     * the 16-bit MFMA rate (1.5 instead of 2 pass-equivalents).  f4_seg > 0 (a multiple of 256; excludes f8_seg and seg1): every
-     * A row (conv: every pixel vector, f4_seg = Cin) continues, after its K (Cin) 16-bit values, with f4_seg / 2 bytes of e2m1(a / s_hi)
-     * and f4_seg / 2 bytes of e2m1((a - round16(a)) / s_lo); W rows with e2m1 of (W - round16(W)) and of round16(W) in that order
-     * (conv: [plane][256-channel unit][tap][128 bytes], bodyslam_amd/_lib.py f4_conv_weight()).  Scales: one E8M0 byte per
-     * 64 values, at byte f4_a_scale_off of the A row / pixel vector (all s_hi bytes, then all s_lo bytes) and at byte
-     * f4_w_scale_off of the W row in stage order; W rows are w_pitch bytes apart.  Inside every 128-byte unit (256 values) the
-     * halves of 64-value group g sit at 16-byte chunks g and g + 4 (BS_F4 format below).
-     * out_f4 != 0 (out_split_off = channels C, C % 256 == 0, ldo * 2 >= 4C + C/32): the output row / pixel is written in the F4
-     * activation format. */
-    int32_t f4_seg;
-    int32_t f4_a_scale_off;
-    int32_t f4_w_scale_off;
-    int32_t w_pitch;
-    int32_t out_f4;
     int32_t qkv_lo_off;            /* BS_OUT_QKV, > 0: the rounding residuals of Q, K and V^T (y - round16(y) as a second 16-bit value, unscaled)
                                     * are stored too, this many ELEMENTS behind the respective value in out / out2 / out3 (each tensor
                                     * allocated twice over): the operands of bs_attention_table_corr */
 } bs_gemm_desc;
-/* The F4 activation format (pixel / row of C channels, C % 256 == 0, pitch >= 4C + C/32 bytes; BS_F4_PITCH_ELEMS(C) 16-bit elements
- * keeps 128-byte alignment):  [0, 2C) round16(y) | [2C, 2.5C) e2m1(y / s_hi), even channel in the low nibble | [2.5C, 3C)
- * e2m1((y - round16(y)) / s_lo) | [3C, 4C) e4m3((y - round16(y)) * 2^BS_F8_ACT_LO_EXP) | [4C, 4C + C/64) E8M0(s_hi) per 64 channels |
- * [4C + C/64, 4C + C/32) E8M0(s_lo);  s = 2^(floor(log2 amax) - 2).  Inside each 128-byte unit of an e2m1 plane (256 channels)
- * channels [64g, 64g + 32) occupy 16-byte chunk g and channels [64g + 32, 64g + 64) chunk g + 4.  Producers: bs_gemm (out_f4),
- * bs_cast_split / bs_relu_split / bs_resize_bilinear_nhwc with their F4 flags. */
-#define BS_F4_PITCH_ELEMS(C) (2 * (C) + 64)
 int bs_gemm(const bs_gemm_desc* d, void* stream);
 /* the tile variant bs_gemm will pick for this descriptor (1: 128x128, 2: 128x64, 3: 128x32, 4: 256x128) */
 int bs_gemm_tile(const bs_gemm_desc* d);

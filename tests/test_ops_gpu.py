@@ -321,129 +321,6 @@ def test_rank1_bias(L, G, N, K):
     assert torch.equal(out, again)                                # the four k-quarters of a block meet in LDS in wave order: a fixed sum
 
 
-def _f4_emulated_gemm(L_, x, w, dtype):
-    """what bs_gemm's FP4 path computes, in fp64: A16 W16^T + dq(e2m1 A_hi) dq(e2m1 W_lo)^T + dq(e2m1 A_lo) dq(e2m1 W_hi)^T"""
-    x, w = x.cpu().float(), w.cpu().float()
-    a16, w16 = x.to(dtype).float(), w.to(dtype).float()
-    _, _, ah = L_.f4_quant(x)
-    _, _, al = L_.f4_quant(x - a16)
-    _, _, wl = L_.f4_quant(w - w16)
-    _, _, wh = L_.f4_quant(w16)
-    return a16.double() @ w16.double().t() + ah.double() @ wl.double().t() + al.double() @ wh.double().t()
-
-
-@pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("tile", [0, 9, 1, 2])
-def test_f4_correction_gemm(L, dtype, tile):
-    """Split-precision product with the correction products on e2m1 operands and per-64 block scales (4x MFMA rate): A rows in the F4
-    format (host statement f4_rows), W = f4_weight.  The kernel must reproduce the emulated sum to fp32 accumulation accuracy
-    (plumbing: planes, chunk order, scale bytes) and land well below the single-pass error against the exact product."""
-    M, N, K = 700, 512, 512
-    x = rnd(M, K, seed=1).cpu() * (0.25 + 4 * torch.rand(M, 1, generator=torch.Generator().manual_seed(5)))      # rows of different magnitude
-    w = rnd(N, K, seed=2, scale=1 / math.sqrt(K)).cpu()
-    A4 = L.f4_rows(x, dtype).to(dev())
-    W4, f4 = L.f4_weight(w, dtype)
-    W4 = W4.to(dev())
-    out = torch.empty(M, N, device=dev())
-    L.gemm(A4, W4, out, M=M, N=N, K=K, lda=L.f4_pitch(K), f4=f4, tile=tile)
-    emu = _f4_emulated_gemm(L, x, w, dtype)
-    ref = x.double() @ w.double().t()
-    e_emu = (out.cpu().double() - emu).abs().max().item()
-    err = (out.cpu().double() - ref).abs().max().item()
-    single = torch.empty(M, N, device=dev())
-    L.gemm(A4, w.to(dtype).to(dev()), single, M=M, N=N, K=K, lda=L.f4_pitch(K), tile=tile)
-    err1 = (single.cpu().double() - ref).abs().max().item()
-    report(f"f4 correction gemm {dtype} tile{tile}: vs emulation {e_emu:.2e}, vs exact {err:.2e}, single-pass {err1:.2e}")
-    assert e_emu < 2e-5 * max(1.0, ref.abs().max().item())
-    assert err < 0.4 * err1
-    if tile == 2:
-        return
-    # epilogue writing the F4 format: decode and compare with the host statement of the format
-    o4 = torch.zeros(M, L.f4_pitch(N), device=dev(), dtype=dtype)
-    L.gemm(A4, W4, o4, M=M, N=N, K=K, lda=L.f4_pitch(K), f4=f4, ldo=L.f4_pitch(N), out_split_off=N, out_f4=True, tile=tile)
-    val, h4, l4 = L.f4_decode_rows(o4, N)
-    y = out.cpu()
-    assert torch.equal(o4[:, :N].float().cpu(), y.to(dtype).float())
-    assert ((val - y).abs() <= y.abs() * (2.0 ** -15 if dtype == torch.float16 else 2.0 ** -12) + 2.0 ** -20).all()
-    _, eh, dq = L.f4_quant(y)
-    _, el, dql = L.f4_quant(y - y.to(dtype).float())
-    raw = o4.cpu().contiguous().view(torch.uint8).view(M, -1)
-    assert torch.equal(raw[:, 4 * N:4 * N + N // 64], eh) and torch.equal(raw[:, 4 * N + N // 64:4 * N + N // 32], el)
-    assert torch.equal(h4, dq) and torch.equal(l4, dql)
-
-
-@pytest.mark.parametrize("tile", [0, 9, 1])
-def test_f4_correction_conv(L, tile):
-    """3x3 conv with the FP4 correction stages: NHWC pixels in the F4 format, weights f4_conv_weight, a residual in the same format,
-    output re-emitted in it; against the emulated sum and the exact conv."""
-    dtype = torch.float16
-    B, H, Wd, C, Co = 2, 20, 24, 256, 256
-    x = rnd(B, H, Wd, C, seed=1).cpu()
-    w = rnd(Co, C, 3, 3, seed=2, scale=1 / math.sqrt(9 * C)).cpu()
-    res = rnd(B, H, Wd, Co, seed=3).cpu()
-    x4 = L.f4_rows(x.view(-1, C), dtype).view(B, H, Wd, -1).to(dev())
-    r4 = L.f4_rows(res.view(-1, Co), dtype).view(B, H, Wd, -1).to(dev())
-    W4, f4 = L.f4_conv_weight(w.permute(0, 2, 3, 1), dtype)
-    W4 = W4.to(dev())
-    g = L.conv_geom(H, Wd, C, 3, 3, 1, 1)
-    out = torch.zeros(B, H, Wd, L.f4_pitch(Co), device=dev(), dtype=dtype)
-    L.gemm(x4, W4, out, M=B * H * Wd, N=Co, K=9 * C, lda=L.f4_pitch(C), conv=g, f4=f4, res=r4, ldr=L.f4_pitch(Co), res_f8=True,
-           ldo=L.f4_pitch(Co), out_split_off=Co, out_f4=True, tile=tile)
-    rv = L.f4_decode_rows(r4, Co)[0].double()
-    cv = lambda a_, w_: F.conv2d(a_.double().permute(0, 3, 1, 2), w_.double(), padding=1).permute(0, 2, 3, 1)
-    a16, w16 = x.to(dtype).float(), w.to(dtype).float()
-    q = lambda t, dim: L.f4_quant(t.movedim(dim, -1))[2].movedim(-1, dim)
-    emu = cv(a16, w16) + cv(q(x, 3), q(w - w16, 1)) + cv(q(x - a16, 3), q(w16, 1)) + rv
-    ref = cv(x, w) + rv
-    val = L.f4_decode_rows(out, Co)[0].double()
-    e_emu = (val - emu).abs().max().item()
-    err = (val - ref).abs().max().item()
-    single = torch.empty(B, H, Wd, Co, device=dev())
-    L.gemm(x.to(dtype).to(dev()), L.conv_weight(w.permute(0, 2, 3, 1)).to(dtype).to(dev()), single, M=B * H * Wd, N=Co, K=9 * C, lda=C,
-           conv=L.conv_geom(H, Wd, C, 3, 3, 1, 1), tile=tile)
-    err1 = (single.cpu().double() - (ref - rv)).abs().max().item()
-    report(f"f4 correction conv tile{tile}: vs emulation {e_emu:.2e}, vs exact {err:.2e}, single-pass {err1:.2e}")
-    assert e_emu < 1e-4 and err < 0.4 * err1
-
-
-def _f4_used_bytes(rows, C):
-    """the bytes of F4 rows that the format defines (the tail of the pitch is padding)"""
-    raw = rows.cpu().contiguous().view(torch.uint8).view(-1, rows.shape[-1] * 2)
-    return raw[:, :4 * C + C // 32]
-
-
-@pytest.mark.parametrize("dtype", DT)
-def test_f4_pointwise_producers(L, dtype):
-    """bs_cast_split | 64, bs_relu_split | 64, bs_resize_bilinear_nhwc | 8: the F4 producers against the host statement of the format"""
-    lib = L.load_library()
-    R, C = 300, 512
-    x = rnd(R, C, seed=4) * (0.1 + 3 * torch.rand(R, 1, device=dev()))
-    out = torch.zeros(R, L.f4_pitch(C), device=dev(), dtype=dtype)
-    assert lib.bs_cast_split(L.p(x), L.p(out), R, C, L.dt(out) | 64, L.stream_ptr()) == 0
-    want = L.f4_rows(x.cpu(), dtype)
-    assert torch.equal(_f4_used_bytes(out, C), _f4_used_bytes(want, C))
-    # ReLU: rectified value (hi16 + lo8), re-encoded
-    ro = torch.zeros_like(out)
-    assert lib.bs_relu_split(L.p(out), L.p(ro), R, C, L.dt(out) | 64, L.stream_ptr()) == 0
-    val = L.f4_decode_rows(out, C)[0]
-    rv = torch.where(out[:, :C].float().cpu() > 0, val, torch.zeros_like(val))
-    assert torch.equal(_f4_used_bytes(ro, C), _f4_used_bytes(L.f4_rows(rv, dtype), C))
-    # resize x2, align_corners: against torch on the decoded values
-    B, H, W, Cc = 2, 6, 8, 256
-    xm = rnd(B, H, W, Cc, seed=6)
-    xin = L.f4_rows(xm.cpu().view(-1, Cc), dtype).view(B, H, W, -1).to(dev())
-    o = torch.zeros(B, 2 * H, 2 * W, L.f4_pitch(Cc), device=dev(), dtype=dtype)
-    assert lib.bs_resize_bilinear_nhwc(L.p(xin), L.p(o), B, H, W, Cc, 2 * H, 2 * W, 1 | 8, L.dt(o), L.stream_ptr()) == 0
-    vin = L.f4_decode_rows(xin, Cc)[0]
-    ref = F.interpolate(vin.permute(0, 3, 1, 2).double(), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
-    got, h4, _ = L.f4_decode_rows(o, Cc)
-    # (the stored value hi16 + lo8 carries ~15 bits in fp16, ~12 in bf16)
-    assert ((got.double() - ref).abs() <= ref.abs() * (2.0 ** -14 if dtype == torch.float16 else 2.0 ** -11) + 1e-6).all()
-    # the e2m1 plane is the quantisation of the value the kernel computed (its hi16 + lo8 statement is within 2^-15 of it)
-    _, _, dq = L.f4_quant(got)
-    assert ((h4 - dq).abs() > 0).float().mean().item() < 2e-3
-
-
 def to_f8_pairs(x, dtype):
     """fp32 [..., C] -> [..., 2C] `dtype`-typed rows of (hi16 | hi8 | lo8) -- the torch statement of the operand format."""
     import bodyslam_amd._lib as L_
