@@ -434,8 +434,10 @@ class ZoeDepthEngine:
         report.update(class_modes={**{k: self.class_modes[k] for k in BACKBONE_CLASSES}, **chosen}, neck_mode=neck, attn_mode=attn,
                       l1_total_vs_full_m=total, l1_abs_vs_reference_m=l1_abs)
         if l1_abs is not None and l1_abs > TOLERANCE_M:
-            report["warning"] = (f"depth L1 of the calibration frame against the reference-precision engine is {l1_abs:.2e} m with every "
-                                 f"correction on: above the {TOLERANCE_M:.0e} m tolerance for these weights")
+            fixed = [k for k in BACKBONE_CLASSES if k not in switchable]
+            report["warning"] = (f"depth L1 of the calibration frame against the reference-precision engine is {l1_abs:.2e} m with every calibrated "
+                                 f"choice at its most accurate: above the {TOLERANCE_M:.0e} m tolerance for these weights"
+                                 + (f" (modes fixed by the caller, not calibrated: {({k: self.class_modes[k] for k in fixed})})" if fixed else ""))
             warnings.warn("ZoeDepthEngine.calibrate: " + report["warning"])
         elif truth is None:
             report["note"] = "no absolute reference (the engine holds no source weights): l1_total_vs_full_m is relative to the best mode only"
