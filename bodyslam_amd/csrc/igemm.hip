@@ -205,6 +205,10 @@ extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
     BS_REQUIRE(d->out_split_off == 0 || (d->out_mode != BS_OUT_QKV && d->out_dtype == d->dtype), "bs_gemm: split output needs a plain / shuffle 16-bit output");
     BS_REQUIRE(d->res_split_off == 0 || (d->res && d->res_dtype == d->dtype), "bs_gemm: split residual must be 16-bit");
     p.ablate = d->tile >= 100 ? d->tile / 100 : 0;
+    {
+        static const int strip_env = getenv("BS_GEMM_STRIP") ? atoi(getenv("BS_GEMM_STRIP")) : 0;
+        p.strip = d->conv ? 0 : strip_env;
+    }
     BS_REQUIRE(!d->relu_a || d->conv, "bs_gemm: relu_a is only built for conv mode");
     p.bias = d->bias; p.bias_group_rows = d->bias_group_rows; p.act = d->act; p.scale = d->scale;
     p.res = d->res; p.res2 = d->res2; p.res_dtype = d->res_dtype; p.ldr = d->ldr;

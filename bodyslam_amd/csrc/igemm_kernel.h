@@ -78,6 +78,7 @@ struct IgemmParams {
     int out_planes_rows; // > 0: tiles that start at a row >= this store hi16 only (no FP8 plane; fc1 -> fc2 with f8_skip_from)
     const float* bias2;  // optional fp32 [groups, N] added to rows >= bias2_row0, group = (m - bias2_row0) / bias2_group_rows
     int bias2_row0, bias2_group_rows;
+    int strip;    // work id -> tile order: 0 = row-major (N fastest over the whole width), w > 0 = strips of w N-tiles
     int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue, 8 = no tail split (host side), 128 = the Q / K epilogue without its stores, 256 = no fast Q / K patch-tile path,
 };
 
@@ -243,7 +244,16 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + loc;
-    const int tm = wg / p.ntn, tn = wg - tm * p.ntn;
+    int tm, tn;
+    if (p.strip > 0) {       // column strips of p.strip N-tiles, M fastest across strips: a strip's W tiles stay in the XCD's L2 while A streams through
+        const int per = p.ntm * p.strip, s = wg / per, r = wg - s * per;
+        const int wl = p.ntn - s * p.strip < p.strip ? p.ntn - s * p.strip : p.strip;
+        tm = r / wl;
+        tn = s * p.strip + (r - tm * wl);
+    } else {
+        tm = wg / p.ntn;
+        tn = wg - tm * p.ntn;
+    }
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

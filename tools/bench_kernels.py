@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--tiles", default="1,9,10", help="tile ids (igemm.hip); + 100 x ablation bits for diagnostics, e.g. 409 = tile 9 without epilogue")
     ap.add_argument("--only", default="")
+    ap.add_argument("--variants", default="wcls,wmean,wmean-compactA", help="f8 shapes: which class modes to run")
     a = ap.parse_args()
     L.init(0)
     dev = torch.device("cuda:0")
@@ -86,7 +87,7 @@ def main():
                 k2, vt2 = torch.zeros_like(out), torch.zeros(NB, 16, 64, Sp, device=dev, dtype=dt)
                 kw.update(qkv=(1024, 769, Sp, 0.18, k2, vt2, True, NB, 256))
             b2 = torch.randn(NB, N_, device=dev)
-            for variant in ("wcls", "wmean", "wmean-compactA"):       # 1.5 passes / one pass + per-image bias2 on the patch tiles (the default)
+            for variant in [v for v in ("wcls", "wmean", "wmean-compactA") if v in a.variants.split(",")]:       # 1.5 passes / one pass + per-image bias2 on the patch tiles (the default)
                 kv = dict(kw)
                 if variant == "wmean-compactA":      # timing experiment only: rows of K 16-bit values, no room for the planes
                     kv.update(lda=K_)
