@@ -79,7 +79,7 @@ struct IgemmParams {
     const float* bias2;  // optional fp32 [groups, N] added to rows >= bias2_row0, group = (m - bias2_row0) / bias2_group_rows
     int bias2_row0, bias2_group_rows;
     int strip;    // work id -> tile order: 0 = row-major (N fastest over the whole width), w > 0 = strips of w N-tiles
-    int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue, 8 = no tail split (host side), 128 = the Q / K epilogue without its stores, 256 = no fast Q / K patch-tile path,
+    int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue, 8 = no tail split (host side), 128 = the Q / K epilogue without its stores, 256 = no fast Q / K patch-tile path, 512 = no fast V^T patch-tile path,
 };
 
 template <typename T>
@@ -554,6 +554,16 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
     // row i; the activation is selected once, outside the fragment loops.  Only the V third of the fused QKV projection
     // still goes through LDS: it is written TRANSPOSED (V^T [B,nh,64,Sp]), consecutive lanes taking consecutive tokens.
     //   lane: m = m0 + wm*TM + i*16 + (lane & 15),  n = tn*BN + wn*TN + (j>>1)*32 + (lane >> 4)*8 + (j&1)*4 + 0..3
+    // (The lane id afresh: the thread id and what derives from it need not live through the main loop, which runs at 245-252 of 256
+    // registers, for the epilogue's sake.)
+    // Each epilogue form reads it again at its top (BS_FRESH_LANE, two instructions the compiler may not merge): merged into one value
+    // it is spilled to scratch right behind the main loop and reloaded per form.
+#define BS_FRESH_LANE                                                                                                       \
+    int lane;                                                                                                               \
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));                             \
+    const int frow = lane & 15, fq = lane >> 4;                                                                             \
+    (void)frow; (void)fq;
+    {
     const int n_wave = tn * BN + wn * TN;
     const bool v_tile = (p.out_mode == BS_OUT_QKV) && (tn * BN >= 2 * p.qkv_hidden);
     if (p.ablate & 4) {
@@ -574,6 +584,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
     if (!v_tile) {
         auto epi = [&](auto act_tag) {
             constexpr int ACT = decltype(act_tag)::value;
+            BS_FRESH_LANE
             f32x4 bj[FN], sj[FN];
             int n0j[FN];
             int64_t coff[FN];        // column part of the store offset (elements)
@@ -734,7 +745,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
             // o_proj / fc2: x += scale * (acc + bias), fp32 in place.  The generic loop reads the residual where it needs it and the
             // kernel has no register to spare for the compiler to hoist those loads: every fragment pair waited out a full memory
             // latency (220 us of a 500 us o_proj launch).  Here the loads run DEPTH pairs ahead of their use.
-            constexpr int NP = FM * (FN / 2), DEPTH = 4;
+            BS_FRESH_LANE
+            constexpr int NP = FM * (FN / 2), DEPTH = 8;
             const float* resp = reinterpret_cast<const float*>(p.res);
             float* outp = reinterpret_cast<float*>(p.out);
             f32x4 bj[FN], sj[FN];
@@ -780,6 +792,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
             if (plain_full && p.act == BS_ACT_GELU && !p.res && p.out_f8 && !p.scale && p.split_off == p.N && p.N % 8 == 0) {
                 // fc1: gelu(acc + bias) as (hi16 | hi8 | lo8) rows; VALU-bound (a third of the launch): no scale multiply, and past
                 // out_lo8_rows no lo8 plane
+                BS_FRESH_LANE
                 const bool lo = !(p.out_lo8_rows > 0 && m0 >= p.out_lo8_rows);
                 const bool planes = !(p.out_planes_rows > 0 && m0 >= p.out_planes_rows);
                 f32x4 bj[FN];
@@ -821,6 +834,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
             // Q / K tile of the QKV product (a 256-column tile lies inside one of the three): (acc + bias) * scale as 16-bit rows of
             // [image, head, position, 64].  The generic loop re-derives the part, the column offset and the store shape per fragment
             // pair; at K = 1024 that epilogue was 47 % of the launch (920 -> 816 us).
+            BS_FRESH_LANE
             const int part = (tn * BN) / p.qkv_hidden;                      // 0 = Q, 1 = K (V tiles take the transposing path below)
             T* dst = reinterpret_cast<T*>(part == 1 ? p.out2 : p.out);
             const float qs = part == 0 ? p.q_scale : 1.0f;
@@ -940,6 +954,78 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
         T* vt = reinterpret_cast<T*>(p.out3);
         const int nh = p.qkv_hidden >> 6;
         __syncthreads();  // every wave is done reading the main-loop LDS
+        if constexpr (PASS_R == 64 && TN == 64) {
+            // Patch tiles of the grouped layout (round 4): a 64-row pass is 64 consecutive tokens of ONE image and the wave's 64 columns
+            // are ONE head, so V^T gets, per d, 128 contiguous bytes.  fp32 rows to LDS, then a lane takes 8 consecutive tokens of one d: eight ds_read_b32, one 16-byte store -- an
+            // instruction writes 8 full 128-byte lines.  (The general form below loads its bias per column inside the loop and stores
+            // 2 bytes per lane: 128 serialised load -> read -> store round trips per wave, 3x the time of a Q / K tile; PMC study,
+            // profiles/r04_gemm_experiments.txt (6).)  LDS swizzle f(r): 16-byte group g of row r sits at g ^ f(r); conflict-free for the
+            // b128 writes (16 rows x one group) and for the b32 reads (8 token octets x 8 d).
+            const int tpi = p.qkv_tokens - 1;
+            const bool fastv = p.qkv_cls_rows > 0 && m0 >= p.qkv_patch_row0 && m0 + BM <= p.M && !b2_rows && !(p.qkv_sp & 7) && tpi % 64 == 0 &&
+                               (m0 - p.qkv_patch_row0) % 64 == 0 && !(p.ablate & (128 | 512));
+            if (fastv) {
+                BS_FRESH_LANE
+                const int tg = lane & 7, dl = lane >> 3;
+                float bd[8];        // bias of this lane's eight d (d = 8 it + dl)
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int n = n_wave + it * 8 + dl;
+                    bd[it] = p.bias ? p.bias[n] : 0.f;
+                    if (g2 >= 0) bd[it] += p.bias2[(int64_t)g2 * p.N + n];
+                }
+                // Byte address of (row r, 16-byte group g) in the wave's region: r * 256 + ((g ^ f(r)) << 4), f(r) = 2 (r >> 3) ^ h(r & 7),
+                // h(k) = {0, 1, 4, 5, 8, 9, 12, 13}[k].  Row and group bits do not overlap, so the swizzle is ONE xor of a lane base with a
+                // compile-time constant (the row's multiple of 16 or 8 and the fragment / column indices are unrolled).
+                auto hk = [](int k) { return ((k & 6) << 1) | (k & 1); };
+                char* scb = reinterpret_cast<char*>(sc);
+                // write side: r = 16 i' + frow, g = 8 (j >> 1) + 2 fq + (j & 1)
+                const int wbase = frow * 256 + (((fq << 1) ^ ((frow >> 3) << 1) ^ hk(frow & 7)) << 4);
+                // read side: r = 8 tg + k, g = 2 it + (dl >> 2), word dl & 3
+                const int rbase = tg * 2048 + ((((dl >> 2) ^ (tg << 1)) << 4) | ((dl & 3) << 2));
+                const int head = (n_wave - 2 * p.qkv_hidden) >> 6;
+                for (int ps = 0; ps < PASSES; ++ps) {
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+                        if ((i * 16) / PASS_R == ps) {
+                            const int i4 = i & (PASS_R / 16 - 1);
+#pragma unroll
+                            for (int j = 0; j < FN; ++j) {
+                                const int c = ((j >> 1) * 8 + (j & 1)) ^ (((i4 * 2) & 7) << 1);
+                                *reinterpret_cast<f32x4*>(scb + (wbase ^ (c << 4)) + i4 * 16 * 256) = acc[i][j];
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const int mp = m0 + wm * TM + ps * PASS_R - p.qkv_patch_row0;
+                    const int ob = mp / tpi, otok = mp - ob * tpi + tg * 8;
+                    T* vrow = vt + (((int64_t)ob * nh + head) * 64) * p.qkv_sp + otok;
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int d = it * 8 + dl;
+                        float y[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            y[k] = *reinterpret_cast<const float*>(scb + (rbase ^ (((it * 2) ^ hk(k)) << 4)) + k * 256) + bd[it];
+                        typename T16<T>::v8 vh;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) vh[k] = T16<T>::from_f32(y[k]);
+                        *reinterpret_cast<typename T16<T>::v8*>(vrow + (int64_t)d * p.qkv_sp) = vh;
+                        if (p.qkv_lo_off) {
+                            typename T16<T>::v8 vl;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) vl[k] = T16<T>::from_f32(y[k] - T16<T>::to_f32(vh[k]));
+                            *reinterpret_cast<typename T16<T>::v8*>(vrow + (int64_t)d * p.qkv_sp + p.qkv_lo_off) = vl;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();   // the next pass overwrites this wave's region
+                }
+                return;
+            }
+        }
+        BS_FRESH_LANE
         for (int ps = 0; ps < PASSES; ++ps) {
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
@@ -993,6 +1079,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
             __builtin_amdgcn_wave_barrier();   // the next pass overwrites this wave's region
         }
     }
+    }
+#undef BS_FRESH_LANE
 #endif
 }
 

@@ -16,6 +16,7 @@ pl.run()
 torch.cuda.synchronize()
 st = torch.cuda.current_stream().cuda_stream
 rows = []
+gi = []
 for i, (fn, args) in enumerate(pl.calls):
     if isinstance(fn, str):
         continue
@@ -28,6 +29,8 @@ for i, (fn, args) in enumerate(pl.calls):
     e1.record()
     torch.cuda.synchronize()
     rows.append((fn.__name__, pl.names[i], e0.elapsed_time(e1) * 100.0))       # us per launch
+    if i in pl.gemm_info:
+        gi.append((pl.names[i], e0.elapsed_time(e1) * 100.0, pl.gemm_info[i]))
 tot = sum(r[2] for r in rows)
 by = collections.defaultdict(lambda: [0, 0.0])
 for fn, name, us in rows:
@@ -40,3 +43,8 @@ for k, (n, us) in sorted(by.items(), key=lambda kv: -kv[1][1]):
 print("largest non-GEMM launches:")
 for fn, name, us in sorted([r for r in rows if r[0] != "bs_gemm"], key=lambda r: -r[2])[:25]:
     print(f"  {fn:28s} {name:28s} {us:9.1f} us")
+print("GEMM launches outside the 24 backbone layers (name, us, tile, algorithmic / executed TFLOP/s):")
+neck = [g for g in gi if not (g[0].startswith("l") and g[0][1].isdigit())]
+for name, us, info in sorted(neck, key=lambda g: -g[1]):
+    print(f"  {name:18s} {us:9.1f} us  tile {info.get('tile')!s:4s} conv {int(bool(info.get('conv')))}  {info.get('alg_flops', 0) / us / 1e6:8.1f} TFLOP/s algorithmic {info.get('flops', 0) / us / 1e6:8.1f} executed")
+print(f"  total {sum(g[1] for g in neck) / 1e3:.2f} ms in {len(neck)} launches; backbone {sum(g[1] for g in gi if g not in neck) / 1e3:.2f} ms in {len(gi) - len(neck)}")
