@@ -79,7 +79,7 @@ struct IgemmParams {
     const float* bias2;  // optional fp32 [groups, N] added to rows >= bias2_row0, group = (m - bias2_row0) / bias2_group_rows
     int bias2_row0, bias2_group_rows;
     int strip;    // work id -> tile order: 0 = row-major (N fastest over the whole width), w > 0 = strips of w N-tiles
-    int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue, 8 = no tail split (host side), 128 = the Q / K epilogue without its stores, 256 = no fast Q / K patch-tile path, 512 = no fast V^T patch-tile path,
+    int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue, 8 = no tail split (host side), 128 = the Q / K epilogue without its stores, 256 = no fast Q / K patch-tile path, 512 = no fast V^T patch-tile path, 1024 = no LDS-staged full-line stores (Q / K tiles),
 };
 
 template <typename T>
@@ -802,6 +802,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                     bj[j] = *reinterpret_cast<const f32x4*>(p.bias + n0);
                     if (g2 >= 0) bj[j] += *reinterpret_cast<const f32x4*>(p.bias2 + (int64_t)g2 * p.N + n0);
                 }
+                // (Full-line stores through LDS, as the Q / K tiles below, LOSE here: 930 vs 920 us -- the GELU arithmetic between the stores
+                // hides their latency, a staged burst behind a block barrier does not.)
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     const int m = m0 + wm * TM + i * 16 + frow;
@@ -869,6 +871,52 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                 int otok = mp0 - ob0 * Tk;
                 const unsigned img_bytes = (unsigned)(nhead * p.qkv_sp) * 128u;
                 unsigned roff = (unsigned)ob0 * img_bytes + (unsigned)otok * 128u;
+                if constexpr (TM == 128 && TN == 64 && LDS_BYTES >= WM * WN * 16384) {
+                    // Whole tiles (round 4): the 16-bit rows go through the wave's 16 KiB of the (now idle) main-loop LDS so that an
+                    // instruction stores 8 FULL 128-byte lines, consecutive lanes consecutive 16-byte pieces.  In the register layout an
+                    // instruction covers 16 rows x 64 bytes with lane = row: 64 separate requests, 3x the time per tile when the stores sit
+                    // between compute phases (tools/probes/store_pattern.hip: +4.8 us against +1.6 us per 256 x 256 tile).
+                    if (m0 + BM <= p.M && Tk % 8 == 0 && (m0 - p.qkv_patch_row0) % 8 == 0 && !(p.ablate & 1024)) {
+                        __syncthreads();          // every wave is done reading the main-loop LDS
+                        char* sw = smem + wave * 16384;
+                        const int s7 = frow & 7;
+                        const int wb0 = frow * 128 + ((fq ^ s7) << 4), wb1 = frow * 128 + (((4 + fq) ^ s7) << 4);
+#pragma unroll
+                        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+                            for (int jp = 0; jp < FN / 2; ++jp) {
+                                typename T16<T>::v8 v;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    v[e] = T16<T>::from_f32((acc[i][2 * jp][e] + bj[2 * jp][e]) * sj[2 * jp][e]);
+                                    v[4 + e] = T16<T>::from_f32((acc[i][2 * jp + 1][e] + bj[2 * jp + 1][e]) * sj[2 * jp + 1][e]);
+                                }
+                                *reinterpret_cast<typename T16<T>::v8*>(sw + (jp ? wb1 : wb0) + i * 2048) = v;
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        const int rr = lane >> 3, pc = lane & 7;
+                        const int mpl = m0 + wm * TM + rr - p.qkv_patch_row0;
+                        const int obl = mpl / Tk;
+                        int tokl = mpl - obl * Tk;
+                        const int rem0 = n_wave - part * p.qkv_hidden;           // the wave's 64 columns are one head
+                        unsigned ro = (unsigned)obl * img_bytes + (unsigned)tokl * 128u + (unsigned)(rem0 >> 6) * (unsigned)p.qkv_sp * 128u + pc * 16u;
+                        const int rb = rr * 128 + ((pc ^ rr) << 4);
+#pragma unroll
+                        for (int it = 0; it < 16; ++it) {
+                            const u32x4_ x = *reinterpret_cast<const u32x4_*>(sw + rb + it * 1024);
+                            __builtin_amdgcn_raw_buffer_store_b128(x, orsrc, ro, 0, 0);
+                            tokl += 8;
+                            ro += 8u * 128u;
+                            if (tokl >= Tk) {
+                                tokl -= Tk;
+                                ro += img_bytes - (unsigned)Tk * 128u;
+                            }
+                        }
+                        return;
+                    }
+                }
                 unsigned cb[FN / 2];
 #pragma unroll
                 for (int jp = 0; jp < FN / 2; ++jp) cb[jp] = (unsigned)coff[jp] * 2u;

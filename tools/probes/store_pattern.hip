@@ -4,6 +4,7 @@
 //   pattern 0: igemm_kernel's register layout -- an instruction covers 16 rows x 64 contiguous bytes (lane = row frow, 16-byte piece fq)
 //   pattern 1: full lines -- an instruction covers 8 rows x 128 contiguous bytes (what a transpose through LDS would give)
 //   pattern 2: no stores (the spin only)
+//   pattern 4: full lines in the lane order a DPP half-row exchange of the register layout gives (lane = row frow & 7, piece fq + 4 (frow >> 3))
 //   pattern 3: pattern 1 with the LDS round trip that produces it (ds_write_b128 in the register layout, ds_read_b128 in the line layout)
 // hipcc -O3 --offload-arch=gfx950 -o /tmp/store_pattern tools/probes/store_pattern.hip && /tmp/store_pattern
 #include <hip/hip_runtime.h>
@@ -42,6 +43,10 @@ __global__ __launch_bounds__(512) void k(_Float16* out, int ntm, int ntn, int N,
 #pragma unroll
         for (int it = 0; it < 16; ++it)
             *reinterpret_cast<h8*>(base + (long long)(it * 8 + (lane >> 3)) * N + (lane & 7) * 8) = v[it];
+    } else if (PAT == 4) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it)
+            *reinterpret_cast<h8*>(base + (long long)(it * 8 + (frow & 7)) * N + (fq + 4 * (frow >> 3)) * 8) = v[it];
     } else {
         char* sw = smem + wave * 16384;          // this wave's 128 rows x 128 bytes
 #pragma unroll
@@ -69,12 +74,12 @@ int main(int argc, char** argv) {
     hipMalloc(&out, M * N * 2);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    void (*ks[4])(_Float16*, int, int, int, long long) = {k<0>, k<1>, k<2>, k<3>};
-    for (int p = 0; p < 4; ++p) hipFuncSetAttribute((const void*)ks[p], hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    void (*ks[5])(_Float16*, int, int, int, long long) = {k<0>, k<1>, k<2>, k<3>, k<4>};
+    for (int p = 0; p < 5; ++p) hipFuncSetAttribute((const void*)ks[p], hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     printf("N = %d: %d tiles of 256 x 256 fp16 = %.0f MB per launch; wall_clock64 at 100 MHz\n", N, ntm * ntn, M * N * 2 / 1e6);
-    for (int spin_us = 0; spin_us <= 30; spin_us += 15) {
+    for (int spin_us = 0; spin_us <= 30; spin_us += 30) {
         for (int rep = 0; rep < 2; ++rep)
-            for (int p = 0; p < 4; ++p) {
+            for (int p = 0; p < 5; ++p) {
                 for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(ks[p], dim3(ntm * ntn), dim3(512), 131072, 0, out, ntm, ntn, N, (long long)spin_us * 100);
                 hipEventRecord(e0, 0);
                 for (int w = 0; w < 5; ++w) hipLaunchKernelGGL(ks[p], dim3(ntm * ntn), dim3(512), 131072, 0, out, ntm, ntn, N, (long long)spin_us * 100);
