@@ -79,7 +79,7 @@ struct IgemmParams {
     const float* bias2;  // optional fp32 [groups, N] added to rows >= bias2_row0, group = (m - bias2_row0) / bias2_group_rows
     int bias2_row0, bias2_group_rows;
     int strip;    // work id -> tile order: 0 = row-major (N fastest over the whole width), w > 0 = strips of w N-tiles
-    int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue, 8 = no tail split (host side), 128 = the Q / K epilogue without its stores, 256 = no fast Q / K patch-tile path, 512 = no fast V^T patch-tile path, 1024 = no LDS-staged full-line stores (Q / K tiles),
+    int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue, 8 = no tail split (host side), 128 = the Q / K epilogue without its stores, 256 = no fast Q / K patch-tile path, 512 = no fast V^T patch-tile path, 1024 = no LDS-staged full-line stores (Q / K tiles), 2048 = no lean (hi16 | hi8 | lo8) epilogue (neck),
 };
 
 template <typename T>
@@ -789,6 +789,87 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
             return;
         }
         if constexpr (F8) {
+            // The neck's convolutions and 1x1 projections (round 4): (acc + bias) [ReLU] [+ residual(s)] as (hi16 | hi8 | lo8) rows.  The
+            // generic loop above decides mode, activation and residual format per fragment and loads every residual piece (8 + 4 bytes,
+            // two tensors in the fusion blocks' second conv) right where it adds it: fu3.r1.c2's epilogue was 56 us of a tile against
+            // 18 us for the same conv without residuals (tools/probes/plan_epilogue_share.py).  Here the residual pieces of a fragment
+            // pair (16 + 8 bytes per tensor) run RDEPTH pairs ahead of their use; same operations in the same order, same bits.
+            if (p.out_mode == BS_OUT_PLAIN && !p.out_group_rows && !p.bias_group_rows && p.N % BN == 0 && p.ldo % 8 == 0 && !b2_rows &&
+                !(p.ablate & (16 | 2048)) && p.out_f8 && !p.scale && (p.act == BS_ACT_NONE || p.act == BS_ACT_RELU) && p.split_off == p.N &&
+                p.N % 8 == 0 && p.out_dtype != BS_F32 &&
+                (!p.res || (p.res_f8 && p.res_dtype != BS_F32 && p.res_split_off == 0 && p.ldr % 8 == 0)) && (!p.res2 || p.res)) {
+                BS_FRESH_LANE
+                typedef typename T16<T>::v8 v8;
+                typedef int i32x2 __attribute__((ext_vector_type(2)));
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                constexpr int NP = FM * (FN / 2), RDEPTH = 4;
+                f32x4 bj[FN];
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int n0 = n_wave + (j >> 1) * 32 + fq * 8 + (j & 1) * 4;
+                    bj[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (g2 >= 0) bj[j] += *reinterpret_cast<const f32x4*>(p.bias2 + (int64_t)g2 * p.N + n0);
+                }
+                const bool relu = p.act == BS_ACT_RELU;
+                const int mrow = m0 + wm * TM + frow;
+                const int ea = p.out_f8 & 0xff, el = (p.out_f8 >> 8) & 0xff;
+                const float lsc = __builtin_ldexpf(1.0f, -BS_F8_ACT_LO_EXP);
+                auto body = [&](auto nres_tag) {
+                    constexpr int NRES = decltype(nres_tag)::value;
+                    v8 rh[NRES ? RDEPTH : 1][NRES ? NRES : 1];
+                    i32x2 rl[NRES ? RDEPTH : 1][NRES ? NRES : 1];
+                    auto issue = [&](int it, int slot) {
+                        const int i = it / (FN / 2), jp = it - i * (FN / 2);
+                        int m = mrow + i * 16;
+                        m = m < p.M ? m : p.M - 1;
+                        const int n = n_wave + jp * 32 + fq * 8;
+#pragma unroll
+                        for (int q = 0; q < NRES; ++q) {
+                            const T* rp = reinterpret_cast<const T*>(q ? p.res2 : p.res) + (int64_t)m * p.ldr;
+                            rh[slot][q] = *reinterpret_cast<const v8*>(rp + n);
+                            rl[slot][q] = *reinterpret_cast<const i32x2*>(reinterpret_cast<const char*>(rp + p.N + (p.N >> 1)) + n);
+                        }
+                    };
+                    if constexpr (NRES > 0) {
+#pragma unroll
+                        for (int it = 0; it < RDEPTH; ++it) issue(it, it);
+                    }
+#pragma unroll
+                    for (int it = 0; it < NP; ++it) {
+                        const int i = it / (FN / 2), jp = it - i * (FN / 2);
+                        const int m = mrow + i * 16;
+                        float y8[8];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float y = acc[i][2 * jp + h][e] + bj[2 * jp + h][e];
+                                if (relu) y = fmaxf(y, 0.0f);
+                                y8[4 * h + e] = y;
+                            }
+                        if constexpr (NRES > 0) {
+#pragma unroll
+                            for (int q = 0; q < NRES; ++q) {
+                                const v8 hv = rh[it % RDEPTH][q];
+                                const i32x2 lv = rl[it % RDEPTH][q];
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) {      // (the generic loop's order: a fragment's four hi16 values, then its four lo8 values)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) y8[4 * h + e] += T16<T>::to_f32(hv[4 * h + e]);
+                                    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(lv[h], false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lv[h], true);
+                                    y8[4 * h] += a[0] * lsc; y8[4 * h + 1] += a[1] * lsc; y8[4 * h + 2] += b[0] * lsc; y8[4 * h + 3] += b[1] * lsc;
+                                }
+                            }
+                            if (it + RDEPTH < NP) issue(it + RDEPTH, it % RDEPTH);
+                        }
+                        if (m < p.M) store8_f8<T>(p.out, (int64_t)m * p.ldo, n_wave + jp * 32 + fq * 8, p.split_off, y8, ea, el);
+                    }
+                };
+                if (p.res2) body(std::integral_constant<int, 2>{});
+                else if (p.res) body(std::integral_constant<int, 1>{});
+                else body(std::integral_constant<int, 0>{});
+                return;
+            }
             if (plain_full && p.act == BS_ACT_GELU && !p.res && p.out_f8 && !p.scale && p.split_off == p.N && p.N % 8 == 0) {
                 // fc1: gelu(acc + bias) as (hi16 | hi8 | lo8) rows; VALU-bound (a third of the launch): no scale multiply, and past
                 // out_lo8_rows no lo8 plane
