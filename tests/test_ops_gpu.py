@@ -720,13 +720,15 @@ def test_resize_and_add(L, dtype):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("split", [0, 1, 2])
-@pytest.mark.parametrize("geom", [(2, 12, 16, 24, 32, True), (1, 5, 7, 10, 14, True), (1, 6, 5, 12, 10, False), (1, 1, 1, 2, 2, True)])
+@pytest.mark.parametrize("geom", [(2, 12, 16, 24, 32, True), (1, 5, 7, 10, 14, True), (1, 6, 5, 12, 10, False), (1, 1, 1, 2, 2, True),
+                                  # 32 output channels at x2: the LDS-staged kernel (16 x 16 output tiles, ragged last tiles, both conventions)
+                                  (2, 12, 16, 24, 32, True, 32), (1, 41, 53, 82, 106, True, 32), (1, 21, 19, 42, 38, False, 32), (1, 2, 2, 4, 4, True, 32)])
 def test_upconv_tapsum(L, dtype, split, geom):
     """relu(conv3x3(interpolate(x))) from low-resolution tap products (the relative head's upsample + conv2, HF
     modeling_zoedepth.py:358-362) against torch's conv2d(interpolate(x)) in fp64: the two orders of the linear steps agree to fp32
     rounding, and the conv's zero padding applies to the UPSAMPLED map (border rows / columns)."""
-    B, H, W, Ho, Wo, align = geom
-    C, Co = 16, 8
+    B, H, W, Ho, Wo, align = geom[:6]
+    C, Co = 16, (geom[6] if len(geom) > 6 else 8)
     x = rnd(B, H, W, C, seed=3).double()
     w = (rnd(Co, C, 3, 3, seed=4) * 0.2).double()
     bias = rnd(Co, seed=5)
