@@ -676,7 +676,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             if (ACT == BS_ACT_RELU) y[e] = fmaxf(y[e], 0.0f);
-                            else if (ACT == BS_ACT_SOFTPLUS) y[e] = softplus20(y[e]);
+                            else if (ACT == BS_ACT_SOFTPLUS) y[e] = softplus_fast(y[e]);
                             if (!res32) y[e] *= sj[j][e];
                         }
                         if (p.res) {

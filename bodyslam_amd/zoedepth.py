@@ -233,6 +233,7 @@ class ZoeDepthEngine:
         # DPT neck / heads (no cls rows there): "full" = both correction products, "w" = the weight-rounding correction only
         self.neck_mode = neck_mode or os.environ.get("BS_NECK_MODE") or ACCURATE_NECK_MODE
         # (probes: a comma-separated list of weight-key prefixes that KEEP both products, e.g. "ro,ra,nc": everything else "w")
+        self.fuse_mlp = os.environ.get("BS_NO_MLP2") is None        # the attractor MLPs as one launch each (bs_mlp2); off: two bs_gemm (A / B)
         c_ = self.cfg
         # the neck switches to the (hi16 | hi8 | lo8) operand format as a whole: every K / Cin on it must be whole 128-byte FP8 stages
         self.neck_f8 = self.acc and self.neck_mode != "pairs" and all(v % 128 == 0 for v in (c_.hidden, c_.fusion, c_.fusion // 2, *c_.neck_hidden))
@@ -1148,13 +1149,20 @@ class _ZoePlan:
             y = e16(Mi, E * m2)
             P.add(f"at{i}.add", "bs_add_resized", emb, emb_prev, y, NB, ph_, pw_, fh, fw, E, L.dt(y) | (16 if acc else 0))
             free(emb_prev)
-            a1 = e16(Mi, 2 * E)
-            P.gemm(f"at{i}.c1", y, w[f"at{i}.c1.w"], a1, M=Mi, N=2 * E, K=E, lda=E * m2, bias=w[f"at{i}.c1.b"], act=L.ACT_RELU)
-            free(y)
             na = eng.na_eff[i]                                     # attractors of this level (replicated up to a multiple of 4)
             A = e32(Mi, 2 * na)
-            P.gemm(f"at{i}.c2", a1, w[f"at{i}.c2.w"], A, M=Mi, N=2 * na, K=2 * E, lda=2 * E, bias=w[f"at{i}.c2.b"], act=L.ACT_SOFTPLUS)
-            free(a1)
+            if E == 128 and 2 * na <= 32 and eng.fuse_mlp and tuple(w[f"at{i}.c1.w"].shape) == (256, 128):
+                # both 1x1 convolutions in one launch: the 256-channel hidden map (3.2 GB at the finest level) never reaches memory;
+                # bit-identical to the two launches below (bs_mlp2, csrc/mlp2.hip)
+                P.add(f"at{i}.mlp", "bs_mlp2", y, E * m2, w[f"at{i}.c1.w"], w[f"at{i}.c1.b"], w[f"at{i}.c2.w"], w[f"at{i}.c2.b"], A, Mi, E, 2 * E,
+                      2 * na, L.ACT_SOFTPLUS, L.dt(y))
+                free(y)
+            else:
+                a1 = e16(Mi, 2 * E)
+                P.gemm(f"at{i}.c1", y, w[f"at{i}.c1.w"], a1, M=Mi, N=2 * E, K=E, lda=E * m2, bias=w[f"at{i}.c1.b"], act=L.ACT_RELU)
+                free(y)
+                P.gemm(f"at{i}.c2", a1, w[f"at{i}.c2.w"], A, M=Mi, N=2 * na, K=2 * E, lda=2 * E, bias=w[f"at{i}.c2.b"], act=L.ACT_SOFTPLUS)
+                free(a1)
             bins = e32(NB, fh, fw, 2 * nb)
             P.add(f"at{i}.step", "bs_attractor_step", A, bins_prev, bins, self.route, NB, ph_, pw_, fh, fw, 2, nb, na)
             free(A, bins_prev)

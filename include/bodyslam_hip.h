@@ -247,6 +247,13 @@ int bs_upconv_tapsum(const float* y, const float* bias, void* out, int32_t B, in
 int bs_attractor_step(const float* A, const float* bins_prev, float* bins_out, const int32_t* route, int32_t B,
                       int32_t Hp, int32_t Wp, int32_t H, int32_t W, int32_t groups, int32_t n_bins, int32_t n_attr,
                       void* stream);
+/* The attractor MLP in one launch, HF modeling_zoedepth.py:665-700 (`Conv2d(E, 2E, 1)`, ReLU, `Conv2d(2E, n_attractors, 1)`, softplus;
+ * both metric heads' MLPs stacked):  out = act2(round16(relu(x W1^T + b1)) W2^T + b2).
+ * x rows of ldx 16-bit values (the first K1 are read), W1 [N1, K1], W2 [N2, N1] 16-bit, b1 / b2 fp32, out fp32 [M, N2].
+ * Built for K1 = 128, N1 = 256, N2 a multiple of 4 up to 32; bit-identical to bs_gemm(act = ReLU, 16-bit out) followed by
+ * bs_gemm(act = act2, fp32 out) -- the hidden map (M x 256) never reaches memory. */
+int bs_mlp2(const void* x, int32_t ldx, const void* W1, const float* b1, const void* W2, const float* b2, float* out, int32_t M,
+            int32_t K1, int32_t N1, int32_t N2, int32_t act2, int32_t dtype, void* stream);
 /* out[b,y,x,:] = x[b,y,x,:] + bilinear_align_corners(prev)[b,y,x,:] (fp16/bf16 NHWC); HF :726-730.
  * dtype bit 4 (| 16): x, prev and out hold (hi | lo) pairs of C channels each (pixel stride 2C), see bs_cast_split. */
 int bs_add_resized(const void* x, const void* prev, void* out, int32_t B, int32_t Hp, int32_t Wp, int32_t H,

@@ -1065,3 +1065,29 @@ def test_attention_table_is_deterministic_at_scale(L):
         for b in (0, 63, B - 1):
             one = run(q[b:b + 1].contiguous(), k[b:b + 1].contiguous(), vt[b:b + 1].contiguous(), 1)
             assert torch.equal(one, a[b * S:(b + 1) * S]), f"image {b} of the batch differs from the same image alone"
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N2,pairs", [(1000, 8, True), (256, 32, False), (777, 16, True), (70000, 8, True), (5, 4, False)])
+def test_mlp2(L, dtype, M, N2, pairs):
+    """bs_mlp2 (the attractor MLP in one launch, HF modeling_zoedepth.py:665-700) against the two bs_gemm launches it replaces -- bit for bit --
+    and against torch in fp64; ragged last block, pair rows (only the hi half is read), every output width."""
+    K1, N1 = 128, 256
+    ldx = 2 * K1 if pairs else K1
+    x = rnd(M, ldx, seed=11, dtype=dtype)
+    w1 = (rnd(N1, K1, seed=12) / K1 ** 0.5).to(dtype)
+    w2 = (rnd(N2, N1, seed=13) / N1 ** 0.5).to(dtype)
+    b1, b2 = rnd(N1, seed=14), rnd(N2, seed=15)
+    out = torch.full((M, N2), -7.0, device=dev())
+    L.mlp2(x, ldx, w1, b1, w2, b2, out, M, K1, N1, N2, L.ACT_SOFTPLUS)
+    hid = torch.empty(M, N1, device=dev(), dtype=dtype)
+    L.gemm(x, w1, hid, M=M, N=N1, K=K1, lda=ldx, bias=b1, act=L.ACT_RELU)
+    two = torch.empty(M, N2, device=dev())
+    L.gemm(hid, w2, two, M=M, N=N2, K=N1, lda=N1, bias=b2, act=L.ACT_SOFTPLUS)
+    torch.cuda.synchronize()
+    assert torch.equal(out, two), f"max |fused - two launches| = {(out - two).abs().max().item():.3e}"
+    h64 = torch.relu(x[:, :K1].double() @ w1.double().t() + b1.double()).to(dtype).double()
+    ref = F.softplus(h64 @ w2.double().t() + b2.double())
+    err = (out.double() - ref).abs().max().item()
+    report(f"mlp2 {dtype} M={M} N2={N2} pairs={pairs}: max err vs fp64 {err:.2e}")
+    assert err < 5e-3       # (a hidden unit on a 16-bit rounding boundary may round the other way than in fp64)
