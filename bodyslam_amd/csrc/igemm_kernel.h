@@ -1191,8 +1191,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                     const int n = n_wave + c;
                     if (n >= p.N) continue;
                     float y = sc[r * TN + ((((c >> 2) ^ (r & (S4 - 1))) << 2) | (c & 3))];
-                    if (p.bias) y += p.bias[n];
-                    if (b2) y += b2[n];
+                    // acc + (bias + bias2), the association of every other form: a row's bits must not depend on which form its tile takes
+                    float bsum = p.bias ? p.bias[n] : 0.0f;
+                    if (b2) bsum += b2[n];
+                    y += bsum;
                     const int rem = n - 2 * p.qkv_hidden;
                     const int64_t vo = (((int64_t)ob * nh + (rem >> 6)) * 64 + (rem & 63)) * p.qkv_sp + otok;
                     const T vh = T16<T>::from_f32(y);
