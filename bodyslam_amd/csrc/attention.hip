@@ -715,22 +715,18 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
             m_run += sh;
             first = false;
         }
-        f32x2_ psum2 = {0.f, 0.f};      // even / odd keys: eight v_pk_add_f32 instead of sixteen v_add_f32
+        float psum = 0.f;
         v8 pf[2], pfl[CORR ? 2 : 1];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                const f32x2_ pv = {__builtin_amdgcn_exp2f(sacc[8 * s2 + e]), __builtin_amdgcn_exp2f(sacc[8 * s2 + e + 1])};
-                psum2 += pv;
-                pf[s2][e] = T16<T>::from_f32(pv[0]);
-                pf[s2][e + 1] = T16<T>::from_f32(pv[1]);
-                if constexpr (CORR) {
-                    pfl[s2][e] = T16<T>::from_f32(pv[0] - T16<T>::to_f32(pf[s2][e]));
-                    pfl[s2][e + 1] = T16<T>::from_f32(pv[1] - T16<T>::to_f32(pf[s2][e + 1]));
-                }
+            for (int e = 0; e < 8; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(sacc[8 * s2 + e]);
+                psum += pv;
+                pf[s2][e] = T16<T>::from_f32(pv);
+                if constexpr (CORR) pfl[s2][e] = T16<T>::from_f32(pv - T16<T>::to_f32(pf[s2][e]));
             }
-        l_run += psum2[0] + psum2[1];
+        l_run += psum;
         if (NEXT) load_bias(sacc, next_ky);
 #pragma unroll
         for (int dh = 0; dh < 2; ++dh) {
