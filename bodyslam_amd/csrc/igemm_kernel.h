@@ -79,7 +79,7 @@ struct IgemmParams {
     const float* bias2;  // optional fp32 [groups, N] added to rows >= bias2_row0, group = (m - bias2_row0) / bias2_group_rows
     int bias2_row0, bias2_group_rows;
     int strip;    // work id -> tile order: 0 = row-major (N fastest over the whole width), w > 0 = strips of w N-tiles
-    int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue, 8 = no tail split (host side), 128 = the Q / K epilogue without its stores, 256 = no fast Q / K patch-tile path, 512 = no fast V^T patch-tile path, 1024 = no LDS-staged full-line stores (Q / K tiles), 2048 = no lean (hi16 | hi8 | lo8) epilogue (neck),
+    int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue, 8 = no tail split (host side), 128 = the Q / K epilogue without its stores, 256 = no fast Q / K patch-tile path, 512 = no fast V^T patch-tile path, 1024 = no LDS-staged full-line stores (Q / K tiles, fc1's hi16 tiles), 2048 = no lean (hi16 | hi8 | lo8) epilogue (neck),
 };
 
 template <typename T>
@@ -883,8 +883,50 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                     bj[j] = *reinterpret_cast<const f32x4*>(p.bias + n0);
                     if (g2 >= 0) bj[j] += *reinterpret_cast<const f32x4*>(p.bias2 + (int64_t)g2 * p.N + n0);
                 }
-                // (Full-line stores through LDS, as the Q / K tiles below, LOSE here: 930 vs 920 us -- the GELU arithmetic between the stores
-                // hides their latency, a staged burst behind a block barrier does not.)
+                // hi16-only tiles (the patch tiles when fc2 runs "wmean"): full-line stores through the wave's LDS region as for the Q / K
+                // tiles below, but 32 rows at a time, BETWEEN the GELU arithmetic of consecutive row groups (staging the whole tile and
+                // storing it in one burst behind the arithmetic loses: 930 vs 920 us -- the arithmetic is what hides the stores).
+                if constexpr (TM == 128 && TN == 64 && LDS_BYTES >= WM * WN * 16384) {
+                    if (!planes && m0 + BM <= p.M && !(p.ablate & 1024)) {
+                        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                        __syncthreads();          // every wave is done reading the main-loop LDS
+                        char* sw = smem + wave * 16384;
+                        const int s7 = frow & 7;
+                        const int wb0 = frow * 128 + ((fq ^ s7) << 4), wb1 = frow * 128 + (((4 + fq) ^ s7) << 4);
+                        const int rr = lane >> 3, pc = lane & 7;
+                        const int rb = rr * 128 + ((pc ^ rr) << 4);
+                        T* op = reinterpret_cast<T*>(p.out) + (int64_t)(m0 + wm * TM + rr) * p.ldo + n_wave + pc * 8;
+                        const int64_t step = (int64_t)8 * p.ldo;
+#pragma unroll
+                        for (int ip = 0; ip < FM; ip += 2) {
+                            char* sr = sw + ((ip >> 1) & 1) * 4096;       // two 32-row regions in turn: round k + 1 writes while round k's reads drain
+#pragma unroll
+                            for (int ii = 0; ii < 2; ++ii) {
+                                const int i = ip + ii;
+#pragma unroll
+                                for (int jp = 0; jp < FN / 2; ++jp) {
+                                    typename T16<T>::v8 h8v;
+#pragma unroll
+                                    for (int h = 0; h < 2; ++h) {
+                                        const f32x4 v = acc[i][2 * jp + h] + bj[2 * jp + h];
+                                        const f32x2_ g0 = gelu_erf2(f32x2_{v[0], v[1]}), g1 = gelu_erf2(f32x2_{v[2], v[3]});
+                                        h8v[4 * h] = T16<T>::from_f32(g0[0]); h8v[4 * h + 1] = T16<T>::from_f32(g0[1]);
+                                        h8v[4 * h + 2] = T16<T>::from_f32(g1[0]); h8v[4 * h + 3] = T16<T>::from_f32(g1[1]);
+                                    }
+                                    *reinterpret_cast<typename T16<T>::v8*>(sr + (jp ? wb1 : wb0) + ii * 2048) = h8v;
+                                }
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                            for (int it = 0; it < 4; ++it) {
+                                *reinterpret_cast<u32x4_*>(op) = *reinterpret_cast<const u32x4_*>(sr + rb + it * 1024);
+                                op += step;
+                            }
+                        }
+                        return;
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     const int m = m0 + wm * TM + i * 16 + frow;
