@@ -431,8 +431,10 @@ __global__ __launch_bounds__(256) void upconv_tapsum_kernel(const float* y, cons
 // The same sum with the tap products of a 16 x 16 output tile's low-resolution window staged in LDS (round 4; x2 upsampling, Co = 32: the
 // relative head).  The kernel above gathers its 36 corner vectors per (pixel, channel group) through L1 / L2: 21 GB through L1 for 7.2 GB
 // of products, 4.6 ms.  Here a block of 512 threads copies the window -- at most 11 x 11 low-resolution pixels x 1152 bytes, whole rows
-// contiguous in memory -- by LDS-DMA and every corner read is a ds_read_b128; the arithmetic is the kernel's above, operation by operation.
-constexpr int TS_TW = 16, TS_TH = 16, TS_LW = 11, TS_LH = 11;
+// contiguous in memory -- by LDS-DMA and every corner read is a ds_read_b128.  The four corner weights of a tap are formed once (w = {hy, ly} x
+// {hx, lx}) and the corners accumulated by fused multiply-adds, two channels per instruction: 8 v_pk_fma_f32 per tap instead of the gather
+// form's 12 packed operations + 4 adds (another association of the same fp32 sum).
+constexpr int TS_TW = 16, TS_TH = 16, TS_LW = 11, TS_LH = 11, TS_TAB = 1024;   // TS_TAB: bytes of the per-block tables in front of the window
 template <typename T, int SPLIT>
 __global__ __launch_bounds__(512) void upconv_tapsum_lds_kernel(const float* y, const float* bias, T* out, int B, int Hin, int Win, int Hout, int Wout,
                                                                  float sy, float sx, int align, int relu) {
@@ -464,56 +466,71 @@ __global__ __launch_bounds__(512) void upconv_tapsum_lds_kernel(const float* y, 
         const int k = k0 + lane;
         if (k < total16) {
             const int ly = k / row16, rem = k - ly * row16;
-            glds16(ybase + ((int64_t)ly * Win * ld * 4) + (int64_t)rem * 16, smem + k0 * 16);
+            glds16(ybase + ((int64_t)ly * Win * ld * 4) + (int64_t)rem * 16, smem + TS_TAB + k0 * 16);
         }
+    }
+    // Per-block tables in front of the window: for the TH + 2 output rows and TW + 2 output columns the tile's taps touch, the byte offsets of
+    // the two corner rows / columns inside the window and the two interpolation weights.  A tap outside the image gets weights 0 (its
+    // offsets point at the window's first pixel): no branches in the item loop, and the eight channel groups of a pixel no longer
+    // recompute what they share.
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef int i32x4_ __attribute__((ext_vector_type(4)));
+    i32x4_* tabs = reinterpret_cast<i32x4_*>(smem);          // [0, TH + 2): rows, [TH + 2, TH + TW + 4): columns; the window starts TS_TAB bytes in
+    if (tid < TS_TH + 2 + TS_TW + 2) {
+        const bool isrow = tid < TS_TH + 2;
+        const int r = isrow ? ty0 - 1 + tid : tx0 - 1 + (tid - (TS_TH + 2));
+        const int nout = isrow ? Hout : Wout, nin = isrow ? Hin : Win, w0 = isrow ? wy0 : wx0;
+        const float s = isrow ? sy : sx;
+        const int unit = isrow ? LWc * ld * 4 : ld * 4;
+        i32x4_ e = {0, 0, 0, 0};
+        if (r >= 0 && r < nout) {
+            const float f = src(r, s, nin);
+            int i0 = (int)f;
+            i0 = i0 > nin - 1 ? nin - 1 : i0;
+            const int i1 = i0 + (i0 < nin - 1 ? 1 : 0);
+            const float l = f - (float)i0, h = 1.0f - l;
+            e = i32x4_{(i0 - w0) * unit, (i1 - w0) * unit, __float_as_int(h), __float_as_int(l)};
+        }
+        tabs[tid] = e;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const float* ys = reinterpret_cast<const float*>(smem);
     const int g = tid & 7;
-    typedef float f32x4_ __attribute__((ext_vector_type(4)));
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
     const f32x4_ bias4 = *reinterpret_cast<const f32x4_*>(bias + 4 * g);
+    const char* yg = smem + TS_TAB + 16 * g;
     for (int it = 0; it < TS_TW * TS_TH / 64; ++it) {
         const int px = it * 64 + (tid >> 3);
-        const int ox = tx0 + (px % TS_TW), oy = ty0 + (px / TS_TW);
+        const int lx_ = px % TS_TW, ly_ = px / TS_TW;
+        const int ox = tx0 + lx_, oy = ty0 + ly_;
         if (ox >= Wout || oy >= Hout) continue;
-        f32x4_ acc = bias4;
+        f32x2 a01 = {bias4[0], bias4[1]}, a23 = {bias4[2], bias4[3]};
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const int r = oy + ky - 1;
-            if (r < 0 || r >= Hout) continue;
-            const float fy = src(r, sy, Hin);
-            int y0 = (int)fy;
-            y0 = y0 > Hin - 1 ? Hin - 1 : y0;
-            const int y1 = y0 + (y0 < Hin - 1 ? 1 : 0);
-            const float ly = fy - (float)y0, hy = 1.0f - ly;
+            const i32x4_ ry = tabs[ly_ + ky];
+            const float hy = __int_as_float(ry[2]), wy = __int_as_float(ry[3]);
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int c = ox + kx - 1;
-                if (c < 0 || c >= Wout) continue;
-                const float fx = src(c, sx, Win);
-                int x0 = (int)fx;
-                x0 = x0 > Win - 1 ? Win - 1 : x0;
-                const int x1 = x0 + (x0 < Win - 1 ? 1 : 0);
-                const float lx = fx - (float)x0, hx = 1.0f - lx;
-                const float* yt = ys + (ky * 3 + kx) * Co + 4 * g;
-                const int r0 = (y0 - wy0) * LWc - wx0, r1 = (y1 - wy0) * LWc - wx0;
-                const f32x4_ q00 = *reinterpret_cast<const f32x4_*>(yt + (r0 + x0) * ld);
-                const f32x4_ q01 = *reinterpret_cast<const f32x4_*>(yt + (r0 + x1) * ld);
-                const f32x4_ q10 = *reinterpret_cast<const f32x4_*>(yt + (r1 + x0) * ld);
-                const f32x4_ q11 = *reinterpret_cast<const f32x4_*>(yt + (r1 + x1) * ld);
-                const f32x2 hx2 = {hx, hx}, lx2 = {lx, lx}, hy2 = {hy, hy}, ly2 = {ly, ly};
-#pragma unroll
-                for (int e = 0; e < 4; e += 2) {
-                    const f32x2 top = __builtin_elementwise_fma(lx2, f32x2{q01[e], q01[e + 1]}, hx2 * f32x2{q00[e], q00[e + 1]});
-                    const f32x2 bot = __builtin_elementwise_fma(lx2, f32x2{q11[e], q11[e + 1]}, hx2 * f32x2{q10[e], q10[e + 1]});
-                    const f32x2 v = __builtin_elementwise_fma(ly2, bot, hy2 * top);
-                    acc[e] += v[0];
-                    acc[e + 1] += v[1];
-                }
+                const i32x4_ cx = tabs[TS_TH + 2 + lx_ + kx];
+                const float hx = __int_as_float(cx[2]), wx = __int_as_float(cx[3]);
+                const char* yt = yg + (ky * 3 + kx) * Co * 4;
+                const f32x4_ q00 = *reinterpret_cast<const f32x4_*>(yt + ry[0] + cx[0]);
+                const f32x4_ q01 = *reinterpret_cast<const f32x4_*>(yt + ry[0] + cx[1]);
+                const f32x4_ q10 = *reinterpret_cast<const f32x4_*>(yt + ry[1] + cx[0]);
+                const f32x4_ q11 = *reinterpret_cast<const f32x4_*>(yt + ry[1] + cx[1]);
+                const float w00 = hy * hx, w01 = hy * wx, w10 = wy * hx, w11 = wy * wx;
+                const f32x2 v00 = {w00, w00}, v01 = {w01, w01}, v10 = {w10, w10}, v11 = {w11, w11};
+                a01 = __builtin_elementwise_fma(v00, f32x2{q00[0], q00[1]}, a01);
+                a23 = __builtin_elementwise_fma(v00, f32x2{q00[2], q00[3]}, a23);
+                a01 = __builtin_elementwise_fma(v01, f32x2{q01[0], q01[1]}, a01);
+                a23 = __builtin_elementwise_fma(v01, f32x2{q01[2], q01[3]}, a23);
+                a01 = __builtin_elementwise_fma(v10, f32x2{q10[0], q10[1]}, a01);
+                a23 = __builtin_elementwise_fma(v10, f32x2{q10[2], q10[3]}, a23);
+                a01 = __builtin_elementwise_fma(v11, f32x2{q11[0], q11[1]}, a01);
+                a23 = __builtin_elementwise_fma(v11, f32x2{q11[2], q11[3]}, a23);
             }
         }
+        f32x4_ acc = {a01[0], a01[1], a23[0], a23[1]};
         if (relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.0f);
@@ -958,7 +975,8 @@ static int launch_tapsum(const float* y, const float* bias, void* out, int B, in
     // the LDS-staged form: the relative head's geometry (x2, 32 channels; its window bound of 11 x 11 holds for scale factors >= 0.49)
     static const bool no_lds = getenv("BS_TAPSUM_NO_LDS") != nullptr;     // diagnostics
     if (!no_lds && Co == 32 && Hout == 2 * Hin && Wout == 2 * Win && Hin >= 2 && Win >= 2) {
-        constexpr int smem = TS_LW * TS_LH * 9 * 32 * 4;
+        constexpr int smem = TS_TAB + TS_LW * TS_LH * 9 * 32 * 4;
+        static_assert((TS_TH + 2 + TS_TW + 2) * 16 <= TS_TAB, "tables");
         const dim3 grid(cdiv(Wout, TS_TW) * cdiv(Hout, TS_TH) * B);
 #define BS_TS(SP)                                                                                                                          \
     do {                                                                                                                                   \
