@@ -105,6 +105,7 @@ _SIGS = {
     "bs_attractor_step": [C.c_void_p] * 4 + [C.c_int32] * 8 + [C.c_void_p],
     "bs_add_resized": [C.c_void_p] * 3 + [C.c_int32] * 7 + [C.c_void_p],
     "bs_mlp2": [C.c_void_p, C.c_int32] + [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p],
+    "bs_mlp2_add": [C.c_void_p] * 7 + [C.c_int32] * 10 + [C.c_void_p],
     "bs_logbinom_depth": [C.c_void_p] * 8 + [C.c_int32] * 5 + [C.c_float, C.c_float, C.c_int32, C.c_void_p],
     "bs_logbinom_depth_ex": [C.c_void_p] * 7 + [C.c_int32] + [C.c_void_p] * 2 + [C.c_int32] * 5 + [C.c_float, C.c_float, C.c_int32, C.c_void_p],
     "bs_small_attention": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
@@ -602,6 +603,12 @@ def attractor_step(A, bins_prev, bins_out, route, B, Hp, Wp, H, W, groups, n_bin
 def mlp2(x, ldx, W1, b1, W2, b2, out, M, K1, N1, N2, act2=ACT_SOFTPLUS):
     """out = act2(round16(relu(x W1^T + b1)) W2^T + b2) in one launch (include/bodyslam_hip.h: bs_mlp2)"""
     check(load_library().bs_mlp2(p(x), ldx, p(W1), p(b1), p(W2), p(b2), p(out), M, K1, N1, N2, act2, dt(x), stream_ptr()), "bs_mlp2")
+
+
+def mlp2_add(emb, prev, W1, b1, W2, b2, out, B, Hp, Wp, H, W, K1, N1, N2, act2=ACT_SOFTPLUS, split=False):
+    """bs_add_resized + bs_mlp2 in one launch (include/bodyslam_hip.h: bs_mlp2_add)"""
+    check(load_library().bs_mlp2_add(p(emb), p(prev), p(W1), p(b1), p(W2), p(b2), p(out), B, Hp, Wp, H, W, K1, N1, N2, act2,
+                                     dt(emb) | (16 if split else 0), stream_ptr()), "bs_mlp2_add")
 
 
 def add_resized(x, prev, out, B, Hp, Wp, H, W, Cch, split=False):

@@ -15,10 +15,19 @@ namespace bs {
 
 constexpr int MLP_BM = 256, MLP_K1 = 128, MLP_N1 = 256, MLP_LDS = 131072;
 
-template <typename T>
+// FUSE (bs_mlp2_add): the input row is not read but formed, x[m] = emb[m] + bilinear_align_corners(prev)[m] rounded to the 16-bit type -- the
+// hi half of what bs_add_resized would store (HF modeling_zoedepth.py:726-730; same operations in the same order, same bits), SPLIT: emb and
+// prev hold (hi | lo) pairs.  The attractor level's sum then exists only as this kernel's LDS tile.
+struct MlpAddGeom {
+    const void* prev;
+    int Hp, Wp, H, W;
+    float sy, sx;
+};
+
+template <typename T, int FUSE, int SPLIT>
 __global__ __launch_bounds__(512) void mlp2_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ W1, const float* __restrict__ b1,
                                                    const T* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ out, int M, int N2,
-                                                   int act2) {
+                                                   int act2, MlpAddGeom ag) {
     typedef typename T16<T>::v8 v8;
     typedef typename T16<T>::v4 v4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -45,9 +54,57 @@ __global__ __launch_bounds__(512) void mlp2_kernel(const T* __restrict__ x, int 
             }
 #pragma unroll
             for (int seg = 0; seg < 2; ++seg) {
-                glds16(xs + seg * 128, smem + seg * 32768 + rg * 1024);
+                if (!FUSE) glds16(xs + seg * 128, smem + seg * 32768 + rg * 1024);
                 glds16(wl + (int64_t)rg * 8 * MLP_K1 * 2 + seg * 128, smem + 65536 + seg * 32768 + rg * 1024);
             }
+        }
+    }
+    if constexpr (FUSE) {
+        // item = (row, 8-channel group): consecutive threads take the 16 groups of a row (256 contiguous bytes of each operand half)
+        const T* prev = reinterpret_cast<const T*>(ag.prev);
+        constexpr int C = MLP_K1, PS = SPLIT ? 2 : 1;
+        auto ld8 = [&](const T* ptr, float (&dst)[8]) {
+            const v8 h = *reinterpret_cast<const v8*>(ptr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dst[e] = (float)h[e];
+            if (SPLIT) {
+                const v8 l = *reinterpret_cast<const v8*>(ptr + C);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dst[e] += (float)l[e];
+            }
+        };
+#pragma unroll 2
+        for (int k = 0; k < MLP_BM * 16 / 512; ++k) {
+            const int idx = tid + k * 512, r = idx >> 4, c8 = idx & 15;
+            int m = m0 + r;
+            m = m < M ? m : M - 1;
+            const int hw = ag.H * ag.W;
+            const int b = m / hw, rem = m - b * hw;
+            const int oy = rem / ag.W, ox = rem - oy * ag.W;
+            const float fy = ag.sy * (float)oy, fx = ag.sx * (float)ox;
+            int y0 = (int)fy, x0 = (int)fx;
+            y0 = y0 > ag.Hp - 1 ? ag.Hp - 1 : y0;
+            x0 = x0 > ag.Wp - 1 ? ag.Wp - 1 : x0;
+            const int y1 = y0 + (y0 < ag.Hp - 1 ? 1 : 0), x1 = x0 + (x0 < ag.Wp - 1 ? 1 : 0);
+            const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+            const T* pb = prev + (int64_t)b * ag.Hp * ag.Wp * C * PS + c8 * 8;
+            float q00[8], q01[8], q10[8], q11[8], av[8];
+            ld8(pb + ((int64_t)y0 * ag.Wp + x0) * C * PS, q00);
+            ld8(pb + ((int64_t)y0 * ag.Wp + x1) * C * PS, q01);
+            ld8(pb + ((int64_t)y1 * ag.Wp + x0) * C * PS, q10);
+            ld8(pb + ((int64_t)y1 * ag.Wp + x1) * C * PS, q11);
+            ld8(x + (int64_t)m * ldx + c8 * 8, av);
+            const f32x2_ hx2 = {hx, hx}, lx2 = {lx, lx}, hy2 = {hy, hy}, ly2 = {ly, ly};
+            v8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                f32x2_ v = bilerp2(f32x2_{q00[e], q00[e + 1]}, f32x2_{q01[e], q01[e + 1]}, f32x2_{q10[e], q10[e + 1]}, f32x2_{q11[e], q11[e + 1]}, hx2, lx2,
+                                   hy2, ly2);
+                v += f32x2_{av[e], av[e + 1]};
+                o[e] = T16<T>::from_f32(v[0]);
+                o[e + 1] = T16<T>::from_f32(v[1]);
+            }
+            *reinterpret_cast<v8*>(smem + (c8 >> 3) * 32768 + r * 128 + (((c8 & 7) ^ (r & 7)) << 4)) = o;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -141,17 +198,29 @@ __global__ __launch_bounds__(512) void mlp2_kernel(const T* __restrict__ x, int 
     }
 }
 
-template <typename T>
+template <typename T, int FUSE, int SPLIT>
 static int launch_mlp2(const void* x, int ldx, const void* W1, const float* b1, const void* W2, const float* b2, float* out, int M, int N2, int act2,
-                       hipStream_t st) {
+                       const MlpAddGeom& ag, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        BS_CHECK_HIP(hipFuncSetAttribute((const void*)mlp2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
+        BS_CHECK_HIP(hipFuncSetAttribute((const void*)mlp2_kernel<T, FUSE, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
         attr_done = true;
     }
-    hipLaunchKernelGGL((mlp2_kernel<T>), dim3(cdiv(M, MLP_BM)), dim3(512), MLP_LDS, st, (const T*)x, ldx, (const T*)W1, b1, (const T*)W2, b2, out, M, N2,
-                       act2);
+    hipLaunchKernelGGL((mlp2_kernel<T, FUSE, SPLIT>), dim3(cdiv(M, MLP_BM)), dim3(512), MLP_LDS, st, (const T*)x, ldx, (const T*)W1, b1, (const T*)W2, b2,
+                       out, M, N2, act2, ag);
     BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+static int mlp2_check(const char* who, const void* x, const void* W1, const float* b1, const void* W2, const float* b2, float* out, int M, int K1,
+                      int N1, int N2, int act2, int dtype) {
+    if (!initialized()) { set_error("%s: call bs_init first", who); return BS_ERR_NOT_INIT; }
+    BS_REQUIRE(x && W1 && b1 && W2 && b2 && out, "%s: null operand", who);
+    BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "%s: dtype must be f16 or bf16", who);
+    BS_REQUIRE(K1 == MLP_K1 && N1 == MLP_N1, "%s: built for K1 = %d, N1 = %d (got %d, %d)", who, MLP_K1, MLP_N1, K1, N1);
+    BS_REQUIRE(N2 > 0 && N2 <= 32 && N2 % 4 == 0, "%s: N2 = %d must be a multiple of 4 in 4 .. 32", who, N2);
+    BS_REQUIRE(M > 0, "%s: M = %d", who, M);
+    BS_REQUIRE(act2 == BS_ACT_NONE || act2 == BS_ACT_RELU || act2 == BS_ACT_SOFTPLUS || act2 == BS_ACT_GELU, "%s: unknown activation %d", who, act2);
     return BS_OK;
 }
 
@@ -160,13 +229,35 @@ static int launch_mlp2(const void* x, int ldx, const void* W1, const float* b1, 
 extern "C" int bs_mlp2(const void* x, int32_t ldx, const void* W1, const float* b1, const void* W2, const float* b2, float* out, int32_t M,
                        int32_t K1, int32_t N1, int32_t N2, int32_t act2, int32_t dtype, void* stream) {
     using namespace bs;
-    if (!initialized()) { set_error("bs_mlp2: call bs_init first"); return BS_ERR_NOT_INIT; }
-    BS_REQUIRE(x && W1 && b1 && W2 && b2 && out, "bs_mlp2: null operand");
-    BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_mlp2: dtype must be f16 or bf16");
-    BS_REQUIRE(K1 == MLP_K1 && N1 == MLP_N1, "bs_mlp2: built for K1 = %d, N1 = %d (got %d, %d)", MLP_K1, MLP_N1, K1, N1);
-    BS_REQUIRE(N2 > 0 && N2 <= 32 && N2 % 4 == 0, "bs_mlp2: N2 = %d must be a multiple of 4 in 4 .. 32", N2);
-    BS_REQUIRE(M > 0 && ldx >= K1 && ldx % 8 == 0, "bs_mlp2: M = %d, ldx = %d (rows of >= K1 16-bit values, 16-byte aligned)", M, ldx);
-    BS_REQUIRE(act2 == BS_ACT_NONE || act2 == BS_ACT_RELU || act2 == BS_ACT_SOFTPLUS || act2 == BS_ACT_GELU, "bs_mlp2: unknown activation %d", act2);
+    const int rc = mlp2_check("bs_mlp2", x, W1, b1, W2, b2, out, M, K1, N1, N2, act2, dtype);
+    if (rc != BS_OK) return rc;
+    BS_REQUIRE(ldx >= K1 && ldx % 8 == 0, "bs_mlp2: ldx = %d (rows of >= K1 16-bit values, 16-byte aligned)", ldx);
     hipStream_t st = (hipStream_t)stream;
-    return dtype == BS_F16 ? launch_mlp2<f16>(x, ldx, W1, b1, W2, b2, out, M, N2, act2, st) : launch_mlp2<bf16>(x, ldx, W1, b1, W2, b2, out, M, N2, act2, st);
+    const MlpAddGeom ag{};
+    return dtype == BS_F16 ? launch_mlp2<f16, 0, 0>(x, ldx, W1, b1, W2, b2, out, M, N2, act2, ag, st)
+                           : launch_mlp2<bf16, 0, 0>(x, ldx, W1, b1, W2, b2, out, M, N2, act2, ag, st);
+}
+
+extern "C" int bs_mlp2_add(const void* emb, const void* prev, const void* W1, const float* b1, const void* W2, const float* b2, float* out,
+                           int32_t B, int32_t Hp, int32_t Wp, int32_t H, int32_t W, int32_t K1, int32_t N1, int32_t N2, int32_t act2, int32_t dtype,
+                           void* stream) {
+    using namespace bs;
+    const int split = (dtype & 16) ? 1 : 0;           // bit 4: emb and prev hold (hi | lo) pairs of K1 channels each
+    dtype &= 15;
+    BS_REQUIRE(B > 0 && Hp > 0 && Wp > 0 && H > 0 && W > 0 && (int64_t)B * H * W < 0x7FFFFFFFll, "bs_mlp2_add: bad geometry");
+    const int M = B * H * W;
+    const int rc = mlp2_check("bs_mlp2_add", emb, W1, b1, W2, b2, out, M, K1, N1, N2, act2, dtype);
+    if (rc != BS_OK) return rc;
+    BS_REQUIRE(prev, "bs_mlp2_add: null operand");
+    MlpAddGeom ag;
+    ag.prev = prev; ag.Hp = Hp; ag.Wp = Wp; ag.H = H; ag.W = W;
+    ag.sy = H > 1 ? (float)(Hp - 1) / (float)(H - 1) : 0.f;      // align_corners = True, as bs_add_resized
+    ag.sx = W > 1 ? (float)(Wp - 1) / (float)(W - 1) : 0.f;
+    const int ldx = K1 * (split ? 2 : 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == BS_F16)
+        return split ? launch_mlp2<f16, 1, 1>(emb, ldx, W1, b1, W2, b2, out, M, N2, act2, ag, st)
+                     : launch_mlp2<f16, 1, 0>(emb, ldx, W1, b1, W2, b2, out, M, N2, act2, ag, st);
+    return split ? launch_mlp2<bf16, 1, 1>(emb, ldx, W1, b1, W2, b2, out, M, N2, act2, ag, st)
+                 : launch_mlp2<bf16, 1, 0>(emb, ldx, W1, b1, W2, b2, out, M, N2, act2, ag, st);
 }

@@ -233,7 +233,8 @@ class ZoeDepthEngine:
         # DPT neck / heads (no cls rows there): "full" = both correction products, "w" = the weight-rounding correction only
         self.neck_mode = neck_mode or os.environ.get("BS_NECK_MODE") or ACCURATE_NECK_MODE
         # (probes: a comma-separated list of weight-key prefixes that KEEP both products, e.g. "ro,ra,nc": everything else "w")
-        self.fuse_mlp = os.environ.get("BS_NO_MLP2") is None        # the attractor MLPs as one launch each (bs_mlp2); off: two bs_gemm (A / B)
+        # the attractor levels: 2 = add + resize + MLP in one launch (bs_mlp2_add), 1 = bs_add_resized + bs_mlp2, 0 = three launches (A / B)
+        self.fuse_mlp = int(os.environ.get("BS_MLP2", "2"))
         c_ = self.cfg
         # the neck switches to the (hi16 | hi8 | lo8) operand format as a whole: every K / Cin on it must be whole 128-byte FP8 stages
         self.neck_f8 = self.acc and self.neck_mode != "pairs" and all(v % 128 == 0 for v in (c_.hidden, c_.fusion, c_.fusion // 2, *c_.neck_hidden))
@@ -1146,12 +1147,23 @@ class _ZoePlan:
             P.gemm(f"pj{i}.c2", e1, w[f"pj{i}.c2.w"], emb, M=Mi, N=E, K=PM * np3, lda=PM * m2, seg1=PM if acc else 0,
                    ldo=E * m2, out_split_off=E if acc else 0, bias=w[f"pj{i}.c2.b"], precision_passes=np3)
             free(e1)
-            y = e16(Mi, E * m2)
-            P.add(f"at{i}.add", "bs_add_resized", emb, emb_prev, y, NB, ph_, pw_, fh, fw, E, L.dt(y) | (16 if acc else 0))
-            free(emb_prev)
             na = eng.na_eff[i]                                     # attractors of this level (replicated up to a multiple of 4)
             A = e32(Mi, 2 * na)
-            if E == 128 and 2 * na <= 32 and eng.fuse_mlp and tuple(w[f"at{i}.c1.w"].shape) == (256, 128):
+            fuse = E == 128 and 2 * na <= 32 and eng.fuse_mlp and tuple(w[f"at{i}.c1.w"].shape) == (256, 128)
+            if fuse and eng.fuse_mlp > 1:
+                # the level in ONE launch: emb + resize(emb_prev) is formed inside the MLP kernel (its hi half is all the MLP reads) and
+                # never stored -- bit-identical to bs_add_resized + bs_mlp2 (csrc/mlp2.hip, FUSE)
+                P.add(f"at{i}.mlp", "bs_mlp2_add", emb, emb_prev, w[f"at{i}.c1.w"], w[f"at{i}.c1.b"], w[f"at{i}.c2.w"], w[f"at{i}.c2.b"], A, NB, ph_,
+                      pw_, fh, fw, E, 2 * E, 2 * na, L.ACT_SOFTPLUS, L.dt(emb) | (16 if acc else 0))
+                free(emb_prev)
+                y = None
+            else:
+                y = e16(Mi, E * m2)
+                P.add(f"at{i}.add", "bs_add_resized", emb, emb_prev, y, NB, ph_, pw_, fh, fw, E, L.dt(y) | (16 if acc else 0))
+                free(emb_prev)
+            if y is None:
+                pass
+            elif fuse:
                 # both 1x1 convolutions in one launch: the 256-channel hidden map (3.2 GB at the finest level) never reaches memory;
                 # bit-identical to the two launches below (bs_mlp2, csrc/mlp2.hip)
                 P.add(f"at{i}.mlp", "bs_mlp2", y, E * m2, w[f"at{i}.c1.w"], w[f"at{i}.c1.b"], w[f"at{i}.c2.w"], w[f"at{i}.c2.b"], A, Mi, E, 2 * E,

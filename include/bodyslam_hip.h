@@ -254,6 +254,13 @@ int bs_attractor_step(const float* A, const float* bins_prev, float* bins_out, c
  * bs_gemm(act = act2, fp32 out) -- the hidden map (M x 256) never reaches memory. */
 int bs_mlp2(const void* x, int32_t ldx, const void* W1, const float* b1, const void* W2, const float* b2, float* out, int32_t M,
             int32_t K1, int32_t N1, int32_t N2, int32_t act2, int32_t dtype, void* stream);
+/* bs_add_resized + bs_mlp2 in one launch (an attractor level, HF modeling_zoedepth.py:726-730 then :665-700): the MLP's input row is
+ * formed in the kernel, x[m] = round16(emb[m] + bilinear_align_corners(prev)[m]), and never stored.  emb [B,H,W,K1] and prev [B,Hp,Wp,K1]
+ * 16-bit NHWC; dtype bit 4 (| 16): both hold (hi | lo) pairs of K1 channels each (pixel stride 2 K1), the sum uses hi + lo.
+ * Bit-identical to bs_add_resized followed by bs_mlp2 on its hi half. */
+int bs_mlp2_add(const void* emb, const void* prev, const void* W1, const float* b1, const void* W2, const float* b2, float* out,
+                int32_t B, int32_t Hp, int32_t Wp, int32_t H, int32_t W, int32_t K1, int32_t N1, int32_t N2, int32_t act2, int32_t dtype,
+                void* stream);
 /* out[b,y,x,:] = x[b,y,x,:] + bilinear_align_corners(prev)[b,y,x,:] (fp16/bf16 NHWC); HF :726-730.
  * dtype bit 4 (| 16): x, prev and out hold (hi | lo) pairs of C channels each (pixel stride 2C), see bs_cast_split. */
 int bs_add_resized(const void* x, const void* prev, void* out, int32_t B, int32_t Hp, int32_t Wp, int32_t H,

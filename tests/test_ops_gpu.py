@@ -1091,3 +1091,31 @@ def test_mlp2(L, dtype, M, N2, pairs):
     err = (out.double() - ref).abs().max().item()
     report(f"mlp2 {dtype} M={M} N2={N2} pairs={pairs}: max err vs fp64 {err:.2e}")
     assert err < 5e-3       # (a hidden unit on a 16-bit rounding boundary may round the other way than in fp64)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("geom", [(2, 6, 8, 12, 16, 8, True), (1, 12, 16, 24, 32, 16, True), (3, 5, 7, 9, 13, 32, False), (1, 1, 1, 1, 1, 8, True),
+                                  (1, 24, 32, 48, 64, 8, True)])
+def test_mlp2_add(L, dtype, geom):
+    """bs_mlp2_add (an attractor level in one launch) against bs_add_resized followed by bs_mlp2 on its output -- bit for bit: ragged last
+    block, pair and single rows, 1x1 maps, every output width."""
+    B, Hp, Wp, H, W, N2, pairs = geom
+    K1, N1 = 128, 256
+    m2 = 2 if pairs else 1
+    emb = rnd(B, H, W, K1 * m2, seed=21, dtype=dtype)
+    prev = rnd(B, Hp, Wp, K1 * m2, seed=22, dtype=dtype)
+    if pairs:       # lo halves of a realistic magnitude
+        emb[..., K1:] *= 2.0 ** -11
+        prev[..., K1:] *= 2.0 ** -11
+    w1 = (rnd(N1, K1, seed=23) / K1 ** 0.5).to(dtype)
+    w2 = (rnd(N2, N1, seed=24) / N1 ** 0.5).to(dtype)
+    b1, b2 = rnd(N1, seed=25), rnd(N2, seed=26)
+    M = B * H * W
+    out = torch.full((M, N2), -7.0, device=dev())
+    L.mlp2_add(emb, prev, w1, b1, w2, b2, out, B, Hp, Wp, H, W, K1, N1, N2, L.ACT_SOFTPLUS, split=pairs)
+    y = torch.empty_like(emb)
+    L.add_resized(emb, prev, y, B, Hp, Wp, H, W, K1, split=pairs)
+    two = torch.empty(M, N2, device=dev())
+    L.mlp2(y, K1 * m2, w1, b1, w2, b2, two, M, K1, N1, N2, L.ACT_SOFTPLUS)
+    torch.cuda.synchronize()
+    assert torch.equal(out, two), f"max |fused - two launches| = {(out - two).abs().max().item():.3e}"
