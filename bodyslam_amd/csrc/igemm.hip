@@ -48,6 +48,12 @@ static int launch_tile(IgemmParams& p, int dtype, bool conv, int tile, hipStream
     tile_dims(tile, BM, BN);
     p.ntm = cdiv(p.M - p.m_begin, BM);
     p.ntn = cdiv(p.N, BN);
+    // Tile order.  Wide plain products on the 256 x 256 tile (fc1, the reassemble ConvT's: >= 8 N-tiles) walk column strips of four N-tiles,
+    // M fastest: the strip's W tiles stay in the XCD's L2 while the A panels stream through once per strip -- 37-40 % fewer L2 refills at the
+    // same launch time (profiles/r04_gemm_experiments.txt (7)).  Not the QKV product: its V^T tiles would bunch up at the end (+45 %).
+    // BS_GEMM_STRIP = w forces a width (0 = row-major) for every non-convolution launch: diagnostics.
+    static const int strip_env = getenv("BS_GEMM_STRIP") ? atoi(getenv("BS_GEMM_STRIP")) : -1;
+    p.strip = conv ? 0 : (strip_env >= 0 ? strip_env : ((BM == 256 && BN == 256 && p.out_mode != BS_OUT_QKV && p.ntn >= 8) ? 4 : 0));
     // correction mode of the instantiation: 1 = FP8 stages / (hi16 | hi8 | lo8) formats, 0 = plain
     const int cm = (p.f8_stages > 0 || p.out_f8 || p.res_f8) ? 1 : 0;
     const bool h = dtype == BS_F16;
@@ -205,10 +211,7 @@ extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
     BS_REQUIRE(d->out_split_off == 0 || (d->out_mode != BS_OUT_QKV && d->out_dtype == d->dtype), "bs_gemm: split output needs a plain / shuffle 16-bit output");
     BS_REQUIRE(d->res_split_off == 0 || (d->res && d->res_dtype == d->dtype), "bs_gemm: split residual must be 16-bit");
     p.ablate = d->tile >= 100 ? d->tile / 100 : 0;
-    {
-        static const int strip_env = getenv("BS_GEMM_STRIP") ? atoi(getenv("BS_GEMM_STRIP")) : 0;
-        p.strip = d->conv ? 0 : strip_env;
-    }
+
     BS_REQUIRE(!d->relu_a || d->conv, "bs_gemm: relu_a is only built for conv mode");
     p.bias = d->bias; p.bias_group_rows = d->bias_group_rows; p.act = d->act; p.scale = d->scale;
     p.res = d->res; p.res2 = d->res2; p.res_dtype = d->res_dtype; p.ldr = d->ldr;
