@@ -34,11 +34,14 @@ __device__ __forceinline__ Lerp2 lerp_ac(int oy, int ox, int Hin, int Win, float
 // attractors.  thread = (pixel, group, 4 consecutive bins).  With `route`, only the group that an
 // image is routed to is computed (the other group's output is left untouched).
 // ---------------------------------------------------------------------------------------------
+// NQ: bin quads per thread (2 where n_bins % 8 == 0: twice the bytes in flight per thread, half the threads -- the kernel is bound by the
+// latency of its few loads, not by arithmetic or bytes)
+template <int NQ>
 __global__ __launch_bounds__(256) void attractor_kernel(const float* A, const float* bins_prev, float* bins_out, const int32_t* route,
                                                          int B, int Hp, int Wp, int H, int W, int G, int nb, int na, float sy, float sx) {
-    // grid.y = (image, output row); grid.x covers (column, group, bin quad) of that row: no 64-bit div/mod per thread
+    // grid.y = (image, output row); grid.x covers (column, group, bin quad group) of that row: no 64-bit div/mod per thread
     // with `route` the grid covers the routed group only (no idle lanes for the head that is not computed)
-    const int q4 = nb >> 2;
+    const int q4 = nb / (4 * NQ);
     const int GG = route ? 1 : G;
     const unsigned per_row = (unsigned)W * GG * q4;
     const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -50,14 +53,23 @@ __global__ __launch_bounds__(256) void attractor_kernel(const float* A, const fl
     const int64_t pix = ((int64_t)b * H + oy) * W + ox;
     const Lerp2 l = lerp_ac(oy, ox, Hp, Wp, sy, sx);
     const int CB = G * nb, CA = G * na;
-    const float* pb = bins_prev + (int64_t)b * Hp * Wp * CB + g * nb + q * 4;
-    const f32x4 p00 = *reinterpret_cast<const f32x4*>(pb + ((int64_t)l.y0 * Wp + l.x0) * CB);
-    const f32x4 p01 = *reinterpret_cast<const f32x4*>(pb + ((int64_t)l.y0 * Wp + l.x1) * CB);
-    const f32x4 p10 = *reinterpret_cast<const f32x4*>(pb + ((int64_t)l.y1 * Wp + l.x0) * CB);
-    const f32x4 p11 = *reinterpret_cast<const f32x4*>(pb + ((int64_t)l.y1 * Wp + l.x1) * CB);
-    float c[4], dsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* pb = bins_prev + (int64_t)b * Hp * Wp * CB + g * nb + q * 4 * NQ;
+    f32x4 p00[NQ], p01[NQ], p10[NQ], p11[NQ];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) c[e] = l.hy * (l.hx * p00[e] + l.lx * p01[e]) + l.ly * (l.hx * p10[e] + l.lx * p11[e]);
+    for (int u = 0; u < NQ; ++u) {
+        p00[u] = *reinterpret_cast<const f32x4*>(pb + ((int64_t)l.y0 * Wp + l.x0) * CB + 4 * u);
+        p01[u] = *reinterpret_cast<const f32x4*>(pb + ((int64_t)l.y0 * Wp + l.x1) * CB + 4 * u);
+        p10[u] = *reinterpret_cast<const f32x4*>(pb + ((int64_t)l.y1 * Wp + l.x0) * CB + 4 * u);
+        p11[u] = *reinterpret_cast<const f32x4*>(pb + ((int64_t)l.y1 * Wp + l.x1) * CB + 4 * u);
+    }
+    float c[4 * NQ], dsum[4 * NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            c[4 * u + e] = l.hy * (l.hx * p00[u][e] + l.lx * p01[u][e]) + l.ly * (l.hx * p10[u][e] + l.lx * p11[u][e]);
+            dsum[4 * u + e] = 0.f;
+        }
     const float* pa = A + pix * CA + g * na;
     for (int a4 = 0; a4 < na; a4 += 4) {
         const f32x4 av = *reinterpret_cast<const f32x4*>(pa + a4);
@@ -66,7 +78,7 @@ __global__ __launch_bounds__(256) void attractor_kernel(const float* A, const fl
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < 2 * NQ; ++h) {
                 const f32x2_ dx = f32x2_{av[k], av[k]} - f32x2_{c[2 * h], c[2 * h + 1]};
                 const f32x2_ den = __builtin_elementwise_fma(dx * f32x2_{300.0f, 300.0f}, dx, f32x2_{1.0f, 1.0f});
                 const f32x2_ r = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
@@ -75,10 +87,13 @@ __global__ __launch_bounds__(256) void attractor_kernel(const float* A, const fl
                 dsum[2 * h + 1] = d2[1];
             }
     }
-    f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = c[e] + dsum[e] / (float)na;
-    *reinterpret_cast<f32x4*>(bins_out + pix * CB + g * nb + q * 4) = o;
+    for (int u = 0; u < NQ; ++u) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = c[4 * u + e] + dsum[4 * u + e] / (float)na;
+        *reinterpret_cast<f32x4*>(bins_out + pix * CB + g * nb + q * 4 * NQ + 4 * u) = o;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -341,9 +356,16 @@ extern "C" int bs_attractor_step(const float* A, const float* bins_prev, float* 
     if (B == 0) return BS_OK;
     const float sy = H > 1 ? (float)(Hp - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(Wp - 1) / (float)(W - 1) : 0.f;
     BS_REQUIRE(n_attr % 4 == 0, "bs_attractor_step: n_attr must be a multiple of 4");
-    const unsigned per_row = (unsigned)W * (route ? 1 : groups) * (n_bins / 4);
-    hipLaunchKernelGGL(attractor_kernel, dim3(cdiv((int)per_row, 256), B * H), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A,
-                       bins_prev, bins_out, route, B, Hp, Wp, H, W, groups, n_bins, n_attr, sy, sx);
+    static const bool one_quad = getenv("BS_ATTRACTOR_NQ1") != nullptr;        // diagnostics (A / B)
+    if (n_bins % 8 == 0 && !one_quad) {      // (four quads per thread: 1.65 ms against 1.59 for the bench's four levels; one: 1.72)
+        const unsigned per_row = (unsigned)W * (route ? 1 : groups) * (n_bins / 8);
+        hipLaunchKernelGGL(attractor_kernel<2>, dim3(cdiv((int)per_row, 256), B * H), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A,
+                           bins_prev, bins_out, route, B, Hp, Wp, H, W, groups, n_bins, n_attr, sy, sx);
+    } else {
+        const unsigned per_row = (unsigned)W * (route ? 1 : groups) * (n_bins / 4);
+        hipLaunchKernelGGL(attractor_kernel<1>, dim3(cdiv((int)per_row, 256), B * H), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A,
+                           bins_prev, bins_out, route, B, Hp, Wp, H, W, groups, n_bins, n_attr, sy, sx);
+    }
     BS_CHECK_LAUNCH();
     return BS_OK;
 }
