@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BODYSLAM_HIP_LIB") or os.path.join(_HERE, "libbodyslam_hip.so")      # (the override: A/B runs of two builds in one call)
 
 F32, F16, BF16 = 0, 1, 2
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_SOFTPLUS = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SOFTPLUS, ACT_SOFTPLUS_FAST = 0, 1, 2, 3, 4
 OUT_PLAIN, OUT_SHUFFLE, OUT_QKV = 0, 1, 2
 
 _TORCH2BS = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
@@ -600,12 +600,12 @@ def attractor_step(A, bins_prev, bins_out, route, B, Hp, Wp, H, W, groups, n_bin
                                            stream_ptr()), "bs_attractor_step")
 
 
-def mlp2(x, ldx, W1, b1, W2, b2, out, M, K1, N1, N2, act2=ACT_SOFTPLUS):
+def mlp2(x, ldx, W1, b1, W2, b2, out, M, K1, N1, N2, act2=ACT_SOFTPLUS_FAST):
     """out = act2(round16(relu(x W1^T + b1)) W2^T + b2) in one launch (include/bodyslam_hip.h: bs_mlp2)"""
     check(load_library().bs_mlp2(p(x), ldx, p(W1), p(b1), p(W2), p(b2), p(out), M, K1, N1, N2, act2, dt(x), stream_ptr()), "bs_mlp2")
 
 
-def mlp2_add(emb, prev, W1, b1, W2, b2, out, B, Hp, Wp, H, W, K1, N1, N2, act2=ACT_SOFTPLUS, split=False):
+def mlp2_add(emb, prev, W1, b1, W2, b2, out, B, Hp, Wp, H, W, K1, N1, N2, act2=ACT_SOFTPLUS_FAST, split=False):
     """bs_add_resized + bs_mlp2 in one launch (include/bodyslam_hip.h: bs_mlp2_add)"""
     check(load_library().bs_mlp2_add(p(emb), p(prev), p(W1), p(b1), p(W2), p(b2), p(out), B, Hp, Wp, H, W, K1, N1, N2, act2,
                                      dt(emb) | (16 if split else 0), stream_ptr()), "bs_mlp2_add")

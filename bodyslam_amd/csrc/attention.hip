@@ -796,7 +796,9 @@ static int launch_attn_tab(const void* q, const void* k, const void* vt, const v
         auto kc = attention_tab2_kernel<T, QW, 2, true>;
         static bool attrc = false;
         if (!attrc) {
-            BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            // the cap covers the largest table the entry admits (hp = 40: 64 KiB + 20.3 KiB); up to hp = 30 the ring + table stay within
+            // 80 KiB and two blocks share a CU, beyond that one block per CU (round-4 advisor: the cap was 80 KiB and hp 32 ... 40 failed)
+            BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, 88 * 1024));
             attrc = true;
         }
         hipLaunchKernelGGL(kc, dim3(B * nh * nqb), dim3(QW * 64), 64 * 1024 + tab_bytes, st, (const T*)q, (const T*)k, (const T*)vt, (const T*)ql,

@@ -150,7 +150,7 @@ __device__ __forceinline__ f32x2_ gelu_erf_as2(f32x2_ x) {
 }
 // torch.nn.Softplus(beta=1, threshold=20)
 __device__ __forceinline__ float softplus20(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
-// The GEMM epilogues' softplus (torch's threshold 20): v_exp / v_log and a four-term series of log1p below e = 2^-6 -- 14 instructions
+// BS_ACT_SOFTPLUS_FAST, the attractor MLPs' softplus (torch's threshold 20): v_exp / v_log and a four-term series of log1p below e = 2^-6 -- 14 instructions
 // where libm's expf + log1pf take ~80 (the attractor MLP's epilogue was VALU-bound on them).  Relative error <= 4e-6 (at e = 2^-6, from
 // rounding 1 + e), absolute <= 6e-8: two orders below the 16-bit rounding of the hidden units that feed it.  The log-binomial head
 // (metric.hip), whose softmax amplifies its inputs' errors, keeps softplus20.
@@ -165,7 +165,8 @@ __device__ __forceinline__ float softplus_fast(float x) {
 __device__ __forceinline__ float apply_act(float y, int act) {
     if (act == BS_ACT_RELU) return fmaxf(y, 0.0f);
     if (act == BS_ACT_GELU) return gelu_erf(y);
-    if (act == BS_ACT_SOFTPLUS) return softplus_fast(y);
+    if (act == BS_ACT_SOFTPLUS) return softplus20(y);
+    if (act == BS_ACT_SOFTPLUS_FAST) return softplus_fast(y);
     return y;
 }
 

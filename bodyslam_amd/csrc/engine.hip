@@ -12,6 +12,7 @@
 #include <tuple>
 #include <type_traits>
 #include <utility>
+#include <memory>
 #include <vector>
 
 #include "common.h"
@@ -134,6 +135,9 @@ static int engine_load_impl(const char* path, bs_engine** out) {
     *out = nullptr;
     FILE* f = fopen(path, "rb");
     BS_REQUIRE(f, "bs_engine_load: cannot open %s", path);
+    // the file and the partly built engine are owned by guards: every early return AND an exception out of a std::vector / new (caught at
+    // the C boundary below) closes the file and frees the device buffers (round-4 advisor)
+    std::unique_ptr<FILE, int (*)(FILE*)> file_guard(f, fclose);
     Reader r{f};
     char magic[8];
     r.bytes(magic, 8);
@@ -148,25 +152,21 @@ static int engine_load_impl(const char* path, bs_engine** out) {
     }
     if (r.ok && memcmp(magic, kMagic, 8) == 0 &&
         ((long)n_buf * 20 > file_size || (long)n_io * 52 > file_size || (long)n_ops * 56 > file_size || calls_bytes < 0 || calls_bytes > file_size)) {
-        fclose(f);
         set_error("bs_engine_load: %s: record counts exceed the file size (corrupt or truncated)", path);
         return BS_ERR_INVALID;
     }
     if (!r.ok || memcmp(magic, kMagic, 8) != 0) {
-        fclose(f);
         set_error("bs_engine_load: %s is not an engine file of this version", path);
         return BS_ERR_INVALID;
     }
     if (desc_size != sizeof(bs_gemm_desc)) {
-        fclose(f);
         set_error("bs_engine_load: %s was exported against a bs_gemm_desc of %u bytes, this library's has %zu: re-export it", path, desc_size,
                   sizeof(bs_gemm_desc));
         return BS_ERR_INVALID;
     }
-    bs_engine* e = new bs_engine();
+    std::unique_ptr<bs_engine, void (*)(bs_engine*)> engine_guard(new bs_engine(), engine_free);
+    bs_engine* e = engine_guard.get();
     auto fail = [&](const char* what) {
-        fclose(f);
-        engine_free(e);
         set_error("bs_engine_load: %s (%s)", what, path);
         return BS_ERR_INVALID;
     };
@@ -188,9 +188,9 @@ static int engine_load_impl(const char* path, bs_engine** out) {
     }
     if (!r.ok) return fail("truncated header");
     for (auto& b : recs)
-        if (b.nbytes < 0 || (b.kind == KIND_DATA && (b.off < 0 || b.off + b.nbytes > file_size))) return fail("bad buffer record");
+        if (b.nbytes < 0 || (b.kind == KIND_DATA && (b.off < 0 || b.off > file_size || b.nbytes > file_size - b.off))) return fail("bad buffer record");
     for (auto& i : ios)
-        if (i.buf >= n_buf || i.nbytes < 0 || i.off < 0 || i.off + i.nbytes > recs[i.buf].nbytes) return fail("io record outside its buffer");
+        if (i.buf >= n_buf || i.nbytes < 0 || i.off < 0 || i.off > recs[i.buf].nbytes || i.nbytes > recs[i.buf].nbytes - i.off) return fail("io record outside its buffer");
     // buffers
     e->bufs.assign(n_buf, nullptr);
     for (uint32_t i = 0; i < n_buf; ++i) {
@@ -256,8 +256,6 @@ static int engine_load_impl(const char* path, bs_engine** out) {
         if (op.kind == OP_CALL) {
             auto it = tab.find(op.name);
             if (it == tab.end()) {
-                fclose(f);
-                engine_free(e);
                 set_error("bs_engine_load: the engine calls %s, which this library's engine runner does not know", name);
                 return BS_ERR_INVALID;
             }
@@ -278,15 +276,13 @@ static int engine_load_impl(const char* path, bs_engine** out) {
         if (fseek(f, data0 + (long)recs[i].off, SEEK_SET) != 0 || fread(host.data(), 1, host.size(), f) != host.size()) return fail("truncated constants");
         if (hipMemcpy(e->bufs[i], host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
     }
-    fclose(f);
+    file_guard.reset();
     // the zero-fills and uploads above ran on the null stream; bs_engine_run may be given a non-blocking stream that does not wait for it
     if (hipDeviceSynchronize() != hipSuccess) {
-        engine_free(e);
         set_error("bs_engine_load: device synchronisation failed");
         return BS_ERR_HIP;
     }
     if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) {
-        engine_free(e);
         set_error("bs_engine_load: cannot create the side stream");
         return BS_ERR_HIP;
     }
@@ -294,13 +290,12 @@ static int engine_load_impl(const char* path, bs_engine** out) {
         if (op.kind != OP_CALL && !e->events.count((int)op.args[0].i)) {
             hipEvent_t ev;
             if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
-                engine_free(e);
                 set_error("bs_engine_load: cannot create an event");
                 return BS_ERR_HIP;
             }
             e->events[(int)op.args[0].i] = ev;
         }
-    *out = e;
+    *out = engine_guard.release();
     return BS_OK;
 }
 

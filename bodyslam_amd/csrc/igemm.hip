@@ -216,6 +216,7 @@ extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
     p.ablate = d->tile >= 100 ? d->tile / 100 : 0;
 
     BS_REQUIRE(!d->relu_a || d->conv, "bs_gemm: relu_a is only built for conv mode");
+    BS_REQUIRE(d->act >= BS_ACT_NONE && d->act <= BS_ACT_SOFTPLUS_FAST, "bs_gemm: unknown activation %d", d->act);
     p.bias = d->bias; p.bias_group_rows = d->bias_group_rows; p.act = d->act; p.scale = d->scale;
     p.res = d->res; p.res2 = d->res2; p.res_dtype = d->res_dtype; p.ldr = d->ldr;
     BS_REQUIRE(!d->res2 || d->res, "bs_gemm: res2 needs res (they share ldr)");

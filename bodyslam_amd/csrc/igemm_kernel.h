@@ -679,7 +679,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             if (ACT == BS_ACT_RELU) y[e] = fmaxf(y[e], 0.0f);
-                            else if (ACT == BS_ACT_SOFTPLUS) y[e] = softplus_fast(y[e]);
+                            else if (ACT == BS_ACT_SOFTPLUS) y[e] = softplus20(y[e]);
+                            else if (ACT == BS_ACT_SOFTPLUS_FAST) y[e] = softplus_fast(y[e]);
                             if (!res32) y[e] *= sj[j][e];
                         }
                         if (p.res) {
@@ -1115,6 +1116,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
         if (p.act == BS_ACT_GELU) epi(std::integral_constant<int, BS_ACT_GELU>{});
         else if (p.act == BS_ACT_RELU) epi(std::integral_constant<int, BS_ACT_RELU>{});
         else if (p.act == BS_ACT_SOFTPLUS) epi(std::integral_constant<int, BS_ACT_SOFTPLUS>{});
+        else if (p.act == BS_ACT_SOFTPLUS_FAST) epi(std::integral_constant<int, BS_ACT_SOFTPLUS_FAST>{});
         else epi(std::integral_constant<int, BS_ACT_NONE>{});
     } else {
         // V part: per-wave LDS transpose, then consecutive lanes store consecutive tokens of one (head, d) row

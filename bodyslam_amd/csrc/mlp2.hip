@@ -235,7 +235,7 @@ static int mlp2_check(const char* who, const void* x, const void* W1, const floa
     BS_REQUIRE(K1 == MLP_K1 && N1 == MLP_N1, "%s: built for K1 = %d, N1 = %d (got %d, %d)", who, MLP_K1, MLP_N1, K1, N1);
     BS_REQUIRE(N2 > 0 && N2 <= 32 && N2 % 4 == 0, "%s: N2 = %d must be a multiple of 4 in 4 .. 32", who, N2);
     BS_REQUIRE(M > 0, "%s: M = %d", who, M);
-    BS_REQUIRE(act2 == BS_ACT_NONE || act2 == BS_ACT_RELU || act2 == BS_ACT_SOFTPLUS || act2 == BS_ACT_GELU, "%s: unknown activation %d", who, act2);
+    BS_REQUIRE(act2 == BS_ACT_NONE || act2 == BS_ACT_RELU || act2 == BS_ACT_SOFTPLUS || act2 == BS_ACT_SOFTPLUS_FAST || act2 == BS_ACT_GELU, "%s: unknown activation %d", who, act2);
     return BS_OK;
 }
 

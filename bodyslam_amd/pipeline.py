@@ -53,11 +53,16 @@ def gather_relative_poses(t_local: torch.Tensor, counts: Sequence[int], group=No
     if len(counts) != world or t_local.shape[0] != counts[dist.get_rank(group)]:
         raise ValueError(f"gather_relative_poses: counts {list(counts)} do not match world {world} / local pairs {t_local.shape[0]}")
     pmax = max(counts)
-    buf = torch.zeros(pmax, 16, dtype=torch.float32, device=t_local.device)
+    # RCCL gathers device buffers in place; a gloo group (CPU tests, two processes sharing one GPU) gets the few KB through the host
+    cdev = t_local.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    buf = torch.zeros(pmax, 16, dtype=torch.float32, device=cdev)
     buf[: t_local.shape[0]] = t_local
-    out = torch.empty(world * pmax, 16, dtype=torch.float32, device=t_local.device)
-    dist.all_gather_into_tensor(out, buf, group=group)
-    return torch.cat([out[r * pmax: r * pmax + counts[r]] for r in range(world)], dim=0)
+    out = torch.empty(world * pmax, 16, dtype=torch.float32, device=cdev)
+    if cdev.type == "cpu":
+        dist.all_gather(list(out.view(world, pmax, 16).unbind(0)), buf, group=group)
+    else:
+        dist.all_gather_into_tensor(out, buf, group=group)
+    return torch.cat([out[r * pmax: r * pmax + counts[r]] for r in range(world)], dim=0).to(t_local.device)
 
 
 def share_calibration(make_report: Callable[[], dict], group=None, device=None) -> dict:
@@ -69,10 +74,23 @@ def share_calibration(make_report: Callable[[], dict], group=None, device=None) 
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return make_report()
     rank = dist.get_rank(group)
-    box = [make_report() if rank == 0 else None]
+    # rank 0's failure (out of memory while the reference engine is up, a launch error) must not leave the others waiting in the
+    # broadcast: the outcome travels as (ok, report-or-message) and every rank raises (round-4 advisor)
+    box, err = [None], None
+    if rank == 0:
+        try:
+            box = [(True, make_report())]
+        except Exception as e:      # noqa: BLE001 -- re-raised below, on every rank
+            err = e
+            box = [(False, f"{type(e).__name__}: {e}")]
     src = dist.get_global_rank(group, 0) if group is not None else 0
     dist.broadcast_object_list(box, src=src, group=group, device=device)
-    return box[0]
+    ok, payload = box[0]
+    if not ok:
+        if err is not None:
+            raise err
+        raise RuntimeError(f"share_calibration: rank 0 failed to calibrate: {payload}")
+    return payload
 
 
 @dataclass
@@ -118,12 +136,21 @@ class BodySlamPipeline:
         z = self.zoe
         if not (z.acc and z.auto_modes):
             return z.calibration
-        if z.calibration is None:
-            import torch.distributed as dist
-            first = not dist.is_initialized() or dist.get_rank(group) == 0
-            rep = share_calibration(lambda: z.calibrate(H, W), group, self.dev)
+        import torch.distributed as dist
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            if z.calibration is None:
+                z.calibrate(H, W)
+            return z.calibration
+        # whether the collective below is entered is decided from what ALL ranks hold, never from this rank's state alone (a rank that
+        # was calibrated earlier, or had a report applied, would otherwise skip a broadcast the others wait in: round-4 advisor)
+        cdev = self.dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        need = torch.tensor([1 if z.calibration is None else 0], dtype=torch.int32, device=cdev)
+        dist.all_reduce(need, op=dist.ReduceOp.MAX, group=group)
+        if int(need.item()):
+            first = dist.get_rank(group) == 0
+            rep = share_calibration(lambda: z.calibration if z.calibration is not None else z.calibrate(H, W), group, cdev)
             if not first:
-                z.apply_calibration(rep)
+                z.apply_calibration(rep)        # (also on a rank that held one: every rank runs rank 0's arithmetic)
         return z.calibration
 
     # -- stage 1+2 for one block of frames ----------------------------------------------------------

@@ -182,3 +182,42 @@ def random_cyclepose_weights(seed: int = 0) -> dict:
         out[name] = (0.1 * x if name.endswith("bias") else x / math.sqrt(int(np.prod(shape[1:])))).contiguous()
     out["pose_dense.3.bias"][3] += 4.0      # keep the quaternion near identity (small inter-frame rotations)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# Weight statistics that do not look like the seeded Gaussian ones (trained BEiT-L checkpoints carry a per-channel layer-scale
+# spanning decades, a few outlier channels behind the LayerNorms and heavy-tailed weights).  Each edits a random_zoedepth_weights /
+# oracle synth_weights dict IN PLACE; tests/test_zoedepth_gpu.py holds the 1e-4 m tolerance on each, bench.py --weights outlier
+# measures the throughput of what the calibration has to switch on for the outlier set.
+# ---------------------------------------------------------------------------------------------------
+def layerscale_wide(w):
+    import torch
+    g = torch.Generator().manual_seed(101)
+    for k in w:
+        if k.endswith("lambda_1") or k.endswith("lambda_2"):          # log-uniform 1e-3 .. 1 per channel (trained BEiT: 1e-5 init, grown unevenly)
+            w[k] = w[k].sign() * torch.pow(10.0, -3.0 * torch.rand(w[k].shape, generator=g)) * 0.3
+
+
+def outlier_channels(w):
+    import torch
+    g = torch.Generator().manual_seed(102)
+    idx = torch.randperm(1024, generator=g)[:6]
+    for k in w:
+        if k.endswith("layernorm_before.weight") or k.endswith("layernorm_after.weight"):       # 6 channels 50x larger after every LayerNorm
+            w[k] = w[k].clone()
+            w[k][idx] *= 50.0
+        if k.endswith("attention.q_proj.weight") or k.endswith("mlp.fc1.weight"):               # ... and damped again where they are consumed, so
+            w[k] = w[k].clone()                                                                     # the network stays in range
+            w[k][:, idx] /= 25.0
+
+
+def heavy_tailed(w):
+    import torch
+    g = torch.Generator().manual_seed(103)
+    for k in w:
+        if w[k].dim() >= 2 and w[k].numel() >= 1 << 16 and "position_bias" not in k:
+            t = torch.randn(w[k].shape, generator=g) / torch.randn(w[k].shape, generator=g).abs().clamp_min(0.35)   # ratio of normals: heavy tails
+            w[k] = w[k] * (0.6 + 0.4 * t.abs().clamp_max(12.0) / 1.6)
+
+
+WEIGHT_VARIANTS = {"gaussian": None, "outlier": outlier_channels, "layerscale": layerscale_wide, "heavytail": heavy_tailed}

@@ -126,6 +126,13 @@ AUTO_SAVING_MS = {"fc1": 8.7, "fc2": 8.0, "qkv": 3.7, "o": 1.8, "neck": 2.0, "at
 # calibration frame is one frame).  Without that reference (no source weights) the neck stays "full".
 AUTO_NECK_CANDIDATES = (NECK_RELHEAD_WONLY, "full")
 AUTO_TOL_NECK_ABS_M = 5.0e-5
+# Round 5: the neck is calibrated PER SITE (VERDICT r4 #1c).  With the absolute reference available, calibrate() measures what each of the
+# neck's / heads' FP8-format products costs when it alone drops the activation-rounding correction, orders the sites by depth error per
+# FLOP saved and keeps the longest prefix of that order whose combination stays under AUTO_TOL_NECK_ABS_M against the reference
+# (tools/probes/neck_site_study.py: on the bench weights 11 ... 19 sites, not only the relative head, fit that budget).  The choice is
+# the neck mode "wonly:<site>,<site>,..." (ZoeDepthEngine.neck_site_wonly).  Sites below this share of the neck's FLOPs are not worth a
+# calibration forward and keep both products.
+AUTO_NECK_SITE_MIN_SHARE = 0.004
 ACCURATE_NECK_MODE = "full"
 # (Round 3 also had neck_corr="f4": e2m1 correction planes with E8M0 block scales on the FP4 MFMA -- +1.4 % frames/s for 1.5x the depth error,
 # profiles/r03_fp4_corrections.txt.  It never paid and was removed in round 4; the correction products run on the block-scaled FP8 MFMA.)
@@ -291,6 +298,21 @@ class ZoeDepthEngine:
             return self.class_modes.get(wkey.split(".")[-2], m)
         return m
 
+    def neck_site_wonly(self, wkey: str) -> bool:
+        """does this neck / head product run the weight-rounding correction only (1.5 pass-equivalents) under the current neck mode?
+        neck_mode: "full" (both products everywhere), "w" (none), "wonly:a,b,..." (exactly these sites weight-only: the per-site
+        calibration's form), or a comma list of weight-key prefixes that KEEP both products (everything else weight-only)."""
+        nm = self.neck_mode
+        if wkey.endswith("w_cls") or nm in ("full", "pairs"):
+            # the per-image readout bias (cls row x W_cls, added to every token of the image) always gets both products: an error there
+            # is a coherent offset of the whole map
+            return False
+        if nm == "w":
+            return True
+        if nm.startswith("wonly:"):
+            return wkey in nm[6:].split(",")
+        return not any(wkey.startswith(p_) for p_ in nm.split(","))
+
     def set_class_modes(self, modes: Dict[str, str], neck_mode: Optional[str] = None, attn_mode: Optional[str] = None) -> None:
         """switch the backbone classes between "full" / "wcls" / "wmean" (and the neck mode, the attention mode) without re-ingesting
         the weights; plans built so far are dropped"""
@@ -353,11 +375,18 @@ class ZoeDepthEngine:
         switchable = [k for k in BACKBONE_CLASSES if self.class_modes[k] in ("full", "wcls", "wmean")] if self.auto_classes else []
         neck_cands = ["full"] if (not self.neck_f8 or not self.auto_classes or (neck_candidates is None and (not reference or self._sd is None))) \
             else list(neck_candidates or AUTO_NECK_CANDIDATES)
+        # default (no explicit candidates, absolute reference available): the neck is calibrated per site AFTER the backbone classes and
+        # the attention have been settled with the neck on both products (below); the group candidates are for explicit requests
+        per_site = neck_candidates is None and len(neck_cands) > 1
+        if per_site:
+            neck_cands = ["full"]
         nh_, nw_ = net_size(H, W, self.target_hw)
         corr_ok = nw_ // self.cfg.patch == 32 and (nh_ // self.cfg.patch) % 2 == 0 and nh_ // self.cfg.patch <= 40
         attn_best = ("corr" if corr_ok else "single") if self.auto_attn else self.attn_mode
         saved_auto, self.auto_modes = self.auto_modes, False
         neck0 = self.neck_mode
+
+        site_flops: Dict[str, float] = {}
 
         def depth(modes, neck, attn):
             self.set_class_modes(modes, neck, attn)
@@ -366,11 +395,12 @@ class ZoeDepthEngine:
             plan.run(None)
             d = plan.depth_m.clone()
             torch.cuda.synchronize(self.dev)
+            site_flops.update(plan.site_flops)
             del plan
             return d
 
         full = {k: "full" for k in switchable}
-        neck_full = "full" if len(neck_cands) > 1 else neck0
+        neck_full = "full" if (len(neck_cands) > 1 or per_site) else neck0
         ref = depth(full, neck_full, attn_best)
         report = {"frame": f"{H}x{W}", "tol_class_m": tol_class, "tol_total_m": tol_total, "tol_abs_m": tol_abs, "l1_vs_full_m": {}}
         truth = None
@@ -433,6 +463,33 @@ class ZoeDepthEngine:
                 break
             if not step_up():
                 break
+        if per_site and truth is not None and l1_abs is not None and l1_abs <= AUTO_TOL_NECK_ABS_M:
+            # ---- the neck, site by site: what each product costs when it alone drops the activation-rounding correction (against the
+            # combination chosen so far), then the longest prefix of the error-per-FLOP order that stays within the neck's budget
+            # against the reference.  The error grows along that order (tools/probes/neck_site_study.py), so the prefix is bisected.
+            tot_f = sum(site_flops.values()) or 1.0
+            sites = [k_ for k_, f_ in site_flops.items() if f_ >= AUTO_NECK_SITE_MIN_SHARE * tot_f and not k_.endswith("w_cls")]
+            err = {k_: (depth(chosen, "wonly:" + k_, attn) - d_c).abs().mean().item() for k_ in sites}
+            order = sorted(sites, key=lambda k_: err[k_] / site_flops[k_])
+            lo, hi, kept = 0, len(order), None
+            while lo < hi:
+                mid = (lo + hi + 1) // 2
+                d_s = depth(chosen, "wonly:" + ",".join(order[:mid]), attn)
+                a_, t_ = (d_s - truth).abs().mean().item(), (d_s - ref).abs().mean().item()
+                if a_ <= AUTO_TOL_NECK_ABS_M and t_ <= tol_total:
+                    lo, kept = mid, (a_, t_)
+                else:
+                    hi = mid - 1
+            report["neck_sites"] = {"tol_abs_m": AUTO_TOL_NECK_ABS_M, "l1_alone_vs_chosen_m": {k_: round(err[k_], 8) for k_ in order},
+                                    "weight_only": order[:lo], "flops_share_weight_only": round(sum(site_flops[k_] for k_ in order[:lo]) / tot_f, 4)}
+            if lo > 0:
+                neck = "wonly:" + ",".join(sorted(order[:lo]))
+                l1_abs, total = kept
+        if self.auto_attn and not corr_ok:
+            # the split-precision kernel could not be tried on this geometry (every candidate above ran "single"): the engine keeps "corr",
+            # which a plan of a capable geometry then uses and this one falls back from (_ZoePlan) -- "single" must be earned by a measurement
+            attn = "corr"
+            report["attn_note"] = f"attention not calibrated on a {nh_}x{nw_} network input (no split-precision kernel for it): kept at 'corr'"
         report.update(class_modes={**{k: self.class_modes[k] for k in BACKBONE_CLASSES}, **chosen}, neck_mode=neck, attn_mode=attn,
                       l1_total_vs_full_m=total, l1_abs_vs_reference_m=l1_abs)
         if l1_abs is not None and l1_abs > TOLERANCE_M:
@@ -749,6 +806,7 @@ class _ZoePlan:
         Sp = (S + 63) // 64 * 64
         Hd = c.hidden
         self.geom = dict(B=B, NB=NB, H=H, W=W, nh=nh_, nw=nw_, hp=hp, wp=wp, S=S, Sp=Sp)
+        self.site_flops: Dict[str, float] = {}      # FP8-format neck / head products of this plan: weight key -> algorithmic FLOPs
         P = L.Plan(dev)
         self.plan = P
         # intermediates of the neck / heads come from a pool and are handed on after their last reader (free); the backbone's
@@ -909,11 +967,7 @@ class _ZoePlan:
 
         def f8kw(wkey):
             sb0, sb1 = f8s[wkey]
-            # the per-image readout bias (cls row x W_cls, added to every token of the image) always gets both products: an error
-            # there is a coherent offset of the whole map
-            wonly = eng.neck_mode == "w" or (eng.neck_mode != "full" and not any(wkey.startswith(p_) for p_ in eng.neck_mode.split(",")))
-            if wkey.endswith("w_cls"):
-                wonly = False
+            wonly = eng.neck_site_wonly(wkey)
             return dict(f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1), f8_wonly_from=-1 if wonly else 0)
 
         def okw(Cout, out_pairs, out8):
@@ -933,6 +987,7 @@ class _ZoePlan:
             if not out_pairs:
                 ok = dict(ldo=ok["ldo"], out_split_off=0)
             if acc and wkey in f8s:
+                self.site_flops[wkey] = self.site_flops.get(wkey, 0.0) + 2.0 * M * N * K      # (calibrate(): what a site's second product is worth)
                 P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=kw.pop("lda", 2 * K), f8_seg=2 * K, shuffle=shuffle,
                        precision_passes=1, **ok, **f8kw(wkey), **kw)
             else:
@@ -946,6 +1001,7 @@ class _ZoePlan:
             ho, wo = g_[3], g_[4]
             has_res = "res" in kw
             if use8:
+                self.site_flops[wkey] = self.site_flops.get(wkey, 0.0) + 2.0 * NB * ho * wo * Co * 9 * Ci
                 P.gemm(name, A, w[wkey], out, M=NB * ho * wo, N=Co, K=9 * Ci, lda=2 * Ci, conv=g_, f8_seg=2 * Ci, ldo=2 * Co,
                        ldr=2 * Co if has_res else 0, res_f8=has_res, out_split_off=Co, out_f8=F8O, precision_passes=1, **f8kw(wkey), **kw)
             else:
@@ -1154,7 +1210,7 @@ class _ZoePlan:
                 # the level in ONE launch: emb + resize(emb_prev) is formed inside the MLP kernel (its hi half is all the MLP reads) and
                 # never stored -- bit-identical to bs_add_resized + bs_mlp2 (csrc/mlp2.hip, FUSE)
                 P.add(f"at{i}.mlp", "bs_mlp2_add", emb, emb_prev, w[f"at{i}.c1.w"], w[f"at{i}.c1.b"], w[f"at{i}.c2.w"], w[f"at{i}.c2.b"], A, NB, ph_,
-                      pw_, fh, fw, E, 2 * E, 2 * na, L.ACT_SOFTPLUS, L.dt(emb) | (16 if acc else 0))
+                      pw_, fh, fw, E, 2 * E, 2 * na, L.ACT_SOFTPLUS_FAST, L.dt(emb) | (16 if acc else 0))
                 free(emb_prev)
                 y = None
             else:
@@ -1167,13 +1223,13 @@ class _ZoePlan:
                 # both 1x1 convolutions in one launch: the 256-channel hidden map (3.2 GB at the finest level) never reaches memory;
                 # bit-identical to the two launches below (bs_mlp2, csrc/mlp2.hip)
                 P.add(f"at{i}.mlp", "bs_mlp2", y, E * m2, w[f"at{i}.c1.w"], w[f"at{i}.c1.b"], w[f"at{i}.c2.w"], w[f"at{i}.c2.b"], A, Mi, E, 2 * E,
-                      2 * na, L.ACT_SOFTPLUS, L.dt(y))
+                      2 * na, L.ACT_SOFTPLUS_FAST, L.dt(y))
                 free(y)
             else:
                 a1 = e16(Mi, 2 * E)
                 P.gemm(f"at{i}.c1", y, w[f"at{i}.c1.w"], a1, M=Mi, N=2 * E, K=E, lda=E * m2, bias=w[f"at{i}.c1.b"], act=L.ACT_RELU)
                 free(y)
-                P.gemm(f"at{i}.c2", a1, w[f"at{i}.c2.w"], A, M=Mi, N=2 * na, K=2 * E, lda=2 * E, bias=w[f"at{i}.c2.b"], act=L.ACT_SOFTPLUS)
+                P.gemm(f"at{i}.c2", a1, w[f"at{i}.c2.w"], A, M=Mi, N=2 * na, K=2 * E, lda=2 * E, bias=w[f"at{i}.c2.b"], act=L.ACT_SOFTPLUS_FAST)
                 free(a1)
             bins = e32(NB, fh, fw, 2 * nb)
             P.add(f"at{i}.step", "bs_attractor_step", A, bins_prev, bins, self.route, NB, ph_, pw_, fh, fw, 2, nb, na)

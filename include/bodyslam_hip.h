@@ -28,7 +28,11 @@ typedef enum {
 } bs_status;
 
 enum { BS_F32 = 0, BS_F16 = 1, BS_BF16 = 2 };
-enum { BS_ACT_NONE = 0, BS_ACT_RELU = 1, BS_ACT_GELU = 2, BS_ACT_SOFTPLUS = 3 };
+/* BS_ACT_SOFTPLUS: torch.nn.Softplus(beta = 1, threshold = 20) through libm (log1pf(expf(x))), what the oracle computes.
+ * BS_ACT_SOFTPLUS_FAST: the same function on v_exp / v_log (relative error <= 4e-6): the attractor MLPs only, whose epilogue was bound by
+ * libm's arithmetic and whose inputs are 16-bit hidden units anyway; the seed regressors (bin start values) and the reference
+ * precision use the exact form. */
+enum { BS_ACT_NONE = 0, BS_ACT_RELU = 1, BS_ACT_GELU = 2, BS_ACT_SOFTPLUS = 3, BS_ACT_SOFTPLUS_FAST = 4 };
 enum { BS_OUT_PLAIN = 0, BS_OUT_SHUFFLE = 1, BS_OUT_QKV = 2 };
 
 /* library ------------------------------------------------------------------------------------ */

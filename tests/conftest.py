@@ -18,3 +18,41 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# ---- the two-process sharded run on the GPU box (tests/test_pipeline_gpu.py::test_two_process_sharded_sequence).  Its processes must be
+# started from a process that has NOT initialised the GPU, so the helper is launched here, before the first test runs, in the background;
+# the test waits for it.  Only when the gpu tests are selected and a device exists (counting devices does not initialise one).
+TWO_PROC = {"proc": None, "dir": os.path.join(ROOT, "gpurun_out", "two_process"), "log": None}
+
+
+def pytest_sessionstart(session):
+    expr = getattr(session.config.option, "markexpr", "") or ""
+    if "gpu" not in expr or "not gpu" in expr:
+        return
+    try:
+        import torch
+        if torch.cuda.device_count() < 1:
+            return
+    except Exception:
+        return
+    import shutil
+    import subprocess
+    shutil.rmtree(TWO_PROC["dir"], ignore_errors=True)
+    os.makedirs(TWO_PROC["dir"], exist_ok=True)
+    TWO_PROC["log"] = open(os.path.join(TWO_PROC["dir"], "log.txt"), "w")
+    TWO_PROC["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "two_process_shard.py"), TWO_PROC["dir"]],
+                                        stdout=TWO_PROC["log"], stderr=subprocess.STDOUT, cwd=ROOT)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    p = TWO_PROC["proc"]
+    if p is not None and p.poll() is None:
+        p.kill()
+    if TWO_PROC["log"] is not None:
+        TWO_PROC["log"].close()
+
+
+@pytest.fixture(scope="session")
+def two_process_run():
+    return TWO_PROC

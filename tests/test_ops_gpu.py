@@ -532,7 +532,10 @@ def test_attention_table(L, dtype, B, hp, nh, split, grouped):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("B,hp,nh,split,grouped,spike", [(2, 24, 4, 0, 0, False), (1, 26, 2, 32, 0, False), (3, 24, 2, 32, 256, False), (2, 4, 2, 0, 2, False),
-                                                         (1, 24, 2, 16, 0, True)])
+                                                         (1, 24, 2, 16, 0, True),
+                                                         # hp 32 ... 40: ring + table pass 80 KiB of LDS (one block per CU; round-4 advisor:
+                                                         # these geometries -- square 512x512 network inputs -- failed at launch)
+                                                         (1, 32, 2, 16, 0, False), (1, 40, 1, 32, 0, False)])
 def test_attention_table_corr(L, dtype, B, hp, nh, split, grouped, spike):
     """bs_attention_table_corr: the QKV product with qkv_lo_off leaves the rounding residuals of Q / K / V^T behind the values, and the
     split-precision kernel (S = Q K^T + Q_lo K^T + Q K_lo^T, O = V P + V P_lo + V_lo P) reproduces fp64 softmax attention on the
@@ -1079,11 +1082,11 @@ def test_mlp2(L, dtype, M, N2, pairs):
     w2 = (rnd(N2, N1, seed=13) / N1 ** 0.5).to(dtype)
     b1, b2 = rnd(N1, seed=14), rnd(N2, seed=15)
     out = torch.full((M, N2), -7.0, device=dev())
-    L.mlp2(x, ldx, w1, b1, w2, b2, out, M, K1, N1, N2, L.ACT_SOFTPLUS)
+    L.mlp2(x, ldx, w1, b1, w2, b2, out, M, K1, N1, N2, L.ACT_SOFTPLUS_FAST)
     hid = torch.empty(M, N1, device=dev(), dtype=dtype)
     L.gemm(x, w1, hid, M=M, N=N1, K=K1, lda=ldx, bias=b1, act=L.ACT_RELU)
     two = torch.empty(M, N2, device=dev())
-    L.gemm(hid, w2, two, M=M, N=N2, K=N1, lda=N1, bias=b2, act=L.ACT_SOFTPLUS)
+    L.gemm(hid, w2, two, M=M, N=N2, K=N1, lda=N1, bias=b2, act=L.ACT_SOFTPLUS_FAST)
     torch.cuda.synchronize()
     assert torch.equal(out, two), f"max |fused - two launches| = {(out - two).abs().max().item():.3e}"
     h64 = torch.relu(x[:, :K1].double() @ w1.double().t() + b1.double()).to(dtype).double()
@@ -1112,10 +1115,10 @@ def test_mlp2_add(L, dtype, geom):
     b1, b2 = rnd(N1, seed=25), rnd(N2, seed=26)
     M = B * H * W
     out = torch.full((M, N2), -7.0, device=dev())
-    L.mlp2_add(emb, prev, w1, b1, w2, b2, out, B, Hp, Wp, H, W, K1, N1, N2, L.ACT_SOFTPLUS, split=pairs)
+    L.mlp2_add(emb, prev, w1, b1, w2, b2, out, B, Hp, Wp, H, W, K1, N1, N2, L.ACT_SOFTPLUS_FAST, split=pairs)
     y = torch.empty_like(emb)
     L.add_resized(emb, prev, y, B, Hp, Wp, H, W, K1, split=pairs)
     two = torch.empty(M, N2, device=dev())
-    L.mlp2(y, K1 * m2, w1, b1, w2, b2, two, M, K1, N1, N2, L.ACT_SOFTPLUS)
+    L.mlp2(y, K1 * m2, w1, b1, w2, b2, two, M, K1, N1, N2, L.ACT_SOFTPLUS_FAST)
     torch.cuda.synchronize()
     assert torch.equal(out, two), f"max |fused - two launches| = {(out - two).abs().max().item():.3e}"

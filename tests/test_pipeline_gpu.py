@@ -249,3 +249,35 @@ def test_reference_golden_pair_with_real_weights(golden_dir):
     report(f"reference golden pair: u16 max diff {diff.max()} LSB, mean {diff.mean():.3f}")
     # the golden file came from the reference's own GPU run (cuDNN / TF32 defaults): a few LSB of 1/256 m
     assert diff.mean() < 0.5 and diff.max() <= 3
+
+
+def test_two_process_sharded_sequence(two_process_run):
+    """SURVEY 8(e) with a real process group on the GPU box: two fresh processes share the GPU over gloo and run
+    BodySlamPipeline.run_sequence(frames, rank, 2) with NO gather hook -- calibration through share_calibration, the relatives
+    through gather_relative_poses -- and must reproduce, bit for bit, what one unsharded process computes.  The processes are
+    started by tests/conftest.py before this pytest process touches the GPU (tests/two_process_shard.py)."""
+    import subprocess
+    import sys
+    import time
+    tp = two_process_run
+    if tp["proc"] is None:
+        if torch.cuda.is_initialized():
+            pytest.skip("the two-process run must be started before this process initialises the GPU: run the suite with `-m gpu`")
+        os.makedirs(tp["dir"], exist_ok=True)
+        tp["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "two_process_shard.py"), tp["dir"]], cwd=ROOT)
+    t0 = time.time()
+    while tp["proc"].poll() is None and time.time() - t0 < 900:
+        time.sleep(1.0)
+    log = os.path.join(tp["dir"], "log.txt")
+    tail = open(log).read()[-3000:] if os.path.exists(log) else ""
+    assert tp["proc"].poll() == 0 and os.path.exists(os.path.join(tp["dir"], "done")), f"the two-process run failed or hung:\n{tail}"
+    r0, r1, one = (np.load(os.path.join(tp["dir"], n)) for n in ("w2_r0.npz", "w2_r1.npz", "w1_r0.npz"))
+    assert (int(r0["start"]), int(r0["end"]), int(r1["start"]), int(r1["end"])) == (0, 4, 4, 7) and (int(one["start"]), int(one["end"])) == (0, 7)
+    assert str(r0["modes"]) == str(r1["modes"]) == str(one["modes"]), "the ranks must run rank 0's calibration"
+    for k in ("t_rel", "g_abs"):            # the gathered relatives and the replicated chain: identical on both ranks and to the unsharded run
+        assert np.array_equal(r0[k], r1[k]) and np.array_equal(r0[k], one[k]), k
+    assert one["t_rel"].shape == (6, 4, 4) and one["g_abs"].shape == (7, 4, 4)
+    for k in ("depth_u16", "depth_m", "counts"):
+        assert np.array_equal(np.concatenate([r0[k], r1[k]]), one[k]), k
+    assert np.isfinite(one["depth_m"]).all() and (one["counts"] > 0).all()
+    report(f"two-process sharded run (gloo, one GPU): blocks [0,4) + [4,7) bit-equal to the unsharded run; modes {one['modes']}")

@@ -129,3 +129,35 @@ def test_calibration_is_made_by_rank0_and_shared(tmp_path):
     # without a process group: the report is simply made
     from bodyslam_amd.pipeline import share_calibration
     assert share_calibration(lambda: {"x": 1}) == {"x": 1}
+
+
+def _calib_fail_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bodyslam_amd.pipeline import share_calibration
+
+    def make():
+        raise MemoryError("reference engine does not fit")       # only ever called on rank 0
+    try:
+        share_calibration(make)
+        msg = "no exception"
+    except Exception as e:          # noqa: BLE001
+        msg = f"{type(e).__name__}: {e}"
+    with open(os.path.join(out_dir, f"fail_{rank}"), "w") as f:
+        f.write(msg)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_calibration_failure_on_rank0_raises_everywhere(tmp_path):
+    """rank 0 failing inside calibrate() (out of memory next to the reference engine, a launch error) must not leave the other ranks
+    blocked in the broadcast: the failure is broadcast and raised on every rank (round-4 advisor)"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_calib_fail_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    m0, m1 = (open(tmp_path / f"fail_{r}").read() for r in range(2))
+    assert m0.startswith("MemoryError") and "reference engine does not fit" in m0
+    assert m1.startswith("RuntimeError") and "reference engine does not fit" in m1

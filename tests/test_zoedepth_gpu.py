@@ -345,31 +345,10 @@ def test_reference_precision_engine(hook):
 # The tolerance against weights that do not look like the seeded ones: trained BEiT-L checkpoints carry a
 # per-channel layer-scale spanning decades, a few outlier channels and heavy-tailed weights.  "auto" (the default) must hold the
 # north star's 1e-4 m on each, whatever it has to switch back on; the fixed cheap mode is reported beside it.
-def _hook_layerscale_wide(w):
-    g = torch.Generator().manual_seed(101)
-    for k in w:
-        if k.endswith("lambda_1") or k.endswith("lambda_2"):          # log-uniform 1e-3 .. 1 per channel (trained BEiT: 1e-5 init, grown unevenly)
-            w[k] = w[k].sign() * torch.pow(10.0, -3.0 * torch.rand(w[k].shape, generator=g)) * 0.3
-
-
-def _hook_outlier_channels(w):
-    g = torch.Generator().manual_seed(102)
-    idx = torch.randperm(1024, generator=g)[:6]
-    for k in w:
-        if k.endswith("layernorm_before.weight") or k.endswith("layernorm_after.weight"):       # 6 channels 50x larger after every LayerNorm
-            w[k] = w[k].clone()
-            w[k][idx] *= 50.0
-        if k.endswith("attention.q_proj.weight") or k.endswith("mlp.fc1.weight"):               # ... and damped again where they are consumed, so
-            w[k] = w[k].clone()                                                                     # the network stays in range
-            w[k][:, idx] /= 25.0
-
-
-def _hook_heavy_tailed(w):
-    g = torch.Generator().manual_seed(103)
-    for k in w:
-        if w[k].dim() >= 2 and w[k].numel() >= 1 << 16 and "position_bias" not in k:
-            t = torch.randn(w[k].shape, generator=g) / torch.randn(w[k].shape, generator=g).abs().clamp_min(0.35)   # ratio of normals: heavy tails
-            w[k] = w[k] * (0.6 + 0.4 * t.abs().clamp_max(12.0) / 1.6)
+# (the constructions live in bodyslam_amd/synthetic.py: bench.py --weights outlier measures the same set)
+from bodyslam_amd.synthetic import heavy_tailed as _hook_heavy_tailed  # noqa: E402
+from bodyslam_amd.synthetic import layerscale_wide as _hook_layerscale_wide  # noqa: E402
+from bodyslam_amd.synthetic import outlier_channels as _hook_outlier_channels  # noqa: E402
 
 
 @pytest.mark.parametrize("hook", [_hook_layerscale_wide, _hook_outlier_channels, _hook_heavy_tailed])
