@@ -71,6 +71,7 @@ _SIGS = {
     "bs_fill_rows": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
     "bs_resize_bilinear_nhwc": [C.c_void_p, C.c_void_p] + [C.c_int32] * 8 + [C.c_void_p],
     "bs_upconv_tapsum": [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p],
+    "bs_upconv_fused": [C.c_void_p] * 4 + [C.c_int32] * 15 + [C.c_void_p],
     "bs_col_mean": [C.c_void_p, C.c_int64] + [C.c_int32] * 5 + [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p],
     "bs_rank1_bias": [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p],
     "bs_depth_u16_to_m": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p],
@@ -593,6 +594,13 @@ def upconv_tapsum(y, bias, out, B, Hin, Win, Cout, Hout, Wout, align_corners=Tru
     check(load_library().bs_upconv_tapsum(p(y), p(bias), p(out), B, Hin, Win, Cout, Hout, Wout,
                                           int(align_corners) | (4 if split == 2 else (2 if split else 0)), int(relu), dt(out), stream_ptr()),
           "bs_upconv_tapsum")
+
+
+def upconv_fused(x, w, bias, out, B, Hin, Win, Cin, Cout, mode=0, split=0, relu=True, f8_scales=(127, 127, 127, 127)):
+    """relu(conv3x3(interpolate x2, align_corners(x))) in one launch from the low-resolution input (include/bodyslam_hip.h)"""
+    check(load_library().bs_upconv_fused(p(x), p(w), p(bias), p(out), B, Hin, Win, Cin, Cout, 2 * Hin, 2 * Win,
+                                         1 | (4 if split == 2 else (2 if split else 0)), int(relu), mode, *[int(v) for v in f8_scales], dt(out),
+                                         stream_ptr()), "bs_upconv_fused")
 
 
 def attractor_step(A, bins_prev, bins_out, route, B, Hp, Wp, H, W, groups, n_bins, n_attr):

@@ -1,0 +1,372 @@
+// relu(conv3x3(upsample_x2(x)) + b) of the relative head (HF modeling_zoedepth.py:358-362: interpolate(scale 2, bilinear, align_corners) ->
+// conv2 3x3 128 -> 32 -> ReLU) in ONE launch, from the low-resolution input (round 5, VERDICT r4 #1a).
+//
+// Both steps are linear and the resize acts on each channel alone, so with the tap products  T[q, tap, o] = sum_c W[o, c, tap] x[q, c]  taken at
+// the LOW resolution (a quarter of the convolution's FLOPs)   out(p, o) = relu(b[o] + sum_tap [p + d_tap inside] * bilinear(T[., tap, o])(p + d_tap)).
+// Rounds 2-4 ran that as two launches -- a plain GEMM writing T (fp32 [NB,192,256,288]: 7.2 GB at the bench batch) and bs_upconv_tapsum
+// gathering it back: 17.6 GB moved for 3.2 GB in + 3.2 GB out, 3.4 + 3.0 ms.  Here T exists only as an LDS tile:
+//
+//   block = 512 threads, persistent over 16 x 16 output tiles (x fastest).  Per tile the low-resolution window the tile's taps touch (at most
+//   11 x 11 pixels for the x2 geometry) is staged by LDS-DMA as the MFMA A operand -- (hi16 | hi8 | lo8) planes, 128-byte rows, 16-byte chunks
+//   XOR-swizzled by (row & 7), the implicit-GEMM kernel's image -- and multiplied against the weights of ONE tap row ky at a time (96 columns =
+//   3 taps x 32 channels, also staged by DMA): wave w takes window rows 32 (w >> 1) .. + 31 against three of the six 16-column tiles of the round; the same
+//   MFMAs in the same K order as bs_gemm runs for this product (four v_mfma_f32_16x16x32 over the 16-bit planes, then A_hi8 W_lo8 and -- unless
+//   the site is weight-only -- A_lo8 W_hi8 on v_mfma_scale_f32_16x16x128_f8f6f4), so T has the bits the two-launch path stored.  The round's T
+//   [121 rows][96] fp32 goes to LDS and the 512 threads interpolate: thread = (4 channels, one output column, 4 consecutive output rows).
+//   The interpolation is SEPARABLE -- per low-resolution row yl the x-direction sum  U[yl] = sum_kx in_x (hx T[yl, x0, kx] + lx T[yl, x1, kx])
+//   is formed once and shared by the output rows whose taps interpolate from yl (kept in two registers sets that slide down the window):
+//   ~63 ds_read_b128 and ~175 packed FMAs per thread and tile where the corner form needs 144 and 430.  Another association of the same fp32
+//   sum than bs_upconv_tapsum's (tests: both against torch's conv2d(interpolate(x)) in fp64).
+//   The next round's weights, and after the first round the next tile's window, are in flight under the interpolation.
+#include "common.h"
+
+namespace bs {
+
+namespace ucf {
+constexpr int C = 128, CO = 32, TW = 16, TH = 16, LW = 11, LH = 11, NR = LW * LH;   // NR = 121 window rows (pixels)
+constexpr int TAB = 2048;                  // two sets of per-tile tables (row / column corner offsets and weights)
+constexpr int PLANE = NR * 128;            // one 128-byte-row plane of the window
+constexpr int WROWS = 3 * CO;              // weight rows (output columns) of one tap row
+constexpr int WPLANE = WROWS * 128;
+constexpr int YSTRIDE = 400;               // bytes per row of the round's products: 96 fp32 + 16 (a 16-lane ds_write_b128 group covers 64 banks)
+constexpr int YBYTES = NR * YSTRIDE;
+// MODE: 0 = single 16-bit operands (fast mode: rows of C 16-bit values), 1 = (hi16 | hi8 | lo8) rows with the weight-rounding correction only,
+// 2 = both corrections
+template <int MODE> constexpr int a_planes() { return 2 + MODE; }     // hi16 channels 0-63, 64-127, (hi8), (lo8)
+template <int MODE> constexpr int lds_bytes() { return TAB + a_planes<MODE>() * PLANE + a_planes<MODE>() * WPLANE + YBYTES; }
+}  // namespace ucf
+
+struct UpconvFusedArgs {
+    const void* x;
+    const void* w;
+    const float* bias;
+    void* out;
+    int B, Hin, Win, Hout, Wout;
+    float sy, sx;
+    int relu, ntx, nty, ntiles;
+    int sa0, sb0, sa1, sb1;      // E8M0 exponents of the FP8 planes (bs_gemm's f8_scales)
+};
+
+template <typename T, int SPLIT, int MODE>
+__global__ __launch_bounds__(512) void upconv_fused_kernel(const UpconvFusedArgs p) {
+    using namespace ucf;
+    typedef typename T16<T>::v8 v8;
+    typedef int i32x4_ __attribute__((ext_vector_type(4)));
+    typedef int i32x8_ __attribute__((ext_vector_type(8)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr int NPL = a_planes<MODE>();
+    constexpr bool FULL = MODE == 2;
+    constexpr int ROWB = MODE == 0 ? 2 * C : 4 * C;      // bytes of a pixel / weight row in memory
+    constexpr int OFF_A = TAB, OFF_W = OFF_A + NPL * PLANE, OFF_Y = OFF_W + NPL * WPLANE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+    const int Hin = p.Hin, Win = p.Win, Hout = p.Hout, Wout = p.Wout;
+
+    auto lo_idx = [&](int r, float s, int n) {      // first corner row / column of output row / column r (align_corners)
+        int i0 = (int)(s * (float)r);
+        return i0 > n - 1 ? n - 1 : i0;
+    };
+    struct Win_ { int b, ty0, tx0, wy0, wx0, LWc, LHc; };
+    auto window = [&](int tile) {
+        Win_ w;
+        const int txi = tile % p.ntx, t2 = tile / p.ntx;
+        w.tx0 = txi * TW;
+        w.ty0 = (t2 % p.nty) * TH;
+        w.b = t2 / p.nty;
+        const int rmin = w.ty0 > 0 ? w.ty0 - 1 : 0, rmax = w.ty0 + TH < Hout ? w.ty0 + TH : Hout - 1;
+        const int cmin = w.tx0 > 0 ? w.tx0 - 1 : 0, cmax = w.tx0 + TW < Wout ? w.tx0 + TW : Wout - 1;
+        w.wy0 = lo_idx(rmin, p.sy, Hin);
+        w.wx0 = lo_idx(cmin, p.sx, Win);
+        int wy1 = lo_idx(rmax, p.sy, Hin), wx1 = lo_idx(cmax, p.sx, Win);
+        wy1 += wy1 < Hin - 1 ? 1 : 0;
+        wx1 += wx1 < Win - 1 ? 1 : 0;
+        w.LWc = wx1 - w.wx0 + 1;        // <= LW, LH: checked on the host for the x2 geometry
+        w.LHc = wy1 - w.wy0 + 1;
+        return w;
+    };
+    // ---- LDS-DMA of a tile's window: plane pl, row group rg (8 rows x 128 B per wave instruction; lane -> row l / 8, chunk position l % 8
+    // <- source chunk (l % 8) ^ (row & 7)).  Pixel row in memory: [hi16 256 B | hi8 128 B | lo8 128 B].
+    const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;
+    auto issue_window = [&](const Win_& w) {
+        const int nv = w.LWc * w.LHc;
+        const char* xb = reinterpret_cast<const char*>(p.x) + ((int64_t)w.b * Hin * Win) * ROWB;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // (always 2 NPL instructions per wave -- the round-1 wait below counts them: rows past the window re-fetch its last pixel, only
+            // rows past the plane's 121 are masked off, and those share their instruction with row 120)
+            const int rg = wave + 8 * h, row = rg * 8 + r8;
+            if (row < NR) {
+                const int rw = row < nv ? row : nv - 1;
+                const int ly = rw / w.LWc, lx = rw - ly * w.LWc;
+                const char* px = xb + ((int64_t)(w.wy0 + ly) * Win + (w.wx0 + lx)) * ROWB + chunk * 16;
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+                    glds16(px + pl * 128, smem + OFF_A + pl * PLANE + rg * 1024);
+            }
+        }
+    };
+    // weights of tap row ky: rows n = 96 ky .. 96 ky + 95 of [W_hi16 256 B | W_lo8 128 B | W_hi8 128 B]
+    auto issue_weights = [&](int ky) {
+        const char* wb = reinterpret_cast<const char*>(p.w) + (int64_t)(ky * WROWS) * ROWB + chunk * 16;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rg = wave + 8 * h;
+            if (rg < WROWS / 8) {
+                const char* pw = wb + (int64_t)(rg * 8 + r8) * ROWB;
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+                    glds16(pw + pl * 128, smem + OFF_W + pl * WPLANE + rg * 1024);
+            }
+        }
+    };
+
+    // thread's role in the interpolation: 4 channels g, output column X of the tile, output rows 4 seg .. 4 seg + 3 (seg is wave-uniform)
+    const int g = tid & 7, X = (tid >> 3) & 15, seg = tid >> 7;
+    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + 4 * g);
+    const int sca0 = p.sa0 * 0x01010101, scb0 = p.sb0 * 0x01010101, sca1 = p.sa1 * 0x01010101, scb1 = p.sb1 * 0x01010101;
+    const int sw = frow & 7;
+    const int koff0 = (fq ^ sw) << 4, koff1 = ((4 + fq) ^ sw) << 4;
+
+    int tile = blockIdx.x;
+    if (tile >= p.ntiles) return;
+    Win_ cur = window(tile);
+    issue_window(cur);
+    issue_weights(0);
+    for (int it = 0; tile < p.ntiles; tile += gridDim.x, ++it) {
+        const int next = tile + gridDim.x;
+        // ---- per-tile tables (double-buffered: slower waves may still read the previous tile's): entries [0, TH + 2) = output rows ty0 - 1 ..,
+        // [TH + 2, TH + TW + 4) = output columns tx0 - 1 ..: byte offsets of the two corner rows / columns inside the round's product tile and the
+        // two weights, zero for a row / column outside the image (the conv's zero padding applies to the UPSAMPLED map)
+        i32x4_* tabs = reinterpret_cast<i32x4_*>(smem + (it & 1) * (TAB / 2));
+        if (tid < TH + 2 + TW + 2) {
+            const bool isrow = tid < TH + 2;
+            const int r = isrow ? cur.ty0 - 1 + tid : cur.tx0 - 1 + (tid - (TH + 2));
+            const int nout = isrow ? Hout : Wout, nin = isrow ? Hin : Win, w0 = isrow ? cur.wy0 : cur.wx0;
+            const float s = isrow ? p.sy : p.sx;
+            const int unit = isrow ? cur.LWc * YSTRIDE : YSTRIDE;
+            i32x4_ e = {0, 0, 0, 0};
+            if (r >= 0 && r < nout) {
+                const float f = s * (float)r;
+                int i0 = (int)f;
+                i0 = i0 > nin - 1 ? nin - 1 : i0;
+                const int i1 = i0 + (i0 < nin - 1 ? 1 : 0);
+                const float l = f - (float)i0, h = 1.0f - l;
+                e = i32x4_{(i0 - w0) * unit, (i1 - w0) * unit, __float_as_int(h), __float_as_int(l)};
+            }
+            tabs[tid] = e;
+        }
+        // MFMA role of a wave: window rows 32 (wave >> 1) + 16 i + frow (two 16-row fragments, in registers for the whole tile) against the
+        // three 16-column tiles 48 (wave & 1) + 16 j of the round.  (One row fragment against all six column tiles read every weight row from
+        // LDS in every wave: the phase was bound by those reads, 1.35 of the launch's 3.4 ms.)
+        const int mg = wave >> 1, ng = wave & 1;
+        v8 af[2][4];
+        i32x8_ a8h[2], a8l[2];
+        f32x4 acc[4];
+#pragma unroll
+        for (int yy = 0; yy < 4; ++yy) acc[yy] = bias4;
+        i32x4_ ctab[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            // my pieces of this round's weights (and, round 0, of the window) have landed.  Round 1: the next tile's window, issued behind
+            // round 1's weights, stays in flight (vmcnt counts in issue order)
+            if (ky == 1 && next < p.ntiles && !(p.relu & 32)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                       // ... everyone's; everyone is done reading the previous round's products
+            auto ld8 = [&](const char* base) {
+                const i32x4_ lo = *reinterpret_cast<const i32x4_*>(base + koff0);
+                const i32x4_ hi = *reinterpret_cast<const i32x4_*>(base + koff1);
+                return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            };
+            if (ky == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const char* ar = smem + OFF_A + (mg * 32 + i * 16 + frow) * 128;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) af[i][kk] = *reinterpret_cast<const v8*>(ar + (kk >> 1) * PLANE + ((kk & 1) ? koff1 : koff0));
+                    if constexpr (MODE >= 1) a8h[i] = ld8(ar + 2 * PLANE);
+                    if constexpr (FULL) a8l[i] = ld8(ar + 3 * PLANE);
+                }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) ctab[kx] = tabs[TH + 2 + X + kx];
+            }
+            // ---- products of the round: lane -> row m = 32 mg + 16 i + frow, columns 48 ng + 16 j + 4 fq + e
+            if (!(p.relu & 8)) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const char* wr = smem + OFF_W + (ng * 48 + j * 16 + frow) * 128;
+                    v8 wf[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) wf[kk] = *reinterpret_cast<const v8*>(wr + (kk >> 1) * WPLANE + ((kk & 1) ? koff1 : koff0));
+                    i32x8_ w8l, w8h;
+                    if constexpr (MODE >= 1) w8l = ld8(wr + 2 * WPLANE);
+                    if constexpr (FULL) w8h = ld8(wr + 3 * WPLANE);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) c = T16<T>::mfma16(wf[kk], af[i][kk], c);
+                        if constexpr (MODE >= 1) c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8l, a8h[i], c, 0, 0, 0, scb0, 0, sca0);
+                        if constexpr (FULL) c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8h, a8l[i], c, 0, 0, 0, scb1, 0, sca1);
+                        const int m = mg * 32 + i * 16 + frow;
+                        if (m < NR) *reinterpret_cast<f32x4*>(smem + OFF_Y + m * YSTRIDE + (ng * 48 + j * 16) * 4 + fq * 16) = c;
+                    }
+                }
+            }
+            __syncthreads();            // the products are in LDS; the window (in registers since round 0) and this round's weights are free
+            if (ky < 2) {
+                if (!(p.relu & 2)) issue_weights(ky + 1);
+                if (ky == 0 && next < p.ntiles && !(p.relu & 32)) {
+                    const Win_ nw = window(next);
+                    issue_window(nw);
+                }
+            } else if (next < p.ntiles) {
+                if (!(p.relu & 2)) issue_weights(0);
+            }
+            // ---- interpolation of tap row ky: output rows Y = 4 seg + yy read upsampled row Y + ky - 1 = table entry Y + ky
+            if (!(p.relu & 4)) {
+                const char* yb = smem + OFF_Y + g * 16;
+                auto rowsum = [&](int roff) {        // U[yl]: the x-direction sum of the three taps of this row at low-resolution row yl
+                    f32x2 u01 = {0.f, 0.f}, u23 = {0.f, 0.f};
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const char* q = yb + roff + kx * (CO * 4);
+                        const f32x4 q0 = *reinterpret_cast<const f32x4*>(q + ctab[kx][0]);
+                        const f32x4 q1 = *reinterpret_cast<const f32x4*>(q + ctab[kx][1]);
+                        const float hx = __int_as_float(ctab[kx][2]), lx = __int_as_float(ctab[kx][3]);
+                        const f32x2 h2 = {hx, hx}, l2 = {lx, lx};
+                        u01 = __builtin_elementwise_fma(h2, f32x2{q0[0], q0[1]}, u01);
+                        u23 = __builtin_elementwise_fma(h2, f32x2{q0[2], q0[3]}, u23);
+                        u01 = __builtin_elementwise_fma(l2, f32x2{q1[0], q1[1]}, u01);
+                        u23 = __builtin_elementwise_fma(l2, f32x2{q1[2], q1[3]}, u23);
+                    }
+                    return f32x4{u01[0], u01[1], u23[0], u23[1]};
+                };
+                int have0 = -1, have1 = -1;       // (wave-uniform) window rows whose sums are held
+                f32x4 U0 = {0.f, 0.f, 0.f, 0.f}, U1 = U0;
+#pragma unroll
+                for (int yy = 0; yy < 4; ++yy) {
+                    const i32x4_ ry = tabs[4 * seg + yy + ky];
+                    const int o0 = __builtin_amdgcn_readfirstlane(ry[0]), o1 = __builtin_amdgcn_readfirstlane(ry[1]);
+                    if (o0 != have0) {
+                        U0 = (o0 == have1) ? U1 : rowsum(o0);
+                        have0 = o0;
+                    }
+                    if (o1 != have1) {
+                        U1 = (o1 == have0) ? U0 : rowsum(o1);
+                        have1 = o1;
+                    }
+                    const float hy = __int_as_float(ry[2]), ly = __int_as_float(ry[3]);
+                    const f32x2 h2 = {hy, hy}, l2 = {ly, ly};
+                    f32x2 a01 = {acc[yy][0], acc[yy][1]}, a23 = {acc[yy][2], acc[yy][3]};
+                    a01 = __builtin_elementwise_fma(h2, f32x2{U0[0], U0[1]}, a01);
+                    a23 = __builtin_elementwise_fma(h2, f32x2{U0[2], U0[3]}, a23);
+                    a01 = __builtin_elementwise_fma(l2, f32x2{U1[0], U1[1]}, a01);
+                    a23 = __builtin_elementwise_fma(l2, f32x2{U1[2], U1[3]}, a23);
+                    acc[yy] = f32x4{a01[0], a01[1], a23[0], a23[1]};
+                }
+            }
+        }
+        // ---- epilogue: ReLU, output format, stores (8 lanes = the 64 + 32 + 32 bytes of one pixel).  (Assembling the tile's rows in LDS and
+        // storing full lines, 16 bytes per lane, measured SLOWER: 3.24 vs 3.16 ms -- two more barriers per tile for stores that already overlap
+        // the next tile's first round.)
+        const int ox = cur.tx0 + X;
+#pragma unroll
+        for (int yy = 0; yy < 4; ++yy) {
+            const int oy = cur.ty0 + 4 * seg + yy;
+            if (ox >= Wout || oy >= Hout || (p.relu & 16)) continue;
+            f32x4 a = acc[yy];
+            if (p.relu & 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], 0.0f);
+            }
+            const int64_t pix = ((int64_t)cur.b * Hout + oy) * Wout + ox;
+            typedef T t4 __attribute__((ext_vector_type(4)));
+            t4 hi;
+            float rl[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hi[e] = T16<T>::from_f32(a[e]);
+                rl[e] = a[e] - T16<T>::to_f32(hi[e]);
+            }
+            T* out = reinterpret_cast<T*>(p.out);
+            if (SPLIT == 0) {
+                *reinterpret_cast<t4*>(out + pix * CO + 4 * g) = hi;
+            } else if (SPLIT == 1) {      // (hi | lo) 16-bit pairs
+                t4 lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lo[e] = T16<T>::from_f32(rl[e]);
+                *reinterpret_cast<t4*>(out + pix * 2 * CO + 4 * g) = hi;
+                *reinterpret_cast<t4*>(out + pix * 2 * CO + CO + 4 * g) = lo;
+            } else {                      // (hi16 | hi8 | lo8)
+                T* op = out + pix * 2 * CO;
+                *reinterpret_cast<t4*>(op + 4 * g) = hi;
+                const float sh = __builtin_ldexpf(1.0f, F8_ACT_HI_EXP), sl = __builtin_ldexpf(1.0f, F8_ACT_LO_EXP);
+                char* planes = reinterpret_cast<char*>(op + CO);
+                *reinterpret_cast<int*>(planes + 4 * g) = f8_pack4(a[0] * sh, a[1] * sh, a[2] * sh, a[3] * sh);
+                *reinterpret_cast<int*>(planes + CO + 4 * g) = f8_pack4(rl[0] * sl, rl[1] * sl, rl[2] * sl, rl[3] * sl);
+            }
+        }
+        if (next < p.ntiles) cur = window(next);
+    }
+}
+
+template <typename T, int SPLIT, int MODE>
+static int launch_upconv_fused(const UpconvFusedArgs& a, hipStream_t st) {
+    constexpr int smem = ucf::lds_bytes<MODE>();
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static_assert((ucf::TH + 2 + ucf::TW + 2) * 16 <= ucf::TAB / 2, "tables");
+    static bool attr_done = false;
+    if (!attr_done) {
+        BS_CHECK_HIP(hipFuncSetAttribute((const void*)upconv_fused_kernel<T, SPLIT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_done = true;
+    }
+    const int grid = a.ntiles < cu_count() ? a.ntiles : cu_count();          // one 512-thread block per CU (LDS), persistent over the tiles
+    hipLaunchKernelGGL((upconv_fused_kernel<T, SPLIT, MODE>), dim3(grid), dim3(512), smem, st, a);
+    BS_CHECK_LAUNCH();
+    return BS_OK;
+}
+
+}  // namespace bs
+
+extern "C" int bs_upconv_fused(const void* x, const void* w, const float* bias, void* out, int32_t B, int32_t Hin, int32_t Win, int32_t Cin,
+                               int32_t Cout, int32_t Hout, int32_t Wout, int32_t flags, int32_t relu, int32_t mode, int32_t sa0, int32_t sb0,
+                               int32_t sa1, int32_t sb1, int32_t dtype, void* stream) {
+    using namespace bs;
+    if (!initialized()) { set_error("bs_upconv_fused: call bs_init first"); return BS_ERR_NOT_INIT; }
+    BS_REQUIRE(x && w && bias && out, "bs_upconv_fused: null operand");
+    BS_REQUIRE(B > 0 && Hin >= 2 && Win >= 2, "bs_upconv_fused: empty problem");
+    BS_REQUIRE(Cin == ucf::C && Cout == ucf::CO, "bs_upconv_fused: built for %d -> %d channels (got %d -> %d): use bs_gemm + bs_upconv_tapsum", ucf::C,
+               ucf::CO, Cin, Cout);
+    BS_REQUIRE(Hout == 2 * Hin && Wout == 2 * Win && (flags & 1), "bs_upconv_fused: built for x2 upsampling with align_corners (the 11 x 11 window bound)");
+    BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_upconv_fused: dtype must be f16 or bf16");
+    BS_REQUIRE(mode >= 0 && mode <= 2, "bs_upconv_fused: mode %d (0 single 16-bit operands, 1 weight-rounding correction, 2 both corrections)", mode);
+    BS_REQUIRE((mode == 0) == ((flags & 6) == 0), "bs_upconv_fused: single operands write a single 16-bit output, split operands a split one");
+    UpconvFusedArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.out = out;
+    a.B = B; a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout;
+    a.sy = (float)(Hin - 1) / (float)(Hout - 1);
+    a.sx = (float)(Win - 1) / (float)(Wout - 1);
+    a.relu = relu;
+    a.ntx = cdiv(Wout, ucf::TW);
+    a.nty = cdiv(Hout, ucf::TH);
+    BS_REQUIRE((int64_t)a.ntx * a.nty * B <= 0x7fffffffll, "bs_upconv_fused: too many tiles");
+    a.ntiles = a.ntx * a.nty * B;
+    a.sa0 = sa0 & 0xff; a.sb0 = sb0 & 0xff; a.sa1 = sa1 & 0xff; a.sb1 = sb1 & 0xff;
+    const int split = (flags & 4) ? 2 : ((flags & 2) ? 1 : 0);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define BS_UCF(TT)                                                                                                          \
+    do {                                                                                                                    \
+        if (mode == 0) return launch_upconv_fused<TT, 0, 0>(a, st);                                                         \
+        if (mode == 1) {                                                                                                    \
+            if (split == 2) return launch_upconv_fused<TT, 2, 1>(a, st);                                                    \
+            return launch_upconv_fused<TT, 1, 1>(a, st);                                                                    \
+        }                                                                                                                   \
+        if (split == 2) return launch_upconv_fused<TT, 2, 2>(a, st);                                                        \
+        return launch_upconv_fused<TT, 1, 2>(a, st);                                                                        \
+    } while (0)
+    if (dtype == BS_F16) BS_UCF(f16);
+    BS_UCF(bf16);
+#undef BS_UCF
+}

@@ -1180,14 +1180,32 @@ class _ZoePlan:
         # per channel, so conv2(up(x))(p) = sum_tap up(W_tap x)(p + d_tap): the nine 1x1 tap products run as ONE plain GEMM at the low
         # resolution (N = 9 * 32, a quarter of the conv's FLOPs; the N = 32 conv ran at 20 % of the MFMA peak, bound by the LDS fill
         # rate) and bs_upconv_tapsum gathers / interpolates / sums them -- the upsampled map is never materialised.
-        y9 = e32(NB, h3, w3, 9 * c.rel_features)
-        # (K = 128: a block's main loop is four K steps, the launch is bound by block turnover -- the 128x64 tile, 3 blocks per CU,
-        # takes 3.8 ms where the 128x128 one takes 5.9, tools/probes/rh_conv2_tiles.py)
-        nplain("rh.conv2", r1, "rh.conv2.w", y9, NB * h3 * w3, 9 * c.rel_features, Fc // 2, out_pairs=False, tile=2)
-        free(r1)
-        last = e16(NB, 2 * h3, 2 * w3, c.rel_features * m2)
-        P.add("rh.tapsum", "bs_upconv_tapsum", y9, w["rh.conv2.b"], last, NB, h3, w3, c.rel_features, 2 * h3, 2 * w3, RZ, 1, L.dt(last))
-        free(y9)
+        # Round 5: one launch (bs_upconv_fused, csrc/upconv_fused.hip) -- the tap products of a 16 x 16 output tile's low-resolution window are
+        # formed by MFMA into LDS and interpolated from there, the 7.2 GB fp32 tap-product tensor of the two-launch path (bs_gemm +
+        # bs_upconv_tapsum, kept for the (hi | lo) pair formats and for A / B runs: BS_UPCONV_FUSED=0) never exists.
+        fused_up = (os.environ.get("BS_UPCONV_FUSED", "1") != "0" and Fc // 2 == 128 and c.rel_features == 32
+                    and ((not acc) or (nf8 and "rh.conv2.w" in f8s)))
+        last = None
+        if fused_up:
+            last = e16(NB, 2 * h3, 2 * w3, c.rel_features * m2)
+            if acc:
+                sb0, sb1 = f8s["rh.conv2.w"]
+                umode, usc = (1 if eng.neck_site_wonly("rh.conv2.w") else 2), (127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1)
+                self.site_flops["rh.conv2.w"] = 2.0 * NB * h3 * w3 * 9 * c.rel_features * (Fc // 2)
+            else:
+                umode, usc = 0, (127, 127, 127, 127)
+            P.add("rh.conv2", "bs_upconv_fused", r1, w["rh.conv2.w"], w["rh.conv2.b"], last, NB, h3, w3, Fc // 2, c.rel_features, 2 * h3, 2 * w3,
+                  RZ, 1, umode, *usc, L.dt(last))
+            free(r1)
+        else:
+            y9 = e32(NB, h3, w3, 9 * c.rel_features)
+            # (K = 128: a block's main loop is four K steps, the launch is bound by block turnover -- the 128x64 tile, 3 blocks per CU,
+            # takes 3.8 ms where the 128x128 one takes 5.9, tools/probes/rh_conv2_tiles.py)
+            nplain("rh.conv2", r1, "rh.conv2.w", y9, NB * h3 * w3, 9 * c.rel_features, Fc // 2, out_pairs=False, tile=2)
+            free(r1)
+            last = e16(NB, 2 * h3, 2 * w3, c.rel_features * m2)
+            P.add("rh.tapsum", "bs_upconv_tapsum", y9, w["rh.conv2.b"], last, NB, h3, w3, c.rel_features, 2 * h3, 2 * w3, RZ, 1, L.dt(last))
+            free(y9)
         P.mark("rel_features", last, ("nhwc", NB, 2 * h3, 2 * w3, c.rel_features, (2 if nf8 else 1) if acc else 0))
         # ---- Z7 (continued): projector / attractor levels on the fusion outputs, after the side lane's router + seeds
         # (putting this chain on the side lane as well, beside the relative head, measured neutral)

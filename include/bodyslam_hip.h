@@ -238,6 +238,16 @@ int bs_resize_bilinear_nhwc(const void* x, void* out, int32_t B, int32_t Hin, in
 int bs_upconv_tapsum(const float* y, const float* bias, void* out, int32_t B, int32_t Hin, int32_t Win, int32_t Cout,
                      int32_t Hout, int32_t Wout, int32_t align_corners, int32_t relu, int32_t dtype, void* stream);
 
+/* The same relu(conv3x3(pad 1)(interpolate x2, align_corners(x))) in ONE launch, from the low-resolution input itself (round 5): the tap
+ * products exist only as LDS tiles (bodyslam_amd/csrc/upconv_fused.hip).  Replaces bs_gemm (the tap products) + bs_upconv_tapsum for the
+ * relative head's geometry: Cin = 128, Cout = 32, Hout = 2 Hin, Wout = 2 Win.  x: NHWC rows of Cin 16-bit values (mode 0) or
+ * (hi16 | hi8 | lo8) rows (mode 1: weight-rounding correction only, mode 2: both corrections); w: [9*Cout] rows, n = (ky*3+kx)*Cout + o, of
+ * Cin 16-bit values (mode 0) or [W_hi16 | W_lo8 | W_hi8] (bs_gemm's FP8 correction packing; sa0, sb0, sa1, sb1 = its f8_scales bytes).
+ * flags: bit 0 align_corners (required), bits 1 / 2 the output pair format as for bs_upconv_tapsum (modes 1, 2 need one). */
+int bs_upconv_fused(const void* x, const void* w, const float* bias, void* out, int32_t B, int32_t Hin, int32_t Win, int32_t Cin,
+                    int32_t Cout, int32_t Hout, int32_t Wout, int32_t flags, int32_t relu, int32_t mode, int32_t sa0, int32_t sb0,
+                    int32_t sa1, int32_t sb1, int32_t dtype, void* stream);
+
 /* metric-bins head ---------------------------------------------------------------------------- *
  * Both heads (nyu | kitti) are carried side by side as channel groups; `route` int32 [B] (from
  * bs_route_argmax) says which group an image uses -- per image, because the reference always runs

@@ -756,6 +756,68 @@ def test_upconv_tapsum(L, dtype, split, geom):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("geom", [(2, 12, 20), (1, 24, 32), (3, 5, 7), (6, 48, 64), (1, 2, 2), (2, 9, 33)])
+def test_upconv_fused(L, dtype, mode, geom):
+    """bs_upconv_fused: relu(conv3x3(interpolate x2(x)) + b), 128 -> 32 channels (the relative head's upsample + conv2, HF
+    modeling_zoedepth.py:358-362) in one launch from the low-resolution input, in its three operand modes -- against torch's
+    conv2d(interpolate(x)) in fp64 on the values the operands carry, and against the two-launch path it replaces (bs_gemm tap products +
+    bs_upconv_tapsum: the same MFMAs, another association of the interpolation's fp32 sum).  Geometries: partial tiles, windows smaller than a
+    tile, more tiles than compute units (the persistent loop), 2 x 2 inputs."""
+    B, H, W = geom
+    C, Co = 128, 32
+    x = rnd(B, H, W, C, seed=3)
+    w = rnd(Co, C, 3, 3, seed=4) * 0.05
+    bias = rnd(Co, seed=5)
+    w2 = w.permute(2, 3, 0, 1).reshape(9 * Co, C).contiguous()         # n = (ky*3 + kx)*Co + o
+    M = B * H * W
+    if mode == 0:
+        xin = x.to(dtype).contiguous()
+        wp = w2.to(dtype).contiguous()
+        scales = (127, 127, 127, 127)
+        x_val, w_val = xin.double(), wp.double()
+        out = torch.zeros(B, 2 * H, 2 * W, Co, device=dev(), dtype=dtype)
+        split = 0
+    else:
+        xin = torch.empty(B, H, W, 2 * C, device=dev(), dtype=dtype)
+        L.cast_split(x.view(M, C), xin, M, C, f8=True)
+        wp, (sb0, sb1) = L.f8_weight(w2, dtype)
+        wp = wp.to(dev())
+        scales = (127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1)
+        hi, val = from_f8_pairs(xin, C)
+        x_val = (hi if mode == 1 else val).double()                  # mode 1 drops the activation-rounding correction
+        w_val = w2.double()
+        out = torch.zeros(B, 2 * H, 2 * W, 2 * Co, device=dev(), dtype=dtype)
+        split = 2
+    L.upconv_fused(xin, wp, bias, out, B, H, W, C, Co, mode=mode, split=split, relu=True, f8_scales=scales)
+    up = F.interpolate(x_val.permute(0, 3, 1, 2), size=(2 * H, 2 * W), mode="bilinear", align_corners=True)
+    wk = w_val.view(3, 3, Co, C).permute(2, 3, 0, 1)
+    ref = F.relu(F.conv2d(up, wk, bias.double(), padding=1)).permute(0, 2, 3, 1)
+    # the two-launch path on the same operands
+    y9 = torch.empty(M, 9 * Co, device=dev(), dtype=torch.float32)
+    if mode == 0:
+        L.gemm(xin.view(M, C), wp, y9, M=M, N=9 * Co, K=C, lda=C)
+    else:
+        L.gemm(xin.view(M, 2 * C), wp, y9, M=M, N=9 * Co, K=C, lda=2 * C, f8_seg=2 * C, f8_wonly_from=-1 if mode == 1 else 0,
+               f8_scales=scales)
+    two = torch.zeros_like(out)
+    L.upconv_tapsum(y9, bias, two, B, H, W, Co, 2 * H, 2 * W, True, split, True)
+    dec = (lambda t: from_f8_pairs(t, Co)[1].double()) if split else (lambda t: t.double())
+    scale = ref.abs().max().item() + 1.0
+    e_ref, e_two = (dec(out) - ref).abs().max().item(), (dec(out) - dec(two)).abs().max().item()
+    report(f"upconv_fused {dtype} mode {mode} {geom}: vs fp64 {e_ref:.2e}, vs gemm + tapsum {e_two:.2e} (scale {scale:.2f})")
+    assert torch.isfinite(dec(out)).all()
+    res = (2.0 ** -11 if dtype == torch.float16 else 2.0 ** -8) if mode == 0 else (2.0 ** -15 if dtype == torch.float16 else 2.0 ** -12)
+    # against fp64: the output format's resolution + (modes 1, 2) the e4m3 rounding inside the correction products
+    assert e_ref < (1.5 * res + (0.0 if mode == 0 else (3e-5 if dtype == torch.float16 else 3e-4))) * scale
+    # against the two-launch path: identical products, the fp32 sums associate differently -- one step of the output format at most
+    assert e_two < 1.1 * res * scale
+    out2 = torch.zeros_like(out)
+    L.upconv_fused(xin, wp, bias, out2, B, H, W, C, Co, mode=mode, split=split, relu=True, f8_scales=scales)
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_split_pointwise(L, dtype):
     """(hi | lo) carriers of accurate mode: cast_split, relu_split, split resize and split add_resized keep ~2x the mantissa."""
     B, H, W, C = 2, 12, 16, 64
