@@ -19,7 +19,6 @@ BS_DECL_TILE(3, 0) BS_DECL_TILE(3, 1)
 BS_DECL_TILE(9, 0) BS_DECL_TILE(9, 1)
 BS_DECL_TILE(10, 0) BS_DECL_TILE(11, 0)
 #undef BS_DECL_TILE
-int igemm_launch_tile9_f16_cm1_persist(const IgemmParams&, bool, hipStream_t);
 
 // tile ids (BMxBNxBK, LDS stages): 1 128x128x64 s2 (2 blocks/CU) | 2 128x64x64 s2 | 3 128x32x64 s2 | 9 256x256x64 s2 (128 KiB)
 //   10 256x256x32 s4 ping-pong (two wave groups alternate MFMA / load phases) | 11 256x128x32 s3, 4 waves (2 blocks/CU)
@@ -70,11 +69,7 @@ static int launch_tile(IgemmParams& p, int dtype, bool conv, int tile, hipStream
         case 30: return BS_TILE(3, 0);
         case 31: return BS_TILE(3, 1);
         case 90: return BS_TILE(9, 0);
-        case 91: {
-            static const bool persist = getenv("BS_GEMM_PERSIST") != nullptr;       // experiment (round 5)
-            if (persist && h) return igemm_launch_tile9_f16_cm1_persist(p, conv, st);
-            return BS_TILE(9, 1);
-        }
+        case 91: return BS_TILE(9, 1);
         case 100: return BS_TILE(10, 0);
         case 110: return BS_TILE(11, 0);
 #undef BS_TILE

@@ -214,9 +214,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 // (accurate mode); 0 = the plain instantiation, which carries none of that code, so fast-mode launches are not affected by its
 // register pressure.  (CM = 2, FP4 correction stages with per-block scales, existed in round 3: +1.4 % frames/s for 1.5x the depth error --
 // removed in round 4, profiles/r03_fp4_corrections.txt keeps the measurements.)
-// One output tile: `bid` of `nwg` work ids (the launch's blocks, or the virtual block ids a persistent block walks through).
-template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int MODE, bool PP = false, int CM = 0, typename P = IgemmParams>
-__device__ __forceinline__ void igemm_tile_body(const P& p, const int nwg, const int bid) {
+template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int MODE, bool PP = false, int CM = 0>
+__global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins exist in the device pass only; the host pass needs just the stub
     constexpr bool CONV = MODE != 0;
     constexpr bool RELU_A = MODE == 2;
@@ -241,13 +240,9 @@ __device__ __forceinline__ void igemm_tile_body(const P& p, const int nwg, const
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    // (diagnostics, ablate bit 4096: half of the first round's blocks -- every other block of an XCD -- start (ablate >> 13) x 4 us late, so that the two
-    // halves of the chip are out of phase for the rest of the launch: do epilogues, which all hit HBM at once when every CU runs in step, gain?)
-    if ((p.ablate & 4096) && (bid & 8) && bid < 256) {
-        for (int i = 0; i < ((p.ablate >> 13) & 15); ++i) __builtin_amdgcn_s_sleep(127);
-    }
     // ---- work id -> tile, XCD-aware (blocks b and b+8 share an XCD; give each XCD a contiguous
     // run of work ids so that the N-tiles of one M-tile hit the same L2)
+    const int nwg = gridDim.x, bid = blockIdx.x;
     const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + loc;
     int tm, tn;
@@ -1267,44 +1262,11 @@ __device__ __forceinline__ void igemm_tile_body(const P& p, const int nwg, const
 #endif
 }
 
-// PERSIST: one block per CU walks the work ids blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x a multiple of 8: a block's tiles keep its
-// XCD, the remap above sees the same ids the hardware dispatcher would have handed out).  What it buys is the hand-over between two tiles
-// of a CU: a retiring block drains its stores and the next one starts cold (2-7 us of a 36-60 us backbone tile, tools/probes/
-// store_pattern.hip); here the next tile's first DMA stages are issued while the previous tile's stores are still in flight.
-// The tile body as a real function (PERSIST): inlined into a loop the register allocator spills ~400 registers of the 256 x 256 tile (the
-// loop's merges); as a call the body keeps the allocation it has as a kernel.  The descriptor is read through the kernarg segment
-// (constant address space: scalar loads, as in the kernel).
-template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int MODE, bool PP, int CM>
-__device__ __attribute__((noinline)) void igemm_tile_call(const __attribute__((address_space(4))) IgemmParams* pp, int nwg, int bid) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    igemm_tile_body<T, BM, BN, WM, WN, BK, STAGES, MODE, PP, CM, __attribute__((address_space(4))) IgemmParams>(*pp, nwg, bid);
-#endif
-}
-
-template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int MODE, bool PP = false, int CM = 0, bool PERSIST = false>
-__global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams p) {
-    if constexpr (!PERSIST) {
-        igemm_tile_body<T, BM, BN, WM, WN, BK, STAGES, MODE, PP, CM>(p, (int)gridDim.x, (int)blockIdx.x);
-    } else {
-#if defined(__HIP_DEVICE_COMPILE__)
-        const __attribute__((address_space(4))) IgemmParams* pp =
-            (const __attribute__((address_space(4))) IgemmParams*)__builtin_amdgcn_kernarg_segment_ptr();
-        const int total = pp->ntm * pp->ntn;
-#pragma nounroll
-        for (int v = blockIdx.x; v < total; v += gridDim.x) {
-            igemm_tile_call<T, BM, BN, WM, WN, BK, STAGES, MODE, PP, CM>(pp, total, v);
-            __syncthreads();          // every wave is done with the LDS (ring, epilogue staging) before the next tile's DMA lands in it
-        }
-#endif
-    }
-}
-
-template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int MODE, bool PP = false, int CM = 0, bool PERSIST = false>
+template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int MODE, bool PP = false, int CM = 0>
 inline int launch_mode(const IgemmParams& p, hipStream_t st) {
     constexpr int smem = STAGES * (BM + BN) * BK * 2;
-    const int total = p.ntm * p.ntn, cus = cu_count() & ~7;
-    dim3 grid(PERSIST && total > cus ? cus : total), block(WM * WN * 64);
-    auto k = igemm_kernel<T, BM, BN, WM, WN, BK, STAGES, MODE, PP, CM, PERSIST>;
+    dim3 grid(p.ntm * p.ntn), block(WM * WN * 64);
+    auto k = igemm_kernel<T, BM, BN, WM, WN, BK, STAGES, MODE, PP, CM>;
     static bool attr = false;
     if (!attr) {
         BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -1327,13 +1289,6 @@ inline int launch_cm(const IgemmParams& p, bool conv, hipStream_t st) {
         if (!conv) return launch_mode<T, BM, BN, WM, WN, BK, STAGES, 0, PP, CM>(p, st);
         return launch_mode<T, BM, BN, WM, WN, BK, STAGES, 1, PP, CM>(p, st);
     }
-}
-
-// the persistent form of a correction-mode tile (its own translation unit)
-template <typename T, int BM, int BN, int WM, int WN, int BK, int STAGES, int CM>
-inline int launch_cm_persist(const IgemmParams& p, bool conv, hipStream_t st) {
-    if (!conv) return launch_mode<T, BM, BN, WM, WN, BK, STAGES, 0, false, CM, true>(p, st);
-    return launch_mode<T, BM, BN, WM, WN, BK, STAGES, 1, false, CM, true>(p, st);
 }
 
 }  // namespace bs
