@@ -47,7 +47,7 @@ class GemmDesc(C.Structure):
         ("qkv_cls_last", C.c_int32), ("qkv_cls_rows", C.c_int32), ("qkv_patch_row0", C.c_int32), ("f8_wonly_from", C.c_int32), ("out_lo8_rows", C.c_int32),
         ("f8_skip_from", C.c_int32), ("bias2_row0", C.c_int32), ("bias2_group_rows", C.c_int32), ("out_planes_rows", C.c_int32),
         ("bias2", C.c_void_p),
-        ("qkv_lo_off", C.c_int32),
+        ("qkv_lo_off", C.c_int32), ("out2_relu", C.c_int32),
     ]
 
 
@@ -72,6 +72,7 @@ _SIGS = {
     "bs_resize_bilinear_nhwc": [C.c_void_p, C.c_void_p] + [C.c_int32] * 8 + [C.c_void_p],
     "bs_upconv_tapsum": [C.c_void_p] * 3 + [C.c_int32] * 9 + [C.c_void_p],
     "bs_upconv_fused": [C.c_void_p] * 4 + [C.c_int32] * 15 + [C.c_void_p],
+    "bs_resize_bias_relu_nhwc": [C.c_void_p] * 3 + [C.c_int32] * 8 + [C.c_void_p],
     "bs_col_mean": [C.c_void_p, C.c_int64] + [C.c_int32] * 5 + [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p],
     "bs_rank1_bias": [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p],
     "bs_depth_u16_to_m": [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p],
@@ -190,7 +191,7 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
                    shuffle=None, qkv=None, a_offset: int = 0, tile: int = 0, seg1: int = 0, out_split_off: int = 0,
                    res_split_off: int = 0, f8_seg: int = 0, f8_scales=(127, 127, 127, 127), out_f8=None, res_f8: bool = False,
                    f8_wonly_from: int = 0, out_lo8_rows: int = 0, f8_skip_from: int = 0, bias2=None, out_planes_rows: int = 0,
-                   ) -> GemmDesc:
+                   out_relu: Optional[torch.Tensor] = None) -> GemmDesc:
     """Fill a bs_gemm_desc.  conv = (Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_h, pad_w) or None;
     out_group = (rows, stride, offset); shuffle = (s, Cout, Hgrid, Wgrid);
     qkv = (hidden, tokens, Sp, q_scale, out_k, out_vt[, cls_last[, cls_rows[, patch_row0[, lo_off]]]]); a_offset in elements;
@@ -253,6 +254,10 @@ def make_gemm_desc(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: in
         b2, row0, grows = bias2
         assert b2.dtype == torch.float32 and b2.shape[-1] == N
         d.bias2, d.bias2_row0, d.bias2_group_rows = b2.data_ptr(), row0, grows
+    if out_relu is not None:         # second output: relu(y) in out's (hi16 | hi8 | lo8) format (bs_gemm_desc.out2_relu)
+        assert qkv is None and out_f8 is not None and out_relu.dtype == out.dtype and out_relu.numel() == out.numel()
+        d.out2 = out_relu.data_ptr()
+        d.out2_relu = 1
     return d
 
 
@@ -601,6 +606,12 @@ def upconv_fused(x, w, bias, out, B, Hin, Win, Cin, Cout, mode=0, split=0, relu=
     check(load_library().bs_upconv_fused(p(x), p(w), p(bias), p(out), B, Hin, Win, Cin, Cout, 2 * Hin, 2 * Win,
                                          1 | (4 if split == 2 else (2 if split else 0)), int(relu), mode, *[int(v) for v in f8_scales], dt(out),
                                          stream_ptr()), "bs_upconv_fused")
+
+
+def resize_bias_relu_nhwc(x, bias, out, B, Hin, Win, Cch, Hout, Wout, split=False):
+    """relu(bilinear(x, align_corners) + bias) on NHWC 16-bit rows / (hi | lo) pairs (include/bodyslam_hip.h)"""
+    check(load_library().bs_resize_bias_relu_nhwc(p(x), p(bias), p(out), B, Hin, Win, Cch, Hout, Wout, 1 | (2 if split else 0), dt(out), stream_ptr()),
+          "bs_resize_bias_relu_nhwc")
 
 
 def attractor_step(A, bins_prev, bins_out, route, B, Hp, Wp, H, W, groups, n_bins, n_attr):

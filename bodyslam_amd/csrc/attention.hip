@@ -569,6 +569,7 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
                                                                   const float* __restrict__ table, T* __restrict__ out, int split, int B, int nh,
                                                                   int hp, int Sp, int nqb, int ntab, int grouped) {
     const bool cls_planes = (split & 4) != 0;   // FP8 planes for the cls query's row only (bs_attention_table, dtype bit 6)
+    const int abl = split >> 3;                 // diagnostics (BS_ATTN_ABL): 1 = no ring barrier, 2 = no DMA wait, 4 = no DMA after tile 1 -- wrong results, timing only
     split &= 3;
     typedef typename T16<T>::v8 v8;
     constexpr int HALF = 16 * 1024;             // K tile 8 KiB + V^T tile 8 KiB
@@ -755,8 +756,14 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
     load_bias(sa, 0);
     load_bias(sb2, 1);
     for (int kt = 0; kt < NT - 1; ++kt) {
-        if (kt > 0) dma_barrier();      // tile kt has landed; everyone is done with tile kt - 1
-        stage(kt + 1, (kt + 1) & 1);
+        if (kt > 0) {                   // tile kt has landed; everyone is done with tile kt - 1
+            if (abl == 0) dma_barrier();
+            else {
+                if (!(abl & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!(abl & 1)) __syncthreads();
+            }
+        }
+        if (!(abl & 4) || kt == 0) stage(kt + 1, (kt + 1) & 1);
         const char* sk = smem + (kt & 1) * STAGE;
         qk(sa, sk, 0);
         qk(sb2, sk, 1);
@@ -829,8 +836,9 @@ static int launch_attn_tab(const void* q, const void* k, const void* vt, const v
             BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
             attr2 = true;
         }
+        static const int abl = getenv("BS_ATTN_ABL") ? atoi(getenv("BS_ATTN_ABL")) : 0;      // diagnostics (timing only)
         hipLaunchKernelGGL(kern2, dim3(B * nh * nqb), dim3(QW * 64), 32 * 1024 + tab_bytes, st, (const T*)q, (const T*)k, (const T*)vt, (const T*)nullptr,
-                           (const T*)nullptr, (const T*)nullptr, table, (T*)out, split, B, nh, hp, Sp, nqb, ntab, grouped);
+                           (const T*)nullptr, (const T*)nullptr, table, (T*)out, split | (abl << 3), B, nh, hp, Sp, nqb, ntab, grouped);
         BS_CHECK_LAUNCH();
         return BS_OK;
     }

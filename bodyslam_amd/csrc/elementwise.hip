@@ -565,9 +565,11 @@ __global__ __launch_bounds__(512) void upconv_tapsum_lds_kernel(const float* y, 
 
 // NHWC bilinear resize (+ optional add): thread = one 8-channel group of one output pixel
 // ---------------------------------------------------------------------------------------------
-template <typename T, bool ADD, int SPLIT>
+// BIAS_RELU (bs_resize_bias_relu_nhwc): out = relu(resize(x) + bias[c]) -- a 1x1 convolution + ReLU whose input is an upsampled map, evaluated as
+// the convolution at the LOW resolution (linear, commutes with the resize) and this kernel.
+template <typename T, bool ADD, int SPLIT, bool BIAS_RELU = false>
 __global__ __launch_bounds__(256) void resize_nhwc_kernel(const T* x, const T* addend, T* out, int B, int Hin, int Win, int C, int Hout,
-                                                           int Wout, float sy, float sx, int align) {
+                                                           int Wout, float sy, float sx, int align, const float* bias = nullptr) {
     // SPLIT: the tensors hold (hi | lo) pairs, C channels each (pixel stride 2C); the value hi + lo is resampled and re-split
     // grid.y = (image, output row); grid.x covers (column, 8-channel group) of that row
     const int c8n = C >> 3;
@@ -627,6 +629,10 @@ __global__ __launch_bounds__(256) void resize_nhwc_kernel(const T* x, const T* a
     for (int e = 0; e < 8; e += 2) {
         f32x2_ v = bilerp2(f32x2_{q00[e], q00[e + 1]}, f32x2_{q01[e], q01[e + 1]}, f32x2_{q10[e], q10[e + 1]}, f32x2_{q11[e], q11[e + 1]}, hx2, lx2, hy2, ly2);
         if (ADD) v += f32x2_{av[e], av[e + 1]};
+        if (BIAS_RELU) {
+            v += *reinterpret_cast<const f32x2_*>(bias + c8 * 8 + e);
+            v = f32x2_{fmaxf(v[0], 0.0f), fmaxf(v[1], 0.0f)};
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             vv[e + u] = v[u];
@@ -1048,6 +1054,32 @@ extern "C" int bs_add_resized(const void* x, const void* prev, void* out, int32_
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return dtype == BS_F16 ? launch_resize<f16>(prev, x, out, B, Hp, Wp, C, H, W, 1, st, split)
                            : launch_resize<bf16>(prev, x, out, B, Hp, Wp, C, H, W, 1, st, split);
+}
+
+extern "C" int bs_resize_bias_relu_nhwc(const void* x, const float* bias, void* out, int32_t B, int32_t Hin, int32_t Win, int32_t C, int32_t Hout,
+                                        int32_t Wout, int32_t flags, int32_t dtype, void* stream) {
+    BS_ENTRY("bs_resize_bias_relu_nhwc");
+    BS_REQUIRE(x && bias && out, "bs_resize_bias_relu_nhwc: null operand");
+    BS_REQUIRE(B > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && C > 0 && C % 8 == 0, "bs_resize_bias_relu_nhwc: bad shape (C %% 8 == 0)");
+    BS_REQUIRE((flags & 1) && !(flags & 4), "bs_resize_bias_relu_nhwc: align_corners, single 16-bit or (hi | lo) pair rows");
+    BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_resize_bias_relu_nhwc: dtype must be f16 or bf16");
+    const float sy = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f, sx = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
+    const dim3 blocks(cdiv(Wout * (C / 8), 256), B * Hout);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define BS_RBR(TT)                                                                                                                        \
+    do {                                                                                                                                  \
+        if (flags & 2)                                                                                                                    \
+            hipLaunchKernelGGL((resize_nhwc_kernel<TT, false, 1, true>), blocks, dim3(256), 0, st, (const TT*)x, (const TT*)nullptr, (TT*)out, B, Hin, \
+                               Win, C, Hout, Wout, sy, sx, 1, bias);                                                                     \
+        else                                                                                                                              \
+            hipLaunchKernelGGL((resize_nhwc_kernel<TT, false, 0, true>), blocks, dim3(256), 0, st, (const TT*)x, (const TT*)nullptr, (TT*)out, B, Hin, \
+                               Win, C, Hout, Wout, sy, sx, 1, bias);                                                                     \
+    } while (0)
+    if (dtype == BS_F16) BS_RBR(f16);
+    else BS_RBR(bf16);
+#undef BS_RBR
+    BS_CHECK_LAUNCH();
+    return BS_OK;
 }
 
 extern "C" int bs_postprocess_depth(const float* depth_net, float* depth_m, uint16_t* depth_u16, int32_t B, int32_t H, int32_t W,

@@ -228,6 +228,12 @@ extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
     p.qkv_cls_rows = d->qkv_cls_rows;
     p.qkv_patch_row0 = d->qkv_patch_row0;
     p.qkv_lo_off = d->qkv_lo_off;
+    p.out2_relu = d->out2_relu;
+    // (the second output exists in the lean (hi16 | hi8 | lo8) epilogue only: the conditions below are that form's, igemm_kernel.h)
+    BS_REQUIRE(!d->out2_relu || (d->out2 && d->out_mode == BS_OUT_PLAIN && d->out_f8 && !d->scale && !d->out_group_rows && !d->bias_group_rows &&
+                                 !d->bias2 && (d->act == BS_ACT_NONE || d->act == BS_ACT_RELU) && d->out_split_off == d->N && d->N % 256 == 0 &&
+                                 d->ldo % 8 == 0 && d->out_dtype == d->dtype && (!d->res || d->res_f8)),
+               "bs_gemm: out2_relu needs the plain (hi16 | hi8 | lo8) output form (out_f8, N %% 256 == 0, no scale / row groups / bias2)");
     BS_REQUIRE(d->qkv_lo_off == 0 || (d->out_mode == BS_OUT_QKV && d->qkv_lo_off > 0 && d->qkv_lo_off % 8 == 0),
                "bs_gemm: qkv_lo_off needs BS_OUT_QKV and a multiple of 8 elements");
     p.f8_wonly_from = d->f8_wonly_from;

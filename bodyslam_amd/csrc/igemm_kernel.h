@@ -72,6 +72,7 @@ struct IgemmParams {
     int f8_stages;       // number of trailing 128-byte K stages that are FP8 (host: f8_seg / 128, times the taps for a conv)
     int res_f8;          // != 0: the 16-bit residual(s) are (hi16 | hi8 | lo8) rows of N channels; value = hi16 + lo8 * 2^-BS_F8_ACT_LO_EXP
     int out_f8;          // > 0 with split_off: the output pair is (hi16 | hi8 | lo8), see store8_f8
+    int out2_relu;       // != 0 (lean (hi16 | hi8 | lo8) epilogue only): out2 receives relu(y) in the same format and geometry
     int out_lo8_rows;    // > 0: only output rows below this index need their lo8 plane (the consumer drops the activation-rounding
                          //      correction on the others, f8_wonly_from): tiles past it skip that plane
     int f8_skip_from;    // > 0: tiles that start at a row >= this run no FP8 stage at all
@@ -867,6 +868,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                             if (it + RDEPTH < NP) issue(it + RDEPTH, it % RDEPTH);
                         }
                         if (m < p.M) store8_f8<T>(p.out, (int64_t)m * p.ldo, n_wave + jp * 32 + fq * 8, p.split_off, y8, ea, el);
+                        if (p.out2_relu) {      // (wave-uniform) the ReLU'd copy the next residual unit's first convolution reads
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) y8[e] = fmaxf(y8[e], 0.0f);
+                            if (m < p.M) store8_f8<T>(p.out2, (int64_t)m * p.ldo, n_wave + jp * 32 + fq * 8, p.split_off, y8, ea, el);
+                        }
                     }
                 };
                 if (p.res2) body(std::integral_constant<int, 2>{});

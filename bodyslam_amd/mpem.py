@@ -22,7 +22,11 @@ class MPEMInterface:
     def infer_relative_pose_between(self, path_frame1, path_frame2, type_of_trans='crop'):
         """two frame paths -> (4,4) float32 SE(3) relative pose (prev -> curr)."""
         assert type_of_trans == 'crop' or type_of_trans == 'resize', "type_of_trans must be 'crop' or 'resize'!"
-        i1, i2 = Image.open(path_frame1).convert('RGB'), Image.open(path_frame2).convert('RGB')      # FrameIO.load_p_img (io_utils.py:33-47)
+        # FrameIO.load_p_img(path) (io_utils.py:33-47) opens with convert_to_rgb=False, i.e. WITHOUT a colour conversion: for the RGB JPEG / PNG
+        # frames of the reference's datasets the two are the same image.  A greyscale or RGBA file would reach the reference's network as a
+        # 1- or 4-channel tensor and fail in its first convolution (6 input channels = two RGB frames); here it is converted to RGB instead --
+        # a deliberate divergence on inputs the reference cannot process at all.
+        i1, i2 = Image.open(path_frame1).convert('RGB'), Image.open(path_frame2).convert('RGB')
         window = None
         if type_of_trans == 'resize':
             # transforms.Resize(128) (mpem_interface.py:45-50): the smaller edge becomes 128, aspect kept, PIL bilinear -- the same

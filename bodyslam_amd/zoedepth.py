@@ -1026,7 +1026,11 @@ class _ZoePlan:
             g_ = L.conv_geom(hh, ww, Ci if use8 else Ci * m2, 3, 3, stride, 1)
             ho, wo = g_[3], g_[4]
             has_res = "res" in kw
+            out_relu = kw.pop("out_relu", None)
+            assert out_relu is None or use8
             if use8:
+                if out_relu is not None:
+                    kw["out_relu"] = out_relu
                 self.site_flops[wkey] = self.site_flops.get(wkey, 0.0) + 2.0 * NB * ho * wo * Co * 9 * Ci
                 P.gemm(name, A, w[wkey], out, M=NB * ho * wo, N=Co, K=9 * Ci, lda=2 * Ci, conv=g_, f8_seg=2 * Ci, ldo=2 * Co,
                        ldr=2 * Co if has_res else 0, res_f8=has_res, out_split_off=Co, out_f8=F8O, precision_passes=1, **f8kw(wkey), **kw)
@@ -1038,7 +1042,8 @@ class _ZoePlan:
             return ho, wo
 
         # ---- Z4: reassemble (readout project, 1x1 projection, resize) + neck 3x3 convs
-        feats, fshape = [], []
+        feats, fshape, feats_relu = [], [], []
+        relu_out = bool(acc and nf8 and os.environ.get("BS_RELU_OUT", "1") != "0")
         cb = e32(NB, Hd)
         r16 = e16(NB * T0, PE(Hd))
         for i, ch in enumerate(c.neck_hidden):
@@ -1075,7 +1080,11 @@ class _ZoePlan:
                 free(pr)
             P.mark(f"reassemble{i}", src, ("nhwc", NB, fh, fw, ch, mfmt(ch)))
             f16_ = e16(NB, fh, fw, PE(c.fusion))
-            nconv(f"nc{i}", src, f"nc{i}.w", f16_, fh, fw, ch, c.fusion)
+            # Round 5: the fusion stage's residual units read x (the skip) AND relu(x) (their first convolution's input): the producing
+            # convolution's epilogue writes both (bs_gemm_desc.out2_relu) instead of a bs_relu_split launch re-reading x.  BS_RELU_OUT=0: the launch.
+            fr_ = e16(NB, fh, fw, PE(c.fusion)) if relu_out else None
+            nconv(f"nc{i}", src, f"nc{i}.w", f16_, fh, fw, ch, c.fusion, out_relu=fr_)
+            feats_relu.append(fr_)
             free(src)                                                  # (level 2: src is pr)
             P.mark(f"neckconv{i}", f16_, ("nhwc", NB, fh, fw, c.fusion, mfmt(c.fusion)))
             feats.append(f16_)
@@ -1149,35 +1158,47 @@ class _ZoePlan:
         # ---- Z5: fusion stage (pre-activation residual units, x2 bilinear, 1x1 projection)
         Fc = c.fusion
 
-        def res_unit(name, xin, hh, ww, other=None):
-            """y = conv2(relu(conv1(relu(x)))) + x (+ other)."""
+        def res_unit(name, xin, hh, ww, other=None, xin_relu=None, want_relu=False):
+            """y = conv2(relu(conv1(relu(x)))) + x (+ other).  xin_relu: relu(x) as its producer wrote it (else a bs_relu_split launch forms it);
+            want_relu: also return relu(y), written by conv2's epilogue, for the next unit."""
             t = e16(NB, hh, ww, PE(Fc))
             y = e16(NB, hh, ww, PE(Fc))
+            yr = e16(NB, hh, ww, PE(Fc)) if (want_relu and relu_out) else None
             if acc:
-                xr = e16(NB, hh, ww, PE(Fc))
-                P.add(name + ".relu", "bs_relu_split", xin, xr, NB * hh * ww, Fc, L.dt(xr) | (32 if nf8 else 0))
+                xr = xin_relu
+                if xr is None:
+                    xr = e16(NB, hh, ww, PE(Fc))
+                    P.add(name + ".relu", "bs_relu_split", xin, xr, NB * hh * ww, Fc, L.dt(xr) | (32 if nf8 else 0))
                 nconv(name + ".c1", xr, name + ".c1.w", t, hh, ww, Fc, Fc, bias=w[name + ".c1.b"], act=L.ACT_RELU)
                 free(xr)
             else:
                 nconv(name + ".c1", xin, name + ".c1.w", t, hh, ww, Fc, Fc, relu_a=True, bias=w[name + ".c1.b"], act=L.ACT_RELU)
-            nconv(name + ".c2", t, name + ".c2.w", y, hh, ww, Fc, Fc, bias=w[name + ".c2.b"], res=xin, res2=other)
+            nconv(name + ".c2", t, name + ".c2.w", y, hh, ww, Fc, Fc, bias=w[name + ".c2.b"], res=xin, res2=other, out_relu=yr)
             free(t)
-            return y
+            return y, yr
 
+        # Round 5: the bins head's projectors (pj{i}.c1: 1x1 conv 256 -> 64 + ReLU on the fused maps, HF modeling_zoedepth.py:749-772) read an
+        # UPSAMPLED map too: their convolution runs on the low-resolution projection output (a quarter of the pixels; the product is kept as
+        # (hi | lo) pairs) and bs_resize_bias_relu_nhwc upsamples it, adds the bias and applies the ReLU where the level needs it -- instead of
+        # reading the 256-channel fused map at full resolution (pj3.c1: 6.4 GB in for 1.6 GB out, 1.36 ms).  BS_PJ_LOWRES=0: the direct form.
+        pj_lowres = os.environ.get("BS_PJ_LOWRES", "1") != "0"
+        pj_low = []
         fused_list = []
         fused = None
         for li in range(4):
             feat = feats[3 - li]
             fh, fw = fshape[3 - li]
             if fused is None:
-                cur = feat                                                  # (the bottleneck map: the side lane reads it until wait(1))
+                cur, cur_relu = feat, feats_relu[3 - li]                    # (the bottleneck map: the side lane reads it until wait(1))
                 own = False
             else:
-                cur = res_unit(f"fu{li}.r1", feat, fh, fw, other=fused)     # fused + residual_layer1(feat)
-                free(feat)                                                  # (fused stays: the bins head reads it later)
+                cur, cur_relu = res_unit(f"fu{li}.r1", feat, fh, fw, other=fused, xin_relu=feats_relu[3 - li], want_relu=True)     # fused + residual_layer1(feat)
+                free(feat)
+                if pj_lowres:
+                    free(fused)                                             # (its projector input was taken at the low resolution)
                 own = True
             cur_in = cur
-            cur = res_unit(f"fu{li}.r2", cur, fh, fw)
+            cur, _ = res_unit(f"fu{li}.r2", cur, fh, fw, xin_relu=cur_relu)
             if own:
                 free(cur_in)
             # HF upsamples, then applies the 1x1 projection (modeling_zoedepth.py:316-322).  Both are linear and the bilinear weights
@@ -1186,6 +1207,10 @@ class _ZoePlan:
             lowp = e16(NB, fh, fw, PE(Fc))
             nplain(f"fu{li}.proj", cur, f"fu{li}.proj.w", lowp, NB * fh * fw, Fc, Fc, bias=w[f"fu{li}.proj.b"])
             free(cur)
+            if pj_lowres:
+                z = e16(NB * fh * fw, PM * m2)
+                nplain(f"pj{li}.c1", lowp, f"pj{li}.c1.w", z, NB * fh * fw, PM, Fc, out8=False)
+                pj_low.append((z, fh, fw))
             fused = e16(NB, 2 * fh, 2 * fw, PE(Fc))
             P.add(f"fu{li}.up", "bs_resize_bilinear_nhwc", lowp, fused, NB, fh, fw, Fc, 2 * fh, 2 * fw, RZ, L.dt(fused))
             free(lowp)
@@ -1198,9 +1223,11 @@ class _ZoePlan:
             nconv("rh.projection", f3, "rh.projection.w", rp, h3, w3, Fc, Fc, bias=w["rh.projection.b"], act=L.ACT_RELU)
         else:
             rp = f3
+        if eng.add_projection and pj_lowres:
+            free(f3)
         r1 = e16(NB, h3, w3, (Fc // 2) * m2)
         nconv("rh.conv1", rp, "rh.conv1.w", r1, h3, w3, Fc, Fc // 2, bias=w["rh.conv1.b"])
-        if eng.add_projection:
+        if eng.add_projection or pj_lowres:
             free(rp)
         # HF: interpolate x2 (align_corners), conv2 3x3 128 -> 32, ReLU (modeling_zoedepth.py:358-362).  Both are linear and the resize acts
         # per channel, so conv2(up(x))(p) = sum_tap up(W_tap x)(p + d_tap): the nine 1x1 tap products run as ONE plain GEMM at the low
@@ -1241,8 +1268,13 @@ class _ZoePlan:
             feat, fh, fw = fused_list[i]
             Mi = NB * fh * fw
             e1 = e16(Mi, PM * m2)
-            nplain(f"pj{i}.c1", feat, f"pj{i}.c1.w", e1, Mi, PM, Fc, bias=w[f"pj{i}.c1.b"], act=L.ACT_RELU, out8=False)
-            free(feat)                                             # the fused map's last reader (fused 3 fed the relative head earlier)
+            if pj_lowres:
+                z, zh, zw = pj_low[i]
+                P.add(f"pj{i}.up", "bs_resize_bias_relu_nhwc", z, w[f"pj{i}.c1.b"], e1, NB, zh, zw, PM, fh, fw, 1 | (2 if acc else 0), L.dt(e1))
+                free(z)
+            else:
+                nplain(f"pj{i}.c1", feat, f"pj{i}.c1.w", e1, Mi, PM, Fc, bias=w[f"pj{i}.c1.b"], act=L.ACT_RELU, out8=False)
+                free(feat)                                         # the fused map's last reader (fused 3 fed the relative head earlier)
             emb = e16(Mi, E * m2)
             P.gemm(f"pj{i}.c2", e1, w[f"pj{i}.c2.w"], emb, M=Mi, N=E, K=PM * np3, lda=PM * m2, seg1=PM if acc else 0,
                    ldo=E * m2, out_split_off=E if acc else 0, bias=w[f"pj{i}.c2.b"], precision_passes=np3)

@@ -145,6 +145,10 @@ typedef struct bs_gemm_desc {
     int32_t qkv_lo_off;            /* BS_OUT_QKV, > 0: the rounding residuals of Q, K and V^T (y - round16(y) as a second 16-bit value, unscaled)
                                     * are stored too, this many ELEMENTS behind the respective value in out / out2 / out3 (each tensor
                                     * allocated twice over): the operands of bs_attention_table_corr */
+    int32_t out2_relu;             /* BS_OUT_PLAIN with out_f8, != 0: out2 receives relu(y) in the same (hi16 | hi8 | lo8) row format and geometry as
+                                    * out (a second output of the epilogue).  The fusion stage's pre-activation residual units read both x (the skip)
+                                    * and relu(x) (their first convolution's input): the producing convolution writes the two instead of a
+                                    * bs_relu_split launch re-reading x (HF modeling_zoedepth.py:262-297) */
 } bs_gemm_desc;
 int bs_gemm(const bs_gemm_desc* d, void* stream);
 /* the tile variant bs_gemm will pick for this descriptor (1: 128x128, 2: 128x64, 3: 128x32, 4: 256x128) */
@@ -228,6 +232,13 @@ int bs_fill_rows(float* x, const float* v, int32_t B, int32_t rows_per_image, in
  * modeling_zoedepth.py:259,319,360 */
 int bs_resize_bilinear_nhwc(const void* x, void* out, int32_t B, int32_t Hin, int32_t Win, int32_t C,
                             int32_t Hout, int32_t Wout, int32_t align_corners, int32_t dtype, void* stream);
+
+/* out = relu(bilinear resize(x, align_corners) + bias[c]): the second half of a 1x1 convolution + ReLU whose input is an upsampled map -- the
+ * bins head's projectors read the fusion stage's x2 outputs (HF modeling_zoedepth.py:749-772 on :316-322's maps); the convolution is linear and
+ * commutes with the resize, so it runs at the LOW resolution (a quarter of the pixels, bs_gemm without bias) and this call upsamples its output.
+ * x, out: NHWC 16-bit rows of C values, or (hi | lo) pairs (flags bit 1); flags bit 0 (align_corners) is required; bias fp32 [C]. */
+int bs_resize_bias_relu_nhwc(const void* x, const float* bias, void* out, int32_t B, int32_t Hin, int32_t Win, int32_t C, int32_t Hout,
+                             int32_t Wout, int32_t flags, int32_t dtype, void* stream);
 
 /* conv3x3(pad 1)(interpolate x2(x)) evaluated from tap products taken at the low resolution -- the relative head's
  * `upsample` + `conv2` (+ ReLU), HF modeling_zoedepth.py:358-362.  y fp32 [B, Hin, Win, 9*Cout] holds, per low-resolution pixel,

@@ -369,6 +369,18 @@ def test_f8_correction_conv(L, tile):
     err1 = (single.double() - (ref - from_f8_pairs(r8, Co)[1].double())).abs().max().item()
     report(f"f8 correction conv tile{tile}: max|err|={err:.2e} vs single-pass {err1:.2e}")
     assert err < 2e-4 and err < 0.2 * err1
+    # the ReLU'd second output (bs_gemm_desc.out2_relu: what the next residual unit's first convolution reads): relu of the fp32 result in the
+    # same row format -- equal to relu of the main output's value up to the lo8 plane's resolution, the main output unchanged by its presence
+    out_b, outr = torch.zeros_like(out), torch.zeros_like(out)
+    L.gemm(x8, W8, out_b, M=B * H * Wd, N=Co, K=9 * C, lda=2 * C, conv=g, f8_seg=2 * C, f8_scales=sc, res=r8, ldr=2 * Co, res_f8=True,
+           ldo=2 * Co, out_split_off=Co, out_f8=(L.F8_ACT_HI_EXP, L.F8_ACT_LO_EXP), tile=tile, out_relu=outr)
+    assert torch.equal(out_b, out)
+    hr, vr = from_f8_pairs(outr, Co)
+    assert torch.equal(hr, hi.clamp(min=0)) and (vr >= 0).all()
+    assert (vr.double() - val.double().clamp(min=0)).abs().max().item() < 2.0 ** -14
+    planes = outr[..., Co:].contiguous().view(torch.uint8).view(B, H, Wd, 2 * Co)
+    hi8r = planes[..., :Co].contiguous().view(torch.float8_e4m3fn).float() * 2.0 ** -L.F8_ACT_HI_EXP
+    assert (hi8r - hr).abs().max().item() <= 0.07 * hr.abs().max().item() + 1e-2
 
 
 def test_split_precision_conv(L):
