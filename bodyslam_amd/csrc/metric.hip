@@ -4,8 +4,6 @@
 // the expectation in registers.
 //   HF modeling_zoedepth.py:376-491 (log-binomial), :665-746 (attractor, unnormed), :885-962 (router),
 //   :965-1103 (multi-head forward)
-#include <type_traits>
-
 #include "common.h"
 
 namespace bs {
@@ -148,115 +146,11 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
     }
     __syncthreads();
     const int oy = ty0 + (threadIdx.x >> 4), ox = tx0 + (threadIdx.x & 15);
-    const int64_t gid = ((int64_t)b * H + oy) * W + ox;      // (pixels outside the image: not used before their threads return)
+    if (oy >= H || ox >= W) return;
+    const int64_t gid = ((int64_t)b * H + oy) * W + ox;
     const Lerp2 l = lerp_ac(oy, ox, He, We, sy, sx);
     const int c00 = (l.y0 - sy0) * nc + (l.x0 - sx0), c01 = (l.y0 - sy0) * nc + (l.x1 - sx0);
     const int c10 = (l.y1 - sy0) * nc + (l.x0 - sx0), c11 = (l.y1 - sy0) * nc + (l.x1 - sx0);
-    float pt[4];
-    if constexpr (std::is_same<T, f16>::value && LSPLIT != 1) {
-        // ---- Round 5: the hidden layer on the matrix cores.  W0_last . last is 40 x 32 multiply-adds per pixel -- 640 packed FMAs per thread, over a
-        // third of this VALU-bound kernel -- and a [64 pixels x 32] x [32 x 48] product per wave.  Lane (r, q) = (lane & 15, lane >> 4) takes
-        // pixel x = r of each of the wave's four tile rows t (one 16-pixel row = one MFMA row fragment) and, after the product, the hidden
-        // units 16 j + 4 q .. + 3 of those pixels (operands swapped as in igemm_kernel.h: D[unit][pixel]).  Precision: both operands are split --
-        // last = hi16 + lo8 2^-11 (its stored format), W0 = round16(W0) + round16((W0 - hi) 2^11) 2^-11 -- and the two cross terms run in a second
-        // accumulator scaled by 2^11; only lo x lo (2^-22 relative) is dropped, the level of the fp32 FMA chain this replaces.  The rest of
-        // the layer (Eh interpolation, GELU, the 4 x 40 output product) runs on each lane's 12 units; the partial outputs are summed over q
-        // (two xor-shuffles), after which lane (r, q) holds the complete pt of the wave's pixel (row q, x = r) = ITS OWN pixel in the
-        // thread-per-pixel layout of the softmax below: no transpose.
-        typedef typename T16<T>::v8 v8;
-        constexpr int NTL = (LB_HID + 15) / 16;
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
-        const float* __restrict__ gw0 = w0_last + g * LB_HID * LB_IN;
-        const float* __restrict__ gw2 = w2 + g * 4 * LB_HID;
-        v8 wh[NTL], wl[NTL];
-#pragma unroll
-        for (int j = 0; j < NTL; ++j) {
-            const int n = 16 * j + r;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float wv_ = n < LB_HID ? gw0[n * LB_IN + 8 * q + e] : 0.0f;
-                wh[j][e] = (T)wv_;
-                wl[j][e] = (T)((wv_ - (float)wh[j][e]) * 2048.0f);
-            }
-        }
-#pragma unroll
-        for (int o = 0; o < 4; ++o) pt[o] = 0.0f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float ptl[4] = {0.f, 0.f, 0.f, 0.f};
-            int py = ty0 + 4 * wv + t, px = tx0 + r;
-            py = py < H ? py : H - 1;
-            px = px < W ? px : W - 1;
-            const int64_t pg = ((int64_t)b * H + py) * W + px;
-            const T* lp = last + pg * LB_IN * (LSPLIT ? 2 : 1);
-            const v8 ah = *reinterpret_cast<const v8*>(lp + 8 * q);
-            v8 al;
-            if (LSPLIT == 2) {      // the lo8 plane: e4m3((x - hi16) 2^11), exact in 16 bits
-                const char* l8 = reinterpret_cast<const char*>(lp + LB_IN + LB_IN / 2) + 8 * q;
-                float l0[4], l1[4];
-                f8_unpack4(*reinterpret_cast<const int*>(l8), l0);
-                f8_unpack4(*reinterpret_cast<const int*>(l8 + 4), l1);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    al[e] = (T)l0[e];
-                    al[4 + e] = (T)l1[e];
-                }
-            }
-            // relative depth relu(conv3(last)) of a single-head model: this lane's 8 channels, summed over q below
-            float rd = 0.0f;
-            const float* __restrict__ grel = rel_w ? rel_w + g * (LB_HID + LB_IN + 1) : nullptr;
-            if (grel) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float xv = (float)ah[e];
-                    if (LSPLIT == 2) xv = fmaf((float)al[e], 1.0f / 2048.0f, xv);
-                    rd = fmaf(grel[LB_HID + 8 * q + e], xv, rd);
-                }
-                rd += __shfl_xor(rd, 16, 64);
-                rd += __shfl_xor(rd, 32, 64);
-                rd = fmaxf(rd + grel[LB_HID + LB_IN], 0.0f);
-            }
-            const Lerp2 lt = lerp_ac(py, px, He, We, sy, sx);
-            const int t00 = (lt.y0 - sy0) * nc + (lt.x0 - sx0), t01 = (lt.y0 - sy0) * nc + (lt.x1 - sx0);
-            const int t10 = (lt.y1 - sy0) * nc + (lt.x0 - sx0), t11 = (lt.y1 - sy0) * nc + (lt.x1 - sx0);
-#pragma unroll
-            for (int j = 0; j < NTL; ++j) {
-                f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-                c0 = T16<T>::mfma16(wh[j], ah, c0);
-                c1 = T16<T>::mfma16(wl[j], ah, c1);
-                if (LSPLIT == 2) c1 = T16<T>::mfma16(wh[j], al, c1);
-                const int h0 = 16 * j + 4 * q;
-                if (h0 < LB_HID) {          // (LB_HID is a multiple of 4: a lane's four units are all real or all padding)
-                    const f32x4 e00 = *reinterpret_cast<const f32x4*>(s_eh + t00 * LB_HID + h0), e01 = *reinterpret_cast<const f32x4*>(s_eh + t01 * LB_HID + h0);
-                    const f32x4 e10 = *reinterpret_cast<const f32x4*>(s_eh + t10 * LB_HID + h0), e11 = *reinterpret_cast<const f32x4*>(s_eh + t11 * LB_HID + h0);
-                    float a4[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {      // the bilinear operation order of torch, then the product's two parts
-                        const float eh = lt.hy * (lt.hx * e00[e] + lt.lx * e01[e]) + lt.ly * (lt.hx * e10[e] + lt.lx * e11[e]);
-                        a4[e] = eh + fmaf(c1[e], 1.0f / 2048.0f, c0[e]);
-                        if (grel) a4[e] = fmaf(grel[h0 + e], rd, a4[e]);
-                    }
-                    const f32x2_ g01 = gelu_erf_as2(f32x2_{a4[0], a4[1]}), g23 = gelu_erf_as2(f32x2_{a4[2], a4[3]});
-                    const float ga[4] = {g01[0], g01[1], g23[0], g23[1]};
-#pragma unroll
-                    for (int o = 0; o < 4; ++o) {
-                        const f32x4 w2v = *reinterpret_cast<const f32x4*>(gw2 + o * LB_HID + h0);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) ptl[o] = fmaf(w2v[e], ga[e], ptl[o]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                float v = ptl[o];
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
-                pt[o] = (q == t) ? b2[g * 4 + o] + v : pt[o];      // row t of the wave is lane group q = t's own pixel row
-            }
-        }
-        if (oy >= H || ox >= W) return;
-    } else {
-    if (oy >= H || ox >= W) return;
 
     // the 32 `last` features of this pixel
     float xin[LB_IN];
@@ -291,7 +185,7 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
     // through 1280 LDS broadcast reads per pixel.
     const float* __restrict__ gw0 = w0_last + g * LB_HID * LB_IN;
     const float* __restrict__ gw2 = w2 + g * 4 * LB_HID;
-    pt[0] = b2[g * 4 + 0]; pt[1] = b2[g * 4 + 1]; pt[2] = b2[g * 4 + 2]; pt[3] = b2[g * 4 + 3];
+    float pt[4] = {b2[g * 4 + 0], b2[g * 4 + 1], b2[g * 4 + 2], b2[g * 4 + 3]};
     // single-head models feed the relative depth relu(conv3(last)) as a 33rd input (HF modeling_zoedepth.py:1186-1191, :367-371):
     // rel_w[g] = [W0 column of that input (LB_HID) | conv3 weight (32) | conv3 bias]
     const float* __restrict__ grel = rel_w ? rel_w + g * (LB_HID + LB_IN + 1) : nullptr;
@@ -331,7 +225,6 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int o = 0; o < 4; ++o) pt[o] = fmaf(gw2[o * LB_HID + h + u], ga[u], pt[o]);
-    }
     }
 #pragma unroll
     for (int o = 0; o < 4; ++o) pt[o] = softplus20(pt[o]);

@@ -902,9 +902,19 @@ def test_attractor_step(L):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_logbinom_depth(L, dtype):
-    B, He, We, H, W = 2, 6, 8, 12, 16
+@pytest.mark.parametrize("lfmt", [0, 2])
+@pytest.mark.parametrize("geom", [(6, 8), (24, 40)])
+def test_logbinom_depth(L, dtype, lfmt, geom):
+    """lfmt 2: `last` in the (hi16 | hi8 | lo8) row format the relative head writes (its value = hi16 + lo8 2^-11); the second geometry has
+    several 16 x 16 output tiles per image (windows that do not start at the map's origin)"""
+    B, He, We = 2, geom[0], geom[1]
+    H, W = 2 * He, 2 * We
     last = rnd(B, H, W, 32, seed=1, dtype=dtype)
+    last_arg, flag = last, 0
+    if lfmt == 2:
+        last32 = rnd(B, H, W, 32, seed=1)
+        last_arg, flag = to_f8_pairs(last32, dtype), 32
+        last = from_f8_pairs(last_arg, 32)[1]
     Eh = rnd(B, He, We, 80, seed=2)
     bins = F.softplus(rnd(B, He, We, 128, seed=3, scale=2.0))
     w0 = rnd(2, 40, 32, seed=4, scale=0.3)
@@ -912,7 +922,9 @@ def test_logbinom_depth(L, dtype):
     b2 = rnd(2, 4, seed=6)
     route = torch.tensor([0, 1], dtype=torch.int32, device=dev())
     depth = torch.empty(B, H, W, device=dev())
-    L.logbinom_depth(last, Eh, bins, w0, w2, b2, route, depth, B, H, W, He, We, 0.0212, 50.0)
+    from bodyslam_amd._lib import load_library, check, p as ptr, dt as dtc, stream_ptr
+    check(load_library().bs_logbinom_depth_ex(ptr(last_arg), ptr(Eh), ptr(bins), ptr(w0), ptr(w2), ptr(b2), None, 40, ptr(route), ptr(depth), B, H, W,
+                                              He, We, 0.0212, 50.0, dtc(last_arg) | flag, stream_ptr()), "bs_logbinom_depth_ex")
     up = lambda t: F.interpolate(t.permute(0, 3, 1, 2), (H, W), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
     Ehu, bu = up(Eh), up(bins)
     for b in range(B):
@@ -932,7 +944,7 @@ def test_logbinom_depth(L, dtype):
         px = torch.softmax(y / t[..., None], dim=-1)
         ref = (px * bu[b, :, :, g * 64:(g + 1) * 64]).sum(-1)
         err = (depth[b] - ref).abs().max().item()
-        report(f"logbinom {dtype} b{b}: max|err|={err:.3e}")
+        report(f"logbinom {dtype} lfmt{lfmt} b{b}: max|err|={err:.3e}")
         assert err < 2e-4
 
 
