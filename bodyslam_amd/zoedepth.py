@@ -1043,7 +1043,9 @@ class _ZoePlan:
 
         # ---- Z4: reassemble (readout project, 1x1 projection, resize) + neck 3x3 convs
         feats, fshape, feats_relu = [], [], []
-        relu_out = bool(acc and nf8 and os.environ.get("BS_RELU_OUT", "1") != "0")
+        # (bs_gemm_desc.out2_relu, see the residual units below: measured a wash -- the seven bs_relu_split launches cost 1.55 ms per step, the second
+        # output adds 1.1-1.8 ms to the producing convolutions' epilogues, profiles/r05_plan_call_times.txt -- and left off; BS_RELU_OUT=1 turns it on)
+        relu_out = bool(acc and nf8 and os.environ.get("BS_RELU_OUT", "0") == "1")
         cb = e32(NB, Hd)
         r16 = e16(NB * T0, PE(Hd))
         for i, ch in enumerate(c.neck_hidden):
@@ -1081,7 +1083,7 @@ class _ZoePlan:
             P.mark(f"reassemble{i}", src, ("nhwc", NB, fh, fw, ch, mfmt(ch)))
             f16_ = e16(NB, fh, fw, PE(c.fusion))
             # Round 5: the fusion stage's residual units read x (the skip) AND relu(x) (their first convolution's input): the producing
-            # convolution's epilogue writes both (bs_gemm_desc.out2_relu) instead of a bs_relu_split launch re-reading x.  BS_RELU_OUT=0: the launch.
+            # convolution's epilogue can write both (bs_gemm_desc.out2_relu) instead of a bs_relu_split launch re-reading x (off by default, see relu_out).
             fr_ = e16(NB, fh, fw, PE(c.fusion)) if relu_out else None
             nconv(f"nc{i}", src, f"nc{i}.w", f16_, fh, fw, ch, c.fusion, out_relu=fr_)
             feats_relu.append(fr_)
