@@ -781,7 +781,7 @@ class _Pool:
     """Plan-time buffer reuse.  The launch sequence of a plan is fixed, so the lifetime of every intermediate is known while the
     plan is being built: ``free(t)`` -- placed right after the call that reads ``t`` last -- returns its block, and a later
     ``alloc`` of at most that size takes it over (best fit).  Kernels of the main lane run in program order, so a block handed
-    on at build position p is only ever overwritten by work issued after p.  The side lane never uses pooled blocks
+    on at build position p is only ever overwritten by work issued after p.  A side lane (Plan.lane = 1; unused since round 5) must not use pooled blocks
     (``hold``): it runs beside main-lane kernels that were added later."""
 
     def __init__(self, dev):
@@ -836,7 +836,7 @@ class _ZoePlan:
         P = L.Plan(dev)
         self.plan = P
         # intermediates of the neck / heads come from a pool and are handed on after their last reader (free); the backbone's
-        # buffers (whose padding rows must stay zero) and everything the side lane touches are plain allocations
+        # buffers (whose padding rows must stay zero) are plain allocations
         pool = _Pool(dev)
         self.pool = pool
         e16 = lambda *s: pool.alloc(s, dt_)
@@ -1093,17 +1093,14 @@ class _ZoePlan:
             fshape.append((fh, fw))
         free(r16, cb)
         bott, (bh_, bw_) = feats[3], fshape[3]
-        # The router and the seed regressors depend only on the bottleneck map: they are issued on the plan's side stream and run
-        # beside the fusion stage / relative head (small, latency-bound kernels that would otherwise serialise behind them).
-        P.signal(0)
-        P.lane = 1
-        P.wait(0)
-        pool.hold = True
+        # The router and the seed regressors depend only on the bottleneck map.  Rounds 2-4 issued them on a side stream beside the fusion stage;
+        # measured in round 5 (bench, alternating runs: 413.0 / 411.9 frames/s with the side lane, 413.1 / 406.0 without) that lane hides nothing
+        # that can be seen -- the launches fill the chip -- and it is gone: one lane, and these intermediates are pooled like all others.
         # ---- Z7: metric-bins head
         Mb = NB * bh_ * bw_
         xb = e16(Mb, c.bottleneck * m2)                                   # (hi | lo) pairs in accurate mode
         nplain("mh.conv2", bott, "mh.conv2.w", xb, Mb, c.bottleneck, c.bottleneck, bias=w["mh.conv2.b"], out8=False)
-        self.logits = e32(NB, 4)
+        self.logits = torch.empty(NB, 4, device=dev, dtype=torch.float32)      # (a plan output: not pooled)
         self.route = torch.zeros(NB, dtype=torch.int32, device=dev)       # single-head models: every image stays on slot 0
         if not c.single_head:
             # router: 4-layer post-norm transformer over (1 + bh*bw) tokens, classifier on token 0
@@ -1154,9 +1151,6 @@ class _ZoePlan:
         emb_prev = e16(Mb, E * m2)
         P.gemm("seedproj.c2", shp, w["seedproj.c2.w"], emb_prev, M=Mb, N=E, K=PM, lda=PM, bias=w["seedproj.c2.b"],
                ldo=E * m2, out_split_off=E if acc else 0)
-        P.signal(1)
-        P.lane = 0
-        pool.hold = False
         # ---- Z5: fusion stage (pre-activation residual units, x2 bilinear, 1x1 projection)
         Fc = c.fusion
 
@@ -1191,7 +1185,7 @@ class _ZoePlan:
             feat = feats[3 - li]
             fh, fw = fshape[3 - li]
             if fused is None:
-                cur, cur_relu = feat, feats_relu[3 - li]                    # (the bottleneck map: the side lane reads it until wait(1))
+                cur, cur_relu = feat, feats_relu[3 - li]                    # (the bottleneck map)
                 own = False
             else:
                 cur, cur_relu = res_unit(f"fu{li}.r1", feat, fh, fw, other=fused, xin_relu=feats_relu[3 - li], want_relu=True)     # fused + residual_layer1(feat)
@@ -1262,9 +1256,7 @@ class _ZoePlan:
             P.add("rh.tapsum", "bs_upconv_tapsum", y9, w["rh.conv2.b"], last, NB, h3, w3, c.rel_features, 2 * h3, 2 * w3, RZ, 1, L.dt(last))
             free(y9)
         P.mark("rel_features", last, ("nhwc", NB, 2 * h3, 2 * w3, c.rel_features, (2 if nf8 else 1) if acc else 0))
-        # ---- Z7 (continued): projector / attractor levels on the fusion outputs, after the side lane's router + seeds
-        # (putting this chain on the side lane as well, beside the relative head, measured neutral)
-        P.wait(1)
+        # ---- Z7 (continued): projector / attractor levels on the fusion outputs
         ph_, pw_ = bh_, bw_
         for i in range(4):
             feat, fh, fw = fused_list[i]
