@@ -818,6 +818,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                 const bool relu = p.act == BS_ACT_RELU;
                 const int mrow = m0 + wm * TM + frow;
                 const int ea = p.out_f8 & 0xff, el = (p.out_f8 >> 8) & 0xff;
+                // (tile-uniform) no lo8 plane past out_lo8_rows: every consumer of this map drops the activation-rounding correction
+                const bool lo_plane = !(p.out_lo8_rows > 0 && m0 >= p.out_lo8_rows);
                 const float lsc = __builtin_ldexpf(1.0f, -BS_F8_ACT_LO_EXP);
                 auto body = [&](auto nres_tag) {
                     constexpr int NRES = decltype(nres_tag)::value;
@@ -867,7 +869,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                             }
                             if (it + RDEPTH < NP) issue(it + RDEPTH, it % RDEPTH);
                         }
-                        if (m < p.M) store8_f8<T>(p.out, (int64_t)m * p.ldo, n_wave + jp * 32 + fq * 8, p.split_off, y8, ea, el);
+                        if (m < p.M) store8_f8<T>(p.out, (int64_t)m * p.ldo, n_wave + jp * 32 + fq * 8, p.split_off, y8, ea, el, lo_plane);
                         if (p.out2_relu) {      // (wave-uniform) the ReLU'd copy the next residual unit's first convolution reads
 #pragma unroll
                             for (int e = 0; e < 8; ++e) y8[e] = fmaxf(y8[e], 0.0f);

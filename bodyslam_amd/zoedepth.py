@@ -1021,6 +1021,11 @@ class _ZoePlan:
                 P.gemm(name, A, w[wkey], out, M=M, N=N, K=K * np3, lda=kw.pop("lda", K * m2), seg1=K if acc else 0,
                        shuffle=shuffle, precision_passes=np3, **ok, **kw)
 
+        def lo8_rows(*consumer_wkeys):
+            """out_lo8_rows of a producer whose output is read only by the named products: 256 (the first tile alone writes the lo8 plane) when
+            every one of them runs the weight-rounding correction only -- nobody reads that plane then, the epilogue need not form it"""
+            return 256 if (acc and nf8 and all(k_ in f8s and eng.neck_site_wonly(k_) for k_ in consumer_wkeys)) else 0
+
         def nconv(name, A, wkey, out, hh, ww, Ci, Co, stride=1, **kw):
             use8 = acc and wkey in f8s
             g_ = L.conv_geom(hh, ww, Ci if use8 else Ci * m2, 3, 3, stride, 1)
@@ -1165,7 +1170,7 @@ class _ZoePlan:
                 if xr is None:
                     xr = e16(NB, hh, ww, PE(Fc))
                     P.add(name + ".relu", "bs_relu_split", xin, xr, NB * hh * ww, Fc, L.dt(xr) | (32 if nf8 else 0))
-                nconv(name + ".c1", xr, name + ".c1.w", t, hh, ww, Fc, Fc, bias=w[name + ".c1.b"], act=L.ACT_RELU)
+                nconv(name + ".c1", xr, name + ".c1.w", t, hh, ww, Fc, Fc, bias=w[name + ".c1.b"], act=L.ACT_RELU, out_lo8_rows=lo8_rows(name + ".c2.w"))
                 free(xr)
             else:
                 nconv(name + ".c1", xin, name + ".c1.w", t, hh, ww, Fc, Fc, relu_a=True, bias=w[name + ".c1.b"], act=L.ACT_RELU)
@@ -1216,13 +1221,13 @@ class _ZoePlan:
         f3, h3, w3 = fused_list[3]
         if eng.add_projection:
             rp = e16(NB, h3, w3, PE(Fc))
-            nconv("rh.projection", f3, "rh.projection.w", rp, h3, w3, Fc, Fc, bias=w["rh.projection.b"], act=L.ACT_RELU)
+            nconv("rh.projection", f3, "rh.projection.w", rp, h3, w3, Fc, Fc, bias=w["rh.projection.b"], act=L.ACT_RELU, out_lo8_rows=lo8_rows("rh.conv1.w"))
         else:
             rp = f3
         if eng.add_projection and pj_lowres:
             free(f3)
         r1 = e16(NB, h3, w3, (Fc // 2) * m2)
-        nconv("rh.conv1", rp, "rh.conv1.w", r1, h3, w3, Fc, Fc // 2, bias=w["rh.conv1.b"])
+        nconv("rh.conv1", rp, "rh.conv1.w", r1, h3, w3, Fc, Fc // 2, bias=w["rh.conv1.b"], out_lo8_rows=lo8_rows("rh.conv2.w"))
         if eng.add_projection or pj_lowres:
             free(rp)
         # HF: interpolate x2 (align_corners), conv2 3x3 128 -> 32, ReLU (modeling_zoedepth.py:358-362).  Both are linear and the resize acts
