@@ -6,7 +6,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the full loop over one batch of B consecutive frames per rank (default B = 64, 4 steps = 256 frames):
+A step = one pass of the full loop over one batch of B consecutive frames per rank (default B = 128, 2 steps = 256 frames):
   MDEM  B frames -> 2B network forwards (flip-aug) -> B depth maps (fp32 metres + uint16)
   MPEM  the B frame pairs (i-1, i) of the batch (one halo frame) -> B relative poses
   RCCL  all-gather of the per-rank [B,16] relatives (N > 1), fp64 pose chain over the gathered block
@@ -107,9 +107,11 @@ def weak_chunk(k: int, B: int) -> slice:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU (4 steps x 64 = the 256-frame config; 128 network forwards per step)")
+    ap.add_argument("--batch", type=int, default=128,
+                    help="frames per step per GPU (2 steps x 128 = the 256-frame config; 256 network forwards per step).  128 since round 5: the 64-frame "
+                         "step's GEMM grids are 6.02 rounds of the 256 CUs, the 128-frame step's 12.02 (+1.6 %% frames/s, 76 GB per plan)")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
@@ -388,7 +390,7 @@ def main():
         from bodyslam_amd.tsdf import TSDF
         # whole batches only (a ragged last batch runs through the full-size plan and would be timed as B frames: --steps 2 gave 193 frames =
         # 3 batches + 1 frame and read 250 frames/s where 256 frames read 318)
-        nloop = max(min(int(frames.shape[0]), 4 * B) // B, 1) * B
+        nloop = max(min(int(frames.shape[0]), 256) // B, 1) * B          # 256 frames (the configs' sequence length) in whole batches
         nloop = min(nloop, int(frames.shape[0]))
         pipe.run_slam_loop(frames[:min(B + 2, nloop)], vo=True, tsdf=TSDF(device=local_rank))       # plans, odometry buffers (not timed)
         torch.cuda.empty_cache()

@@ -39,30 +39,30 @@ def weights():
     return cfg, random_zoedepth_weights(cfg, seed=0), random_cyclepose_weights(seed=0)
 
 
-@pytest.mark.parametrize("dtype,precision", [(torch.float16, "accurate"), (torch.float16, "fast"),
-                                             (torch.bfloat16, "accurate"), (torch.bfloat16, "fast")])
-def test_bench_batch_equals_single_frame_plan(weights, dtype, precision):
-    """bench.py's plan (B = 64, 640x480, ZoeD_NK) gives, for sampled frames, exactly the bits of the B = 1 plan."""
+@pytest.mark.parametrize("dtype,precision,B", [(torch.float16, "accurate", 128), (torch.float16, "accurate", 64), (torch.float16, "fast", 64),
+                                               (torch.bfloat16, "accurate", 64), (torch.bfloat16, "fast", 64)])
+def test_bench_batch_equals_single_frame_plan(weights, dtype, precision, B):
+    """bench.py's plan (B = 128 since round 5, B = 64 before; 640x480, ZoeD_NK) gives, for sampled frames, exactly the bits of the B = 1 plan."""
     from bodyslam_amd.synthetic import make_sequence
     from bodyslam_amd.zoedepth import ZoeDepthEngine
     cfg, wz, _ = weights
     eng = ZoeDepthEngine(wz, cfg, dtype=dtype, precision=precision)
-    frames = torch.from_numpy(make_sequence(64, 480, 640, seed=0)).cuda()
+    frames = torch.from_numpy(make_sequence(B, 480, 640, seed=0)).cuda()
     dm, du = eng.infer(frames)
     dm, du = dm.clone(), du.clone()
-    plan = eng.plan_for(64, 480, 640, True)
+    plan = eng.plan_for(B, 480, 640, True)
     tiles = sorted({gi["tile"] for gi in plan.plan.gemm_info.values()})
     assert 9 in tiles, tiles                                  # the 256x256x64 tile is what the bench's dominant kernel runs
     route64 = plan.route.clone()
     assert torch.isfinite(dm).all() and (dm > 0).all()
-    sample = (0, 17, 40, 63)
+    sample = (0, 17, 40, B - 1)
     for i in sample:
         d1, u1 = eng.infer(frames[i:i + 1])
-        assert torch.equal(d1[0], dm[i]), f"frame {i}: B=64 plan differs from the B=1 plan (max {(d1[0] - dm[i]).abs().max().item():.3e})"
+        assert torch.equal(d1[0], dm[i]), f"frame {i}: B={B} plan differs from the B=1 plan (max {(d1[0] - dm[i]).abs().max().item():.3e})"
         assert torch.equal(u1[0], du[i])
         r1 = eng.plan_for(1, 480, 640, True).route
-        assert torch.equal(r1, route64[[i, 64 + i]])          # per-image routing: frame i and its flipped copy
-    report(f"B=64 plan == B=1 plan on frames {sample} [{str(dtype)[6:]} {precision}], tiles used {tiles}")
+        assert torch.equal(r1, route64[[i, B + i]])           # per-image routing: frame i and its flipped copy
+    report(f"B={B} plan == B=1 plan on frames {sample} [{str(dtype)[6:]} {precision}], tiles used {tiles}")
     del eng, plan
     _free()
 
