@@ -81,10 +81,10 @@ def main(tag):
                                    eff_clock_ghz=round(cyc / max(ga[k][2], 1.0), 3), total_ms=round(ga[k][2] / 1e6, 3))
             busy["modes"][mode] = dict(sorted(rows.items(), key=lambda kv: -kv[1]["total_ms"])[:16])
     traffic["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on `python3 bench.py --single-mode --precision MODE --steps 1 "
-                       "--warmup 0 --no-cpu-baseline --no-kernel-timing --no-pmc-traffic` (batch 64, f16); values are KB per launch, mean over a kernel's "
+                       "--warmup 0 --no-cpu-baseline --no-kernel-timing --no-pmc-traffic` (default batch, f16); values are KB per launch, mean over a kernel's "
                        "launches; hbm_bytes_per_launch_corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE tallies 64 of every 128 streamed bytes, "
                        "MI355X_MICROARCH.md 'HBM'; it counts L2 misses, Infinity-Cache hits included)")
-    traffic["batch"] = 64
+    traffic["batch"] = 128
     busy["note"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE on the same command. mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / "
                     "(GRBM_GUI_ACTIVE/8 x 1024 SIMDs); eff_clock_ghz = (GRBM_GUI_ACTIVE/8) / summed kernel time")
     json.dump(traffic, open(os.path.join(out, f"{tag}_pmc_hbm_traffic.json"), "w"), indent=1)

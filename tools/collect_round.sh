@@ -15,5 +15,13 @@ python3 bench.py --height 1024 --width 1280 --batch 16 --no-pmc-traffic --no-sla
 python3 tools/probes/plan_call_times.py > $OUT/${TAG}_plan_call_times.txt 2>/dev/null
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 2 --warmup 1 --no-pmc-traffic 2> $OUT/torchrun.err | grep "^{" > $OUT/${TAG}_bench_torchrun_n1.json   # (RCCL prints a version banner on stdout)
 python3 tools/bench_kernels.py --nb 128 2>/dev/null > $OUT/${TAG}_bench_kernels.txt
+# round 5: the driver's command line, the accurate mode on the adversarial weight sets, the per-site neck study, the fused upsample + conv2, eight seeds
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_like_n1.json 2> $OUT/driver_like.err
+python3 bench.py --weights outlier --single-mode --no-pmc-traffic --no-slam-loop > $OUT/${TAG}_bench_outlier_weights.json 2> $OUT/outlier.err
+python3 tools/probes/neck_site_study.py 0 5 > $OUT/${TAG}_neck_site_study.txt 2>/dev/null
+python3 tools/probes/upconv_fused_time.py > $OUT/${TAG}_upconv_fused.txt 2>/dev/null
+ABLATE=1 python3 tools/probes/upconv_fused_time.py >> $OUT/${TAG}_upconv_fused.txt 2>/dev/null
+python3 tools/probes/attn_ablate.py > $OUT/${TAG}_attention_ablations.txt 2>/dev/null
+python3 tools/probes/accurate_seeds.py 1 2 3 4 5 6 7 8 2>/dev/null | cut -c1-400 > $OUT/${TAG}_accurate_seeds.txt
 ls -la $OUT
 tail -c 600 $OUT/${TAG}_bench_n1.json
