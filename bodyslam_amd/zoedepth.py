@@ -682,6 +682,13 @@ class ZoeDepthEngine:
         w00, w01 = two("clb", "0.weight")                          # [HID, R + X + E] = [last R | (rel depth) | emb E]
         w["clb.emb.w"] = self._wn(torch.cat([w00[:, R + X:], w01[:, R + X:]], 0))                               # [2*HID, E]
         w["clb.emb.b"] = self._f(torch.cat(two("clb", "0.bias")))
+        # Round 5: the embedding half of the log-binomial MLP's first layer reads the LAST projector's output emb = W_c2 e1 + b_c2 (a 1x1 convolution
+        # without activation, HF modeling_zoedepth.py:749-772): two linear maps in a row.  Composed here in fp32 -- (W_clb W_c2) e1 + (W_clb b_c2 +
+        # b_clb) -- the product reads the projector's 64-channel hidden map instead of the 128-channel embedding (half the bytes, half the K).
+        wce = torch.cat([w00[:, R + X:], w01[:, R + X:]], 0)                                                   # [2*HID, E]
+        wc2_3, bc2_3 = sq(mh + "projectors.3.conv2.weight"), g(mh + "projectors.3.conv2.bias")                 # [E, PM], [E]
+        w["clb.e1.w"] = self._wn(wce @ wc2_3)                                                                  # [2*HID, PM]
+        w["clb.e1.b"] = self._f(wce @ bc2_3 + torch.cat(two("clb", "0.bias")))
         w["clb.w0_last"] = self._f(torch.stack([w00[:, :R], w01[:, :R]]))                                      # [2, HID, R]
         w["clb.w2"] = self._f(torch.stack(two("clb", "2.weight")))                                             # [2, 4, HID]
         w["clb.b2"] = self._f(torch.stack(two("clb", "2.bias")))                                               # [2, 4]
@@ -1263,6 +1270,7 @@ class _ZoePlan:
         P.mark("rel_features", last, ("nhwc", NB, 2 * h3, 2 * w3, c.rel_features, (2 if nf8 else 1) if acc else 0))
         # ---- Z7 (continued): projector / attractor levels on the fusion outputs
         ph_, pw_ = bh_, bw_
+        clb_composed = os.environ.get("BS_CLB_COMPOSED", "1") != "0"       # (A / B switch: 0 = the embedding product on the 128-channel embedding)
         for i in range(4):
             feat, fh, fw = fused_list[i]
             Mi = NB * fh * fw
@@ -1277,7 +1285,10 @@ class _ZoePlan:
             emb = e16(Mi, E * m2)
             P.gemm(f"pj{i}.c2", e1, w[f"pj{i}.c2.w"], emb, M=Mi, N=E, K=PM * np3, lda=PM * m2, seg1=PM if acc else 0,
                    ldo=E * m2, out_split_off=E if acc else 0, bias=w[f"pj{i}.c2.b"], precision_passes=np3)
-            free(e1)
+            if i == 3 and clb_composed:
+                e1_last = e1                                       # (read once more by the composed log-binomial embedding product below)
+            else:
+                free(e1)
             na = eng.na_eff[i]                                     # attractors of this level (replicated up to a multiple of 4)
             A = e32(Mi, 2 * na)
             fuse = E == 128 and 2 * na <= 32 and eng.fuse_mlp and tuple(w[f"at{i}.c1.w"].shape) == (256, 128)
@@ -1312,8 +1323,13 @@ class _ZoePlan:
             P.mark(f"bins{i}", bins, ("nhwc_route", NB, fh, fw, 2 * nb))
             bins_prev, emb_prev, ph_, pw_ = bins, emb, fh, fw
         Eh = e32(NB * ph_ * pw_, 2 * HID)
-        P.gemm("clb.emb", emb_prev, w["clb.emb.w"], Eh, M=NB * ph_ * pw_, N=2 * HID, K=E * np3, lda=E * m2, seg1=E if acc else 0, bias=w["clb.emb.b"],
-               precision_passes=np3)
+        if clb_composed:
+            P.gemm("clb.emb", e1_last, w["clb.e1.w"], Eh, M=NB * ph_ * pw_, N=2 * HID, K=PM * np3, lda=PM * m2, seg1=PM if acc else 0, bias=w["clb.e1.b"],
+                   precision_passes=np3)
+            free(e1_last)
+        else:
+            P.gemm("clb.emb", emb_prev, w["clb.emb.w"], Eh, M=NB * ph_ * pw_, N=2 * HID, K=E * np3, lda=E * m2, seg1=E if acc else 0, bias=w["clb.emb.b"],
+                   precision_passes=np3)
         free(emb_prev)
         self.depth_net = torch.empty(NB, nh_, nw_, device=dev, dtype=torch.float32)        # plan outputs are not pooled
         assert (nh_, nw_) == (2 * h3, 2 * w3)
