@@ -260,7 +260,8 @@ __global__ __launch_bounds__(256) void pre_image_kernel(const uint8_t* frames, f
 // ---------------------------------------------------------------------------------------------
 // (hi16 | hi8 | lo8) pixels, 16 channels per thread: every access is 16 bytes wide (two for the hi16 values, one per FP8 plane);
 // the x2 upsampling of the fusion stage / relative head writes 6-13 GB per call at the bench batch
-template <typename T>
+// LO: also write the lo8 plane (false: every consumer of the map drops the activation-rounding correction and never reads it)
+template <typename T, bool LO = true>
 __global__ __launch_bounds__(256) void resize_nhwc_f8_kernel(const T* x, T* out, int B, int Hin, int Win, int C, int Hout, int Wout, float sy,
                                                               float sx, int align) {
     const int c16n = C >> 4;
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256) void resize_nhwc_f8_kernel(const T* x, T* out,
             vv[e + u] = v;
             const T h = T16<T>::from_f32(v);
             if (e + u < 8) o0[e + u] = h; else o1[e + u - 8] = h;
-            rl[e + u] = v - (float)h;
+            if (LO) rl[e + u] = v - (float)h;
         }
     }
     T* op = out + pix * C * 2;
@@ -332,10 +333,10 @@ __global__ __launch_bounds__(256) void resize_nhwc_f8_kernel(const T* x, T* out,
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         ph[g] = f8_pack4(vv[4 * g] * sh, vv[4 * g + 1] * sh, vv[4 * g + 2] * sh, vv[4 * g + 3] * sh);
-        pl[g] = f8_pack4(rl[4 * g] * sl, rl[4 * g + 1] * sl, rl[4 * g + 2] * sl, rl[4 * g + 3] * sl);
+        if (LO) pl[g] = f8_pack4(rl[4 * g] * sl, rl[4 * g + 1] * sl, rl[4 * g + 2] * sl, rl[4 * g + 3] * sl);
     }
     *reinterpret_cast<i32x4*>(planes + c16 * 16) = ph;
-    *reinterpret_cast<i32x4*>(planes + C + c16 * 16) = pl;
+    if (LO) *reinterpret_cast<i32x4*>(planes + C + c16 * 16) = pl;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -817,9 +818,12 @@ static int launch_resize(const void* x, const void* addend, void* out, int B, in
         sx = (float)Win / (float)Wout;
     }
     const dim3 blocks(cdiv(Wout * (C / 8), 256), B * Hout);
-    if (split == 2) {      // (hi16 | hi8 | lo8) pixels (no add variant: the bins head's embeddings stay 16-bit pairs)
+    if (split == 2 || split == 3) {      // (hi16 | hi8 | lo8) pixels (no add variant: the bins head's embeddings stay 16-bit pairs); 3: no lo8 plane out
         const dim3 blocks16(cdiv(Wout * (C / 16), 256), B * Hout);
-        hipLaunchKernelGGL((resize_nhwc_f8_kernel<T>), blocks16, dim3(256), 0, st, (const T*)x, (T*)out, B, Hin, Win, C, Hout, Wout, sy, sx, align);
+        if (split == 3)
+            hipLaunchKernelGGL((resize_nhwc_f8_kernel<T, false>), blocks16, dim3(256), 0, st, (const T*)x, (T*)out, B, Hin, Win, C, Hout, Wout, sy, sx, align);
+        else
+            hipLaunchKernelGGL((resize_nhwc_f8_kernel<T, true>), blocks16, dim3(256), 0, st, (const T*)x, (T*)out, B, Hin, Win, C, Hout, Wout, sy, sx, align);
         BS_CHECK_LAUNCH();
         return BS_OK;
     }
@@ -1036,9 +1040,10 @@ extern "C" int bs_resize_bilinear_nhwc(const void* x, void* out, int32_t B, int3
     BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_resize_bilinear_nhwc: dtype");
     if (B == 0) return BS_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int split = (align_corners & 4) ? 2 : ((align_corners & 2) ? 1 : 0);   // bit 1: (hi | lo) 16-bit pairs; bit 2: (hi16 | hi8 | lo8)
+    // bit 1: (hi | lo) 16-bit pairs; bit 2: (hi16 | hi8 | lo8); bit 3 (with bit 2): the output's lo8 plane is not written (no consumer reads it)
+    const int split = (align_corners & 4) ? ((align_corners & 8) ? 3 : 2) : ((align_corners & 2) ? 1 : 0);
     const int ac = align_corners & 1;
-    BS_REQUIRE(split != 2 || C % 16 == 0, "bs_resize_bilinear_nhwc: the FP8 pair format needs C %% 16 == 0");
+    BS_REQUIRE(split < 2 || C % 16 == 0, "bs_resize_bilinear_nhwc: the FP8 pair format needs C %% 16 == 0");
     return dtype == BS_F16 ? launch_resize<f16>(x, nullptr, out, B, Hin, Win, C, Hout, Wout, ac, st, split)
                            : launch_resize<bf16>(x, nullptr, out, B, Hin, Win, C, Hout, Wout, ac, st, split);
 }

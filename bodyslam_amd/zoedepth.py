@@ -1220,9 +1220,12 @@ class _ZoePlan:
                 nplain(f"pj{li}.c1", lowp, f"pj{li}.c1.w", z, NB * fh * fw, PM, Fc, out8=False)
                 pj_low.append((z, fh, fw))
             fused = e16(NB, 2 * fh, 2 * fw, PE(Fc))
-            P.add(f"fu{li}.up", "bs_resize_bilinear_nhwc", lowp, fused, NB, fh, fw, Fc, 2 * fh, 2 * fw, RZ, L.dt(fused))
+            # (the last fused map is read by the relative head's first convolution only: when that product is weight-only the resize does not
+            # form the lo8 plane -- flag bit 3 -- and the tap's format code says so: 3 = (hi16 | hi8 | -))
+            nolo = bool(li == 3 and pj_lowres and lo8_rows("rh.projection.w" if eng.add_projection else "rh.conv1.w"))
+            P.add(f"fu{li}.up", "bs_resize_bilinear_nhwc", lowp, fused, NB, fh, fw, Fc, 2 * fh, 2 * fw, RZ | (8 if nolo else 0), L.dt(fused))
             free(lowp)
-            P.mark(f"fused{li}", fused, ("nhwc", NB, 2 * fh, 2 * fw, Fc, mfmt(Fc)))
+            P.mark(f"fused{li}", fused, ("nhwc", NB, 2 * fh, 2 * fw, Fc, 3 if nolo else mfmt(Fc)))
             fused_list.append((fused, 2 * fh, 2 * fw))
         # ---- Z6: relative head (conv3 + ReLU -> relative depth is dead code for the NK output and not launched)
         f3, h3, w3 = fused_list[3]

@@ -228,8 +228,9 @@ int bs_preprocess_image(const uint8_t* frames, float* out, int32_t B, int32_t H,
 /* rows[b*rows_per_image + 0, :] = v  (cls token, HF modeling_beit.py:166-167) */
 int bs_fill_rows(float* x, const float* v, int32_t B, int32_t rows_per_image, int32_t cols, void* stream);
 
-/* bilinear resize of an NHWC fp16/bf16 map (align_corners as given) -- F.interpolate calls at HF
- * modeling_zoedepth.py:259,319,360 */
+/* bilinear resize of an NHWC fp16/bf16 map -- F.interpolate calls at HF modeling_zoedepth.py:259,319,360.  `align_corners`: bit 0 the flag itself,
+ * bit 1 the tensors hold (hi | lo) 16-bit pairs, bit 2 (hi16 | hi8 | lo8) rows, bit 3 (with bit 2) the OUTPUT's lo8 plane is not written (for a map
+ * whose every consumer runs the weight-rounding correction only: nobody reads that plane) */
 int bs_resize_bilinear_nhwc(const void* x, void* out, int32_t B, int32_t Hin, int32_t Win, int32_t C,
                             int32_t Hout, int32_t Wout, int32_t align_corners, int32_t dtype, void* stream);
 

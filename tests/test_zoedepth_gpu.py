@@ -43,6 +43,10 @@ def to_nchw(t, meta):
     if kind == "tokens_grouped":     # rows: the NB cls tokens, then the S-1 patch tokens of every image -> [NB, S, hidden], cls first
         nb, S, hd, cp = meta[1], meta[2], meta[3], meta[4]      # cp: first patch row (the cls group is padded to whole GEMM tiles)
         return torch.cat([t[:nb].view(nb, 1, hd), t[cp: cp + nb * (S - 1)].view(nb, S - 1, hd)], 1)
+    if kind == "nhwc" and len(meta) > 5 and meta[5] == 3:
+        # (hi16 | hi8 | -): a map whose lo8 plane was not written (every consumer is weight-only): the value is hi16
+        C = meta[4]
+        return t_raw.cpu().view(meta[1], meta[2], meta[3], 2 * C)[..., :C].float().permute(0, 3, 1, 2)
     if kind == "nhwc" and len(meta) > 5 and meta[5] == 2:
         # accurate mode, FP8 pair format: (hi16 | hi8 | lo8) per pixel; the value is hi16 + lo8 * 2^-LO_EXP
         from bodyslam_amd import _lib as L
