@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void relu_split_kernel(const T* x, T* out, int
             v8 h = *reinterpret_cast<const v8*>(x + r * 2 * C + c);
             const unsigned char* pin = reinterpret_cast<const unsigned char*>(x + r * 2 * C + C);
             unsigned char* pout = reinterpret_cast<unsigned char*>(out + r * 2 * C + C);
-            unsigned long long h8 = *reinterpret_cast<const unsigned long long*>(pin + c), l8 = *reinterpret_cast<const unsigned long long*>(pin + C + c);
+            // (f8 == 2: the lo8 plane is neither read nor written -- every consumer of the output is weight-only)
+            unsigned long long h8 = *reinterpret_cast<const unsigned long long*>(pin + c), l8 = f8 == 2 ? 0ull : *reinterpret_cast<const unsigned long long*>(pin + C + c);
             unsigned long long mask = 0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void relu_split_kernel(const T* x, T* out, int
             }
             *reinterpret_cast<v8*>(out + r * 2 * C + c) = h;
             *reinterpret_cast<unsigned long long*>(pout + c) = h8 & mask;
-            *reinterpret_cast<unsigned long long*>(pout + C + c) = l8 & mask;
+            if (f8 != 2) *reinterpret_cast<unsigned long long*>(pout + C + c) = l8 & mask;
             continue;
         }
         v8 h = *reinterpret_cast<const v8*>(x + r * 2 * C + c), l = *reinterpret_cast<const v8*>(x + r * 2 * C + C + c);
@@ -1123,7 +1124,7 @@ extern "C" int bs_cast_split(const float* x, void* out, int64_t rows, int32_t co
 extern "C" int bs_relu_split(const void* x, void* out, int64_t rows, int32_t cols, int32_t dtype, void* stream) {
     BS_ENTRY("bs_relu_split");
     BS_REQUIRE(x && out && rows >= 0 && cols > 0 && cols % 8 == 0, "bs_relu_split: cols must be a multiple of 8");
-    const int f8 = (dtype & 32) ? 1 : 0;              // bit 5: (hi16 | hi8 | lo8) rows
+    const int f8 = (dtype & 32) ? ((dtype & 64) ? 2 : 1) : 0;     // bit 5: (hi16 | hi8 | lo8) rows; bit 6 (with bit 5): without the lo8 plane
     dtype &= 15;
     BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_relu_split: dtype");
     if (rows == 0) return BS_OK;

@@ -1176,7 +1176,8 @@ class _ZoePlan:
                 xr = xin_relu
                 if xr is None:
                     xr = e16(NB, hh, ww, PE(Fc))
-                    P.add(name + ".relu", "bs_relu_split", xin, xr, NB * hh * ww, Fc, L.dt(xr) | (32 if nf8 else 0))
+                    # (bit 6: no lo8 plane when the first convolution, the only reader, is weight-only)
+                    P.add(name + ".relu", "bs_relu_split", xin, xr, NB * hh * ww, Fc, L.dt(xr) | (32 if nf8 else 0) | (64 if lo8_rows(name + ".c1.w") else 0))
                 nconv(name + ".c1", xr, name + ".c1.w", t, hh, ww, Fc, Fc, bias=w[name + ".c1.b"], act=L.ACT_RELU, out_lo8_rows=lo8_rows(name + ".c2.w"))
                 free(xr)
             else:

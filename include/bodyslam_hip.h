@@ -206,7 +206,8 @@ int bs_copy_f32(const float* src, float* dst, int64_t n, void* stream);
  * tensor (the pre-activation residual units, HF modeling_zoedepth.py:225-241).  bs_resize_bilinear_nhwc takes such tensors when
  * bit 1 of align_corners is set; bs_logbinom_depth takes a (hi | lo) `last` when bit 4 of dtype is set.
  * With `| 32` on the dtype argument (bit 2 of align_corners for the resize) the same calls work on the (hi16 | hi8 | lo8)
- * format of the FP8 correction passes (BS_F8_ACT_*_EXP above). */
+ * format of the FP8 correction passes (BS_F8_ACT_*_EXP above); bs_relu_split with `| 32 | 64` leaves the lo8 plane alone (neither read
+ * nor written: an output whose only reader runs the weight-rounding correction only). */
 int bs_cast_split(const float* x, void* out, int64_t rows, int32_t cols, int32_t out_dtype, void* stream);
 int bs_relu_split(const void* x, void* out, int64_t rows, int32_t cols, int32_t dtype, void* stream);
 

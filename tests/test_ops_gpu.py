@@ -830,6 +830,73 @@ def test_upconv_fused(L, dtype, mode, geom):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("split", [False, True])
+def test_resize_bias_relu(L, dtype, split):
+    """bs_resize_bias_relu_nhwc: relu(bilinear x2 (align_corners) of a low-resolution 1x1-convolution output + bias) -- together with that
+    convolution it must equal the convolution + ReLU applied to the upsampled map (the bins head's projectors, HF modeling_zoedepth.py:749-772
+    on the fusion stage's x2 outputs): a 1x1 convolution commutes with the resize."""
+    B, H, W, Cin, C = 2, 9, 13, 32, 64
+    x = rnd(B, H, W, Cin, seed=1)
+    w = rnd(C, Cin, seed=2, scale=0.3)
+    bias = rnd(C, seed=3)
+    z = (x.double() @ w.double().t()).float()                                   # the convolution at the low resolution, no bias
+    if split:
+        zin = torch.empty(B, H, W, 2 * C, device=dev(), dtype=dtype)
+        L.cast_split(z.view(-1, C), zin, B * H * W, C)
+        zval = zin[..., :C].double() + zin[..., C:].double()
+    else:
+        zin = z.to(dtype).contiguous()
+        zval = zin.double()
+    out = torch.zeros(B, 2 * H, 2 * W, C * (2 if split else 1), device=dev(), dtype=dtype)
+    L.resize_bias_relu_nhwc(zin, bias, out, B, H, W, C, 2 * H, 2 * W, split=split)
+    got = (out[..., :C].double() + out[..., C:].double()) if split else out.double()
+    ref = F.relu(F.interpolate(zval.permute(0, 3, 1, 2), size=(2 * H, 2 * W), mode="bilinear", align_corners=True).permute(0, 2, 3, 1) + bias.double())
+    scale = ref.abs().max().item() + 1.0
+    res = ((2.0 ** -21 if dtype == torch.float16 else 2.0 ** -15) if split else (2.0 ** -11 if dtype == torch.float16 else 2.0 ** -8))
+    err = (got - ref).abs().max().item()
+    report(f"resize_bias_relu {dtype} split {split}: max|err| {err:.2e} (scale {scale:.2f})")
+    assert err < (1.5 * res + 2e-6) * scale and (got >= 0).all()
+    # ... and the order of the two linear steps does not matter: conv + bias + relu on the upsampled INPUT
+    up = F.interpolate(x.double().permute(0, 3, 1, 2), size=(2 * H, 2 * W), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    ref2 = F.relu(up @ w.double().t() + bias.double())
+    assert (got - ref2).abs().max().item() < (1e-5 if (split and dtype == torch.float16) else (2e-3 if dtype == torch.float16 else 2e-2)) * scale      # (the stored z's rounding)
+
+
+def test_relu_split_f8_without_lo8_plane(L):
+    """bs_relu_split with dtype bits 5 | 6: hi16 and hi8 planes as with the lo8 plane, whose bytes are neither read nor written"""
+    dtype = torch.float16
+    rows, C = 300, 64
+    x8 = to_f8_pairs(rnd(rows, C, seed=1), dtype)
+    full = torch.zeros(rows, 2 * C, device=dev(), dtype=dtype)
+    part = torch.full((rows, 2 * C), 7.0, device=dev(), dtype=dtype)
+    from bodyslam_amd._lib import load_library, check, p as ptr, dt as dtc, stream_ptr
+    for out, bits in ((full, 32), (part, 32 | 64)):
+        check(load_library().bs_relu_split(ptr(x8), ptr(out), rows, C, dtc(out) | bits, stream_ptr()), "bs_relu_split")
+    fb, pb = full.view(torch.uint8).view(rows, 4 * C), part.view(torch.uint8).view(rows, 4 * C)
+    assert torch.equal(fb[:, :3 * C], pb[:, :3 * C]) and (full[:, :C].float() >= 0).all()
+    seven = torch.full((1,), 7.0, dtype=dtype).view(torch.uint8).to(dev())
+    assert torch.equal(pb[:, 3 * C:], seven.repeat(C // 2).expand(rows, C))
+
+
+def test_resize_f8_without_lo8_plane(L):
+    """bs_resize_bilinear_nhwc, flag bit 3: the (hi16 | hi8 | -) output of a map whose every consumer is weight-only -- hi16 and hi8 planes as with the
+    plane, the lo8 bytes left untouched"""
+    dtype = torch.float16
+    B, H, W, C = 2, 6, 8, 64
+    x = rnd(B, H, W, C, seed=1)
+    x8 = to_f8_pairs(x, dtype)
+    full = torch.zeros(B, 2 * H, 2 * W, 2 * C, device=dev(), dtype=dtype)
+    part = torch.full((B, 2 * H, 2 * W, 2 * C), 7.0, device=dev(), dtype=dtype)
+    from bodyslam_amd._lib import load_library, check, p as ptr, dt as dtc, stream_ptr
+    for out, flags in ((full, 1 | 4), (part, 1 | 4 | 8)):
+        check(load_library().bs_resize_bilinear_nhwc(ptr(x8), ptr(out), B, H, W, C, 2 * H, 2 * W, flags, dtc(out), stream_ptr()), "bs_resize_bilinear_nhwc")
+    fb, pb = full.view(torch.uint8).view(B, 2 * H, 2 * W, 4 * C), part.view(torch.uint8).view(B, 2 * H, 2 * W, 4 * C)
+    assert torch.equal(fb[..., :3 * C], pb[..., :3 * C])                      # hi16 (2C bytes) and hi8 (C bytes)
+    seven = torch.full((1,), 7.0, dtype=dtype).view(torch.uint8).to(dev())
+    assert torch.equal(pb[..., 3 * C:], seven.repeat(C // 2).expand(B, 2 * H, 2 * W, C))     # the lo8 bytes: not written
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_split_pointwise(L, dtype):
     """(hi | lo) carriers of accurate mode: cast_split, relu_split, split resize and split add_resized keep ~2x the mantissa."""
     B, H, W, C = 2, 12, 16, 64

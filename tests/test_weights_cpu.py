@@ -110,3 +110,14 @@ def test_loaded_names_are_what_hf_builds():
     m = tr.ZoeDepthForDepthEstimation(hf_config(cfg))
     hf_names = {k for k in m.state_dict().keys() if not k.endswith("relative_position_index")}
     assert set(W.upstream_to_hf(W.hf_to_upstream(sd))) == hf_names
+
+
+def test_neck_mode_forms():
+    """which neck / head products run weight-only under the forms of ZoeDepthEngine.neck_mode (the per-site calibration writes "wonly:...")"""
+    from bodyslam_amd.zoedepth import ZoeDepthEngine
+    e = ZoeDepthEngine.__new__(ZoeDepthEngine)
+    for mode, expect in (("full", (False, False, False)), ("w", (True, True, False)), ("ro,ra,nc,fu,pj,mh", (False, True, False)),
+                         ("wonly:fu3.r1.c1.w,rh.conv1.w", (True, False, False)), ("wonly:rh.projection.w", (False, True, False))):
+        e.neck_mode = mode
+        got = (e.neck_site_wonly("fu3.r1.c1.w"), e.neck_site_wonly("rh.projection.w"), e.neck_site_wonly("ro2.w_cls"))
+        assert got == expect, (mode, got)
