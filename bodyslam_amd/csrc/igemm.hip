@@ -51,12 +51,11 @@ static int launch_tile(IgemmParams& p, int dtype, bool conv, int tile, hipStream
     // Tile order.  Wide plain products on the 256 x 256 tile (fc1, the reassemble ConvT's: >= 8 N-tiles) walk column strips of four N-tiles,
     // M fastest: the strip's W tiles stay in the XCD's L2 while the A panels stream through once per strip -- 37-40 % fewer L2 refills at the
     // same launch time (profiles/r04_gemm_experiments.txt (7)).  Not the QKV product: its V^T tiles would bunch up at the end (+45 %).
-    // BS_GEMM_STRIP = w forces a width (0 = row-major) for every non-convolution launch: diagnostics.
+    // BS_GEMM_STRIP = w forces a width (0 = row-major) for every non-convolution launch: the one diagnostic switch of this path (read once;
+    // tools/probes/gemm_strip.sh).  (The thirds-interleaved strip walk for the QKV product, round 4's experiment, is gone: -50 % L2 refills, +5.6 % time.)
     static const int strip_env = getenv("BS_GEMM_STRIP") ? atoi(getenv("BS_GEMM_STRIP")) : -1;
-    static const bool qkv_strips = getenv("BS_GEMM_QKV_STRIP") != nullptr;      // experiment
     const bool qkv = p.out_mode == BS_OUT_QKV;
-    p.strip = conv ? 0 : (strip_env >= 0 ? strip_env : ((BM == 256 && BN == 256 && (!qkv || qkv_strips) && p.ntn >= 8) ? 4 : 0));
-    p.strip_thirds = (qkv && p.strip > 0 && p.ntn % 3 == 0) ? 1 : 0;
+    p.strip = conv ? 0 : (strip_env >= 0 ? strip_env : ((BM == 256 && BN == 256 && !qkv && p.ntn >= 8) ? 4 : 0));
     // correction mode of the instantiation: 1 = FP8 stages / (hi16 | hi8 | lo8) formats, 0 = plain
     const int cm = (p.f8_stages > 0 || p.out_f8 || p.res_f8) ? 1 : 0;
     const bool h = dtype == BS_F16;

@@ -80,7 +80,6 @@ struct IgemmParams {
     const float* bias2;  // optional fp32 [groups, N] added to rows >= bias2_row0, group = (m - bias2_row0) / bias2_group_rows
     int bias2_row0, bias2_group_rows;
     int strip;    // work id -> tile order: 0 = row-major (N fastest over the whole width), w > 0 = strips of w N-tiles
-    int strip_thirds;   // != 0 (with strip > 0, ntn % 3 == 0): position t of the walk is N-tile (t % 3) * ntn / 3 + t / 3
     int ablate;   // diagnostics only (tools/bench_kernels.py): 1 = no DMA after the prologue, 2 = no LDS fragment reads after tile 0, 4 = no epilogue, 8 = no tail split (host side), 128 = the Q / K epilogue without its stores, 256 = no fast Q / K patch-tile path, 512 = no fast V^T patch-tile path, 1024 = no LDS-staged full-line stores (Q / K tiles, fc1's hi16 tiles), 2048 = no lean (hi16 | hi8 | lo8) epilogue (neck),
 };
 
@@ -252,8 +251,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
         const int wl = p.ntn - s * p.strip < p.strip ? p.ntn - s * p.strip : p.strip;
         tm = r / wl;
         tn = s * p.strip + (r - tm * wl);
-        // (QKV: the walk is over N-tiles taken in turn from the Q, K and V thirds, so that every strip holds one or two of the slow V^T tiles)
-        if (p.strip_thirds) tn = (tn % 3) * (p.ntn / 3) + tn / 3;
     } else {
         tm = wg / p.ntn;
         tn = wg - tm * p.ntn;
