@@ -799,7 +799,28 @@ static int launch_attn_tab(const void* q, const void* k, const void* vt, const v
     constexpr int QW = 5;
     const int nqt = hp + 1, nqb = cdiv(nqt, QW), ntab = (2 * hp - 1) * 63 + 3;
     const int tab_bytes = (((ntab + 255) & ~255) + 64) * 4;
-    if (ql) {     // split-precision operands (bs_attention_table_corr): 64 KiB ring, two blocks per CU, the 256-register budget
+    if (ql) {     // split-precision operands (bs_attention_table_corr): 64 KiB ring, the 256-register budget = two waves per SIMD, 8 per CU
+        // Round 5: 7- or 8-wave blocks.  A 5-wave block leaves 3 of the CU's 8 wave slots empty (a second block of 5 does not fit them): blocks of
+        // ceil(nqt / ceil(nqt / 8)) waves fill them (25 query tiles: 4 blocks of 7) and stage a tile once per 7-8 query tiles.  Same bits.
+        {
+            const int nb8 = cdiv(nqt, 8), qw8 = cdiv(nqt, nb8);
+#define BS_ATTN_CORR_BIG(QWB)                                                                                                                \
+    do {                                                                                                                                     \
+        auto kb = attention_tab2_kernel<T, QWB, 2, true>;                                                                                    \
+        static bool attrb = false;                                                                                                           \
+        if (!attrb) {                                                                                                                        \
+            BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));     \
+            attrb = true;                                                                                                                    \
+        }                                                                                                                                    \
+        hipLaunchKernelGGL(kb, dim3(B * nh * nb8), dim3(QWB * 64), 64 * 1024 + tab_bytes, st, (const T*)q, (const T*)k, (const T*)vt,        \
+                           (const T*)ql, (const T*)kl, (const T*)vtl, table, (T*)out, split, B, nh, hp, Sp, nb8, ntab, grouped);             \
+        BS_CHECK_LAUNCH();                                                                                                                   \
+        return BS_OK;                                                                                                                        \
+    } while (0)
+            if (qw8 == 7) BS_ATTN_CORR_BIG(7);
+            if (qw8 == 8) BS_ATTN_CORR_BIG(8);
+#undef BS_ATTN_CORR_BIG
+        }
         auto kc = attention_tab2_kernel<T, QW, 2, true>;
         static bool attrc = false;
         if (!attrc) {
@@ -837,6 +858,33 @@ static int launch_attn_tab(const void* q, const void* k, const void* vt, const v
             attr2 = true;
         }
         static const int abl = getenv("BS_ATTN_ABL") ? atoi(getenv("BS_ATTN_ABL")) : 0;      // diagnostics (timing only)
+        // Round 5: large blocks.  With 5 waves per block an (image, head)'s 25 query tiles are 5 blocks, each staging every K / V^T tile for itself
+        // (the staging is 9 % of the launch by ablation, profiles/r05_attention_ablations.txt); with 11-14 waves per block -- 2 blocks for 25 or
+        // 27 query tiles, 3 for 33 or 41 -- a tile is staged once per 11-14 query tiles: 717 -> 669 us at NB = 128 (one block per CU: the epilogue
+        // stages 8 KiB per wave; same bits -- a wave's arithmetic does not depend on its block).  Query-tile counts that do not split into
+        // blocks of 11-14 keep the 5-wave blocks.
+        if (!wpe3 && pk && abl == 0) {
+            const int nb_big = cdiv(nqt, 14), qw_big = cdiv(nqt, nb_big);
+#define BS_ATTN_BIG(QWB)                                                                                                                     \
+    do {                                                                                                                                     \
+        auto kb = attention_tab2_kernel<T, QWB, 4, false, true>;                                                                             \
+        static bool attrb = false;                                                                                                           \
+        if (!attrb) {                                                                                                                        \
+            BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));    \
+            attrb = true;                                                                                                                    \
+        }                                                                                                                                    \
+        const int ldsb = QWB * 8192 > 32 * 1024 + tab_bytes ? QWB * 8192 : 32 * 1024 + tab_bytes;                                            \
+        hipLaunchKernelGGL(kb, dim3(B * nh * nb_big), dim3(QWB * 64), ldsb, st, (const T*)q, (const T*)k, (const T*)vt, (const T*)nullptr,   \
+                           (const T*)nullptr, (const T*)nullptr, table, (T*)out, split, B, nh, hp, Sp, nb_big, ntab, grouped);               \
+        BS_CHECK_LAUNCH();                                                                                                                   \
+        return BS_OK;                                                                                                                        \
+    } while (0)
+            if (qw_big == 11) BS_ATTN_BIG(11);
+            if (qw_big == 12) BS_ATTN_BIG(12);
+            if (qw_big == 13) BS_ATTN_BIG(13);
+            if (qw_big == 14) BS_ATTN_BIG(14);
+#undef BS_ATTN_BIG
+        }
         hipLaunchKernelGGL(kern2, dim3(B * nh * nqb), dim3(QW * 64), 32 * 1024 + tab_bytes, st, (const T*)q, (const T*)k, (const T*)vt, (const T*)nullptr,
                            (const T*)nullptr, (const T*)nullptr, table, (T*)out, split | (abl << 3), B, nh, hp, Sp, nqb, ntab, grouped);
         BS_CHECK_LAUNCH();
