@@ -26,27 +26,37 @@ def make_sequence(n: int, h: int = 480, w: int = 640, seed: int = 0) -> np.ndarr
 
 
 def make_sequence_at(indices, total: int, h: int = 480, w: int = 640, seed: int = 0) -> np.ndarray:
-    """frames `indices` of ONE synthetic sequence of `total` frames (the same construction as make_sequence, with the noise of frame i
-    drawn from its own generator, so any rank can make exactly the frames it owns): what a multi-GPU run needs to process ONE
-    sequence cut into blocks instead of one unrelated sequence per rank"""
+    """frames `indices` of ONE synthetic sequence of `total` frames (the construction of make_sequence -- the same smooth field cropped along its
+    diagonal -- with the noise of frame i drawn from its own generator, so any rank can make exactly the frames it owns): what a multi-GPU run
+    needs to process ONE sequence cut into blocks instead of one unrelated sequence per rank.
+
+    The field is never materialised (at 8 ranks x 25 steps x 128 frames it would be 26 081 x 26 241 x 3 floats per rank): a term
+    amp sin(2 pi (fy y + fx x) + ph) is separable, sin(a_y + ph) cos(b_x) + cos(a_y + ph) sin(b_x), so a frame's window costs two outer products
+    per term.  Frame i depends on (seed, total, i) only, never on which other frames are asked for."""
     rng = np.random.default_rng(seed)
     n = int(total)
-    yy, xx = np.meshgrid(np.arange(h + n, dtype=np.float32), np.arange(w + n, dtype=np.float32), indexing="ij")
-    base = np.zeros((h + n, w + n, 3), np.float32)
+    terms = []
     for c in range(3):
-        f = np.full((h + n, w + n), 106.0, np.float32)
         for _ in range(8):
             fy, fx = rng.uniform(0.002, 0.02, size=2)
             ph = rng.uniform(0, 2 * np.pi)
             amp = rng.uniform(5, 20)
-            f += amp * np.sin(2 * np.pi * (fy * yy + fx * xx) + ph).astype(np.float32)
-        base[..., c] = f
+            terms.append((c, float(fy), float(fx), float(ph), float(amp)))
     indices = [int(i) for i in indices]
+    fyc, fxc, phc, ampc = (np.array([[t[j] for t in terms if t[0] == c] for c in range(3)]) for j in (1, 2, 3, 4))
     out = np.empty((len(indices), h, w, 3), np.uint8)
     for k, i in enumerate(indices):
         assert 0 <= i < n, (i, n)
-        noise = np.random.default_rng([seed, i]).normal(0.0, 8.0, size=(h, w, 3)).astype(np.float32)
-        out[k] = np.clip(np.rint(base[i:i + h, i:i + w] + noise), 0, 255).astype(np.uint8)
+        yy = np.arange(i, i + h, dtype=np.float64)[:, None]
+        xx = np.arange(i, i + w, dtype=np.float64)[None, :]
+        fr = np.random.default_rng([seed, i]).standard_normal(size=(h, w, 3), dtype=np.float32).astype(np.float64) * 8.0 + 106.0
+        for c in range(3):          # the channel's eight terms as one [h, 16] x [16, w] product
+            ay = 2 * np.pi * fyc[c][None, :] * yy + phc[c][None, :]                   # [h, 8]
+            bx = 2 * np.pi * fxc[c][:, None] * xx                                       # [8, w]
+            # (einsum, not `@`: a 480 x 16 x 640 product is far below where a threaded BLAS pays -- 13 ms against 94 ms on 8 cores)
+            fr[..., c] += np.einsum("hk,kw->hw", np.concatenate([np.sin(ay) * ampc[c][None, :], np.cos(ay) * ampc[c][None, :]], 1),
+                                    np.concatenate([np.cos(bx), np.sin(bx)], 0))
+        out[k] = np.clip(np.rint(fr), 0, 255).astype(np.uint8)
     return out
 
 
