@@ -542,6 +542,162 @@ __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restr
                       grouped ? (int64_t)b : (int64_t)b * S, S, q0, active, lane, cls_planes);
 }
 
+// The cls query on its own (round 5, CLS2 builds of attention_tab2_kernel).  As a 25th query tile the cls query costs a whole wave for one
+// valid row, and 25 tiles do not split into blocks that fill a CU's wave slots (13 + 12 waves: one block per CU, 13 of 16 slots, one SIMD
+// with four waves; 4 x 7: 14 of 16).  The 24 patch tiles do -- three blocks of 8, two blocks per CU -- and block 0 of every (image, head) runs
+// this pass after its tiles: the hp + 1 key rows (32-key sub-tiles; the last holds the cls key alone) are dealt over the block's waves, a wave reads
+// its K / V^T fragments straight from global memory (no ring: a sub-tile is read once, by one wave) and keeps a running max / sum / O^T of its
+// own; the partial results meet in LDS and wave 0 merges them (sum_w 2^(m_w - M) (l_w, O_w)) and stores the row through the usual epilogue.
+// Same operands and the same fp32 accumulation as a tile of the main loop; the order of the key rows within a sum differs from it (and is fixed:
+// by the wave count, not by batch or launch).  `area`: 8 KiB of LDS behind the table, the partials and then the staging of the store.
+template <typename T, int QW, bool CORR>
+__device__ __forceinline__ void cls_query_pass(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* __restrict__ Vg, const T* __restrict__ Qlg,
+                                               const T* __restrict__ Klg, const T* __restrict__ Vlg, int Sp, int hp, const float* __restrict__ tail3,
+                                               char* area, int wave, int lane, T* __restrict__ out, int split, int nh, int head, int64_t row0,
+                                               int64_t row_cls, int S, bool cls_planes) {
+    typedef typename T16<T>::v8 v8;
+    const int r = lane & 31, h2 = lane >> 5;
+    const int kap = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+    const int q0 = hp * 32;
+    constexpr float THR = 6.0f;
+    const float b_cp = tail3[0], b_cc = tail3[2];          // cls -> patch, cls -> cls
+    v8 qf[4], qlf[CORR ? 4 : 1];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        qf[ks] = *reinterpret_cast<const v8*>(Qg + (int64_t)(q0 + r) * 64 + ks * 16 + h2 * 8);
+        if constexpr (CORR) qlf[ks] = *reinterpret_cast<const v8*>(Qlg + (int64_t)(q0 + r) * 64 + ks * 16 + h2 * 8);
+    }
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        oacc[0][i] = 0.f;
+        oacc[1][i] = 0.f;
+    }
+    float m_run = 0.f, l_run = 0.f;
+    bool first = true;
+    // K fragments of the wave's next key row are fetched under the arithmetic of the current one, V^T fragments at the top of the row's own step
+    // (they are not needed before the probabilities exist)
+    auto load_k = [&](int ky, v8 (&kf)[4], v8 (&kfl)[CORR ? 4 : 1]) {
+        const int64_t krow = (int64_t)ky * 32 + kap;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[ks] = *reinterpret_cast<const v8*>(Kg + krow * 64 + (2 * ks + h2) * 8);
+            if constexpr (CORR) kfl[ks] = *reinterpret_cast<const v8*>(Klg + krow * 64 + (2 * ks + h2) * 8);
+        }
+    };
+    v8 kf[4], kfl[CORR ? 4 : 1];
+    load_k(wave, kf, kfl);             // (hp + 1 >= QW: every wave has a key row)
+#pragma unroll 1
+    for (int ky = wave; ky <= hp; ky += QW) {
+        v8 vf[4], vfl[CORR ? 4 : 1];
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int64_t voff = (int64_t)(dh * 32 + r) * Sp + ky * 32 + (2 * s2 + h2) * 8;
+                vf[dh * 2 + s2] = *reinterpret_cast<const v8*>(Vg + voff);
+                if constexpr (CORR) vfl[dh * 2 + s2] = *reinterpret_cast<const v8*>(Vlg + voff);
+            }
+        v8 kn[4], knl[CORR ? 4 : 1];
+        const int kyn = ky + QW <= hp ? ky + QW : ky;        // (the last step re-reads its own row: no branch around the loads)
+        load_k(kyn, kn, knl);
+        f32x16 sacc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[i] = (ky < hp ? b_cp : -1.0e30f) - m_run;
+        if (ky == hp && h2 == 0) sacc[0] = b_cc - m_run;     // the cls key: key 0 of the last sub-tile, the rest is padding
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            sacc = T16<T>::mfma32(kf[ks], qf[ks], sacc);
+            if constexpr (CORR) {
+                sacc = T16<T>::mfma32(kf[ks], qlf[ks], sacc);
+                sacc = T16<T>::mfma32(kfl[ks], qf[ks], sacc);
+            }
+        }
+        float mloc = sacc[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mloc = fmaxf(mloc, sacc[i]);
+        mloc = half_swap_max(mloc);
+        if (first || __any(mloc > THR)) {                    // as in the main loop: the shift is the lane's own, never negative after the first
+            const float sh = first ? mloc : fmaxf(mloc, 0.0f);
+            const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-sh);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                oacc[0][i] *= alpha;
+                oacc[1][i] *= alpha;
+                sacc[i] -= sh;
+            }
+            m_run += sh;
+            first = false;
+        }
+        float psum = 0.f;
+        v8 pf[2], pfl[CORR ? 2 : 1];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(sacc[8 * s2 + e]);
+                psum += pv;
+                pf[s2][e] = T16<T>::from_f32(pv);
+                if constexpr (CORR) pfl[s2][e] = T16<T>::from_f32(pv - T16<T>::to_f32(pf[s2][e]));
+            }
+        l_run += psum;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                oacc[dh] = T16<T>::mfma32(vf[dh * 2 + s2], pf[s2], oacc[dh]);
+                if constexpr (CORR) {
+                    oacc[dh] = T16<T>::mfma32(vf[dh * 2 + s2], pfl[s2], oacc[dh]);
+                    oacc[dh] = T16<T>::mfma32(vfl[dh * 2 + s2], pf[s2], oacc[dh]);
+                }
+            }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[ks] = kn[ks];
+            if constexpr (CORR) kfl[ks] = knl[ks];
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);   // the other lane half holds the other 16 keys of every sub-tile
+    // partials of query column 0 (the cls query: lanes 0 and 32), per wave and lane half: [m, l, 32 x O^T]
+    float* part = reinterpret_cast<float*>(area);
+    if (r == 0) {
+        float* pp = part + (wave * 2 + h2) * 36;
+        pp[0] = m_run;
+        pp[1] = l_tot;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            pp[2 + i] = oacc[0][i];
+            pp[18 + i] = oacc[1][i];
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    float M = part[h2 * 36];
+#pragma unroll 1
+    for (int w = 1; w < QW; ++w) M = fmaxf(M, part[(w * 2 + h2) * 36]);
+    float L = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        oacc[0][i] = 0.f;
+        oacc[1][i] = 0.f;
+    }
+#pragma unroll 1
+    for (int w = 0; w < QW; ++w) {
+        const float* pp = part + (w * 2 + h2) * 36;
+        const float f = __builtin_amdgcn_exp2f(pp[0] - M);
+        L = fmaf(pp[1], f, L);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            oacc[0][i] = fmaf(pp[2 + i], f, oacc[0][i]);
+            oacc[1][i] = fmaf(pp[18 + i], f, oacc[1][i]);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the partials are read; the region becomes this wave's store staging
+    __builtin_amdgcn_wave_barrier();
+    store_out_tile<T>(area, oacc, 1.0f / L, out, split, nh, head, row0, row_cls, S, q0, true, lane, cls_planes);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Pipelined form of the table variant (hp even: the 384x512 and 416x512 network inputs).  The loop above runs a wave through
 // QK^T -> softmax -> PV strictly in turn and branches on the kind of key row / query tile inside the loop (the merges cost
@@ -563,7 +719,7 @@ __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restr
 // BEiT checkpoints) the single 16-bit Q / K / V / P of the plain kernel cost 0.9-2.4e-4 m of depth EACH
 // (tools/probes/outlier_rounding_study.py); all four corrected: 1.7e-6 m.  The K / V^T ring holds the lo tiles behind the hi tiles
 // (32 KiB per stage, two blocks per CU).
-template <typename T, int QW, int WPE, bool CORR, bool PK = false>
+template <typename T, int QW, int WPE, bool CORR, bool PK = false, bool CLS2 = false>
 __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ Vt,
                                                                   const T* __restrict__ Ql, const T* __restrict__ Kl, const T* __restrict__ Vtl,
                                                                   const float* __restrict__ table, T* __restrict__ out, int split, int B, int nh,
@@ -579,7 +735,7 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
     float* tab = reinterpret_cast<float*>(smem + 2 * STAGE);
     const int ntab_pad = (ntab + 255) & ~255; // whole 1-KiB DMA pieces
     float* creg = tab + ntab_pad;             // 64 words of the cls->patch entry: the cls query's bias towards every patch key
-    const int S = hp * WP + 1, nqt = hp + 1;
+    const int S = hp * WP + 1, nqt = CLS2 ? hp : hp + 1;       // CLS2: patch tiles only, the cls query is cls_query_pass
 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
@@ -597,7 +753,7 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
     const bool active = qt < nqt;
     qt = active ? qt : nqt - 1;
     const int q0 = qt * 32;
-    const bool cls_tile = qt == hp;
+    const bool cls_tile = !CLS2 && qt == hp;
     const int64_t bh = (int64_t)b * nh + head;
 
     const T* Qg = Q + bh * Sp * 64;
@@ -791,6 +947,15 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
     __syncthreads();                     // every wave is done with the K / V^T ring and the table: the LDS becomes the store staging
     store_out_tile<T>(smem + wave * 8192, oacc, inv, out, split, nh, head, grouped ? (int64_t)grouped + (int64_t)b * (S - 1) : (int64_t)b * S + 1,
                       grouped ? (int64_t)b : (int64_t)b * S, S, q0, active, lane, cls_planes);
+    if constexpr (CLS2) {
+        if (qblk == 0) {    // block-uniform: after their own tiles (K / V^T of this (image, head) are warm in L2) the block's waves share the cls query's key rows
+            __syncthreads();                 // every wave's store staging is read out
+            cls_query_pass<T, QW, CORR>(Qg, Kg, Vg, CORR ? Ql + bh * Sp * 64 : nullptr, Klg, Vlg, Sp, hp, table + (int64_t)head * ntab + ntab - 3,
+                                        (CORR && QW <= 7) ? smem + 7 * 8192 : smem + 2 * STAGE + (ntab_pad + 64) * 4, wave, lane, out, split, nh, head,
+                                        grouped ? (int64_t)grouped + (int64_t)b * (S - 1) : (int64_t)b * S + 1, grouped ? (int64_t)b : (int64_t)b * S, S,
+                                        cls_planes);
+        }
+    }
 }
 
 template <typename T>
@@ -802,6 +967,34 @@ static int launch_attn_tab(const void* q, const void* k, const void* vt, const v
     if (ql) {     // split-precision operands (bs_attention_table_corr): 64 KiB ring, the 256-register budget = two waves per SIMD, 8 per CU
         // Round 5: 7- or 8-wave blocks.  A 5-wave block leaves 3 of the CU's 8 wave slots empty (a second block of 5 does not fit them): blocks of
         // ceil(nqt / ceil(nqt / 8)) waves fill them (25 query tiles: 4 blocks of 7) and stage a tile once per 7-8 query tiles.  Same bits.
+        static const bool cls2_ok = getenv("BS_ATTN_NO_CLS2") == nullptr;     // diagnostics: the round-5 shape before the cls query left the tiles
+        static const bool corr6 = getenv("BS_ATTN_CORR6") != nullptr;
+        if (cls2_ok && corr6 && hp % 6 == 0 && 64 * 1024 + tab_bytes <= 80 * 1024) {
+            // three waves per SIMD (<= 168 registers), 6-wave blocks, two blocks per CU (the cls pass's 8 KiB lie in the ring, free by then)
+            auto kb = attention_tab2_kernel<T, 6, 3, true, false, true>;
+            static bool attrb = false;
+            if (!attrb) {
+                BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                attrb = true;
+            }
+            hipLaunchKernelGGL(kb, dim3(B * nh * (hp / 6)), dim3(6 * 64), 64 * 1024 + tab_bytes, st, (const T*)q, (const T*)k, (const T*)vt,
+                               (const T*)ql, (const T*)kl, (const T*)vtl, table, (T*)out, split, B, nh, hp, Sp, hp / 6, ntab, grouped);
+            BS_CHECK_LAUNCH();
+            return BS_OK;
+        }
+        if (cls2_ok && hp % 8 == 0) {
+            // the cls query as cls_query_pass: 24 patch tiles = 3 blocks of 8 waves, every wave slot of the CU (2 per SIMD at this register budget)
+            auto kb = attention_tab2_kernel<T, 8, 2, true, false, true>;
+            static bool attrb = false;
+            if (!attrb) {
+                BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                attrb = true;
+            }
+            hipLaunchKernelGGL(kb, dim3(B * nh * (hp / 8)), dim3(8 * 64), 64 * 1024 + tab_bytes + 8192, st, (const T*)q, (const T*)k, (const T*)vt,
+                               (const T*)ql, (const T*)kl, (const T*)vtl, table, (T*)out, split, B, nh, hp, Sp, hp / 8, ntab, grouped);
+            BS_CHECK_LAUNCH();
+            return BS_OK;
+        }
         {
             const int nb8 = cdiv(nqt, 8), qw8 = cdiv(nqt, nb8);
 #define BS_ATTN_CORR_BIG(QWB)                                                                                                                \
@@ -863,6 +1056,23 @@ static int launch_attn_tab(const void* q, const void* k, const void* vt, const v
         // 27 query tiles, 3 for 33 or 41 -- a tile is staged once per 11-14 query tiles: 717 -> 669 us at NB = 128 (one block per CU: the epilogue
         // stages 8 KiB per wave; same bits -- a wave's arithmetic does not depend on its block).  Query-tile counts that do not split into
         // blocks of 11-14 keep the 5-wave blocks.
+        static const bool cls2_ok = getenv("BS_ATTN_NO_CLS2") == nullptr;     // diagnostics: the large blocks below
+        if (!wpe3 && pk && abl == 0 && cls2_ok && hp % 8 == 0) {
+            // Round 5, second step: the cls query leaves the tiles (cls_query_pass).  24 (32, 40) patch tiles are 3 (4, 5) blocks of 8 waves, 64 KiB
+            // of LDS each: two blocks per CU fill its 16 wave slots, four waves on every SIMD (13 + 12 waves left 3 slots empty and one SIMD with
+            // four waves against three).  profiles/r05_attention_blocks.txt.
+            auto kb = attention_tab2_kernel<T, 8, 4, false, true, true>;
+            static bool attrb = false;
+            if (!attrb) {
+                BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                attrb = true;
+            }
+            const int ldsb = 8 * 8192 > 32 * 1024 + tab_bytes + 8192 ? 8 * 8192 : 32 * 1024 + tab_bytes + 8192;
+            hipLaunchKernelGGL(kb, dim3(B * nh * (hp / 8)), dim3(8 * 64), ldsb, st, (const T*)q, (const T*)k, (const T*)vt, (const T*)nullptr,
+                               (const T*)nullptr, (const T*)nullptr, table, (T*)out, split, B, nh, hp, Sp, hp / 8, ntab, grouped);
+            BS_CHECK_LAUNCH();
+            return BS_OK;
+        }
         if (!wpe3 && pk && abl == 0) {
             const int nb_big = cdiv(nqt, 14), qw_big = cdiv(nqt, nb_big);
 #define BS_ATTN_BIG(QWB)                                                                                                                     \

@@ -478,7 +478,10 @@ def test_qkv_scatter_and_attention(L, dtype, B, S, nh):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("B,hp,nh,split,grouped", [(2, 24, 16, 0, 0), (1, 26, 4, 0, 0), (3, 3, 2, 0, 0), (2, 24, 2, 16, 0), (2, 24, 2, 32, 0),
-                                                   (3, 24, 2, 32, 256), (2, 4, 2, 0, 2)])
+                                                   (3, 24, 2, 32, 256), (2, 4, 2, 0, 2),
+                                                   # 32 | 64: FP8 planes on the cls query's row only (what the plan asks for); hp 24 / 32: the cls
+                                                   # query as cls_query_pass (8-wave blocks), hp 26: as a 27th tile
+                                                   (3, 24, 2, 96, 256), (2, 24, 2, 96, 0), (1, 32, 2, 96, 0), (2, 26, 2, 96, 0)])
 def test_attention_table(L, dtype, B, hp, nh, split, grouped):
     """bs_attention_table (bias gathered from the per-head table in LDS; Q / K / V^T patches first, cls last) against torch
     softmax attention with HF's gathered [S, S] bias (modeling_beit.py:194-265), for the 24x32 and 26x32 windows of the
@@ -530,11 +533,20 @@ def test_attention_table(L, dtype, B, hp, nh, split, grouped):
     ref = (a @ vf).permute(0, 2, 1, 3).reshape(B * S, hidden)
     if split == 16:
         got = out[:, :hidden].float() + out[:, hidden:].float()
-    elif split == 32:
+    elif split & 32:
         planes = out[:, hidden:].contiguous().view(torch.uint8).view(B * S, 2 * hidden)
-        got = out[:, :hidden].float() + planes[:, hidden:].contiguous().view(torch.float8_e4m3fn).float() * 2.0 ** -L.F8_ACT_LO_EXP
+        lo8 = planes[:, hidden:].contiguous().view(torch.float8_e4m3fn).float() * 2.0 ** -L.F8_ACT_LO_EXP
         hi8 = planes[:, :hidden].contiguous().view(torch.float8_e4m3fn).float() * 2.0 ** -L.F8_ACT_HI_EXP
-        assert (hi8 - ref).abs().max().item() < 0.07 * ref.abs().max().item() + 1e-2
+        if split & 64:      # planes on the cls rows only (image-major rows here: row b * S); the patch rows' plane bytes stay as they were (zero)
+            cls_rows = torch.arange(B, device=dev()) * S
+            keep = torch.zeros(B * S, 1, device=dev())
+            keep[cls_rows] = 1.0
+            assert (planes.float() * (1.0 - keep)).abs().max().item() == 0
+            got = out[:, :hidden].float() + lo8 * keep
+            assert (hi8[cls_rows] - ref[cls_rows]).abs().max().item() < 0.07 * ref.abs().max().item() + 1e-2
+        else:
+            got = out[:, :hidden].float() + lo8
+            assert (hi8 - ref).abs().max().item() < 0.07 * ref.abs().max().item() + 1e-2
     else:
         got = out.float()
     err = (got - ref).abs().max().item()

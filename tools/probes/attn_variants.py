@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-VARIANTS = {"wpe4 + packed pre-shift (default)": {}, "wpe4, scalar pre-shift (round 3)": {"BS_ATTN_NO_PK": "1"}, "wpe3 + packed": {"BS_ATTN_WPE3": "1"}, "wpe3, scalar": {"BS_ATTN_WPE3": "1", "BS_ATTN_NO_PK": "1"}, "corr": {"CORR": "1"}}
+VARIANTS = {"wpe4 + packed pre-shift, 8-wave blocks + cls_query_pass (default)": {}, "wpe4 + packed, the cls query as a 25th tile (13 + 12-wave blocks)": {"BS_ATTN_NO_CLS2": "1"}, "wpe4, scalar pre-shift (round 3)": {"BS_ATTN_NO_PK": "1"}, "wpe3 + packed": {"BS_ATTN_WPE3": "1"}, "wpe3, scalar": {"BS_ATTN_WPE3": "1", "BS_ATTN_NO_PK": "1"}, "corr (8-wave blocks + cls_query_pass)": {"CORR": "1"}, "corr, the cls query as a 25th tile (4 x 7 waves)": {"CORR": "1", "BS_ATTN_NO_CLS2": "1"}}
 
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch
