@@ -951,7 +951,7 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
         if (qblk == 0) {    // block-uniform: after their own tiles (K / V^T of this (image, head) are warm in L2) the block's waves share the cls query's key rows
             __syncthreads();                 // every wave's store staging is read out
             cls_query_pass<T, QW, CORR>(Qg, Kg, Vg, CORR ? Ql + bh * Sp * 64 : nullptr, Klg, Vlg, Sp, hp, table + (int64_t)head * ntab + ntab - 3,
-                                        (CORR && QW <= 7) ? smem + 7 * 8192 : smem + 2 * STAGE + (ntab_pad + 64) * 4, wave, lane, out, split, nh, head,
+                                        smem + 2 * STAGE + (ntab_pad + 64) * 4, wave, lane, out, split, nh, head,
                                         grouped ? (int64_t)grouped + (int64_t)b * (S - 1) : (int64_t)b * S + 1, grouped ? (int64_t)b : (int64_t)b * S, S,
                                         cls_planes);
         }
@@ -968,22 +968,9 @@ static int launch_attn_tab(const void* q, const void* k, const void* vt, const v
         // Round 5: 7- or 8-wave blocks.  A 5-wave block leaves 3 of the CU's 8 wave slots empty (a second block of 5 does not fit them): blocks of
         // ceil(nqt / ceil(nqt / 8)) waves fill them (25 query tiles: 4 blocks of 7) and stage a tile once per 7-8 query tiles.  Same bits.
         static const bool cls2_ok = getenv("BS_ATTN_NO_CLS2") == nullptr;     // diagnostics: the round-5 shape before the cls query left the tiles
-        static const bool corr6 = getenv("BS_ATTN_CORR6") != nullptr;
-        if (cls2_ok && corr6 && hp % 6 == 0 && 64 * 1024 + tab_bytes <= 80 * 1024) {
-            // three waves per SIMD (<= 168 registers), 6-wave blocks, two blocks per CU (the cls pass's 8 KiB lie in the ring, free by then)
-            auto kb = attention_tab2_kernel<T, 6, 3, true, false, true>;
-            static bool attrb = false;
-            if (!attrb) {
-                BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-                attrb = true;
-            }
-            hipLaunchKernelGGL(kb, dim3(B * nh * (hp / 6)), dim3(6 * 64), 64 * 1024 + tab_bytes, st, (const T*)q, (const T*)k, (const T*)vt,
-                               (const T*)ql, (const T*)kl, (const T*)vtl, table, (T*)out, split, B, nh, hp, Sp, hp / 6, ntab, grouped);
-            BS_CHECK_LAUNCH();
-            return BS_OK;
-        }
         if (cls2_ok && hp % 8 == 0) {
-            // the cls query as cls_query_pass: 24 patch tiles = 3 blocks of 8 waves, every wave slot of the CU (2 per SIMD at this register budget)
+            // the cls query as cls_query_pass: 24 patch tiles = 3 blocks of 8 waves, every wave slot of the CU (2 per SIMD at this register budget).
+            // (Three waves per SIMD -- 168 registers, 6-wave blocks, two per CU -- spill 29 registers and run 1 886 us against 1 313.)
             auto kb = attention_tab2_kernel<T, 8, 2, true, false, true>;
             static bool attrb = false;
             if (!attrb) {
