@@ -92,6 +92,61 @@ def measure_pmc_traffic(args):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+class PowerSampler:
+    """Board power and shader clock from the amdgpu hwmon files, sampled by a host thread every 25 ms over a timed region (no GPU call; best effort:
+    `result()` is None where the files are not readable).  With several boards in sysfs the one drawing the most over the region is reported."""
+
+    def __init__(self):
+        import glob
+        self.nodes = [h for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")) if self._rd(os.path.join(h, "name")) == "amdgpu"]
+        self.rows = {h: [] for h in self.nodes}
+        self._stop = False
+        self._thread = None
+
+    @staticmethod
+    def _rd(path):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except OSError:
+            return None
+
+    def _loop(self):
+        while not self._stop:
+            for h in self.nodes:
+                pw = self._rd(os.path.join(h, "power1_average")) or self._rd(os.path.join(h, "power1_input"))
+                fq = self._rd(os.path.join(h, "freq1_input"))
+                if pw and pw.isdigit():
+                    self.rows[h].append((float(pw) / 1e6, float(fq) / 1e6 if fq and fq.isdigit() else None))
+            time.sleep(0.025)
+
+    def start(self):
+        if self.nodes:
+            import threading
+            self._thread = threading.Thread(target=self._loop, daemon=True)
+            self._thread.start()
+        return self
+
+    def result(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join()
+        best = None
+        for h, rows in self.rows.items():
+            if len(rows) >= 4:
+                pw = sorted(r[0] for r in rows)
+                if best is None or pw[len(pw) // 2] > best[0]:
+                    best = (pw[len(pw) // 2], h, rows)
+        if best is None:
+            return None
+        med, h, rows = best
+        fq = sorted(r[1] for r in rows if r[1] is not None)
+        cap = self._rd(os.path.join(h, "power1_cap"))
+        return {"median_w": round(med, 1), "max_w": round(max(r[0] for r in rows), 1), "cap_w": float(cap) / 1e6 if cap and cap.isdigit() else None,
+                "sclk_mhz_median": round(fq[len(fq) // 2], 1) if fq else None, "samples": len(rows),
+                "source": "amdgpu hwmon power1_average / freq1_input, 25 ms samples over the timed steps (host thread)"}
+
+
 def weak_frame_indices(steps: int, B: int, world: int, rank: int):
     """N > 1, weak scaling: (frames of the ONE sequence, the indices rank `rank` holds).  Step k gives rank r the B frames
     (k * world + r) * B + 1 .. + B and, in front of them, the frame before (its halo = the last frame of rank r - 1's block of the same
@@ -264,11 +319,13 @@ def main():
         for k in range(Wm):
             step(k, False)
         barrier()
+        sampler = PowerSampler().start() if rank == 0 else None
         t0 = time.perf_counter()
         for k in range(Wm, Wm + K):
             step(k, not args.no_kernel_timing)
         barrier()
         elapsed = time.perf_counter() - t0
+        power = sampler.result() if sampler is not None else None
         zplan.plan.events = None
         if use_dist:
             te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -334,6 +391,10 @@ def main():
                         executed=round(exe, 1), executed_frac=round(exe / MFMA_PEAK_TFLOPS, 4),
                         avg_launch_us=round(1e3 * a["ms"] / a["n"], 2), gflop_per_launch=round(a["alg"] / a["n"] / 1e9, 3),
                         algorithmic_bytes_per_launch=round(a["bytes"] / a["n"]))
+            if power and power.get("sclk_mhz_median"):
+                # `peak` is the guide's figure at the 2.4 GHz boost clock; the plan runs at the board's power limit and a lower clock
+                roof["sclk_mhz_median"] = power["sclk_mhz_median"]
+                roof["frac_of_peak_at_that_clock"] = round(ach / (MFMA_PEAK_TFLOPS * power["sclk_mhz_median"] / 2400.0), 4)
             cms = sum(a["ms"] for (kd, _), a in agg.items() if kd == "conv")
             cfl = sum(a["alg"] for (kd, _), a in agg.items() if kd == "conv")
             cex = sum(a["flops"] for (kd, _), a in agg.items() if kd == "conv")
@@ -342,7 +403,7 @@ def main():
                                  achieved=round(cfl / (cms * 1e-3) / 1e12, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                                  frac=round(cfl / (cms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                                  executed=round(cex / (cms * 1e-3) / 1e12, 1), executed_frac=round(cex / (cms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4))
-        return dict(pipe=pipe, zplan=zplan, fps=fps, elapsed=elapsed, roof=roof, roof_conv=roof_conv, kern=kern_table, d_timed=d_timed)
+        return dict(pipe=pipe, zplan=zplan, fps=fps, elapsed=elapsed, roof=roof, roof_conv=roof_conv, kern=kern_table, d_timed=d_timed, power=power)
 
     main_run = measure(args.precision)
     pipe, zplan, fps, elapsed = main_run["pipe"], main_run["zplan"], main_run["fps"], main_run["elapsed"]
@@ -474,6 +535,7 @@ def main():
             "kernels": kern_table,
             "calibration": (pipe.zoe.calibration if pipe.zoe.acc else None),
             "hbm_allocated_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+            "power": main_run.get("power"),
         }
         if slam:
             out["slam_loop"] = slam
