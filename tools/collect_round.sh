@@ -22,6 +22,7 @@ python3 tools/probes/neck_site_study.py 0 5 > $OUT/${TAG}_neck_site_study.txt 2>
 python3 tools/probes/upconv_fused_time.py > $OUT/${TAG}_upconv_fused.txt 2>/dev/null
 ABLATE=1 python3 tools/probes/upconv_fused_time.py >> $OUT/${TAG}_upconv_fused.txt 2>/dev/null
 python3 tools/probes/attn_ablate.py > $OUT/${TAG}_attention_ablations.txt 2>/dev/null
+python3 tools/probes/power_trace.py > $OUT/${TAG}_power_trace.txt 2>/dev/null
 python3 tools/probes/accurate_seeds.py 1 2 3 4 5 6 7 8 2>/dev/null | cut -c1-400 > $OUT/${TAG}_accurate_seeds.txt
 ls -la $OUT
 tail -c 600 $OUT/${TAG}_bench_n1.json
