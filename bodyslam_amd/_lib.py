@@ -268,7 +268,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, **kw) -> None:
 
 def _gemm_bytes(d) -> float:
     rows_in = float(d.M if not d.conv else d.M / max(d.stride * d.stride, 1))
-    rows_f8 = rows_in if (d.conv or not d.f8_skip_from) else float(min(d.f8_skip_from, d.M))
+    rows_f8 = 0.0 if d.f8_skip_from < 0 else (rows_in if (d.conv or not d.f8_skip_from) else float(min(d.f8_skip_from, d.M)))
     taps = d.KH * d.KW if d.conv else 1
     a = rows_in * (d.Cin if d.conv else d.K) * 2 + rows_f8 * d.f8_seg
     w = float(d.N) * (d.K * 2 + taps * d.f8_seg)
@@ -355,7 +355,7 @@ class Plan:
             # executed work in 16-bit-MFMA-equivalents: an FP8 correction stage covers 128 k in the time of 64
             # (tiles past f8_wonly_from run only the first FP8 half)
             # (tiles past f8_skip_from run none)
-            flops=2.0 * d.N * (d.M * d.K + (min(d.f8_skip_from, d.M) if d.f8_skip_from else d.M) * (d.KH * d.KW if d.conv else 1) * d.f8_seg
+            flops=2.0 * d.N * (d.M * d.K + (0 if d.f8_skip_from < 0 else (min(d.f8_skip_from, d.M) if d.f8_skip_from else d.M)) * (d.KH * d.KW if d.conv else 1) * d.f8_seg
                                / (4 if d.f8_wonly_from else 2)),
             # algorithmic FLOPs exclude the extra passes of a split-precision product
             alg_flops=2.0 * d.M * d.N * (d.K / kw.get("precision_passes", 1)),

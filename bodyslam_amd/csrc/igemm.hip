@@ -244,8 +244,8 @@ extern "C" int bs_gemm(const bs_gemm_desc* d, void* stream) {
     p.bias2 = d->bias2;
     p.bias2_row0 = d->bias2_row0;
     p.bias2_group_rows = d->bias2_group_rows;
-    BS_REQUIRE(d->f8_skip_from == 0 || (d->f8_seg > 0 && d->f8_skip_from > 0 && d->f8_skip_from % 256 == 0 && !d->conv),
-               "bs_gemm: f8_skip_from needs the FP8 correction segment of a plain GEMM and a multiple of 256 rows");
+    BS_REQUIRE(d->f8_skip_from == 0 || (d->f8_seg > 0 && (d->f8_skip_from == -1 || (d->f8_skip_from > 0 && d->f8_skip_from % 256 == 0 && !d->conv))),
+               "bs_gemm: f8_skip_from needs the FP8 correction segment and is -1 (every tile) or, for a plain GEMM, a multiple of 256 rows");
     BS_REQUIRE(!d->bias2 || (d->bias2_group_rows > 0 && d->bias2_row0 >= 0 && d->bias_group_rows == 0 && !d->conv && d->out_mode != BS_OUT_SHUFFLE &&
                              d->N % 4 == 0),
                "bs_gemm: bias2 needs bias2_group_rows > 0, a plain GEMM (PLAIN or QKV output) and no bias_group_rows");

@@ -75,7 +75,7 @@ struct IgemmParams {
     int out2_relu;       // != 0 (lean (hi16 | hi8 | lo8) epilogue only): out2 receives relu(y) in the same format and geometry
     int out_lo8_rows;    // > 0: only output rows below this index need their lo8 plane (the consumer drops the activation-rounding
                          //      correction on the others, f8_wonly_from): tiles past it skip that plane
-    int f8_skip_from;    // > 0: tiles that start at a row >= this run no FP8 stage at all
+    int f8_skip_from;    // > 0: tiles that start at a row >= this run no FP8 stage at all; -1: no tile does (a product calibrated down to one 16-bit pass)
     int out_planes_rows; // > 0: tiles that start at a row >= this store hi16 only (no FP8 plane; fc1 -> fc2 with f8_skip_from)
     const float* bias2;  // optional fp32 [groups, N] added to rows >= bias2_row0, group = (m - bias2_row0) / bias2_group_rows
     int bias2_row0, bias2_group_rows;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
     const int nt16 = F8 ? nt_all - ncorr : nt_all;   // stages multiplied as 16-bit data; the rest are FP8 / FP4 correction stages (BK = 64 tiles)
     // the second half of the FP8 stages (A_lo8 W_hi8) is dropped for tiles past f8_wonly_from: they stop after the first half
     const bool wonly = F8 && p.f8_wonly_from != 0 && (p.f8_wonly_from < 0 || m0 >= p.f8_wonly_from);
-    const bool skip8 = F8 && p.f8_skip_from > 0 && m0 >= p.f8_skip_from;
+    const bool skip8 = F8 && p.f8_skip_from != 0 && (p.f8_skip_from < 0 || m0 >= p.f8_skip_from);
     const int nt = skip8 ? nt16 : (wonly ? nt_all - (ncorr >> 1) : nt_all);
     if constexpr (!PP) {
 #pragma unroll

@@ -133,6 +133,14 @@ AUTO_TOL_NECK_ABS_M = 5.0e-5
 # the neck mode "wonly:<site>,<site>,..." (ZoeDepthEngine.neck_site_wonly).  Sites below this share of the neck's FLOPs are not worth a
 # calibration forward and keep both products.
 AUTO_NECK_SITE_MIN_SHARE = 0.015
+# Round 5, second stage: the large weight-only sites may drop the weight-rounding correction TOO -- one 16-bit pass, `f8_skip_from = -1`, the
+# form "wonly:...;plain:<site>,..." (ZoeDepthEngine.neck_site_plain).  tools/probes/neck_plain_study.py: a site alone moves the map by 2-3e-5 m,
+# but twelve of them together leave the distance to the reference where it was (4.5 -> 4.9e-5 m) -- weight rounding in the neck is incoherent
+# noise, like its activation rounding -- while two small sites (nc2, ra3.down) alone cost 3-8e-5.  So the stage walks the sites by FLOPs, largest
+# first, and keeps a site when the combination stays under AUTO_TOL_NECK_PLAIN_ABS_M against the reference ON TWO FRAMES (the calibration frame
+# and a second synthetic one: a choice made by trying a dozen combinations on one frame fits that frame).  BS_NECK_PLAIN=0 switches the stage off.
+AUTO_NECK_PLAIN_MIN_SHARE = 0.015
+AUTO_TOL_NECK_PLAIN_ABS_M = 5.5e-5
 ACCURATE_NECK_MODE = "full"
 # (Round 3 also had neck_corr="f4": e2m1 correction planes with E8M0 block scales on the FP4 MFMA -- +1.4 % frames/s for 1.5x the depth error,
 # profiles/r03_fp4_corrections.txt.  It never paid and was removed in round 4; the correction products run on the block-scaled FP8 MFMA.)
@@ -312,8 +320,17 @@ class ZoeDepthEngine:
         if nm == "w":
             return True
         if nm.startswith("wonly:"):
-            return wkey in nm[6:].split(",")
+            return any(wkey in part.split(":", 1)[1].split(",") for part in nm.split(";") if ":" in part)
         return not any(wkey.startswith(p_) for p_ in nm.split(","))
+
+    def neck_site_plain(self, wkey: str) -> bool:
+        """does this neck / head product run NO correction at all (one 16-bit pass)?  Only the per-site form names such sites:
+        "wonly:a,b;plain:c,d" (a plain site also counts as weight-only for its producers: nobody reads the lo8 plane).  The fused
+        up-convolution (rh.conv2.w) has no one-pass form on (hi16 | hi8 | lo8) rows and stays weight-only."""
+        nm = self.neck_mode
+        if not nm.startswith("wonly:") or wkey.endswith("w_cls") or wkey == "rh.conv2.w":
+            return False
+        return any(part.startswith("plain:") and wkey in part[6:].split(",") for part in nm.split(";"))
 
     def set_class_modes(self, modes: Dict[str, str], neck_mode: Optional[str] = None, attn_mode: Optional[str] = None) -> None:
         """switch the backbone classes between "full" / "wcls" / "wmean" (and the neck mode, the attention mode) without re-ingesting
@@ -374,7 +391,8 @@ class ZoeDepthEngine:
         ckey = None
         if frames_u8 is None and self._sd is not None and reference and neck_candidates is None:
             ckey = (self._weights_fingerprint(), repr(self.cfg), str(self.dtype), H, W, tuple(self.target_hw), tol_class, tol_total, tol_abs,
-                    self.auto_classes, self.auto_attn, tuple(sorted(self.class_modes.items())), self.attn_mode, self.neck_mode)
+                    self.auto_classes, self.auto_attn, tuple(sorted(self.class_modes.items())), self.attn_mode, self.neck_mode,
+                    os.environ.get("BS_NECK_PLAIN", "1"))
             hit = _CALIBRATION_CACHE.get(ckey)
             if hit is not None:
                 self.apply_calibration(hit)
@@ -499,6 +517,41 @@ class ZoeDepthEngine:
             if lo > 0:
                 neck = "wonly:" + ",".join(sorted(order[:lo]))
                 l1_abs, total = kept
+            if lo > 0 and os.environ.get("BS_NECK_PLAIN", "1") != "0":
+                # ---- second stage: one 16-bit pass for the large weight-only sites, judged on two frames against the reference
+                from .synthetic import make_sequence
+                extra = torch.from_numpy(make_sequence(1, H, W, seed=12)).to(self.dev)
+                frames2 = torch.cat([frames_u8, extra], 0).contiguous()
+                truth2 = torch.cat([truth, self.reference_depth(extra)], 0)
+
+                def depth2(neck_):
+                    self.set_class_modes(chosen, neck_, attn)
+                    plan = _ZoePlan(self, 2, H, W, True)
+                    plan.frames.copy_(frames2)
+                    plan.run(None)
+                    d = plan.depth_m.clone()
+                    torch.cuda.synchronize(self.dev)
+                    del plan
+                    return d
+
+                wsites = sorted(order[:lo])
+                cands = sorted((k_ for k_ in wsites if k_ != "rh.conv2.w" and site_flops[k_] >= AUTO_NECK_PLAIN_MIN_SHARE * tot_f),
+                               key=lambda k_: -site_flops[k_])
+                a0 = (depth2(neck) - truth2).abs().mean().item()
+                plain, trail, a_now = [], {}, a0
+                for k_ in cands:
+                    d_p = depth2("wonly:" + ",".join(wsites) + ";plain:" + ",".join(sorted(plain + [k_])))
+                    a_ = (d_p - truth2).abs().mean().item()
+                    trail[k_] = round(a_, 8)
+                    if a_ <= AUTO_TOL_NECK_PLAIN_ABS_M:
+                        plain.append(k_)
+                        a_now, l1_abs = a_, (d_p[:1] - truth).abs().mean().item()
+                        total = (d_p[:1] - ref).abs().mean().item()
+                report["neck_sites"].update(plain_tol_abs_m=AUTO_TOL_NECK_PLAIN_ABS_M, l1_two_frames_weight_only_m=round(a0, 8),
+                                            l1_two_frames_with_site_plain_m=trail, plain=sorted(plain), l1_two_frames_m=round(a_now, 8),
+                                            flops_share_plain=round(sum(site_flops[k_] for k_ in plain) / tot_f, 4))
+                if plain:
+                    neck = "wonly:" + ",".join(wsites) + ";plain:" + ",".join(sorted(plain))
         if self.auto_attn and not corr_ok:
             # the split-precision kernel could not be tried on this geometry (every candidate above ran "single"): the engine keeps "corr",
             # which a plan of a capable geometry then uses and this one falls back from (_ZoePlan) -- "single" must be earned by a measurement
@@ -1001,7 +1054,8 @@ class _ZoePlan:
         def f8kw(wkey):
             sb0, sb1 = f8s[wkey]
             wonly = eng.neck_site_wonly(wkey)
-            return dict(f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1), f8_wonly_from=-1 if wonly else 0)
+            return dict(f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1), f8_wonly_from=-1 if wonly else 0,
+                        f8_skip_from=-1 if eng.neck_site_plain(wkey) else 0)
 
         def okw(Cout, out_pairs, out8):
             """output-format arguments of a neck GEMM writing Cout channels per row / pixel"""

@@ -134,7 +134,8 @@ typedef struct bs_gemm_desc {
     int32_t out_lo8_rows;          /* with out_f8, > 0: only output rows below this index store their lo8 plane (their consumer is a
                                     * GEMM with f8_wonly_from = this value, which never reads it on the other rows) */
     int32_t f8_skip_from;          /* with f8_seg, k > 0: tiles that start at a row >= k run NO FP8 stage (one 16-bit pass); their
-                                    * weight-rounding error is corrected by its token-independent part instead, see bias2 */
+                                    * weight-rounding error is corrected by its token-independent part instead, see bias2.  -1 = no tile
+                                    * runs one (a neck product the calibration took down to one pass; also with conv) */
     int32_t bias2_row0;            /* bias2 applies to rows m >= bias2_row0 ... */
     int32_t bias2_group_rows;      /* ... with group (m - bias2_row0) / bias2_group_rows (> 0 when bias2 is given) */
     int32_t out_planes_rows;       /* with out_f8, > 0: 256-row tiles that start at a row >= this store the hi16 values only (no FP8

@@ -121,3 +121,9 @@ def test_neck_mode_forms():
         e.neck_mode = mode
         got = (e.neck_site_wonly("fu3.r1.c1.w"), e.neck_site_wonly("rh.projection.w"), e.neck_site_wonly("ro2.w_cls"))
         assert got == expect, (mode, got)
+        assert not e.neck_site_plain("fu3.r1.c1.w") and not e.neck_site_plain("rh.projection.w")
+    # the second stage's form: one-pass sites are a subset of the weight-only ones (their producers skip the lo8 plane all the same); the fused
+    # up-convolution has no one-pass form and the per-image readout bias is never touched
+    e.neck_mode = "wonly:fu3.r1.c1.w,rh.conv1.w,rh.conv2.w,rh.projection.w;plain:rh.conv1.w,rh.conv2.w,rh.projection.w"
+    assert [e.neck_site_wonly(k) for k in ("fu3.r1.c1.w", "rh.conv1.w", "rh.conv2.w", "rh.projection.w", "nc0.w", "ro2.w_cls")] == [True, True, True, True, False, False]
+    assert [e.neck_site_plain(k) for k in ("fu3.r1.c1.w", "rh.conv1.w", "rh.conv2.w", "rh.projection.w", "nc0.w", "ro2.w_cls")] == [False, True, False, True, False, False]
