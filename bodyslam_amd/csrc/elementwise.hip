@@ -153,8 +153,9 @@ __global__ __launch_bounds__(256) void relu_split_kernel(const T* x, T* out, int
             v8 h = *reinterpret_cast<const v8*>(x + r * 2 * C + c);
             const unsigned char* pin = reinterpret_cast<const unsigned char*>(x + r * 2 * C + C);
             unsigned char* pout = reinterpret_cast<unsigned char*>(out + r * 2 * C + C);
-            // (f8 == 2: the lo8 plane is neither read nor written -- every consumer of the output is weight-only)
-            unsigned long long h8 = *reinterpret_cast<const unsigned long long*>(pin + c), l8 = f8 == 2 ? 0ull : *reinterpret_cast<const unsigned long long*>(pin + C + c);
+            // (f8 == 2: the lo8 plane is neither read nor written -- every consumer of the output is weight-only; f8 == 3: nor is the hi8 plane --
+            // every consumer runs one 16-bit pass)
+            unsigned long long h8 = f8 == 3 ? 0ull : *reinterpret_cast<const unsigned long long*>(pin + c), l8 = f8 >= 2 ? 0ull : *reinterpret_cast<const unsigned long long*>(pin + C + c);
             unsigned long long mask = 0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -163,8 +164,8 @@ __global__ __launch_bounds__(256) void relu_split_kernel(const T* x, T* out, int
                 mask |= pos ? (0xffull << (8 * e)) : 0ull;
             }
             *reinterpret_cast<v8*>(out + r * 2 * C + c) = h;
-            *reinterpret_cast<unsigned long long*>(pout + c) = h8 & mask;
-            if (f8 != 2) *reinterpret_cast<unsigned long long*>(pout + C + c) = l8 & mask;
+            if (f8 != 3) *reinterpret_cast<unsigned long long*>(pout + c) = h8 & mask;
+            if (f8 < 2) *reinterpret_cast<unsigned long long*>(pout + C + c) = l8 & mask;
             continue;
         }
         v8 h = *reinterpret_cast<const v8*>(x + r * 2 * C + c), l = *reinterpret_cast<const v8*>(x + r * 2 * C + C + c);
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256) void pre_image_kernel(const uint8_t* frames, f
 // (hi16 | hi8 | lo8) pixels, 16 channels per thread: every access is 16 bytes wide (two for the hi16 values, one per FP8 plane);
 // the x2 upsampling of the fusion stage / relative head writes 6-13 GB per call at the bench batch
 // LO: also write the lo8 plane (false: every consumer of the map drops the activation-rounding correction and never reads it)
-template <typename T, bool LO = true>
+template <typename T, bool LO = true, bool HI8 = true>
 __global__ __launch_bounds__(256) void resize_nhwc_f8_kernel(const T* x, T* out, int B, int Hin, int Win, int C, int Hout, int Wout, float sy,
                                                               float sx, int align) {
     const int c16n = C >> 4;
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(256) void resize_nhwc_f8_kernel(const T* x, T* out,
     T* op = out + pix * C * 2;
     *reinterpret_cast<v8*>(op + c16 * 16) = o0;
     *reinterpret_cast<v8*>(op + c16 * 16 + 8) = o1;
+    if (!HI8) return;       // (hi16 | - | -): every consumer of the map runs one 16-bit pass
     const float sh = __builtin_ldexpf(1.0f, F8_ACT_HI_EXP), sl = __builtin_ldexpf(1.0f, F8_ACT_LO_EXP);
     char* planes = reinterpret_cast<char*>(op + C);
     i32x4 ph, pl;
@@ -819,9 +821,11 @@ static int launch_resize(const void* x, const void* addend, void* out, int B, in
         sx = (float)Win / (float)Wout;
     }
     const dim3 blocks(cdiv(Wout * (C / 8), 256), B * Hout);
-    if (split == 2 || split == 3) {      // (hi16 | hi8 | lo8) pixels (no add variant: the bins head's embeddings stay 16-bit pairs); 3: no lo8 plane out
+    if (split >= 2 && split <= 4) {      // (hi16 | hi8 | lo8) pixels (no add variant: the bins head's embeddings stay 16-bit pairs); 3: no lo8 plane out; 4: no plane out
         const dim3 blocks16(cdiv(Wout * (C / 16), 256), B * Hout);
-        if (split == 3)
+        if (split == 4)
+            hipLaunchKernelGGL((resize_nhwc_f8_kernel<T, false, false>), blocks16, dim3(256), 0, st, (const T*)x, (T*)out, B, Hin, Win, C, Hout, Wout, sy, sx, align);
+        else if (split == 3)
             hipLaunchKernelGGL((resize_nhwc_f8_kernel<T, false>), blocks16, dim3(256), 0, st, (const T*)x, (T*)out, B, Hin, Win, C, Hout, Wout, sy, sx, align);
         else
             hipLaunchKernelGGL((resize_nhwc_f8_kernel<T, true>), blocks16, dim3(256), 0, st, (const T*)x, (T*)out, B, Hin, Win, C, Hout, Wout, sy, sx, align);
@@ -1041,8 +1045,9 @@ extern "C" int bs_resize_bilinear_nhwc(const void* x, void* out, int32_t B, int3
     BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_resize_bilinear_nhwc: dtype");
     if (B == 0) return BS_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    // bit 1: (hi | lo) 16-bit pairs; bit 2: (hi16 | hi8 | lo8); bit 3 (with bit 2): the output's lo8 plane is not written (no consumer reads it)
-    const int split = (align_corners & 4) ? ((align_corners & 8) ? 3 : 2) : ((align_corners & 2) ? 1 : 0);
+    // bit 1: (hi | lo) 16-bit pairs; bit 2: (hi16 | hi8 | lo8); bit 3 (with bit 2): the output's lo8 plane is not written (no consumer reads it);
+    // bit 4 (with bit 2): neither plane is (every consumer runs one 16-bit pass)
+    const int split = (align_corners & 4) ? ((align_corners & 16) ? 4 : ((align_corners & 8) ? 3 : 2)) : ((align_corners & 2) ? 1 : 0);
     const int ac = align_corners & 1;
     BS_REQUIRE(split < 2 || C % 16 == 0, "bs_resize_bilinear_nhwc: the FP8 pair format needs C %% 16 == 0");
     return dtype == BS_F16 ? launch_resize<f16>(x, nullptr, out, B, Hin, Win, C, Hout, Wout, ac, st, split)
@@ -1124,7 +1129,8 @@ extern "C" int bs_cast_split(const float* x, void* out, int64_t rows, int32_t co
 extern "C" int bs_relu_split(const void* x, void* out, int64_t rows, int32_t cols, int32_t dtype, void* stream) {
     BS_ENTRY("bs_relu_split");
     BS_REQUIRE(x && out && rows >= 0 && cols > 0 && cols % 8 == 0, "bs_relu_split: cols must be a multiple of 8");
-    const int f8 = (dtype & 32) ? ((dtype & 64) ? 2 : 1) : 0;     // bit 5: (hi16 | hi8 | lo8) rows; bit 6 (with bit 5): without the lo8 plane
+    // bit 5: (hi16 | hi8 | lo8) rows; bit 6 (with bit 5): without the lo8 plane; bit 7 (with bit 5): without either plane
+    const int f8 = (dtype & 32) ? ((dtype & 128) ? 3 : ((dtype & 64) ? 2 : 1)) : 0;
     dtype &= 15;
     BS_REQUIRE(dtype == BS_F16 || dtype == BS_BF16, "bs_relu_split: dtype");
     if (rows == 0) return BS_OK;

@@ -149,7 +149,8 @@ __device__ __forceinline__ void store8(void* base, int64_t off, int out_dtype, c
 // e4m3((y - hi) * 2^el) in the lo8 plane.  Planes (in 16-bit element units from the row start): hi16 [0, N), hi8 [N, N + N/2),
 // lo8 [N + N/2, 2N).  `off` = row start + n, plane_off = N (= split_off).
 template <typename T>
-__device__ __forceinline__ void store8_f8(void* base, int64_t row_off, int n, int plane_off, const float (&y)[8], int ea, int el, bool lo = true) {
+__device__ __forceinline__ void store8_f8(void* base, int64_t row_off, int n, int plane_off, const float (&y)[8], int ea, int el, bool lo = true,
+                                          bool hi8 = true) {
     typedef typename T16<T>::v8 v8;
     typedef int i32x2 __attribute__((ext_vector_type(2)));
     // (two values per instruction for the scalings, one v_med3_f32 for each clamp: the epilogues that emit planes are VALU-bound)
@@ -166,6 +167,7 @@ __device__ __forceinline__ void store8_f8(void* base, int64_t row_off, int n, in
     }
     T* rowp = reinterpret_cast<T*>(base) + row_off;
     *reinterpret_cast<v8*>(rowp + n) = h;
+    if (!hi8) return;   // (wave-uniform) a map whose every consumer runs one 16-bit pass: no plane is read
     int ph0 = 0, ph1 = 0;
     ph0 = __builtin_amdgcn_cvt_pk_fp8_f32(yh[0][0], yh[0][1], ph0, false);
     ph0 = __builtin_amdgcn_cvt_pk_fp8_f32(yh[1][0], yh[1][1], ph0, true);
@@ -817,6 +819,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                 const int ea = p.out_f8 & 0xff, el = (p.out_f8 >> 8) & 0xff;
                 // (tile-uniform) no lo8 plane past out_lo8_rows: every consumer of this map drops the activation-rounding correction
                 const bool lo_plane = !(p.out_lo8_rows > 0 && m0 >= p.out_lo8_rows);
+                // ... and no plane at all past out_planes_rows: every consumer runs one 16-bit pass (the calibration's "plain" sites)
+                const bool hi_plane = !(p.out_planes_rows > 0 && m0 >= p.out_planes_rows);
                 const float lsc = __builtin_ldexpf(1.0f, -BS_F8_ACT_LO_EXP);
                 auto body = [&](auto nres_tag) {
                     constexpr int NRES = decltype(nres_tag)::value;
@@ -866,7 +870,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
                             }
                             if (it + RDEPTH < NP) issue(it + RDEPTH, it % RDEPTH);
                         }
-                        if (m < p.M) store8_f8<T>(p.out, (int64_t)m * p.ldo, n_wave + jp * 32 + fq * 8, p.split_off, y8, ea, el, lo_plane);
+                        if (m < p.M) store8_f8<T>(p.out, (int64_t)m * p.ldo, n_wave + jp * 32 + fq * 8, p.split_off, y8, ea, el, lo_plane && hi_plane, hi_plane);
                         if (p.out2_relu) {      // (wave-uniform) the ReLU'd copy the next residual unit's first convolution reads
 #pragma unroll
                             for (int e = 0; e < 8; ++e) y8[e] = fmaxf(y8[e], 0.0f);

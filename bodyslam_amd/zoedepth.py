@@ -1087,6 +1087,11 @@ class _ZoePlan:
             every one of them runs the weight-rounding correction only -- nobody reads that plane then, the epilogue need not form it"""
             return 256 if (acc and nf8 and all(k_ in f8s and eng.neck_site_wonly(k_) for k_ in consumer_wkeys)) else 0
 
+        def hi8_rows(*consumer_wkeys):
+            """out_planes_rows of a producer whose output is read only by the named products: 256 (the first tile alone writes its planes) when every
+            one of them runs ONE 16-bit pass (the calibration's "plain" sites) -- nobody reads the hi8 plane either"""
+            return 256 if (acc and nf8 and all(k_ in f8s and eng.neck_site_plain(k_) for k_ in consumer_wkeys)) else 0
+
         def nconv(name, A, wkey, out, hh, ww, Ci, Co, stride=1, **kw):
             use8 = acc and wkey in f8s
             g_ = L.conv_geom(hh, ww, Ci if use8 else Ci * m2, 3, 3, stride, 1)
@@ -1231,8 +1236,9 @@ class _ZoePlan:
                 if xr is None:
                     xr = e16(NB, hh, ww, PE(Fc))
                     # (bit 6: no lo8 plane when the first convolution, the only reader, is weight-only)
-                    P.add(name + ".relu", "bs_relu_split", xin, xr, NB * hh * ww, Fc, L.dt(xr) | (32 if nf8 else 0) | (64 if lo8_rows(name + ".c1.w") else 0))
-                nconv(name + ".c1", xr, name + ".c1.w", t, hh, ww, Fc, Fc, bias=w[name + ".c1.b"], act=L.ACT_RELU, out_lo8_rows=lo8_rows(name + ".c2.w"))
+                    P.add(name + ".relu", "bs_relu_split", xin, xr, NB * hh * ww, Fc, L.dt(xr) | (32 if nf8 else 0) | (64 if lo8_rows(name + ".c1.w") else 0) | (128 if hi8_rows(name + ".c1.w") else 0))
+                nconv(name + ".c1", xr, name + ".c1.w", t, hh, ww, Fc, Fc, bias=w[name + ".c1.b"], act=L.ACT_RELU, out_lo8_rows=lo8_rows(name + ".c2.w"),
+                      out_planes_rows=hi8_rows(name + ".c2.w"))
                 free(xr)
             else:
                 nconv(name + ".c1", xin, name + ".c1.w", t, hh, ww, Fc, Fc, relu_a=True, bias=w[name + ".c1.b"], act=L.ACT_RELU)
@@ -1278,7 +1284,8 @@ class _ZoePlan:
             # (the last fused map is read by the relative head's first convolution only: when that product is weight-only the resize does not
             # form the lo8 plane -- flag bit 3 -- and the tap's format code says so: 3 = (hi16 | hi8 | -))
             nolo = bool(li == 3 and pj_lowres and lo8_rows("rh.projection.w" if eng.add_projection else "rh.conv1.w"))
-            P.add(f"fu{li}.up", "bs_resize_bilinear_nhwc", lowp, fused, NB, fh, fw, Fc, 2 * fh, 2 * fw, RZ | (8 if nolo else 0), L.dt(fused))
+            nopl = bool(nolo and hi8_rows("rh.projection.w" if eng.add_projection else "rh.conv1.w"))
+            P.add(f"fu{li}.up", "bs_resize_bilinear_nhwc", lowp, fused, NB, fh, fw, Fc, 2 * fh, 2 * fw, RZ | (8 if nolo else 0) | (16 if nopl else 0), L.dt(fused))
             free(lowp)
             P.mark(f"fused{li}", fused, ("nhwc", NB, 2 * fh, 2 * fw, Fc, 3 if nolo else mfmt(Fc)))
             fused_list.append((fused, 2 * fh, 2 * fw))

@@ -139,7 +139,7 @@ typedef struct bs_gemm_desc {
     int32_t bias2_row0;            /* bias2 applies to rows m >= bias2_row0 ... */
     int32_t bias2_group_rows;      /* ... with group (m - bias2_row0) / bias2_group_rows (> 0 when bias2 is given) */
     int32_t out_planes_rows;       /* with out_f8, > 0: 256-row tiles that start at a row >= this store the hi16 values only (no FP8
-                                    * plane: their consumer sets f8_skip_from to this value) */
+                                    * plane: their consumer sets f8_skip_from to this value, or -1 with 256 here) */
     const float* bias2;            /* optional fp32 [groups, N], added like the bias: y = acc + bias[n] + bias2[group, n].  The backbone
                                     * uses it for the rank-1 part of the weight-rounding error of a single-pass product:
                                     * A dW^T ~ 1 (mean_tokens(A) dW^T) per image (Numerics); excludes bias_group_rows */
@@ -208,7 +208,8 @@ int bs_copy_f32(const float* src, float* dst, int64_t n, void* stream);
  * bit 1 of align_corners is set; bs_logbinom_depth takes a (hi | lo) `last` when bit 4 of dtype is set.
  * With `| 32` on the dtype argument (bit 2 of align_corners for the resize) the same calls work on the (hi16 | hi8 | lo8)
  * format of the FP8 correction passes (BS_F8_ACT_*_EXP above); bs_relu_split with `| 32 | 64` leaves the lo8 plane alone (neither read
- * nor written: an output whose only reader runs the weight-rounding correction only). */
+ * nor written: an output whose only reader runs the weight-rounding correction only), with `| 32 | 128` both FP8 planes (its only reader
+ * runs one 16-bit pass). */
 int bs_cast_split(const float* x, void* out, int64_t rows, int32_t cols, int32_t out_dtype, void* stream);
 int bs_relu_split(const void* x, void* out, int64_t rows, int32_t cols, int32_t dtype, void* stream);
 
@@ -232,7 +233,8 @@ int bs_fill_rows(float* x, const float* v, int32_t B, int32_t rows_per_image, in
 
 /* bilinear resize of an NHWC fp16/bf16 map -- F.interpolate calls at HF modeling_zoedepth.py:259,319,360.  `align_corners`: bit 0 the flag itself,
  * bit 1 the tensors hold (hi | lo) 16-bit pairs, bit 2 (hi16 | hi8 | lo8) rows, bit 3 (with bit 2) the OUTPUT's lo8 plane is not written (for a map
- * whose every consumer runs the weight-rounding correction only: nobody reads that plane) */
+ * whose every consumer runs the weight-rounding correction only: nobody reads that plane), bit 4 (with bit 2) neither FP8 plane is (every consumer
+ * runs one 16-bit pass) */
 int bs_resize_bilinear_nhwc(const void* x, void* out, int32_t B, int32_t Hin, int32_t Win, int32_t C,
                             int32_t Hout, int32_t Wout, int32_t align_corners, int32_t dtype, void* stream);
 

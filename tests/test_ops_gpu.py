@@ -381,6 +381,27 @@ def test_f8_correction_conv(L, tile):
     planes = outr[..., Co:].contiguous().view(torch.uint8).view(B, H, Wd, 2 * Co)
     hi8r = planes[..., :Co].contiguous().view(torch.float8_e4m3fn).float() * 2.0 ** -L.F8_ACT_HI_EXP
     assert (hi8r - hr).abs().max().item() <= 0.07 * hr.abs().max().item() + 1e-2
+    # f8_skip_from = -1 (a product the calibration took down to ONE 16-bit pass): no FP8 stage runs -- the hi16 values of the single-pass product of the
+    # hi16 operands -- and out_planes_rows = 256 with it (the producer of a map every consumer of which runs one pass): tiles past row 256 write
+    # hi16 only, their plane bytes stay as they were
+    M = B * H * Wd
+    out_p = torch.full((B, H, Wd, 2 * Co), 7.0, device=dev(), dtype=dtype)
+    L.gemm(x8, W8, out_p, M=M, N=Co, K=9 * C, lda=2 * C, conv=g, f8_seg=2 * C, f8_scales=sc, f8_skip_from=-1, f8_wonly_from=-1,
+           ldo=2 * Co, out_split_off=Co, out_f8=(L.F8_ACT_HI_EXP, L.F8_ACT_LO_EXP), out_lo8_rows=256, out_planes_rows=256, tile=tile)
+    xh = x8[..., :C].contiguous()                                                   # the hi16 plane as a plain NHWC map
+    w16 = L.conv_weight(w.permute(0, 2, 3, 1)).to(dtype)
+    one = torch.empty(B, H, Wd, Co, device=dev())
+    L.gemm(xh, w16, one, M=M, N=Co, K=9 * C, lda=C, conv=L.conv_geom(H, Wd, C, 3, 3, 1, 1), tile=tile)
+    ref1 = F.conv2d(xh.double().permute(0, 3, 1, 2), w.to(dtype).double(), padding=1).permute(0, 2, 3, 1)
+    hp = out_p.view(M, 2 * Co)[:, :Co].float()
+    assert (hp.double() - ref1.reshape(M, Co)).abs().max().item() < 2.0 ** -10 * (ref1.abs().max().item() + 1.0)
+    assert (hp - one.view(M, Co)).abs().max().item() <= 2.0 ** -10 * (one.abs().max().item() + 1.0)          # (the same product, rounded to 16 bits)
+    seven = torch.full((1,), 7.0, dtype=dtype).view(torch.uint8).to(dev())
+    first_tile = 256                                                                # rows of the tiles that start below row 256 (128- or 256-row tiles)
+    rows_hi_only = out_p.view(M, 2 * Co)[256:].contiguous().view(torch.uint8).view(-1, 4 * Co)
+    assert torch.equal(rows_hi_only[:, 2 * Co:], seven.repeat(Co).expand(rows_hi_only.shape[0], 2 * Co))     # neither plane written past row 256
+    head = out_p.view(M, 2 * Co)[:first_tile].contiguous().view(torch.uint8).view(-1, 4 * Co)
+    assert not torch.equal(head[:, 2 * Co:3 * Co], seven.repeat(Co // 2).expand(first_tile, Co))             # the first tile keeps its hi8 plane
 
 
 def test_split_precision_conv(L):
@@ -882,12 +903,16 @@ def test_relu_split_f8_without_lo8_plane(L):
     full = torch.zeros(rows, 2 * C, device=dev(), dtype=dtype)
     part = torch.full((rows, 2 * C), 7.0, device=dev(), dtype=dtype)
     from bodyslam_amd._lib import load_library, check, p as ptr, dt as dtc, stream_ptr
-    for out, bits in ((full, 32), (part, 32 | 64)):
+    none = torch.full((rows, 2 * C), 7.0, device=dev(), dtype=dtype)
+    for out, bits in ((full, 32), (part, 32 | 64), (none, 32 | 128)):
         check(load_library().bs_relu_split(ptr(x8), ptr(out), rows, C, dtc(out) | bits, stream_ptr()), "bs_relu_split")
     fb, pb = full.view(torch.uint8).view(rows, 4 * C), part.view(torch.uint8).view(rows, 4 * C)
     assert torch.equal(fb[:, :3 * C], pb[:, :3 * C]) and (full[:, :C].float() >= 0).all()
     seven = torch.full((1,), 7.0, dtype=dtype).view(torch.uint8).to(dev())
     assert torch.equal(pb[:, 3 * C:], seven.repeat(C // 2).expand(rows, C))
+    # bits 5 | 7: hi16 alone (the only reader runs one 16-bit pass)
+    nb = none.view(torch.uint8).view(rows, 4 * C)
+    assert torch.equal(nb[:, :2 * C], fb[:, :2 * C]) and torch.equal(nb[:, 2 * C:], seven.repeat(C).expand(rows, 2 * C))
 
 
 def test_resize_f8_without_lo8_plane(L):
@@ -900,8 +925,12 @@ def test_resize_f8_without_lo8_plane(L):
     full = torch.zeros(B, 2 * H, 2 * W, 2 * C, device=dev(), dtype=dtype)
     part = torch.full((B, 2 * H, 2 * W, 2 * C), 7.0, device=dev(), dtype=dtype)
     from bodyslam_amd._lib import load_library, check, p as ptr, dt as dtc, stream_ptr
-    for out, flags in ((full, 1 | 4), (part, 1 | 4 | 8)):
+    none = torch.full((B, 2 * H, 2 * W, 2 * C), 7.0, device=dev(), dtype=dtype)
+    for out, flags in ((full, 1 | 4), (part, 1 | 4 | 8), (none, 1 | 4 | 8 | 16)):
         check(load_library().bs_resize_bilinear_nhwc(ptr(x8), ptr(out), B, H, W, C, 2 * H, 2 * W, flags, dtc(out), stream_ptr()), "bs_resize_bilinear_nhwc")
+    nb_ = none.view(torch.uint8).view(B, 2 * H, 2 * W, 4 * C)                     # flag bit 4: hi16 alone
+    assert torch.equal(nb_[..., :2 * C], full.view(torch.uint8).view(B, 2 * H, 2 * W, 4 * C)[..., :2 * C])
+    assert torch.equal(nb_[..., 2 * C:], torch.full((1,), 7.0, dtype=dtype).view(torch.uint8).to(dev()).repeat(C).expand(B, 2 * H, 2 * W, 2 * C))
     fb, pb = full.view(torch.uint8).view(B, 2 * H, 2 * W, 4 * C), part.view(torch.uint8).view(B, 2 * H, 2 * W, 4 * C)
     assert torch.equal(fb[..., :3 * C], pb[..., :3 * C])                      # hi16 (2C bytes) and hi8 (C bytes)
     seven = torch.full((1,), 7.0, dtype=dtype).view(torch.uint8).to(dev())
