@@ -19,6 +19,7 @@ python3 tools/bench_kernels.py --nb 128 2>/dev/null > $OUT/${TAG}_bench_kernels.
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_like_n1.json 2> $OUT/driver_like.err
 python3 bench.py --weights outlier --single-mode --no-pmc-traffic --no-slam-loop > $OUT/${TAG}_bench_outlier_weights.json 2> $OUT/outlier.err
 python3 tools/probes/neck_site_study.py 0 5 > $OUT/${TAG}_neck_site_study.txt 2>/dev/null
+python3 tools/probes/neck_plain_study.py 0 2>/dev/null > $OUT/${TAG}_neck_plain_study.txt
 python3 tools/probes/upconv_fused_time.py > $OUT/${TAG}_upconv_fused.txt 2>/dev/null
 ABLATE=1 python3 tools/probes/upconv_fused_time.py >> $OUT/${TAG}_upconv_fused.txt 2>/dev/null
 python3 tools/probes/attn_ablate.py > $OUT/${TAG}_attention_ablations.txt 2>/dev/null
