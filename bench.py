@@ -96,9 +96,14 @@ class PowerSampler:
     """Board power and shader clock from the amdgpu hwmon files, sampled by a host thread every 25 ms over a timed region (no GPU call; best effort:
     `result()` is None where the files are not readable).  With several boards in sysfs the one drawing the most over the region is reported."""
 
-    def __init__(self):
+    def __init__(self, pci: str = None):
         import glob
         self.nodes = [h for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")) if self._rd(os.path.join(h, "name")) == "amdgpu"]
+        # this process's board: the hwmon node under the PCI function torch reports for the device (a box shares its sysfs with the other tenants' GPUs)
+        mine = [h for h in self.nodes if pci and os.path.realpath(os.path.join(h, "..", "..")).lower().endswith(pci.lower())]
+        self.matched = bool(mine)
+        if mine:
+            self.nodes = mine
         self.rows = {h: [] for h in self.nodes}
         self._stop = False
         self._thread = None
@@ -144,6 +149,7 @@ class PowerSampler:
         cap = self._rd(os.path.join(h, "power1_cap"))
         return {"median_w": round(med, 1), "max_w": round(max(r[0] for r in rows), 1), "cap_w": float(cap) / 1e6 if cap and cap.isdigit() else None,
                 "sclk_mhz_median": round(fq[len(fq) // 2], 1) if fq else None, "samples": len(rows),
+                "board": "the device's PCI function" if self.matched else "the board drawing the most (PCI function not matched)",
                 "source": "amdgpu hwmon power1_average / freq1_input, 25 ms samples over the timed steps (host thread)"}
 
 
@@ -319,7 +325,11 @@ def main():
         for k in range(Wm):
             step(k, False)
         barrier()
-        sampler = PowerSampler().start() if rank == 0 else None
+        sampler = None
+        if rank == 0:
+            pr = torch.cuda.get_device_properties(local_rank)
+            pci = ("%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)) if hasattr(pr, "pci_bus_id") else None
+            sampler = PowerSampler(pci).start()
         t0 = time.perf_counter()
         for k in range(Wm, Wm + K):
             step(k, not args.no_kernel_timing)

@@ -43,24 +43,34 @@ def main():
         print("no amdgpu hwmon node readable: falling back to rocm-smi once")
         print(subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showmaxpower"], capture_output=True, text=True).stdout[-3000:])
         return
-    h = hs[0]
-    for name in ("power1_cap", "power1_cap_max", "power1_cap_default"):
-        v = rd(os.path.join(h, name))
-        print(f"{name}: {float(v) / 1e6 if v and v.isdigit() else v} W")
-    print("idle:", sample(h))
+    idle = {h: sample(h) for h in hs}
     args = [sys.executable, os.path.join(ROOT, "bench.py"), "--single-mode", "--no-slam-loop", "--no-pmc-traffic", "--no-outlier-leg", "--no-pcie-leg",
             "--steps", "12", "--warmup", "2"] + sys.argv[1:]
     t0 = time.time()
     child = subprocess.Popen(args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd=ROOT)
-    rows = []
+    allrows = {h: [] for h in hs}
     while child.poll() is None:
-        rows.append((time.time() - t0,) + sample(h))
+        t = time.time() - t0
+        for h in hs:
+            allrows[h].append((t,) + sample(h))
         time.sleep(0.02)
+    # the box's sysfs shows every tenant's board: ours is the one whose power rose the most over its idle reading while the child ran
+    def rise(h):
+        pw = sorted(r[1] for r in allrows[h] if r[1] is not None)
+        return (pw[int(0.9 * len(pw))] - (idle[h][0] or 0.0)) if pw else -1.0
+    h = max(hs, key=rise)
+    rows = allrows[h]
+    print(f"board: {h} (90th-percentile power {rise(h):.0f} W above its idle reading; the others: {sorted(round(rise(o)) for o in hs if o != h)})")
+    for name in ("power1_cap", "power1_cap_max", "power1_cap_default"):
+        v = rd(os.path.join(h, name))
+        print(f"{name}: {float(v) / 1e6 if v and v.isdigit() else v} W")
+    print("idle:", idle[h])
     line = child.stdout.read().strip().splitlines()[-1] if child.stdout else ""
     import json
     try:
         d = json.loads(line)
         print(f"bench: {d['value']} frames/s, {d['ms_per_step']} ms per step, dominant-kernel frac {d['roofline']['frac']}")
+        print(f"bench line's own reading over its timed steps (the board of the device's PCI function): {d.get('power')}")
     except Exception:
         print("bench line unreadable:", line[-300:])
     busy = [r for r in rows if r[1] is not None and r[1] > 0.5 * max(x[1] for x in rows if x[1] is not None)]
