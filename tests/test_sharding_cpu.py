@@ -161,3 +161,36 @@ def test_calibration_failure_on_rank0_raises_everywhere(tmp_path):
     m0, m1 = (open(tmp_path / f"fail_{r}").read() for r in range(2))
     assert m0.startswith("MemoryError") and "reference engine does not fit" in m0
     assert m1.startswith("RuntimeError") and "reference engine does not fit" in m1
+
+
+def test_bench_power_sampler_reads_its_own_board(tmp_path, monkeypatch):
+    """bench.py's `power` key: the hwmon node under the device's PCI function is the one sampled (a box's sysfs shows every tenant's GPU),
+    median / maximum / cap / clock come out in W and MHz, and a host without readable nodes yields None"""
+    import glob
+    import time
+    import bench
+    nodes = []
+    for i, (pci, watts, mhz) in enumerate((("0000:05:00.0", 300, 150), ("0000:85:00.0", 1300, 2100))):
+        dev_dir = tmp_path / "devices" / pci
+        hw = dev_dir / "hwmon" / f"hwmon{i}"
+        hw.mkdir(parents=True)
+        (hw / "name").write_text("amdgpu\n")
+        (hw / "power1_average").write_text(f"{watts * 1000000}\n")
+        (hw / "freq1_input").write_text(f"{mhz * 1000000}\n")
+        (hw / "power1_cap").write_text("1400000000\n")
+        card = tmp_path / "drm" / f"card{i}"
+        card.mkdir(parents=True)
+        (card / "device").symlink_to(dev_dir, target_is_directory=True)
+        nodes.append(str(card / "device" / "hwmon" / f"hwmon{i}"))
+    monkeypatch.setattr(glob, "glob", lambda pattern: list(nodes) if "hwmon" in pattern else [])
+    s = bench.PowerSampler("0000:05:00.0").start()          # the quieter board is ours: matched by PCI function, not by power
+    time.sleep(0.2)
+    r = s.result()
+    assert r["median_w"] == 300.0 and r["max_w"] == 300.0 and r["cap_w"] == 1400.0 and r["sclk_mhz_median"] == 150.0
+    assert r["board"] == "the device's PCI function" and r["samples"] >= 4
+    s = bench.PowerSampler(None).start()                    # no PCI function known: the board drawing the most, and the line says so
+    time.sleep(0.2)
+    r = s.result()
+    assert r["median_w"] == 1300.0 and "not matched" in r["board"]
+    monkeypatch.setattr(glob, "glob", lambda pattern: [])
+    assert bench.PowerSampler("0000:05:00.0").start().result() is None
