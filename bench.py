@@ -31,7 +31,9 @@ roofline: per-kernel HIP-event timing of every bs_gemm launch inside the timed s
 kernel instantiation (tile variant x conv/plain); the dominant one by time is reported against the dense
 fp16/bf16 MFMA peak (2.5 PFLOP/s), next to the conv-stack aggregate the north star names.  `achieved` counts algorithmic
 FLOPs (2*M*N*K of the product computed), `executed` the MFMA work issued in 16-bit-equivalents (2x in accurate mode).
-cpu_baseline: the CPU oracle (torch fp32, all host cores) on ONE frame of the same workload, rank 0 only.
+cpu_baseline: the CPU oracle (torch fp32, up to 32 host threads) on EIGHT frames of the same workload, rank 0 only, taken BEFORE this
+process touches the GPU (round 6: after the GPU legs it read 0.19-0.55 frames/s depending on what had run).  The same eight oracle depth
+maps are the yardstick of `depth_l1_frames`: eight frames spread over the timed steps, copied out of the timed plan's output.
 """
 import argparse
 import json
@@ -46,6 +48,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+CONV_STACK_GFLOP_PER_FORWARD = 233.6   # neck + relative head + metric head + patch-embed convolutions of ONE ZoeD_NK forward
+                                       # at 384x512 (2 x MACs of the reference's own formulation); scales with the network input's pixels
+N_CHECK_FRAMES = 8                     # frames of the timed steps compared with the CPU oracle (depth_l1_frames)
 TILE_NAMES = {1: "128x128x64s2", 2: "128x64x64s2", 3: "128x32x64s2", 9: "256x256x64s2", 10: "256x256x32s4pp", 11: "256x128x32s3"}   # csrc/igemm.hip
 
 
@@ -67,7 +72,7 @@ def measure_pmc_traffic(args):
                    "python3", os.path.join(ROOT, "bench.py"), "--single-mode", "--precision", args.precision, "--steps", "1", "--warmup", "0",
                    "--batch", str(args.batch), "--dtype", args.dtype, "--height", str(args.height), "--width", str(args.width),
                    "--weights", args.weights, "--no-cpu-baseline", "--no-kernel-timing", "--no-pmc-traffic", "--no-slam-loop", "--no-outlier-leg",
-                   "--no-pcie-leg"]
+                   "--no-pcie-leg", "--no-latency-leg"]
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             path = None
             for dp, _, fns in os.walk(tmp):
@@ -191,7 +196,9 @@ def main():
                     help="statistics of the random-init ZoeDepth weights (bodyslam_amd.synthetic.WEIGHT_VARIANTS): 'outlier' = 6 channels 50x larger "
                          "behind every LayerNorm, what a trained BEiT carries -- the calibration then has to switch corrections back on")
     ap.add_argument("--no-outlier-leg", action="store_true", help="skip the extra `outlier_weights` figure (the accurate mode on outlier-channel weights)")
+    ap.add_argument("--no-latency-leg", action="store_true", help="skip the extra `latency_b1_ms` figures (one frame / one pair per call, the reference's call pattern)")
     ap.add_argument("--no-pcie-leg", action="store_true", help="skip the extra `pcie_inclusive` figure (frames from pinned host memory, results copied back)")
+    ap.add_argument("--no-latency-leg", action="store_true", help="skip the extra `latency_b1_ms` figures (one frame / one pair per call: the reference's call pattern)")
     ap.add_argument("--no-pmc-traffic", action="store_true",
                     help="skip the two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic")
     args = ap.parse_args()
@@ -219,12 +226,7 @@ def main():
             sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
         args.gpus = world
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
     use_dist = world > 1 or "RANK" in os.environ        # under torch.distributed.run the RCCL path is exercised even at N=1
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from bodyslam_amd import _lib as L
     from bodyslam_amd import geom3d
@@ -260,7 +262,8 @@ def main():
     else:
         n_frames = (K + Wm) * B + 1
         if world == 1:
-            frames = torch.from_numpy(make_sequence(n_frames, H, W, seed=0)).to(dev)     # resident in HBM
+            # (rank 0 at N = 1 with the CPU baseline: the sequence is made on the host first, the oracle reads it, THEN it goes to HBM -- below)
+            frames = None
         else:
             # ONE sequence of world x (K + Wm) x B frames (+ the frame before it): step k hands rank r the block of B frames that
             # follows rank r - 1's (its one-frame halo is that block's last frame), so the gathered relatives of a step chain into
@@ -268,15 +271,61 @@ def main():
             from bodyslam_amd.synthetic import make_sequence_at
             total, idx = weak_frame_indices(K + Wm, B, world, rank)
             frames = torch.from_numpy(make_sequence_at(idx, total, H, W, seed=0)).to(dev)
-    pairs = torch.tensor([[i, i + 1] for i in range(B)], dtype=torch.int32, device=dev)
     counts = [B] * world
+
+    def check_samples(K_, Wm_):
+        """the (timed step, frame in its batch) pairs whose depth maps are copied out of the timed plan and compared with the oracle:
+        N_CHECK_FRAMES of them, spread over the timed steps and over the batch"""
+        n = N_CHECK_FRAMES
+        if strong:
+            return [(K_ - 1, (j * 37) % B) for j in range(n)]
+        return sorted({(Wm_ + (j * K_) // n, (j * (B // n) + 3 * j) % B) for j in range(n)})
+
+    # ---- CPU baseline + the oracle's depth maps of the check frames: BEFORE this process touches the GPU (rank 0 at N = 1: the contract)
+    cpu, oracle_d, ncores = None, {}, None
+    do_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not strong
+    if do_cpu:
+        from oracle import cyclepose_ref as CP
+        from oracle import geom3d_ref as G
+        from oracle import zoedepth_ref as Z
+        # torch CPU ops stop scaling (and then collapse) far below a 256-thread host: use at most 32 threads
+        ncores = min(os.cpu_count() or 1, 32)
+        torch.set_num_threads(ncores)
+        frames_host = torch.from_numpy(make_sequence(n_frames, H, W, seed=0))
+        tcpu = 0.0
+        for (k_, j_) in check_samples(K, Wm):
+            i0 = k_ * B + 1 + j_                                  # index into the sequence: step k's chunk is frames[k*B : (k+1)*B + 1], halo first
+            f2 = frames_host[i0 - 1: i0 + 1]
+            tc = time.perf_counter()
+            with torch.no_grad():
+                d_ref = Z.infer_depth(wz, Z.ZOED_NK, f2[1:2], flip_aug=True)
+                T = CP.forward_pose(wp, CP.center_crop_pair(f2, torch.tensor([[0, 1]])))
+            g_ref = G.pose_chain(T.numpy())
+            G.backproject(Z.to_uint16(d_ref)[0], pose=g_ref[1])
+            tcpu += time.perf_counter() - tc
+            oracle_d[(k_, j_)] = d_ref[0]
+        cpu = dict(value=round(len(oracle_d) / tcpu, 4), unit="frames/s", cores=ncores, kind="port",
+                   sample=f"{len(oracle_d)} frames {W}x{H} of the timed sequence, each: ZoeD_NK x2 (flip-aug) + 1 CyclePose pair + chain + back-projection, "
+                          f"torch fp32 oracle, {tcpu:.1f} s in all, taken before the process's first GPU call")
+    # ---- from here on the GPU
+    torch.cuda.set_device(local_rank)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if do_cpu:
+        frames = frames_host.to(dev)
+        del frames_host
+    elif frames is None:
+        frames = torch.from_numpy(make_sequence(n_frames, H, W, seed=0)).to(dev)
+    pairs = torch.tensor([[i, i + 1] for i in range(B)], dtype=torch.int32, device=dev)
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(precision, wz=wz, K=K, Wm=Wm, host_io=False, pipe=None):
+    def measure(precision, wz=wz, K=K, Wm=Wm, host_io=False, pipe=None, samples=()):
         """W warm-up + K timed steps of the whole loop in one precision mode -> (pipeline, plan, fps, elapsed, rooflines, table).
         host_io: the PCIe-inclusive variant -- every step's frames come from pinned host memory and its depth maps (uint16), point counts and
         relative poses go back to pinned host buffers, all on the compute stream (nothing overlapped: the conservative figure)."""
@@ -286,6 +335,7 @@ def main():
         zplan = pipe.zoe.plan_for(B, H, W, True)
         pplan = None if strong else pipe.pose.plan_for(B + 1, B, H, W)
         events = []
+        snaps = {}          # (step, frame in batch) -> the timed plan's depth map of that frame (samples: compared with the oracle afterwards)
 
         state = {"g_last": None}
         if host_io:
@@ -305,6 +355,9 @@ def main():
                 chunk = pplan.frames
             zplan.frames.copy_(chunk[1:])
             zplan.plan.run()
+            for (k_, j_) in samples:
+                if k_ == k:
+                    snaps[(k_, j_)] = zplan.depth_m[j_].clone()          # (1.2 MB device-to-device on the compute stream)
             if not host_io:
                 pplan.frames.copy_(chunk)
             pplan.pairs.copy_(pairs)
@@ -342,16 +395,17 @@ def main():
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             elapsed = te.item()
         fps = (K * Nseq if strong else world * K * B) / elapsed
-        # frame 0 of the LAST TIMED step's batch, as the timed plan left it (compared with the oracle below)
-        d_timed = zplan.depth_m[0].detach().cpu().clone()
+        d_timed = {kj: v.cpu() for kj, v in snaps.items()}
 
         # ---- per-kernel roofline from the HIP events of the timed steps (rank 0's view).  "achieved" counts ALGORITHMIC FLOPs
         # (2*M*N*K of the convolution / GEMM being computed); "executed" counts the MFMA work actually issued, which in
         # accurate mode is 2x (backbone) or 3x (neck, heads) larger because every product is a sum of split-precision passes.
         roof, roof_conv, kern_table = None, None, {}
         if events:
+            import re
             agg = {}
-            for (ci, e0, e1) in events:
+            gemm_events = [(ci, e0, e1) for (ci, e0, e1) in events if ci in zplan.plan.gemm_info]
+            for (ci, e0, e1) in gemm_events:
                 gi = zplan.plan.gemm_info[ci]
                 key = ("conv" if gi["conv"] else "gemm", gi["tile"])
                 a = agg.setdefault(key, dict(ms=0.0, flops=0.0, alg=0.0, n=0, bytes=0.0))
@@ -366,10 +420,9 @@ def main():
                     executed_tflops=a["flops"] / (a["ms"] * 1e-3) / 1e12,
                     gflop_per_launch=a["alg"] / a["n"] / 1e9, share_of_step=a["ms"] / (elapsed * 1e3))
             # the same launches by call site (layer index stripped): which GEMM of the network is how far from the roofline
-            import re
             by = {}
             for (ci, e0, e1) in events:
-                gi = zplan.plan.gemm_info[ci]
+                gi = zplan.plan.gemm_info.get(ci) or zplan.plan.stack_info[ci]
                 nm = re.sub(r"^(l|rt|ro|ra|nc|fu|pj|at)\d+", r"\1*", gi["name"])
                 a = by.setdefault(nm, dict(ms=0.0, alg=0.0, ex=0.0, n=0))
                 a["ms"] += e0.elapsed_time(e1); a["alg"] += gi["alg_flops"]; a["ex"] += gi["flops"]; a["n"] += 1
@@ -405,23 +458,46 @@ def main():
                 # `peak` is the guide's figure at the 2.4 GHz boost clock; the plan runs at the board's power limit and a lower clock
                 roof["sclk_mhz_median"] = power["sclk_mhz_median"]
                 roof["frac_of_peak_at_that_clock"] = round(ach / (MFMA_PEAK_TFLOPS * power["sclk_mhz_median"] / 2400.0), 4)
+            # ---- the conv stack of SURVEY section 8(d) -- neck + relative head + metric head + patch embedding, 233.6 GFLOP per forward in the
+            # reference's formulation -- as EVERY launch that carries a piece of it: all bs_gemm launches outside the 24 BEiT layers and the
+            # readout Linears, plus the fused up-convolution and the attractor MLP kernels (Plan.stack_info).  `achieved` prices the
+            # reference's 233.6 GFLOP x forwards against their summed time (VERDICT r5 #1 i); `as_launched` counts the products as this plan
+            # evaluates them (linear maps moved to the low resolution, composed, tap products: fewer FLOPs for the same result);
+            # `conv_mode_only` is rounds 1-5's figure (the 3x3 launches alone).
+            in_stack = lambda nm_: not re.match(r"^(l\d+\.|ro\d)", nm_)
+            st = dict(ms=0.0, alg=0.0, ex=0.0, n=0)
+            for (ci, e0, e1) in events:
+                gi = zplan.plan.gemm_info.get(ci) or zplan.plan.stack_info[ci]
+                if in_stack(gi["name"]):
+                    st["ms"] += e0.elapsed_time(e1); st["alg"] += gi["alg_flops"]; st["ex"] += gi["flops"]; st["n"] += 1
             cms = sum(a["ms"] for (kd, _), a in agg.items() if kd == "conv")
             cfl = sum(a["alg"] for (kd, _), a in agg.items() if kd == "conv")
             cex = sum(a["flops"] for (kd, _), a in agg.items() if kd == "conv")
-            if cms > 0:
-                roof_conv = dict(bound="mfma", what="ZoeDepth conv stack (all conv-mode igemm launches)",
-                                 achieved=round(cfl / (cms * 1e-3) / 1e12, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                                 frac=round(cfl / (cms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
-                                 executed=round(cex / (cms * 1e-3) / 1e12, 1), executed_frac=round(cex / (cms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4))
+            if st["ms"] > 0:
+                g_ = zplan.geom
+                forwards = K * g_["NB"]
+                ref_gflop = CONV_STACK_GFLOP_PER_FORWARD * (g_["nh"] * g_["nw"]) / (384.0 * 512.0)
+                tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12
+                ach_s = tf(ref_gflop * 1e9 * forwards, st["ms"])
+                roof_conv = dict(bound="mfma", what="ZoeDepth conv stack, WHOLE (SURVEY 8(d): neck + relative head + metric head + patch embed): every launch "
+                                                    "that carries a piece of it, incl. bs_upconv_fused and bs_mlp2_add",
+                                 achieved=round(ach_s, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach_s / MFMA_PEAK_TFLOPS, 4),
+                                 gflop_per_forward_reference=round(ref_gflop, 1), forwards=forwards, launches=st["n"], ms_per_step=round(st["ms"] / K, 3),
+                                 as_launched=dict(gflop_per_forward=round(st["alg"] / forwards / 1e9, 1), achieved=round(tf(st["alg"], st["ms"]), 1),
+                                                  frac=round(tf(st["alg"], st["ms"]) / MFMA_PEAK_TFLOPS, 4)),
+                                 executed=round(tf(st["ex"], st["ms"]), 1), executed_frac=round(tf(st["ex"], st["ms"]) / MFMA_PEAK_TFLOPS, 4),
+                                 conv_mode_only=(dict(achieved=round(tf(cfl, cms), 1), frac=round(tf(cfl, cms) / MFMA_PEAK_TFLOPS, 4),
+                                                      executed_frac=round(tf(cex, cms) / MFMA_PEAK_TFLOPS, 4), ms_per_step=round(cms / K, 3)) if cms > 0 else None))
         return dict(pipe=pipe, zplan=zplan, fps=fps, elapsed=elapsed, roof=roof, roof_conv=roof_conv, kern=kern_table, d_timed=d_timed, power=power)
 
-    main_run = measure(args.precision)
+    samples = sorted(oracle_d)
+    main_run = measure(args.precision, samples=samples)
     pipe, zplan, fps, elapsed = main_run["pipe"], main_run["zplan"], main_run["fps"], main_run["elapsed"]
     roof, roof_conv, kern_table = main_run["roof"], main_run["roof_conv"], main_run["kern"]
     other = None
     if not args.single_mode:
         other_name = "fast" if args.precision == "accurate" else "accurate"
-        other = measure(other_name)
+        other = measure(other_name, samples=samples)
         other.pop("pipe"), other.pop("zplan")             # (its plan's buffers go back to the allocator before the next leg)
         torch.cuda.empty_cache()
 
@@ -441,7 +517,7 @@ def main():
     outl = None
     if extra_legs and not args.no_outlier_leg and args.weights == "gaussian":
         wz_o = zoe_weights("outlier")
-        r_ = measure("accurate", wz=wz_o, K=min(K, 4), Wm=1)
+        r_ = measure("accurate", wz=wz_o, K=min(K, 4), Wm=1, samples=[(1, 5), (min(K, 4), B // 2)])
         zo = r_["pipe"].zoe
         outl = {"weights": "random-init + 6 channels x 50 behind every LayerNorm (bodyslam_amd.synthetic.outlier_channels)",
                 "value": round(r_["fps"], 2), "unit": "frames/s", "ms_per_step": round(1e3 * r_["elapsed"] / min(K, 4), 3),
@@ -449,7 +525,6 @@ def main():
                 "l1_abs_vs_reference_m": (zo.calibration or {}).get("l1_abs_vs_reference_m"), "warning": (zo.calibration or {}).get("warning"),
                 "roofline_frac": (r_["roof"] or {}).get("frac"), "conv_stack_frac": (r_["roof_conv"] or {}).get("frac")}
         outl_d = r_["d_timed"]
-        outl_k = min(K, 4)
         r_.pop("pipe"), r_.pop("zplan")
         del r_, zo
         torch.cuda.empty_cache()
@@ -487,43 +562,62 @@ def main():
                 "passes_frames_per_s": [round(nloop / d, 1) for d in dts], "statistic": "median of 3 passes", "best": round(nloop / min(dts), 1),
                 "map_units": units}
 
-    # ---- CPU baseline (rank 0): the oracle on one frame of the same sequence, all host cores
-    cpu = None
-    l1 = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:       # the contract: rank 0 at N = 1 only
-        from oracle import cyclepose_ref as CP
-        from oracle import geom3d_ref as G
-        from oracle import zoedepth_ref as Z
-        # torch CPU ops stop scaling (and then collapse) far below a 256-thread host: use at most 32 threads
-        ncores = min(os.cpu_count() or 1, 32)
-        torch.set_num_threads(ncores)
-        # the frame the timed plan processed last as its frame 0 (and its predecessor, for the pose pair)
-        if strong:      # the last batch of the rank's block: frame 0 of that batch
-            i0 = (s0 - foff) + ((e0 - s0 - 1) // B) * B
-        else:
-            i0 = (Wm + K - 1) * B + 1
-        f2 = frames[max(i0 - 1, 0): i0 + 1].cpu()
-        if f2.shape[0] < 2:
-            f2 = torch.cat([f2, f2], 0)
-        gd = main_run["d_timed"]
-        gd_other = other["d_timed"] if other else None
-        tc = time.perf_counter()
-        with torch.no_grad():
-            d_ref = Z.infer_depth(wz, Z.ZOED_NK, f2[1:2], flip_aug=True)
-            T = CP.forward_pose(wp, CP.center_crop_pair(f2, torch.tensor([[0, 1]])))
-        g_ref = G.pose_chain(T.numpy())
-        G.backproject(Z.to_uint16(d_ref)[0], pose=g_ref[1])
-        tcpu = time.perf_counter() - tc
-        l1 = float((gd - d_ref).abs().mean())
+    # ---- accuracy of the TIMED plans: the check frames (copied out of the timed steps) against the oracle's maps made before the GPU was touched
+    l1 = l1_frames = None
+
+    def frame_stats(dt_):
+        per = [float((dt_[kj] - oracle_d[kj]).abs().mean()) for kj in sorted(dt_) if kj in oracle_d]
+        if not per:
+            return None
+        return {"mean": float(np.mean(per)), "max": float(np.max(per)), "min": float(np.min(per)), "n": len(per),
+                "per_pixel_max": float(max((dt_[kj] - oracle_d[kj]).abs().max() for kj in dt_ if kj in oracle_d)),
+                "frames": [f"step {k_} frame {j_}" for (k_, j_) in sorted(dt_) if (k_, j_) in oracle_d]}
+
+    if do_cpu:
+        l1_frames = frame_stats(main_run["d_timed"])
+        l1 = l1_frames["mean"] if l1_frames else None
         if other:
-            other["l1"] = float((gd_other - d_ref).abs().mean())
-        if outl is not None:        # the outlier-weights leg against the oracle ON THOSE WEIGHTS, frame 0 of its last timed batch
-            i_o = outl_k * B + 1
-            with torch.no_grad():
-                d_ref_o = Z.infer_depth(wz_o, Z.ZOED_NK, frames[i_o: i_o + 1].cpu(), flip_aug=True)
-            outl["depth_l1_vs_oracle_m"] = float((outl_d - d_ref_o).abs().mean())
-        cpu = dict(value=round(1.0 / tcpu, 4), unit="frames/s", cores=ncores, kind="port",
-                   sample=f"1 frame {W}x{H}: ZoeD_NK x2 (flip-aug) + 1 CyclePose pair + chain + back-projection, torch fp32 oracle")
+            st_o = frame_stats(other["d_timed"])
+            other["l1"] = st_o["mean"] if st_o else None
+            other["l1_max"] = st_o["max"] if st_o else None
+        if outl is not None and outl_d:        # the outlier-weights leg against the oracle ON THOSE WEIGHTS: two frames of its timed steps
+            from oracle import zoedepth_ref as Z
+            per = []
+            for (k_, j_) in sorted(outl_d)[:2]:
+                i_o = k_ * B + 1 + j_
+                with torch.no_grad():
+                    d_ref_o = Z.infer_depth(wz_o, Z.ZOED_NK, frames[i_o: i_o + 1].cpu(), flip_aug=True)
+                per.append(float((outl_d[(k_, j_)] - d_ref_o[0]).abs().mean()))
+            outl["depth_l1_vs_oracle_m"] = float(np.max(per))
+            outl["depth_l1_frames"] = {"max": float(np.max(per)), "mean": float(np.mean(per)), "n": len(per)}
+
+    # ---- the surface the reference calls: one frame per call.  infer_depth_map = one B = 1 forward (flip-aug) + the uint16 map
+    # back on the host; infer_relative_pose_between = one pair.  Frames resident on the device (the interface's own H2D of 0.9 MB is not in it).
+    latency = None
+    if rank == 0 and world == 1 and not strong and not args.single_mode and not args.no_latency_leg:
+        z_, p_ = pipe.zoe, pipe.pose
+        f1 = frames[1:2].contiguous()
+        lat = {}
+        for name, graph in (("infer_depth_map_eager_ms", False), ("infer_depth_map_ms", True)):
+            for _ in range(3):
+                z_.infer(f1, graph=graph)[1][0].cpu()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                z_.infer(f1, graph=graph)[1][0].cpu()           # (the call's own synchronisation: the map comes back to the host)
+            lat[name] = round(1e3 * (time.perf_counter() - t0) / 20, 3)
+        pr1 = torch.tensor([[0, 1]], dtype=torch.int32, device=dev)
+        f2_ = frames[0:2].contiguous()
+        for _ in range(3):
+            p_.infer_pairs(f2_, pr1).cpu()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            p_.infer_pairs(f2_, pr1).cpu()
+        lat["infer_relative_pose_between_ms"] = round(1e3 * (time.perf_counter() - t0) / 20, 3)
+        lat["what"] = ("wall time per call, mean of 20: B = 1 ZoeD_NK forward x2 (flip-aug) replayed as one HIP graph + uint16 map D2H; eager = ~500 ctypes "
+                       "launches per call; one CyclePose pair + 4x4 D2H; frames resident on the device")
+        latency = lat
 
     if rank == 0:
         out = {
@@ -543,7 +637,9 @@ def main():
             # per-instantiation / per-site table of the timed GEMM launches and the calibration's full report: the bulky parts come FIRST, the
             # figures a reviewer needs are the LAST ~1500 characters of the line (the driver keeps the tail)
             "kernels": kern_table,
-            "calibration": (pipe.zoe.calibration if pipe.zoe.acc else None),
+            # (the static bias corrections travel in the report for the other ranks: here only how many values each site carries)
+            "calibration": ({k_: (v_ if k_ != "site_bias_corr" else {s_: len(c_) for s_, c_ in v_.items()}) for k_, v_ in (pipe.zoe.calibration or {}).items()}
+                            if pipe.zoe.acc else None),
             "hbm_allocated_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
             "power": main_run.get("power"),
         }
@@ -552,6 +648,7 @@ def main():
         if other:
             out["other_mode"] = {"precision": other_name, "value": round(other["fps"], 2), "unit": "frames/s",
                                  "ms_per_step": round(1e3 * other["elapsed"] / K, 3), "depth_l1_vs_oracle_m": other.get("l1"),
+                                 "depth_l1_max_over_frames_m": other.get("l1_max"),
                                  "roofline_frac": (other["roof"] or {}).get("frac"), "conv_stack_frac": (other["roof_conv"] or {}).get("frac")}
         if outl is not None:
             out["outlier_weights"] = outl
@@ -561,12 +658,26 @@ def main():
         zc = pipe.zoe.calibration or {}
         out["precision"] = args.precision
         out["weights"] = args.weights
-        out["accurate_modes"] = ({"class_modes": pipe.zoe.class_modes, "attn_mode": pipe.zoe.attn_mode, "neck_mode": pipe.zoe.neck_mode,
+        ns_ = zc.get("neck_sites") or {}
+        nm_ = pipe.zoe.neck_mode if pipe.zoe.acc else ""
+        # (the full neck mode string is in `calibration` above; the tail carries its size)
+        out["accurate_modes"] = ({"class_modes": pipe.zoe.class_modes, "attn_mode": pipe.zoe.attn_mode,
+                                  "neck": (nm_ if len(nm_) < 40 else {"weight_only_sites": len(nm_.split(";")[0].split(",")),
+                                                                      "one_pass_sites": (len(nm_.split(";plain:")[1].split(",")) if ";plain:" in nm_ else 0),
+                                                                      "flops_share_weight_only": ns_.get("flops_share_weight_only"),
+                                                                      "flops_share_one_pass": ns_.get("flops_share_plain")}),
                                   "l1_abs_vs_reference_m": zc.get("l1_abs_vs_reference_m"), "warning": zc.get("warning")} if pipe.zoe.acc else None)
         out["slam_loop_frames_per_s"] = slam["value"] if slam else None
+        out["latency_b1_ms"] = latency
+        out["calibrate_s"] = zc.get("calibrate_s")
+        out["calibration_holdout"] = ({k_: zc["holdout"][k_] for k_ in ("frames", "tol_m", "l1_max_m", "l1_mean_m", "withdrawn")} if "holdout" in zc else None)
         out["roofline_conv_stack"] = roof_conv
+        # accuracy of the TIMED plan: N_CHECK_FRAMES frames spread over the timed steps, each against the fp32 CPU oracle; `value` is a
+        # tolerance-meeting figure only while depth_l1_frames.max <= 1e-4 m (the north star's tolerance)
         out["depth_l1_vs_oracle_m"] = l1
-        out["depth_l1_frame"] = "frame 0 of the last timed step's batch, from the timed plan's output"
+        out["depth_l1_frames"] = ({k_: l1_frames[k_] for k_ in ("mean", "max", "min", "n", "per_pixel_max")} if l1_frames else None)
+        out["depth_l1_frame"] = (", ".join(l1_frames["frames"]) + " of the timed plan's output" if l1_frames else None)
+        out["tolerance_met"] = (bool(l1_frames["max"] <= 1e-4) if (l1_frames and args.precision != "fast") else None)
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

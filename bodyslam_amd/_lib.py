@@ -301,6 +301,8 @@ class Plan:
         self.keep_descs = [] # the bs_gemm descriptors in call order (engine export)
         self.marks = {}      # call index -> [(name, tensor)]
         self.gemm_info = {}  # call index -> dict(tile, conv, flops, bytes)
+        self.stack_info = {} # call index -> dict(name, alg_flops, flops): launches other than bs_gemm that carry matrix-core work of a GEMM / conv
+                             # the reference has (the fused up-convolution, the attractor MLPs): timed with the GEMMs for the roofline
         self.lane = 0        # lane of the calls being added: 0 = the caller's stream, 1 = the plan's side stream
         self.lanes = []      # per call
         self.events = None   # a list: run() records a HIP event pair around every bs_gemm launch into it (see run_timed)
@@ -375,6 +377,10 @@ class Plan:
         self.names.append(name)
         self.lanes.append(self.lane)
 
+    def tag_stack(self, alg_flops: float, flops: float):
+        """the call added last carries this much matrix-core work (algorithmic / executed in 16-bit-pass equivalents)"""
+        self.stack_info[len(self.calls) - 1] = dict(name=self.names[-1], alg_flops=float(alg_flops), flops=float(flops))
+
     def mark(self, name, tensor, meta=None):
         self.marks.setdefault(len(self.calls), []).append((name, tensor, meta))
 
@@ -389,7 +395,7 @@ class Plan:
                 self._sync_op(fn, args, main, side)
                 continue
             ln = self.lanes[i]
-            if i in self.gemm_info:
+            if i in self.gemm_info or i in self.stack_info:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(sts[ln])
                 rc = fn(*args, ptrs[ln])
@@ -438,9 +444,18 @@ class Plan:
                     check(rc, self.names[i])
             return
         st = torch.cuda.current_stream(self.device).cuda_stream       # tap mode (tests): one stream, program order
+        means = taps.get("__site_means__")
         for i in range(len(self.calls) + 1):
             for (name, t, meta) in self.marks.get(i, []):
-                taps[name] = (t.clone(), meta)
+                if meta and meta[0] == "chanmean":
+                    # the channel means of a product's 16-bit input rows as the launch that follows will read them (the calibration's static
+                    # bias correction): only when the caller asks for them, never cloned
+                    if means is not None:
+                        _, off, M, lda, K = meta
+                        means[name] = t.view(-1)[off: off + M * lda].view(M, lda)[:, :K].float().mean(0)
+                    continue
+                if means is None:               # (a run made for the channel means clones nothing else)
+                    taps[name] = (t.clone(), meta)
             if i < len(self.calls):
                 fn, args = self.calls[i]
                 if isinstance(fn, str):

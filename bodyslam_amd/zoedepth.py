@@ -116,36 +116,49 @@ TOLERANCE_M = 1.0e-4                             # BASELINE.json north_star: dep
 ACCURATE_ATTN_MODE = "auto"
 # neck: "full", or the list of weight-key prefixes that keep both products (the rest: weight-rounding correction only).
 NECK_RELHEAD_WONLY = "ro,ra,nc,fu,pj,mh"         # everything but the relative head keeps both (mh: the bins head's bottleneck conv)
-# What a class's cheap mode saves per bench step (ms, B = 64, measured: profiles/r02_bench_kernels.txt "wmean" against "wcls"; neck:
-# profiles/r03_neck_relhead_wonly.txt).  When the chosen combination misses the total tolerance, the class that pays the most depth
-# error per millisecond saved goes back up first.  The relative head's weight-only mode buys 1 % for ~2e-5 m: not a default candidate.
-AUTO_SAVING_MS = {"fc1": 8.7, "fc2": 8.0, "qkv": 3.7, "o": 1.8, "neck": 2.0, "attn": 25.0}
+# What a class's cheap mode saves, in executed GFLOP per network input (16-bit-pass equivalents; derived from the shapes in
+# ZoeDepthEngine._saving_gflop, round 6 -- rounds 2-5 carried millisecond figures measured once at B = 64).  When the chosen combination
+# misses the total tolerance, the class that pays the most depth error per unit saved goes back up first.
+AUTO_ATTN_RATE_FACTOR = 1.5                      # the attention kernels run at ~2/3 of the GEMMs' rate: a pass saved there is worth more time
 # The relative head (rh.projection, rh.conv1: 40 % of the conv stack's time) with the weight-rounding correction only is +1.1 % frames/s for
-# +0.7-1.8e-5 m (profiles/r03_neck_relhead_wonly.txt): a candidate since round 4, when calibrate() got an ABSOLUTE reference -- it is kept
-# only while the chosen combination stays under AUTO_TOL_NECK_ABS_M against the reference-precision engine (half the tolerance: the
-# calibration frame is one frame).  Without that reference (no source weights) the neck stays "full".
+# +0.7-1.8e-5 m (profiles/r03_neck_relhead_wonly.txt): a candidate since round 4, when calibrate() got an ABSOLUTE reference.  Without that
+# reference (no source weights) the neck stays "full".
 AUTO_NECK_CANDIDATES = (NECK_RELHEAD_WONLY, "full")
-AUTO_TOL_NECK_ABS_M = 5.0e-5
 # Round 5: the neck is calibrated PER SITE (VERDICT r4 #1c).  With the absolute reference available, calibrate() measures what each of the
 # neck's / heads' FP8-format products costs when it alone drops the activation-rounding correction, orders the sites by depth error per
 # FLOP saved and keeps the longest prefix of that order whose combination stays under AUTO_TOL_NECK_ABS_M against the reference
 # (tools/probes/neck_site_study.py: on the bench weights 11 ... 19 sites, not only the relative head, fit that budget).  The choice is
-# the neck mode "wonly:<site>,<site>,..." (ZoeDepthEngine.neck_site_wonly).  Sites below this share of the neck's FLOPs are not worth a
-# calibration forward and keep both products.
+# the neck mode "wonly:<site>,<site>,..." (ZoeDepthEngine.neck_site_wonly).  Sites below AUTO_NECK_SITE_MIN_SHARE of the neck's FLOPs are
+# not worth a calibration forward EACH; since round 6 they are candidates as GROUPS (AUTO_NECK_SMALL_GROUPS: one forward per group and
+# stage) -- in round 5 none of them was ever calibrated and all ran both corrections, 2-3x their algorithmic work (VERDICT r5 #1 ii).
+AUTO_TOL_NECK_ABS_M = 5.0e-5
 AUTO_NECK_SITE_MIN_SHARE = 0.015
+AUTO_NECK_SMALL_GROUPS = {"readout": ("ro",), "reassemble+projections": ("ra", "fu0.proj", "fu1.proj", "fu2.proj", "fu3.proj", "pj"),
+                          "small3x3": ("nc", "fu")}           # by weight-key prefix, first match; the bins head's bottleneck conv (mh.) stays out
 # Round 5, second stage: the large weight-only sites may drop the weight-rounding correction TOO -- one 16-bit pass, `f8_skip_from = -1`, the
 # form "wonly:...;plain:<site>,..." (ZoeDepthEngine.neck_site_plain).  tools/probes/neck_plain_study.py: a site alone moves the map by 2-3e-5 m,
 # but twelve of them together leave the distance to the reference where it was (4.5 -> 4.9e-5 m) -- weight rounding in the neck is incoherent
 # noise, like its activation rounding -- while two small sites (nc2, ra3.down) alone cost 3-8e-5.  So the stage walks the sites by FLOPs, largest
-# first, and keeps a site when the combination stays under AUTO_TOL_NECK_PLAIN_ABS_M against the reference ON TWO FRAMES (the calibration frame
-# and a second synthetic one: a choice made by trying a dozen combinations on one frame fits that frame).  BS_NECK_PLAIN=0 switches the stage off.
+# first, and keeps a site when the combination stays under AUTO_TOL_NECK_PLAIN_ABS_M against the reference.  BS_NECK_PLAIN=0 switches the stage off.
+# Round 6 (advisor): every stage is judged on the WORST of AUTO_CAL_FRAMES calibration frames (round 5: one frame, the
+# plain stage on the mean of two), a site is kept only when it ALSO stays within `tol_total` of the best mode, and the final combination is
+# validated on AUTO_HOLDOUT_FRAMES frames that no decision has seen: above AUTO_TOL_HOLDOUT_M there, the latest relaxations are withdrawn.
+# And the one-pass sites carry a STATIC bias correction: the token-independent part dW E[a] of their weight-rounding error, from the
+# calibration frames' channel means (site_bias_corr; the data-free-quantisation bias correction) -- no run-time cost.
 AUTO_NECK_PLAIN_MIN_SHARE = 0.015
-AUTO_TOL_NECK_PLAIN_ABS_M = 5.5e-5
+AUTO_TOL_NECK_PLAIN_ABS_M = 6.0e-5
+AUTO_CAL_FRAMES = 4
+AUTO_HOLDOUT_FRAMES = 4
+AUTO_TOL_HOLDOUT_M = 7.0e-5
+AUTO_CAL_SEEDS = (11, 12, 13, 14, 15, 16, 17, 18)        # synthetic.make_sequence(1, H, W, seed): the calibration frames ...
+AUTO_HOLDOUT_SEEDS = (21, 22, 23, 24, 25, 26, 27, 28)    # ... and the held-out ones
 ACCURATE_NECK_MODE = "full"
 # (Round 3 also had neck_corr="f4": e2m1 correction planes with E8M0 block scales on the FP4 MFMA -- +1.4 % frames/s for 1.5x the depth error,
 # profiles/r03_fp4_corrections.txt.  It never paid and was removed in round 4; the correction products run on the block-scaled FP8 MFMA.)
 
 _CALIBRATION_CACHE: Dict[Tuple, dict] = {}        # process-wide: (weights fingerprint, geometry, tolerances, ...) -> calibration report
+# environment switches that change the arithmetic a calibration measures (A / B runs): part of the cache key (round-5 advisor)
+_ARITHMETIC_SWITCHES = ("BS_PJ_LOWRES", "BS_UPCONV_FUSED", "BS_CLB_COMPOSED", "BS_RELU_OUT", "BS_NECK_PLAIN", "BS_MLP2", "BS_NECK_BIAS_CORR")
 
 ZOED_NK = ZoeConfig()
 ZOED_N = ZoeConfig(head_names=("nyu",))
@@ -247,6 +260,12 @@ class ZoeDepthEngine:
         self.auto_modes = self.auto_modes or (self.acc and self.auto_attn)
         self.single_keys = set()
         self.wmode: Dict[str, str] = {}
+        # static bias correction of the neck's one-pass products (calibrate(), second stage): dw_sum[key] = (W - round16(W)) summed over
+        # the filter taps, fp32 [N, Cin], kept from ingestion; site_bias_corr[key] = dw_sum[key] @ E[a] with the calibration frames' channel
+        # means -- added to the product's bias while it runs one pass (the token-independent part of its weight-rounding error)
+        self.dw_sum: Dict[str, torch.Tensor] = {}
+        self.site_bias_corr: Dict[str, torch.Tensor] = {}
+        self._bias_corr_cache: Dict[str, torch.Tensor] = {}
         # DPT neck / heads (no cls rows there): "full" = both correction products, "w" = the weight-rounding correction only
         self.neck_mode = neck_mode or os.environ.get("BS_NECK_MODE") or ACCURATE_NECK_MODE
         # (probes: a comma-separated list of weight-key prefixes that KEEP both products, e.g. "ro,ra,nc": everything else "w")
@@ -352,6 +371,8 @@ class ZoeDepthEngine:
         arithmetic, and ranks calibrating on their own could fall on different sides of a threshold)"""
         self.set_class_modes({k: v for k, v in report["class_modes"].items() if self.class_modes[k] in ("full", "wcls", "wmean")},
                              report["neck_mode"], report.get("attn_mode"))
+        self.site_bias_corr = {k: torch.tensor(v, dtype=torch.float32, device=self.dev) for k, v in (report.get("site_bias_corr") or {}).items()}
+        self._bias_corr_cache.clear()
         self.calibration = dict(report)
 
     def reference_depth(self, frames_u8: torch.Tensor) -> torch.Tensor:
@@ -374,35 +395,54 @@ class ZoeDepthEngine:
         """drop the reference to the caller's weight dict (after this, calibrate() has no absolute reference)"""
         self._sd = None
 
+    def _saving_gflop(self, S: int) -> Dict[str, float]:
+        """what a cheap mode saves per network input, in executed GFLOP (16-bit-pass equivalents): "wmean" against "full" is one pass of the
+        class's products; the single-operand attention against the split-precision one is two passes of 4 S^2 hidden (weighted by
+        AUTO_ATTN_RATE_FACTOR).  step_up()'s yardstick (the error a choice costs per unit it saves)."""
+        c = self.cfg
+        per = lambda n, k: 2.0 * S * n * k * c.layers / 1e9
+        return {"qkv": per(3 * c.hidden, c.hidden), "o": per(c.hidden, c.hidden), "fc1": per(c.intermediate, c.hidden),
+                "fc2": per(c.hidden, c.intermediate), "attn": 2.0 * AUTO_ATTN_RATE_FACTOR * 4.0 * S * S * c.hidden * c.layers / 1e9}
+
     def calibrate(self, H: int = 480, W: int = 640, frames_u8: Optional[torch.Tensor] = None, tol_class: float = AUTO_TOL_CLASS_M,
                   tol_total: float = AUTO_TOL_TOTAL_M, neck_candidates: Optional[Sequence[str]] = None, tol_abs: float = AUTO_TOL_ABS_M,
-                  reference: bool = True) -> dict:
+                  reference: bool = True, holdout_u8: Optional[torch.Tensor] = None) -> dict:
         """Choose, with THESE weights on THIS device, the cheapest correction mode per backbone GEMM class, for the attention operands
-        and for the neck that keeps the depth map of a calibration frame within `tol_class` metres (L1) of the BEST mode's result
-        (all classes "full", attention "corr"), check the combination against `tol_total` and step the most expensive offender back
-        up until it holds.  Then the ABSOLUTE check: the chosen combination against a reference-precision engine built from the same
-        weights (reference_depth: three 16-bit passes everywhere) -- if that exceeds `tol_abs` the stepping continues, and if even the
-        best mode misses the north star's 1e-4 m the report carries a "warning" (bench.py prints it, DepthEstimator warns).  One
-        B = 1 forward per candidate (about fifteen plans, each dropped after use).  The report is kept in ``self.calibration``.
-        Only what was left on "auto" is calibrated; classes / attention given a fixed mode keep it."""
+        and for the neck that keeps the depth maps of the calibration frames within `tol_class` metres (L1, the WORST frame) of the BEST
+        mode's result (all classes "full", attention "corr"), check the combination against `tol_total` and step the most expensive
+        offender back up until it holds.  Then the ABSOLUTE check: the chosen combination against a reference-precision engine built from
+        the same weights (reference_depth: three 16-bit passes everywhere) -- if that exceeds `tol_abs` the stepping continues, and if even
+        the best mode misses the north star's 1e-4 m the report carries a "warning" (bench.py prints it, DepthEstimator warns).  With the
+        reference at hand the neck is then calibrated per product in two stages (AUTO_TOL_NECK_ABS_M, AUTO_TOL_NECK_PLAIN_ABS_M) and the
+        result validated on held-out frames (AUTO_TOL_HOLDOUT_M).
+        `frames_u8` [N,H,W,3]: the caller's own calibration frames -- ALL of them are used, every decision is judged on the worst one
+        (default: AUTO_CAL_FRAMES synthetic frames); `holdout_u8`: frames no decision may see (default: AUTO_HOLDOUT_FRAMES synthetic ones).
+        One forward over the calibration frames per candidate (about fifty plans, each dropped after use).  The report is kept in
+        ``self.calibration``.  Only what was left on "auto" is calibrated; classes / attention given a fixed mode keep it."""
         assert self.acc, "calibrate() is for precision='accurate'"
-        # the same weights, geometry and tolerances give the same choice (every kernel is deterministic): a process that builds several
-        # engines from one weight set (the bench's legs, a test module) calibrates once
+        import time as _time
+        t_start = _time.perf_counter()
+        # the same weights, geometry, tolerances and arithmetic switches give the same choice (every kernel is deterministic): a process that
+        # builds several engines from one weight set (the bench's legs, a test module) calibrates once
         ckey = None
-        if frames_u8 is None and self._sd is not None and reference and neck_candidates is None:
+        if frames_u8 is None and holdout_u8 is None and self._sd is not None and reference and neck_candidates is None:
             ckey = (self._weights_fingerprint(), repr(self.cfg), str(self.dtype), H, W, tuple(self.target_hw), tol_class, tol_total, tol_abs,
                     self.auto_classes, self.auto_attn, tuple(sorted(self.class_modes.items())), self.attn_mode, self.neck_mode,
-                    os.environ.get("BS_NECK_PLAIN", "1"))
+                    self.fuse_mlp, self.add_projection, self.neck_f8,
+                    AUTO_TOL_NECK_ABS_M, AUTO_TOL_NECK_PLAIN_ABS_M, AUTO_TOL_HOLDOUT_M, AUTO_CAL_FRAMES, AUTO_HOLDOUT_FRAMES,
+                    tuple(os.environ.get(k_, "") for k_ in _ARITHMETIC_SWITCHES))
             hit = _CALIBRATION_CACHE.get(ckey)
             if hit is not None:
                 self.apply_calibration(hit)
                 if "warning" in hit:
                     warnings.warn("ZoeDepthEngine.calibrate: " + hit["warning"])
                 return dict(hit)
+        from .synthetic import make_sequence
+        synth = lambda seeds: torch.from_numpy(np.concatenate([make_sequence(1, H, W, seed=s_) for s_ in seeds], 0)).to(self.dev)
         if frames_u8 is None:
-            from .synthetic import make_sequence
-            frames_u8 = torch.from_numpy(make_sequence(1, H, W, seed=11)).to(self.dev)
-        frames_u8 = frames_u8[:1].contiguous()
+            frames_u8 = synth(AUTO_CAL_SEEDS[:AUTO_CAL_FRAMES])
+        frames_u8 = frames_u8.to(self.dev).contiguous()
+        ncal = int(frames_u8.shape[0])
         H, W = int(frames_u8.shape[1]), int(frames_u8.shape[2])
         switchable = [k for k in BACKBONE_CLASSES if self.class_modes[k] in ("full", "wcls", "wmean")] if self.auto_classes else []
         neck_cands = ["full"] if (not self.neck_f8 or not self.auto_classes or (neck_candidates is None and (not reference or self._sd is None))) \
@@ -417,42 +457,55 @@ class ZoeDepthEngine:
         attn_best = ("corr" if corr_ok else "single") if self.auto_attn else self.attn_mode
         saved_auto, self.auto_modes = self.auto_modes, False
         neck0 = self.neck_mode
-
+        self.site_bias_corr = {}
+        self._bias_corr_cache.clear()
         site_flops: Dict[str, float] = {}
 
-        def depth(modes, neck, attn):
+        def depth(modes, neck, attn, frames=frames_u8, means=None):
+            """depth maps [n,H,W] of `frames` under a mode combination (one plan, dropped after use); means: a dict that receives the channel
+            means of every neck product's input rows (the run then goes launch by launch through the plan's tap path)"""
             self.set_class_modes(modes, neck, attn)
-            plan = _ZoePlan(self, 1, H, W, True)
-            plan.frames.copy_(frames_u8)
-            plan.run(None)
+            plan = _ZoePlan(self, int(frames.shape[0]), H, W, True)
+            plan.frames.copy_(frames)
+            plan.run(None if means is None else {"__site_means__": means})
             d = plan.depth_m.clone()
             torch.cuda.synchronize(self.dev)
             site_flops.update(plan.site_flops)
             del plan
             return d
 
+        l1f = lambda a, b: (a - b).abs().flatten(1).mean(1)              # per-frame L1
+        worst = lambda a, b: float(l1f(a, b).max())
+
         full = {k: "full" for k in switchable}
         neck_full = "full" if (len(neck_cands) > 1 or per_site) else neck0
         ref = depth(full, neck_full, attn_best)
-        report = {"frame": f"{H}x{W}", "tol_class_m": tol_class, "tol_total_m": tol_total, "tol_abs_m": tol_abs, "l1_vs_full_m": {}}
-        truth = None
+        report = {"frame": f"{H}x{W}", "frames": ncal, "statistic": "worst frame (max over the calibration frames of the per-frame mean |d - d_ref|)",
+                  "tol_class_m": tol_class, "tol_total_m": tol_total, "tol_abs_m": tol_abs, "l1_vs_full_m": {}}
+        truth = hold = truth_h = None
         if reference and self._sd is not None:
-            truth = self.reference_depth(frames_u8)
-            report["l1_best_vs_reference_m"] = (ref - truth).abs().mean().item()
+            if holdout_u8 is None and per_site and AUTO_HOLDOUT_FRAMES > 0:
+                holdout_u8 = synth(AUTO_HOLDOUT_SEEDS[:AUTO_HOLDOUT_FRAMES])
+            if holdout_u8 is not None:
+                hold = holdout_u8.to(self.dev).contiguous()
+                assert tuple(hold.shape[1:]) == tuple(frames_u8.shape[1:])
+            t_all = self.reference_depth(frames_u8 if hold is None else torch.cat([frames_u8, hold], 0))     # ONE reference engine for both sets
+            truth, truth_h = t_all[:ncal], (t_all[ncal:] if hold is not None else None)
+            report["l1_best_vs_reference_m"] = worst(ref, truth)          # the floor: nothing the calibration chooses can be closer than this
         chosen, cost = dict(full), {}
         for k in switchable:
             for cand in AUTO_CANDIDATES:
                 if cand == "full":
                     chosen[k], cost[k] = "full", 0.0
                     break
-                l1 = (depth({**full, k: cand}, neck_full, attn_best) - ref).abs().mean().item()
+                l1 = worst(depth({**full, k: cand}, neck_full, attn_best), ref)
                 report["l1_vs_full_m"][f"{k}:{cand}"] = l1
                 if l1 <= tol_class:
                     chosen[k], cost[k] = cand, l1
                     break
         attn = attn_best
         if self.auto_attn and attn_best == "corr":
-            l1 = (depth(full, neck_full, "single") - ref).abs().mean().item()
+            l1 = worst(depth(full, neck_full, "single"), ref)
             report["l1_vs_full_m"]["attn:single"] = l1
             if l1 <= tol_class:
                 attn, cost["attn"] = "single", l1
@@ -460,34 +513,40 @@ class ZoeDepthEngine:
         for cand in neck_cands:
             if cand == "full":
                 break
-            l1 = (depth(full, cand, attn_best) - ref).abs().mean().item()
+            l1 = worst(depth(full, cand, attn_best), ref)
             report["l1_vs_full_m"][f"neck:{cand}"] = l1
             if l1 <= tol_class:
                 neck, cost["neck"] = cand, l1
                 break
+        saving = self._saving_gflop(1 + (nh_ // self.cfg.patch) * (nw_ // self.cfg.patch))
+        passes_saved = {"wmean": 1.0, "wcls": 0.5, "full": 0.0}
 
         def step_up():
-            """the live choice that pays the most depth error per millisecond saved goes one step back up; False when none is left"""
+            """the live choice that pays the most depth error per unit of work saved goes one step back up; False when none is left"""
             nonlocal neck, attn
             live = [k_ for k_ in cost if cost[k_] > 0.0]
             if not live:
                 return False
-            worst = max(live, key=lambda k_: cost[k_] / AUTO_SAVING_MS.get(k_, 1.0))
-            if worst == "neck":
+            def worth(k_):
+                if k_ == "neck":
+                    return 0.5 * sum(site_flops.values()) / max(2 * ncal, 1) / 1e9
+                return saving[k_] * (1.0 if k_ == "attn" else passes_saved[chosen[k_]])
+            worst_k = max(live, key=lambda k_: cost[k_] / max(worth(k_), 1e-9))
+            if worst_k == "neck":
                 neck = neck_full
-            elif worst == "attn":
+            elif worst_k == "attn":
                 attn = attn_best
             else:
-                chosen[worst] = AUTO_CANDIDATES[min(AUTO_CANDIDATES.index(chosen[worst]) + 1, len(AUTO_CANDIDATES) - 1)]
-            cost[worst] = 0.0 if (worst in ("neck", "attn") or chosen[worst] == "full") else report["l1_vs_full_m"].get(f"{worst}:{chosen[worst]}", 0.0)
+                chosen[worst_k] = AUTO_CANDIDATES[min(AUTO_CANDIDATES.index(chosen[worst_k]) + 1, len(AUTO_CANDIDATES) - 1)]
+            cost[worst_k] = 0.0 if (worst_k in ("neck", "attn") or chosen[worst_k] == "full") else report["l1_vs_full_m"].get(f"{worst_k}:{chosen[worst_k]}", 0.0)
             return True
 
         # the combination, against the best mode and then against the reference
         while True:
             cheap = any(v != "full" for v in chosen.values()) or neck != neck_full or attn != attn_best
             d_c = depth(chosen, neck, attn) if cheap else ref
-            total = (d_c - ref).abs().mean().item() if cheap else 0.0
-            l1_abs = (d_c - truth).abs().mean().item() if truth is not None else None
+            total = worst(d_c, ref) if cheap else 0.0
+            l1_abs = worst(d_c, truth) if truth is not None else None
             if neck != neck_full and neck_candidates is None and l1_abs is not None and l1_abs > AUTO_TOL_NECK_ABS_M:
                 neck, cost["neck"] = neck_full, 0.0           # the cheaper neck is only worth half the tolerance (see AUTO_TOL_NECK_ABS_M)
                 continue
@@ -495,73 +554,112 @@ class ZoeDepthEngine:
                 break
             if not step_up():
                 break
+        report["l1_backbone_choice_vs_reference_m"] = l1_abs
+        wsites, plain, cand_sites = [], [], {}
+
+        def site_mode(names, pl=()):
+            """the neck mode that runs the named candidates weight-only and those of `pl` on one pass"""
+            return "wonly:" + ",".join(sorted(k_ for n_ in names for k_ in cand_sites[n_])) + \
+                (";plain:" + ",".join(sorted(k_ for n_ in pl for k_ in cand_sites[n_])) if pl else "")
+
         if per_site and truth is not None and l1_abs is not None and l1_abs <= AUTO_TOL_NECK_ABS_M:
-            # ---- the neck, site by site: what each product costs when it alone drops the activation-rounding correction (against the
-            # combination chosen so far), then the longest prefix of the error-per-FLOP order that stays within the neck's budget
-            # against the reference.  The error grows along that order (tools/probes/neck_site_study.py), so the prefix is bisected.
+            # ---- the neck, candidate by candidate: what each product (or group of small products) costs when it alone drops the
+            # activation-rounding correction (against the combination chosen so far), then the longest prefix of the error-per-FLOP order that
+            # stays within the neck's budget against the reference AND within tol_total of the best mode.  The error grows along that order
+            # (tools/probes/neck_site_study.py), so the prefix is bisected.
             tot_f = sum(site_flops.values()) or 1.0
-            sites = [k_ for k_, f_ in site_flops.items() if f_ >= AUTO_NECK_SITE_MIN_SHARE * tot_f and not k_.endswith("w_cls")]
-            err = {k_: (depth(chosen, "wonly:" + k_, attn) - d_c).abs().mean().item() for k_ in sites}
-            order = sorted(sites, key=lambda k_: err[k_] / site_flops[k_])
+            for k_, f_ in site_flops.items():
+                if k_.endswith("w_cls") or k_.startswith("mh."):
+                    continue
+                if f_ >= AUTO_NECK_SITE_MIN_SHARE * tot_f:
+                    cand_sites[k_] = [k_]
+                else:
+                    g_ = next((n_ for n_, pre in AUTO_NECK_SMALL_GROUPS.items() if any(k_.startswith(p_) for p_ in pre)), None)
+                    if g_ is not None:
+                        cand_sites.setdefault("group:" + g_, []).append(k_)
+            cflops = {n_: sum(site_flops[k_] for k_ in ks) for n_, ks in cand_sites.items()}
+            err = {n_: worst(depth(chosen, site_mode([n_]), attn), d_c) for n_ in cand_sites}
+            order = sorted(cand_sites, key=lambda n_: err[n_] / cflops[n_])
             lo, hi, kept = 0, len(order), None
             while lo < hi:
                 mid = (lo + hi + 1) // 2
-                d_s = depth(chosen, "wonly:" + ",".join(order[:mid]), attn)
-                a_, t_ = (d_s - truth).abs().mean().item(), (d_s - ref).abs().mean().item()
+                d_s = depth(chosen, site_mode(order[:mid]), attn)
+                a_, t_ = worst(d_s, truth), worst(d_s, ref)
                 if a_ <= AUTO_TOL_NECK_ABS_M and t_ <= tol_total:
                     lo, kept = mid, (a_, t_)
                 else:
                     hi = mid - 1
-            report["neck_sites"] = {"tol_abs_m": AUTO_TOL_NECK_ABS_M, "l1_alone_vs_chosen_m": {k_: round(err[k_], 8) for k_ in order},
-                                    "weight_only": order[:lo], "flops_share_weight_only": round(sum(site_flops[k_] for k_ in order[:lo]) / tot_f, 4)}
+            wsites = list(order[:lo])
+            report["neck_sites"] = {"tol_abs_m": AUTO_TOL_NECK_ABS_M, "groups": {n_: ks for n_, ks in cand_sites.items() if n_.startswith("group:")},
+                                    "l1_alone_vs_chosen_m": {n_: round(err[n_], 8) for n_ in order}, "weight_only": wsites,
+                                    "flops_share_weight_only": round(sum(cflops[n_] for n_ in wsites) / tot_f, 4)}
             if lo > 0:
-                neck = "wonly:" + ",".join(sorted(order[:lo]))
+                neck = site_mode(wsites)
                 l1_abs, total = kept
             if lo > 0 and os.environ.get("BS_NECK_PLAIN", "1") != "0":
-                # ---- second stage: one 16-bit pass for the large weight-only sites, judged on two frames against the reference
-                from .synthetic import make_sequence
-                extra = torch.from_numpy(make_sequence(1, H, W, seed=12)).to(self.dev)
-                frames2 = torch.cat([frames_u8, extra], 0).contiguous()
-                truth2 = torch.cat([truth, self.reference_depth(extra)], 0)
-
-                def depth2(neck_):
-                    self.set_class_modes(chosen, neck_, attn)
-                    plan = _ZoePlan(self, 2, H, W, True)
-                    plan.frames.copy_(frames2)
-                    plan.run(None)
-                    d = plan.depth_m.clone()
-                    torch.cuda.synchronize(self.dev)
-                    del plan
-                    return d
-
-                wsites = sorted(order[:lo])
-                cands = sorted((k_ for k_ in wsites if k_ != "rh.conv2.w" and site_flops[k_] >= AUTO_NECK_PLAIN_MIN_SHARE * tot_f),
-                               key=lambda k_: -site_flops[k_])
-                a0 = (depth2(neck) - truth2).abs().mean().item()
-                plain, trail, a_now = [], {}, a0
-                for k_ in cands:
-                    d_p = depth2("wonly:" + ",".join(wsites) + ";plain:" + ",".join(sorted(plain + [k_])))
-                    a_ = (d_p - truth2).abs().mean().item()
-                    trail[k_] = round(a_, 8)
-                    if a_ <= AUTO_TOL_NECK_PLAIN_ABS_M:
-                        plain.append(k_)
-                        a_now, l1_abs = a_, (d_p[:1] - truth).abs().mean().item()
-                        total = (d_p[:1] - ref).abs().mean().item()
-                report["neck_sites"].update(plain_tol_abs_m=AUTO_TOL_NECK_PLAIN_ABS_M, l1_two_frames_weight_only_m=round(a0, 8),
-                                            l1_two_frames_with_site_plain_m=trail, plain=sorted(plain), l1_two_frames_m=round(a_now, 8),
-                                            flops_share_plain=round(sum(site_flops[k_] for k_ in plain) / tot_f, 4))
+                # ---- second stage: one 16-bit pass for the weight-only candidates, largest first, with the static bias correction
+                means: Dict[str, torch.Tensor] = {}
+                depth(chosen, neck, attn, means=means)               # channel means of every product's input rows on the calibration frames
+                for k_, m_ in means.items():
+                    k_ = k_[3:]                                       # "in:<weight key>"
+                    if k_ in self.dw_sum:
+                        self.site_bias_corr[k_] = (self.dw_sum[k_] @ m_).contiguous()
+                cands = sorted((n_ for n_ in wsites if cand_sites[n_] != ["rh.conv2.w"] and (n_.startswith("group:") or cflops[n_] >= AUTO_NECK_PLAIN_MIN_SHARE * tot_f)),
+                               key=lambda n_: -cflops[n_])
+                a0 = worst(depth(chosen, neck, attn), truth)
+                trail, a_now = {}, a0
+                for n_ in cands:
+                    d_p = depth(chosen, site_mode(wsites, plain + [n_]), attn)
+                    a_, t_ = worst(d_p, truth), worst(d_p, ref)
+                    trail[n_] = round(a_, 8)
+                    if a_ <= AUTO_TOL_NECK_PLAIN_ABS_M and t_ <= tol_total:
+                        plain.append(n_)
+                        a_now, l1_abs, total = a_, a_, t_
+                report["neck_sites"].update(plain_tol_abs_m=AUTO_TOL_NECK_PLAIN_ABS_M, l1_weight_only_m=round(a0, 8), l1_with_candidate_plain_m=trail,
+                                            plain=list(plain), l1_plain_m=round(a_now, 8),
+                                            flops_share_plain=round(sum(cflops[n_] for n_ in plain) / tot_f, 4),
+                                            static_bias_correction=sorted(self.site_bias_corr))
                 if plain:
-                    neck = "wonly:" + ",".join(wsites) + ";plain:" + ",".join(sorted(plain))
+                    neck = site_mode(wsites, plain)
+        # ---- held-out validation: frames no decision above has seen.  Above the line the latest relaxations are withdrawn, newest first
+        if hold is not None:
+            hv = {"tol_m": AUTO_TOL_HOLDOUT_M, "frames": int(hold.shape[0]), "withdrawn": []}
+            neck_base = neck if not wsites else neck_full
+            while True:
+                per = l1f(depth(chosen, neck, attn, frames=hold), truth_h)
+                if float(per.max()) <= AUTO_TOL_HOLDOUT_M:
+                    break
+                if plain:
+                    hv["withdrawn"].append("plain:" + plain.pop())
+                elif wsites:
+                    hv["withdrawn"].append("wonly:" + wsites.pop())
+                elif step_up():
+                    hv["withdrawn"].append("backbone step")
+                else:
+                    break
+                neck = site_mode(wsites, plain) if wsites else neck_base
+            if hv["withdrawn"]:
+                d_c = depth(chosen, neck, attn)
+                l1_abs, total = worst(d_c, truth), worst(d_c, ref)
+                if "neck_sites" in report:
+                    report["neck_sites"].update(weight_only=list(wsites), plain=list(plain))
+            hv.update(l1_frames_m=[round(float(v), 8) for v in per], l1_max_m=round(float(per.max()), 8), l1_mean_m=round(float(per.mean()), 8))
+            report["holdout"] = hv
         if self.auto_attn and not corr_ok:
             # the split-precision kernel could not be tried on this geometry (every candidate above ran "single"): the engine keeps "corr",
             # which a plan of a capable geometry then uses and this one falls back from (_ZoePlan) -- "single" must be earned by a measurement
             attn = "corr"
             report["attn_note"] = f"attention not calibrated on a {nh_}x{nw_} network input (no split-precision kernel for it): kept at 'corr'"
+        # the static corrections travel with the report (a sharded run's ranks all apply rank 0's): only those of the sites that run one pass
+        keep_corr = {k_ for part in neck.split(";") if part.startswith("plain:") for k_ in part[6:].split(",")}
+        self.site_bias_corr = {k_: v for k_, v in self.site_bias_corr.items() if k_ in keep_corr}
+        self._bias_corr_cache.clear()
         report.update(class_modes={**{k: self.class_modes[k] for k in BACKBONE_CLASSES}, **chosen}, neck_mode=neck, attn_mode=attn,
-                      l1_total_vs_full_m=total, l1_abs_vs_reference_m=l1_abs)
+                      l1_total_vs_full_m=total, l1_abs_vs_reference_m=l1_abs,
+                      site_bias_corr={k_: v.cpu().tolist() for k_, v in self.site_bias_corr.items()})
         if l1_abs is not None and l1_abs > TOLERANCE_M:
             fixed = [k for k in BACKBONE_CLASSES if k not in switchable]
-            report["warning"] = (f"depth L1 of the calibration frame against the reference-precision engine is {l1_abs:.2e} m with every calibrated "
+            report["warning"] = (f"depth L1 of the calibration frames against the reference-precision engine is {l1_abs:.2e} m with every calibrated "
                                  f"choice at its most accurate: above the {TOLERANCE_M:.0e} m tolerance for these weights"
                                  + (f" (modes fixed by the caller, not calibrated: {({k: self.class_modes[k] for k in fixed})})" if fixed else ""))
             warnings.warn("ZoeDepthEngine.calibrate: " + report["warning"])
@@ -569,21 +667,25 @@ class ZoeDepthEngine:
             report["note"] = "no absolute reference (the engine holds no source weights): l1_total_vs_full_m is relative to the best mode only"
         self.set_class_modes(chosen, neck, attn)
         self.auto_modes = saved_auto
+        torch.cuda.synchronize(self.dev)
+        report["calibrate_s"] = round(_time.perf_counter() - t_start, 2)
         self.calibration = report
         if ckey is not None:
             _CALIBRATION_CACHE[ckey] = dict(report)
         torch.cuda.empty_cache()
         return report
 
-    def _weights_fingerprint(self) -> Tuple:
-        """(count, sum, sum of squares) over every source tensor, in double precision: what identifies a weight set for the calibration cache"""
-        n, s1, s2 = 0, 0.0, 0.0
+    def _weights_fingerprint(self) -> str:
+        """blake2b over every source tensor's name, shape and bytes: what identifies a weight set for the calibration cache (round-5
+        advisor: the (count, sum, sum of squares) of rounds 4-5 could not tell a permutation from the original)"""
+        import hashlib
+        h = hashlib.blake2b(digest_size=16)
         for k in sorted(self._sd):
-            t = self._sd[k].detach().double()
-            n += t.numel()
-            s1 += float(t.sum())
-            s2 += float((t * t).sum())
-        return (n, s1, s2)
+            t = self._sd[k].detach().cpu().contiguous()
+            h.update(k.encode())
+            h.update(str((tuple(t.shape), t.dtype)).encode())
+            h.update(memoryview(t.reshape(-1).view(torch.uint8).numpy()))
+        return h.hexdigest()
 
     def _w8conv(self, key: str, t: torch.Tensor) -> torch.Tensor:
         """conv weight [O, I, kh, kw] for the FP8-correction conv path (L.f8_conv_weight); scales to self.f8s[key]."""
@@ -593,10 +695,25 @@ class ZoeDepthEngine:
 
     def _wp(self, key: str, t: torch.Tensor) -> torch.Tensor:
         """plain neck / head weight: FP8-correction packing when the whole neck runs that format, else three 16-bit passes"""
+        if self.neck_f8 and t.shape[1] % 128 == 0:
+            self.dw_sum[key] = (t - t.to(self.dtype).float()).to(self.dev).contiguous()
         return self._w8(key, t) if self.neck_f8 else self._wn(t)
 
     def _wc(self, key: str, t: torch.Tensor) -> torch.Tensor:
+        if self.neck_f8:
+            self.dw_sum[key] = (t - t.to(self.dtype).float()).sum((2, 3)).to(self.dev).contiguous()          # [O, I]: summed over the taps
         return self._w8conv(key, t) if self.neck_f8 else self._wn_conv(t)
+
+    def site_bias(self, wkey: str, bias: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        """the bias a neck / head product runs with: its own, plus -- while the product runs ONE 16-bit pass and the calibration left a
+        correction for it -- the static part dW E[a] of the weight-rounding error that pass makes (site_bias_corr)"""
+        corr = self.site_bias_corr.get(wkey)
+        if corr is None or not self.neck_site_plain(wkey) or os.environ.get("BS_NECK_BIAS_CORR", "1") == "0":
+            return bias
+        hit = self._bias_corr_cache.get(wkey)
+        if hit is None:
+            hit = self._bias_corr_cache[wkey] = (corr if bias is None else (bias + corr)).contiguous()
+        return hit
 
     def _wn(self, t: torch.Tensor) -> torch.Tensor:
         """plain GEMM weight [N, K]; accurate: [N, 3K] = [W_hi | W_hi | W_lo] against A = [hi | lo], then hi again."""
@@ -1075,7 +1192,12 @@ class _ZoePlan:
                 ok = dict(ldo=ok["ldo"], out_split_off=0)
             if acc and wkey in f8s:
                 self.site_flops[wkey] = self.site_flops.get(wkey, 0.0) + 2.0 * M * N * K      # (calibrate(): what a site's second product is worth)
-                P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=kw.pop("lda", 2 * K), f8_seg=2 * K, shuffle=shuffle,
+                lda_ = kw.pop("lda", 2 * K)
+                if not kw.get("bias_group_rows"):
+                    # (calibrate(): the channel means of this product's input, and the static bias correction they give while it runs one pass)
+                    P.mark("in:" + wkey, A, ("chanmean", kw.get("a_offset", 0), M, lda_, K))
+                    kw["bias"] = eng.site_bias(wkey, kw.get("bias"))
+                P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=lda_, f8_seg=2 * K, shuffle=shuffle,
                        precision_passes=1, **ok, **f8kw(wkey), **kw)
             else:
                 ok.pop("out_f8", None)
@@ -1103,6 +1225,8 @@ class _ZoePlan:
                 if out_relu is not None:
                     kw["out_relu"] = out_relu
                 self.site_flops[wkey] = self.site_flops.get(wkey, 0.0) + 2.0 * NB * ho * wo * Co * 9 * Ci
+                P.mark("in:" + wkey, A, ("chanmean", 0, NB * hh * ww, 2 * Ci, Ci))
+                kw["bias"] = eng.site_bias(wkey, kw.get("bias"))
                 P.gemm(name, A, w[wkey], out, M=NB * ho * wo, N=Co, K=9 * Ci, lda=2 * Ci, conv=g_, f8_seg=2 * Ci, ldo=2 * Co,
                        ldr=2 * Co if has_res else 0, res_f8=has_res, out_split_off=Co, out_f8=F8O, precision_passes=1, **f8kw(wkey), **kw)
             else:
@@ -1322,6 +1446,10 @@ class _ZoePlan:
                 umode, usc = 0, (127, 127, 127, 127)
             P.add("rh.conv2", "bs_upconv_fused", r1, w["rh.conv2.w"], w["rh.conv2.b"], last, NB, h3, w3, Fc // 2, c.rel_features, 2 * h3, 2 * w3,
                   RZ, 1, umode, *usc, L.dt(last))
+            # the reference's product: conv 3x3 (Fc/2 -> rel_features) at the UPSAMPLED resolution; what runs: nine tap products at the low one,
+            # plus their FP8 correction stage(s)
+            f_low = 2.0 * NB * h3 * w3 * 9 * c.rel_features * (Fc // 2)
+            P.tag_stack(4.0 * f_low, f_low * (1.0, 1.5, 2.0)[umode])       # (executed: bs_gemm's convention, an FP8 stage = half a pass)
             free(r1)
         else:
             y9 = e32(NB, h3, w3, 9 * c.rel_features)
@@ -1362,6 +1490,7 @@ class _ZoePlan:
                 # never stored -- bit-identical to bs_add_resized + bs_mlp2 (csrc/mlp2.hip, FUSE)
                 P.add(f"at{i}.mlp", "bs_mlp2_add", emb, emb_prev, w[f"at{i}.c1.w"], w[f"at{i}.c1.b"], w[f"at{i}.c2.w"], w[f"at{i}.c2.b"], A, NB, ph_,
                       pw_, fh, fw, E, 2 * E, 2 * na, L.ACT_SOFTPLUS_FAST, L.dt(emb) | (16 if acc else 0))
+                P.tag_stack(2.0 * Mi * (E * 2 * E + 2 * E * 2 * na), 2.0 * Mi * (E * 2 * E + 2 * E * 2 * na))      # the attractor's two 1x1 convolutions
                 free(emb_prev)
                 y = None
             else:
@@ -1375,6 +1504,7 @@ class _ZoePlan:
                 # bit-identical to the two launches below (bs_mlp2, csrc/mlp2.hip)
                 P.add(f"at{i}.mlp", "bs_mlp2", y, E * m2, w[f"at{i}.c1.w"], w[f"at{i}.c1.b"], w[f"at{i}.c2.w"], w[f"at{i}.c2.b"], A, Mi, E, 2 * E,
                       2 * na, L.ACT_SOFTPLUS_FAST, L.dt(y))
+                P.tag_stack(2.0 * Mi * (E * 2 * E + 2 * E * 2 * na), 2.0 * Mi * (E * 2 * E + 2 * E * 2 * na))
                 free(y)
             else:
                 a1 = e16(Mi, 2 * E)

@@ -26,9 +26,10 @@ def golden_dir():
 TWO_PROC = {"proc": None, "dir": os.path.join(ROOT, "gpurun_out", "two_process"), "log": None}
 
 
-def pytest_sessionstart(session):
-    expr = getattr(session.config.option, "markexpr", "") or ""
-    if "gpu" not in expr or "not gpu" in expr:
+def pytest_collection_finish(session):
+    # (after deselection: the helper is started only when the test that waits for it is going to run -- a `-k` subset that leaves it out
+    # does not pay for two extra GPU processes; round-5 advisor)
+    if not any(item.name == "test_two_process_sharded_sequence" for item in session.items) or TWO_PROC["proc"] is not None:
         return
     try:
         import torch
@@ -41,14 +42,19 @@ def pytest_sessionstart(session):
     shutil.rmtree(TWO_PROC["dir"], ignore_errors=True)
     os.makedirs(TWO_PROC["dir"], exist_ok=True)
     TWO_PROC["log"] = open(os.path.join(TWO_PROC["dir"], "log.txt"), "w")
+    # its own session = its own process group: the helper's mp.spawn workers are its children and go down with it (sessionfinish)
     TWO_PROC["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "two_process_shard.py"), TWO_PROC["dir"]],
-                                        stdout=TWO_PROC["log"], stderr=subprocess.STDOUT, cwd=ROOT)
+                                        stdout=TWO_PROC["log"], stderr=subprocess.STDOUT, cwd=ROOT, start_new_session=True)
 
 
 def pytest_sessionfinish(session, exitstatus):
     p = TWO_PROC["proc"]
     if p is not None and p.poll() is None:
-        p.kill()
+        import signal
+        try:
+            os.killpg(p.pid, signal.SIGKILL)        # the launcher AND its workers (exactly the group started above)
+        except (ProcessLookupError, PermissionError):
+            p.kill()
     if TWO_PROC["log"] is not None:
         TWO_PROC["log"].close()
 
