@@ -196,7 +196,6 @@ def main():
                     help="statistics of the random-init ZoeDepth weights (bodyslam_amd.synthetic.WEIGHT_VARIANTS): 'outlier' = 6 channels 50x larger "
                          "behind every LayerNorm, what a trained BEiT carries -- the calibration then has to switch corrections back on")
     ap.add_argument("--no-outlier-leg", action="store_true", help="skip the extra `outlier_weights` figure (the accurate mode on outlier-channel weights)")
-    ap.add_argument("--no-latency-leg", action="store_true", help="skip the extra `latency_b1_ms` figures (one frame / one pair per call, the reference's call pattern)")
     ap.add_argument("--no-pcie-leg", action="store_true", help="skip the extra `pcie_inclusive` figure (frames from pinned host memory, results copied back)")
     ap.add_argument("--no-latency-leg", action="store_true", help="skip the extra `latency_b1_ms` figures (one frame / one pair per call: the reference's call pattern)")
     ap.add_argument("--no-pmc-traffic", action="store_true",

@@ -967,16 +967,12 @@ static int launch_attn_tab(const void* q, const void* k, const void* vt, const v
     if (ql) {     // split-precision operands (bs_attention_table_corr): 64 KiB ring, the 256-register budget = two waves per SIMD, 8 per CU
         // Round 5: 7- or 8-wave blocks.  A 5-wave block leaves 3 of the CU's 8 wave slots empty (a second block of 5 does not fit them): blocks of
         // ceil(nqt / ceil(nqt / 8)) waves fill them (25 query tiles: 4 blocks of 7) and stage a tile once per 7-8 query tiles.  Same bits.
-        static const bool cls2_ok = getenv("BS_ATTN_NO_CLS2") == nullptr;     // diagnostics: the round-5 shape before the cls query left the tiles
+        static const bool cls2_ok = diag_env("BS_ATTN_NO_CLS2") == nullptr;     // diagnostics: the round-5 shape before the cls query left the tiles
         if (cls2_ok && hp % 8 == 0) {
             // the cls query as cls_query_pass: 24 patch tiles = 3 blocks of 8 waves, every wave slot of the CU (2 per SIMD at this register budget).
             // (Three waves per SIMD -- 168 registers, 6-wave blocks, two per CU -- spill 29 registers and run 1 886 us against 1 313.)
             auto kb = attention_tab2_kernel<T, 8, 2, true, false, true>;
-            static bool attrb = false;
-            if (!attrb) {
-                BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-                attrb = true;
-            }
+            BS_MAX_DYNAMIC_LDS(reinterpret_cast<const void*>(kb), 96 * 1024);
             hipLaunchKernelGGL(kb, dim3(B * nh * (hp / 8)), dim3(8 * 64), 64 * 1024 + tab_bytes + 8192, st, (const T*)q, (const T*)k, (const T*)vt,
                                (const T*)ql, (const T*)kl, (const T*)vtl, table, (T*)out, split, B, nh, hp, Sp, hp / 8, ntab, grouped);
             BS_CHECK_LAUNCH();
@@ -987,11 +983,7 @@ static int launch_attn_tab(const void* q, const void* k, const void* vt, const v
 #define BS_ATTN_CORR_BIG(QWB)                                                                                                                \
     do {                                                                                                                                     \
         auto kb = attention_tab2_kernel<T, QWB, 2, true>;                                                                                    \
-        static bool attrb = false;                                                                                                           \
-        if (!attrb) {                                                                                                                        \
-            BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));     \
-            attrb = true;                                                                                                                    \
-        }                                                                                                                                    \
+        BS_MAX_DYNAMIC_LDS(reinterpret_cast<const void*>(kb), 96 * 1024); \
         hipLaunchKernelGGL(kb, dim3(B * nh * nb8), dim3(QWB * 64), 64 * 1024 + tab_bytes, st, (const T*)q, (const T*)k, (const T*)vt,        \
                            (const T*)ql, (const T*)kl, (const T*)vtl, table, (T*)out, split, B, nh, hp, Sp, nb8, ntab, grouped);             \
         BS_CHECK_LAUNCH();                                                                                                                   \
@@ -1002,13 +994,9 @@ static int launch_attn_tab(const void* q, const void* k, const void* vt, const v
 #undef BS_ATTN_CORR_BIG
         }
         auto kc = attention_tab2_kernel<T, QW, 2, true>;
-        static bool attrc = false;
-        if (!attrc) {
-            // the cap covers the largest table the entry admits (hp = 40: 64 KiB + 20.3 KiB); up to hp = 30 the ring + table stay within
+        // the cap covers the largest table the entry admits (hp = 40: 64 KiB + 20.3 KiB); up to hp = 30 the ring + table stay within
             // 80 KiB and two blocks share a CU, beyond that one block per CU (round-4 advisor: the cap was 80 KiB and hp 32 ... 40 failed)
-            BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, 88 * 1024));
-            attrc = true;
-        }
+        BS_MAX_DYNAMIC_LDS(reinterpret_cast<const void*>(kc), 88 * 1024);
         hipLaunchKernelGGL(kc, dim3(B * nh * nqb), dim3(QW * 64), 64 * 1024 + tab_bytes, st, (const T*)q, (const T*)k, (const T*)vt, (const T*)ql,
                            (const T*)kl, (const T*)vtl, table, (T*)out, split, B, nh, hp, Sp, nqb, ntab, grouped);
         BS_CHECK_LAUNCH();
@@ -1017,43 +1005,31 @@ static int launch_attn_tab(const void* q, const void* k, const void* vt, const v
     int smem = 32 * 1024 + ((ntab * 4 + 1023) & ~1023);
     smem = smem < QW * 8192 ? QW * 8192 : smem;                    // the epilogue stages 8 KiB per wave
     auto kern = attention_tab_kernel<T, QW>;
-    static bool attr = false;
-    if (!attr) {
-        BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        attr = true;
-    }
-    static const bool pipelined_ok = getenv("BS_ATTN_NO_PIPE") == nullptr;       // diagnostics: the unpipelined loop
+    BS_MAX_DYNAMIC_LDS(reinterpret_cast<const void*>(kern), 64 * 1024);
+    static const bool pipelined_ok = diag_env("BS_ATTN_NO_PIPE") == nullptr;       // diagnostics: the unpipelined loop
     if (hp % 2 == 0 && pipelined_ok) {
         // 4 waves per SIMD (128 registers, three blocks per CU) with the packed pre-shift: one spilled register, 628 us per NB = 128 launch.
         // With the scalar pre-shift (BS_ATTN_NO_PK, the round-3 kernel) ten registers spill and their reloads put an `s_waitcnt vmcnt(0)`
         // right behind the stage -- the next tile's DMA is waited for at once instead of under the tile's arithmetic: 700 us.  The spill-free
         // 3-waves-per-SIMD build (BS_ATTN_WPE3) overlaps the DMA too and is still slower (811 us): occupancy hides more than the
         // prefetch does (profiles/r04_attention_variants.txt).
-        static const bool wpe3 = getenv("BS_ATTN_WPE3") != nullptr, pk = getenv("BS_ATTN_NO_PK") == nullptr;
+        static const bool wpe3 = diag_env("BS_ATTN_WPE3") != nullptr, pk = diag_env("BS_ATTN_NO_PK") == nullptr;
         auto kern2 = wpe3 ? (pk ? attention_tab2_kernel<T, QW, 3, false, true> : attention_tab2_kernel<T, QW, 3, false>)
                           : (pk ? attention_tab2_kernel<T, QW, 4, false, true> : attention_tab2_kernel<T, QW, 4, false>);
-        static bool attr2 = false;
-        if (!attr2) {
-            BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-            attr2 = true;
-        }
-        static const int abl = getenv("BS_ATTN_ABL") ? atoi(getenv("BS_ATTN_ABL")) : 0;      // diagnostics (timing only)
+        BS_MAX_DYNAMIC_LDS(reinterpret_cast<const void*>(kern2), 64 * 1024);
+        static const int abl = diag_env("BS_ATTN_ABL") ? atoi(diag_env("BS_ATTN_ABL")) : 0;      // diagnostics (timing only)
         // Round 5: large blocks.  With 5 waves per block an (image, head)'s 25 query tiles are 5 blocks, each staging every K / V^T tile for itself
         // (the staging is 9 % of the launch by ablation, profiles/r05_attention_ablations.txt); with 11-14 waves per block -- 2 blocks for 25 or
         // 27 query tiles, 3 for 33 or 41 -- a tile is staged once per 11-14 query tiles: 717 -> 669 us at NB = 128 (one block per CU: the epilogue
         // stages 8 KiB per wave; same bits -- a wave's arithmetic does not depend on its block).  Query-tile counts that do not split into
         // blocks of 11-14 keep the 5-wave blocks.
-        static const bool cls2_ok = getenv("BS_ATTN_NO_CLS2") == nullptr;     // diagnostics: the large blocks below
+        static const bool cls2_ok = diag_env("BS_ATTN_NO_CLS2") == nullptr;     // diagnostics: the large blocks below
         if (!wpe3 && pk && abl == 0 && cls2_ok && hp % 8 == 0) {
             // Round 5, second step: the cls query leaves the tiles (cls_query_pass).  24 (32, 40) patch tiles are 3 (4, 5) blocks of 8 waves, 64 KiB
             // of LDS each: two blocks per CU fill its 16 wave slots, four waves on every SIMD (13 + 12 waves left 3 slots empty and one SIMD with
             // four waves against three).  profiles/r05_attention_blocks.txt.
             auto kb = attention_tab2_kernel<T, 8, 4, false, true, true>;
-            static bool attrb = false;
-            if (!attrb) {
-                BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-                attrb = true;
-            }
+            BS_MAX_DYNAMIC_LDS(reinterpret_cast<const void*>(kb), 128 * 1024);
             const int ldsb = 8 * 8192 > 32 * 1024 + tab_bytes + 8192 ? 8 * 8192 : 32 * 1024 + tab_bytes + 8192;
             hipLaunchKernelGGL(kb, dim3(B * nh * (hp / 8)), dim3(8 * 64), ldsb, st, (const T*)q, (const T*)k, (const T*)vt, (const T*)nullptr,
                                (const T*)nullptr, (const T*)nullptr, table, (T*)out, split, B, nh, hp, Sp, hp / 8, ntab, grouped);
@@ -1065,11 +1041,7 @@ static int launch_attn_tab(const void* q, const void* k, const void* vt, const v
 #define BS_ATTN_BIG(QWB)                                                                                                                     \
     do {                                                                                                                                     \
         auto kb = attention_tab2_kernel<T, QWB, 4, false, true>;                                                                             \
-        static bool attrb = false;                                                                                                           \
-        if (!attrb) {                                                                                                                        \
-            BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));    \
-            attrb = true;                                                                                                                    \
-        }                                                                                                                                    \
+        BS_MAX_DYNAMIC_LDS(reinterpret_cast<const void*>(kb), 128 * 1024); \
         const int ldsb = QWB * 8192 > 32 * 1024 + tab_bytes ? QWB * 8192 : 32 * 1024 + tab_bytes;                                            \
         hipLaunchKernelGGL(kb, dim3(B * nh * nb_big), dim3(QWB * 64), ldsb, st, (const T*)q, (const T*)k, (const T*)vt, (const T*)nullptr,   \
                            (const T*)nullptr, (const T*)nullptr, table, (T*)out, split, B, nh, hp, Sp, nb_big, ntab, grouped);               \
@@ -1088,7 +1060,7 @@ static int launch_attn_tab(const void* q, const void* k, const void* vt, const v
         return BS_OK;
     }
     hipLaunchKernelGGL(kern, dim3(B * nh * nqb), dim3(QW * 64), smem, st, (const T*)q, (const T*)k, (const T*)vt, table, (T*)out, split, B,
-                       nh, hp, Sp, nqb, ntab, grouped, getenv("BS_ATTN_ABLATE") ? atoi(getenv("BS_ATTN_ABLATE")) : 0);
+                       nh, hp, Sp, nqb, ntab, grouped, diag_env("BS_ATTN_ABLATE") ? atoi(diag_env("BS_ATTN_ABLATE")) : 0);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }
@@ -1098,7 +1070,7 @@ static int launch_attn(const void* q, const void* k, const void* vt, const float
                        hipStream_t st) {
     const int nqt = cdiv(S, 32), nqb = cdiv(nqt, QW);
     hipLaunchKernelGGL((attention_kernel<T, QW>), dim3(B * nh * nqb), dim3(QW * 64), 32 * 1024, st, (const T*)q, (const T*)k,
-                       (const T*)vt, bias, (T*)out, split, B, nh, S, Sp, nqt, nqb, getenv("BS_ATTN_ABLATE") ? atoi(getenv("BS_ATTN_ABLATE")) : 0);
+                       (const T*)vt, bias, (T*)out, split, B, nh, S, Sp, nqt, nqb, diag_env("BS_ATTN_ABLATE") ? atoi(diag_env("BS_ATTN_ABLATE")) : 0);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }

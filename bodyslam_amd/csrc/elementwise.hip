@@ -988,18 +988,14 @@ static int launch_tapsum(const float* y, const float* bias, void* out, int B, in
         sx = (float)Win / (float)Wout;
     }
     // the LDS-staged form: the relative head's geometry (x2, 32 channels; its window bound of 11 x 11 holds for scale factors >= 0.49)
-    static const bool no_lds = getenv("BS_TAPSUM_NO_LDS") != nullptr;     // diagnostics
+    static const bool no_lds = diag_env("BS_TAPSUM_NO_LDS") != nullptr;     // diagnostics
     if (!no_lds && Co == 32 && Hout == 2 * Hin && Wout == 2 * Win && Hin >= 2 && Win >= 2) {
         constexpr int smem = TS_TAB + TS_LW * TS_LH * 9 * 32 * 4;
         static_assert((TS_TH + 2 + TS_TW + 2) * 16 <= TS_TAB, "tables");
         const dim3 grid(cdiv(Wout, TS_TW) * cdiv(Hout, TS_TH) * B);
 #define BS_TS(SP)                                                                                                                          \
     do {                                                                                                                                   \
-        static bool attr_done = false;                                                                                                     \
-        if (!attr_done) {                                                                                                                  \
-            BS_CHECK_HIP(hipFuncSetAttribute((const void*)upconv_tapsum_lds_kernel<T, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); \
-            attr_done = true;                                                                                                              \
-        }                                                                                                                                  \
+        BS_MAX_DYNAMIC_LDS(((const void*)upconv_tapsum_lds_kernel<T, SP>), smem); \
         hipLaunchKernelGGL((upconv_tapsum_lds_kernel<T, SP>), grid, dim3(512), smem, st, y, bias, (T*)out, B, Hin, Win, Hout, Wout, sy, sx, align, \
                            relu);                                                                                                          \
     } while (0)

@@ -53,7 +53,7 @@ static int launch_tile(IgemmParams& p, int dtype, bool conv, int tile, hipStream
     // same launch time (profiles/r04_gemm_experiments.txt (7)).  Not the QKV product: its V^T tiles would bunch up at the end (+45 %).
     // BS_GEMM_STRIP = w forces a width (0 = row-major) for every non-convolution launch: the one diagnostic switch of this path (read once;
     // tools/probes/gemm_strip.sh).  (The thirds-interleaved strip walk for the QKV product, round 4's experiment, is gone: -50 % L2 refills, +5.6 % time.)
-    static const int strip_env = getenv("BS_GEMM_STRIP") ? atoi(getenv("BS_GEMM_STRIP")) : -1;
+    static const int strip_env = diag_env("BS_GEMM_STRIP") ? atoi(diag_env("BS_GEMM_STRIP")) : -1;
     const bool qkv = p.out_mode == BS_OUT_QKV;
     p.strip = conv ? 0 : (strip_env >= 0 ? strip_env : ((BM == 256 && BN == 256 && !qkv && p.ntn >= 8) ? 4 : 0));
     // correction mode of the instantiation: 1 = FP8 stages / (hi16 | hi8 | lo8) formats, 0 = plain
@@ -113,7 +113,7 @@ static int dispatch(IgemmParams& p, int dtype, bool conv, int tile, hipStream_t 
     const int rem = p.M % BM, full = p.M / BM, ntn = cdiv(p.N, BN), cus = cu_count();
     // (measured, tools/bench_kernels.py tiles 9 vs 809: -8 % on fc2 (K = 4096); neutral to slightly negative for K = 1024, where a
     // block is short and the second launch costs as much as the saved blocks)
-    static const bool no_split = getenv("BS_NO_TAIL_SPLIT") != nullptr;   // diagnostics
+    static const bool no_split = diag_env("BS_NO_TAIL_SPLIT") != nullptr;   // diagnostics
     if (!no_split && !(p.ablate & 8) && !conv && BM == 256 && p.K >= 2048 && full > 0 && rem > 0 && rem <= 128 && p.N % 128 == 0 &&
         cdiv(full * ntn, cus) < cdiv((full + 1) * ntn, cus)) {
         IgemmParams main = p;
@@ -122,7 +122,7 @@ static int dispatch(IgemmParams& p, int dtype, bool conv, int tile, hipStream_t 
         p.m_begin = full * BM;                 // rows [full*BM, M)
         // The two launches touch disjoint rows, so the short, latency-bound tail (8-32 small blocks, ~60 us on its own) runs on
         // a side stream beside the main launch and fills CUs the main grid leaves idle in its last round: fork / join by events.
-        static const bool side_ok = getenv("BS_NO_TAIL_STREAM") == nullptr;
+        static const bool side_ok = diag_env("BS_NO_TAIL_STREAM") == nullptr;
         hipStream_t side = nullptr;
         hipEvent_t ev_fork = nullptr, ev_join = nullptr;
         if (side_ok) {

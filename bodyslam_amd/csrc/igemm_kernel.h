@@ -1276,11 +1276,7 @@ inline int launch_mode(const IgemmParams& p, hipStream_t st) {
     constexpr int smem = STAGES * (BM + BN) * BK * 2;
     dim3 grid(p.ntm * p.ntn), block(WM * WN * 64);
     auto k = igemm_kernel<T, BM, BN, WM, WN, BK, STAGES, MODE, PP, CM>;
-    static bool attr = false;
-    if (!attr) {
-        BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr = true;
-    }
+    BS_MAX_DYNAMIC_LDS(reinterpret_cast<const void*>(k), smem);
     hipLaunchKernelGGL(k, grid, block, smem, st, p);
     BS_CHECK_LAUNCH();
     return BS_OK;

@@ -356,7 +356,7 @@ extern "C" int bs_attractor_step(const float* A, const float* bins_prev, float* 
     if (B == 0) return BS_OK;
     const float sy = H > 1 ? (float)(Hp - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(Wp - 1) / (float)(W - 1) : 0.f;
     BS_REQUIRE(n_attr % 4 == 0, "bs_attractor_step: n_attr must be a multiple of 4");
-    static const bool one_quad = getenv("BS_ATTRACTOR_NQ1") != nullptr;        // diagnostics (A / B)
+    static const bool one_quad = diag_env("BS_ATTRACTOR_NQ1") != nullptr;        // diagnostics (A / B)
     if (n_bins % 8 == 0 && !one_quad) {      // (four quads per thread: 1.65 ms against 1.59 for the bench's four levels; one: 1.72)
         const unsigned per_row = (unsigned)W * (route ? 1 : groups) * (n_bins / 8);
         hipLaunchKernelGGL(attractor_kernel<2>, dim3(cdiv((int)per_row, 256), B * H), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A,
@@ -394,12 +394,7 @@ extern "C" int bs_logbinom_depth_ex(const void* last, const float* Eh, const flo
     dtype &= 15;
 #define BS_LB_LAUNCH(TT, LS, HD)                                                                                                 \
     do {                                                                                                                         \
-        static bool attr_set = false;                                                                                            \
-        if (!attr_set) {                                                                                                         \
-            BS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&logbinom_kernel<TT, LS, HD>),                        \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));                            \
-            attr_set = true;                                                                                                     \
-        }                                                                                                                        \
+        BS_MAX_DYNAMIC_LDS(reinterpret_cast<const void*>(&logbinom_kernel<TT, LS, HD>), 96 * 1024); \
         hipLaunchKernelGGL((logbinom_kernel<TT, LS, HD>), grid, dim3(256), lds, st, (const TT*)last, Eh, bins, w0_last, w2, b2,   \
                            rel_w, route, depth, B, H, W, He, We, sy, sx, min_temp, max_temp, ncell_max);                         \
     } while (0)

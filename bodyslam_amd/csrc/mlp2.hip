@@ -216,11 +216,7 @@ __global__ __launch_bounds__(512) void mlp2_kernel(const T* __restrict__ x, int 
 template <typename T, int FUSE, int SPLIT>
 static int launch_mlp2(const void* x, int ldx, const void* W1, const float* b1, const void* W2, const float* b2, float* out, int M, int N2, int act2,
                        const MlpAddGeom& ag, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        BS_CHECK_HIP(hipFuncSetAttribute((const void*)mlp2_kernel<T, FUSE, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS + (FUSE ? MLP_BM * 32 : 0)));
-        attr_done = true;
-    }
+    BS_MAX_DYNAMIC_LDS(((const void*)mlp2_kernel<T, FUSE, SPLIT>), MLP_LDS + (FUSE ? MLP_BM * 32 : 0));
     hipLaunchKernelGGL((mlp2_kernel<T, FUSE, SPLIT>), dim3(cdiv(M, MLP_BM)), dim3(512), MLP_LDS + (FUSE ? MLP_BM * 32 : 0), st, (const T*)x, ldx, (const T*)W1, b1, (const T*)W2, b2,
                        out, M, N2, act2, ag);
     BS_CHECK_LAUNCH();

@@ -644,7 +644,7 @@ extern "C" int bs_tsdf_touch(const float* depth, int32_t H, int32_t W, int32_t s
             view.e[4 * r + 3] = -(inv[3 * r] * m[3] + inv[3 * r + 1] * m[7] + inv[3 * r + 2] * m[11]);
         }
     }
-    const int cull = getenv("BS_TSDF_NO_CULL") == nullptr && det_ok(pose);
+    const int cull = diag_env("BS_TSDF_NO_CULL") == nullptr && det_ok(pose);
     hipLaunchKernelGGL(tsdf_assign_kernel, dim3(cdiv(table_cap, 256)), dim3(256), 0, st, reinterpret_cast<const long long*>(table_keys), table_slots,
                        table_stamp, (unsigned)table_cap, frame_id, unit_index, max_units, counters, touched, view, unit_length, W, H, cull);
     BS_CHECK_LAUNCH();
@@ -767,7 +767,7 @@ extern "C" int bs_tsdf_integrate_batch(const void* frames_dev, int32_t n_frames,
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const TsdfFrame* frames = static_cast<const TsdfFrame*>(frames_dev);
     BS_CHECK_HIP(hipMemsetAsync(counters + 1, 0, sizeof(int32_t), st));
-    const int cull = getenv("BS_TSDF_NO_CULL") == nullptr;
+    const int cull = diag_env("BS_TSDF_NO_CULL") == nullptr;
     hipLaunchKernelGGL(tsdf_assign_batch_kernel, dim3(cdiv(table_cap, 256)), dim3(256), 0, st, frames, reinterpret_cast<const long long*>(table_keys),
                        table_slots, reinterpret_cast<unsigned long long*>(table_fmask), (unsigned)table_cap, unit_index, max_units, counters, touched,
                        reinterpret_cast<unsigned long long*>(unit_mask), voxel_length * res, W, H, cull);

@@ -317,11 +317,7 @@ static int launch_upconv_fused(const UpconvFusedArgs& a, hipStream_t st) {
     constexpr int smem = ucf::lds_bytes<MODE>();
     static_assert(smem <= 160 * 1024, "LDS budget");
     static_assert((ucf::TH + 2 + ucf::TW + 2) * 16 <= ucf::TAB / 2, "tables");
-    static bool attr_done = false;
-    if (!attr_done) {
-        BS_CHECK_HIP(hipFuncSetAttribute((const void*)upconv_fused_kernel<T, SPLIT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_done = true;
-    }
+    BS_MAX_DYNAMIC_LDS(((const void*)upconv_fused_kernel<T, SPLIT, MODE>), smem);
     const int grid = a.ntiles < cu_count() ? a.ntiles : cu_count();          // one 512-thread block per CU (LDS), persistent over the tiles
     hipLaunchKernelGGL((upconv_fused_kernel<T, SPLIT, MODE>), dim3(grid), dim3(512), smem, st, a);
     BS_CHECK_LAUNCH();

@@ -132,9 +132,10 @@ AUTO_NECK_CANDIDATES = (NECK_RELHEAD_WONLY, "full")
 # not worth a calibration forward EACH; since round 6 they are candidates as GROUPS (AUTO_NECK_SMALL_GROUPS: one forward per group and
 # stage) -- in round 5 none of them was ever calibrated and all ran both corrections, 2-3x their algorithmic work (VERDICT r5 #1 ii).
 AUTO_TOL_NECK_ABS_M = 5.0e-5
-AUTO_NECK_SITE_MIN_SHARE = 0.015
-AUTO_NECK_SMALL_GROUPS = {"readout": ("ro",), "reassemble+projections": ("ra", "fu0.proj", "fu1.proj", "fu2.proj", "fu3.proj", "pj"),
-                          "small3x3": ("nc", "fu")}           # by weight-key prefix, first match; the bins head's bottleneck conv (mh.) stays out
+# (round 6: a calibration forward over four frames costs ~0.1 s, so every product above 0.1 % of the neck's FLOPs is a candidate of its own --
+# the first grouping tried, "all reassemble / projection GEMMs", hid one sensitive member behind 6.4e-5 m for the whole group)
+AUTO_NECK_SITE_MIN_SHARE = 0.001
+AUTO_NECK_SMALL_GROUPS = {"tiny": ("ro", "ra", "nc", "fu", "pj", "rh")}      # by weight-key prefix, first match; the bins head's bottleneck conv (mh.) stays out
 # Round 5, second stage: the large weight-only sites may drop the weight-rounding correction TOO -- one 16-bit pass, `f8_skip_from = -1`, the
 # form "wonly:...;plain:<site>,..." (ZoeDepthEngine.neck_site_plain).  tools/probes/neck_plain_study.py: a site alone moves the map by 2-3e-5 m,
 # but twelve of them together leave the distance to the reference where it was (4.5 -> 4.9e-5 m) -- weight rounding in the neck is incoherent
@@ -145,7 +146,7 @@ AUTO_NECK_SMALL_GROUPS = {"readout": ("ro",), "reassemble+projections": ("ra", "
 # validated on AUTO_HOLDOUT_FRAMES frames that no decision has seen: above AUTO_TOL_HOLDOUT_M there, the latest relaxations are withdrawn.
 # And the one-pass sites carry a STATIC bias correction: the token-independent part dW E[a] of their weight-rounding error, from the
 # calibration frames' channel means (site_bias_corr; the data-free-quantisation bias correction) -- no run-time cost.
-AUTO_NECK_PLAIN_MIN_SHARE = 0.015
+AUTO_NECK_PLAIN_MIN_SHARE = 0.001
 AUTO_TOL_NECK_PLAIN_ABS_M = 6.0e-5
 AUTO_CAL_FRAMES = 4
 AUTO_HOLDOUT_FRAMES = 4
@@ -1193,9 +1194,10 @@ class _ZoePlan:
             if acc and wkey in f8s:
                 self.site_flops[wkey] = self.site_flops.get(wkey, 0.0) + 2.0 * M * N * K      # (calibrate(): what a site's second product is worth)
                 lda_ = kw.pop("lda", 2 * K)
+                # (calibrate(): the channel means of this product's input, and the static bias correction they give while it runs one pass;
+                # a product with a per-group bias -- the readout's token half -- gets its correction through the product that forms that bias)
+                P.mark("in:" + wkey, A, ("chanmean", kw.get("a_offset", 0), M, lda_, K))
                 if not kw.get("bias_group_rows"):
-                    # (calibrate(): the channel means of this product's input, and the static bias correction they give while it runs one pass)
-                    P.mark("in:" + wkey, A, ("chanmean", kw.get("a_offset", 0), M, lda_, K))
                     kw["bias"] = eng.site_bias(wkey, kw.get("bias"))
                 P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=lda_, f8_seg=2 * K, shuffle=shuffle,
                        precision_passes=1, **ok, **f8kw(wkey), **kw)
@@ -1246,7 +1248,9 @@ class _ZoePlan:
         for i, ch in enumerate(c.neck_hidden):
             t16 = taps16[i]
             # cls half of the readout: per-image bias vector  c_b = cls_b @ W_cls^T + b   (A rows = the cls row of every image)
-            nplain(f"ro{i}.cls", t16, f"ro{i}.w_cls", cb, NB, Hd, Hd, out_pairs=False, lda=(1 if grouped else S) * PE(Hd), bias=w[f"ro{i}.b"])
+            # (its bias also carries the token half's static correction while that product runs one pass: c_b is added to every token row)
+            nplain(f"ro{i}.cls", t16, f"ro{i}.w_cls", cb, NB, Hd, Hd, out_pairs=False, lda=(1 if grouped else S) * PE(Hd),
+                   bias=eng.site_bias(f"ro{i}.w_tok", w[f"ro{i}.b"]))
             # token half: the patch rows of every image, + c_b, GELU.  Grouped rows: a plain GEMM over rows NB..; image-major rows:
             # rows 1..S-1 of every image (a 1-row "conv" with a -1 column crop)
             if grouped:
