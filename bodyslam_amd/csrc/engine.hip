@@ -19,7 +19,9 @@
 
 namespace {
 
-constexpr char kMagic[8] = {'B', 'S', 'E', 'N', 'G', '0', '1', '\0'};
+// (version 02, round 6: BS_ACT_SOFTPLUS became the exact form in round 5 and bs_gemm_desc grew out2_relu inside its tail padding -- a
+// round-4 file would load and replay with other bits; the version is bumped whenever an enum's meaning or the descriptor's layout changes)
+constexpr char kMagic[8] = {'B', 'S', 'E', 'N', 'G', '0', '2', '\0'};
 enum { KIND_WORKSPACE = 0, KIND_ZERO = 1, KIND_DATA = 2 };
 enum { ARG_I64 = 0, ARG_F64 = 1, ARG_PTR = 2, ARG_NULL = 3, ARG_DESC = 4 };
 enum { OP_CALL = 0, OP_SIGNAL = 1, OP_WAIT = 2 };

@@ -28,7 +28,7 @@ import torch
 
 from . import _lib as L
 
-MAGIC = b"BSENG01\0"
+MAGIC = b"BSENG02\0"      # csrc/engine.hip kMagic: bumped with every change of an enum's meaning or of bs_gemm_desc's layout
 KIND_WORKSPACE, KIND_ZERO, KIND_DATA = 0, 1, 2
 ARG_I64, ARG_F64, ARG_PTR, ARG_NULL, ARG_DESC = 0, 1, 2, 3, 4
 OP_CALL, OP_SIGNAL, OP_WAIT = 0, 1, 2

@@ -386,3 +386,55 @@ def test_auto_modes_hold_tolerance_on_adversarial_weights(hook):
         assert cal["attn_mode"] == "corr"
         assert cal["l1_vs_full_m"]["attn:single"] > cal["tol_class_m"]
         assert l1 < 0.5 * l1w
+
+
+# ------------------------------------------------------------------------------------------------
+# Round 6: the calibration judges every stage on several frames and validates its choice on frames it has not
+# seen; the evidence that the tolerance holds is taken on frames that NEITHER has seen.
+def test_calibration_holds_on_held_out_frames():
+    """The bench's weights (random_zoedepth_weights seed 0), calibrated as the bench calibrates them; then 16 consecutive frames of another
+    synthetic sequence -- no calibration frame, no hold-out frame -- against the reference-precision engine on the device (itself held to
+    1e-5 m of the fp32 oracle: test_reference_precision_engine), and two of them against the oracle directly.  Every frame must meet the
+    north star's 1e-4 m; the calibration's own hold-out figures must be inside its line."""
+    from bodyslam_amd.synthetic import make_sequence, random_zoedepth_weights
+    from bodyslam_amd.zoedepth import AUTO_CAL_FRAMES, AUTO_HOLDOUT_FRAMES, AUTO_TOL_HOLDOUT_M, TOLERANCE_M, ZoeConfig, ZoeDepthEngine
+    from oracle import zoedepth_ref as Z
+    cfg = ZoeConfig()
+    w = random_zoedepth_weights(cfg, seed=0)
+    eng = ZoeDepthEngine(w, cfg, precision="accurate")
+    frames = torch.from_numpy(make_sequence(16, 480, 640, seed=77))
+    d = eng.infer(frames.cuda())[0].clone()
+    cal = eng.calibration
+    truth = eng.reference_depth(frames.cuda())
+    per = (d - truth).abs().flatten(1).mean(1).cpu()
+    report(f"[held-out frames] 16 frames vs the reference-precision engine: mean {per.mean():.3e} max {per.max():.3e} min {per.min():.3e} m; "
+           f"calibration: {cal['frames']} frames, worst {cal['l1_abs_vs_reference_m']:.3e}, hold-out {cal.get('holdout')}; "
+           f"one-pass share {cal.get('neck_sites', {}).get('flops_share_plain')}, {cal['calibrate_s']} s")
+    assert cal["frames"] == AUTO_CAL_FRAMES and cal["holdout"]["frames"] == AUTO_HOLDOUT_FRAMES
+    assert cal["holdout"]["l1_max_m"] <= AUTO_TOL_HOLDOUT_M and cal["l1_total_vs_full_m"] <= cal["tol_total_m"]
+    assert float(per.max()) <= TOLERANCE_M, f"a held-out frame misses the tolerance: {per.tolist()}"
+    assert float(per.max()) <= 1.3 * AUTO_TOL_HOLDOUT_M, "frames the calibration has not seen sit far above the ones it validated on"
+    for i in (3, 11):
+        with torch.no_grad():
+            ref = Z.infer_depth(w, Z.ZOED_NK, frames[i:i + 1], flip_aug=True)
+        l1 = (d[i].cpu() - ref[0]).abs().mean().item()
+        report(f"[held-out frames] frame {i} vs the fp32 oracle: {l1:.3e} m (vs the device reference {per[i]:.3e})")
+        assert l1 <= TOLERANCE_M and abs(l1 - float(per[i])) <= 1.5e-5
+
+
+def test_calibration_uses_every_frame_it_is_given():
+    """calibrate(frames_u8=...) judges on ALL the caller's frames (round 5 silently kept the first) and validates on the caller's hold-out set"""
+    from bodyslam_amd.synthetic import make_sequence
+    from bodyslam_amd.zoedepth import ZoeDepthEngine
+    from oracle import zoedepth_ref as Z
+    cfg_o = small_oracle_cfg()
+    eng = ZoeDepthEngine(Z.synth_weights(cfg_o, seed=4), product_cfg(cfg_o), dtype=torch.float16, target_hw=(96, 128), precision="accurate")
+    fr = torch.from_numpy(make_sequence(5, 120, 160, seed=9)).cuda()
+    rep = eng.calibrate(frames_u8=fr[:3], holdout_u8=fr[3:])
+    assert rep["frames"] == 3 and rep["frame"] == "120x160" and rep["holdout"]["frames"] == 2 and len(rep["holdout"]["l1_frames_m"]) == 2
+    assert rep["l1_abs_vs_reference_m"] is not None and rep["l1_abs_vs_reference_m"] <= rep["tol_abs_m"]
+    # the static corrections of the one-pass sites travel with the report and are what another engine applies
+    eng2 = ZoeDepthEngine(Z.synth_weights(cfg_o, seed=4), product_cfg(cfg_o), dtype=torch.float16, target_hw=(96, 128), precision="accurate")
+    eng2.apply_calibration(rep)
+    assert eng2.neck_mode == eng.neck_mode and sorted(eng2.site_bias_corr) == sorted(eng.site_bias_corr)
+    assert torch.equal(eng.infer(fr[:2])[0], eng2.infer(fr[:2])[0])
