@@ -108,6 +108,7 @@ _SIGS = {
     "bs_add_resized": [C.c_void_p] * 3 + [C.c_int32] * 7 + [C.c_void_p],
     "bs_mlp2": [C.c_void_p, C.c_int32] + [C.c_void_p] * 5 + [C.c_int32] * 6 + [C.c_void_p],
     "bs_mlp2_add": [C.c_void_p] * 7 + [C.c_int32] * 10 + [C.c_void_p],
+    "bs_projector_level": [C.c_void_p] * 10 + [C.c_int32] * 9 + [C.c_void_p],
     "bs_logbinom_depth": [C.c_void_p] * 8 + [C.c_int32] * 5 + [C.c_float, C.c_float, C.c_int32, C.c_void_p],
     "bs_logbinom_depth_ex": [C.c_void_p] * 7 + [C.c_int32] + [C.c_void_p] * 2 + [C.c_int32] * 5 + [C.c_float, C.c_float, C.c_int32, C.c_void_p],
     "bs_small_attention": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
@@ -463,13 +464,40 @@ class Plan:
                 check(fn(*args, st), self.names[i])
 
 
-def f8_weight(w: torch.Tensor, dtype, planes: str = "both") -> tuple:
+_F8_ON_DEVICE = {}      # device index -> does torch's fp32 -> e4m3 cast on that device give the CPU cast's bytes (checked once per process)
+
+
+def _f8_pack_device(device):
+    """where the weight planes are formed: on `device` when torch's e4m3 cast there reproduces the CPU cast bit for bit (checked once on a
+    sample that covers ties, the subnormal range and the saturation bound), else on the host.  One-off weight re-layout, not the compute
+    path -- but a ZoeD_NK engine packs 300 M weights, 40 s of an 8-core host against < 1 s on the GPU."""
+    if device is None:
+        return torch.device("cpu")
+    device = torch.device(device)
+    if device.type != "cuda":
+        return torch.device("cpu")
+    ok = _F8_ON_DEVICE.get(device.index)
+    if ok is None:
+        g = torch.Generator().manual_seed(7)
+        t = torch.cat([torch.randn(4096, generator=g) * 100.0, torch.randn(4096, generator=g) * 1e-2, torch.linspace(-460.0, 460.0, 4097),
+                       torch.arange(0, 4096, dtype=torch.float32) * 2.0 ** -11, torch.tensor([0.0, -0.0, 448.0, -448.0, 2.0 ** -9, 2.0 ** -10, 3 * 2.0 ** -11])])
+        t = t.clamp(-448.0, 448.0)
+        try:
+            ok = bool(torch.equal(t.to(torch.float8_e4m3fn).view(torch.uint8), t.to(device).to(torch.float8_e4m3fn).view(torch.uint8).cpu()))
+        except Exception:
+            ok = False
+        _F8_ON_DEVICE[device.index] = ok
+    return device if ok else torch.device("cpu")
+
+
+def f8_weight(w: torch.Tensor, dtype, planes: str = "both", device=None) -> tuple:
     """fp32 [N, K] -> ([N, 2K] `dtype`-typed rows of [W_hi16 | W_lo8 | W_hi8] bytes, (sb0, sb1)): the weight side of bs_gemm's
     FP8 correction segment.  W_hi8 = e4m3(W_hi * 2^e_hi), W_lo8 = e4m3((W - W_hi) * 2^e_lo) with per-matrix power-of-two
     scales that put the largest magnitude just under e4m3's 448; sb0 / sb1 are the E8M0 exponents bs_gemm applies to the
-    lo / hi plane (127 - e).  planes: "both" (default), "lo" = [W_hi16 | W_lo8] only, "hi_only" = the W_lo8 plane zeroed."""
+    lo / hi plane (127 - e).  planes: "both" (default), "lo" = [W_hi16 | W_lo8] only, "hi_only" = the W_lo8 plane zeroed.
+    device: where the planes are formed and returned (_f8_pack_device; default: the host)."""
     import math
-    w = w.detach().float().cpu()
+    w = w.detach().to(_f8_pack_device(device)).float()
     hi = w.to(dtype)
     lo = w - hi.float()
 
@@ -490,11 +518,11 @@ def f8_weight(w: torch.Tensor, dtype, planes: str = "both") -> tuple:
     return row.view(dtype), (127 - e_lo, 127 - e_hi)
 
 
-def f8_conv_weight(w_ohwi: torch.Tensor, dtype) -> tuple:
+def f8_conv_weight(w_ohwi: torch.Tensor, dtype, device=None) -> tuple:
     """fp32 [O, kh, kw, I] -> the conv-mode counterpart of f8_weight: K order [W_hi16: chunk64, tap, 64][W_lo8: chunk128, tap, 128]
     [W_hi8: chunk128, tap, 128] (the kernel's chunk walk continues from the 16-bit channels through the two FP8 planes)."""
     import math
-    w = w_ohwi.detach().float().cpu()
+    w = w_ohwi.detach().to(_f8_pack_device(device)).float()
     O, kh, kw, I = w.shape
     assert I % 128 == 0, I
     hi = w.to(dtype)
@@ -643,6 +671,12 @@ def mlp2_add(emb, prev, W1, b1, W2, b2, out, B, Hp, Wp, H, W, K1, N1, N2, act2=A
     """bs_add_resized + bs_mlp2 in one launch (include/bodyslam_hip.h: bs_mlp2_add)"""
     check(load_library().bs_mlp2_add(p(emb), p(prev), p(W1), p(b1), p(W2), p(b2), p(out), B, Hp, Wp, H, W, K1, N1, N2, act2,
                                      dt(emb) | (16 if split else 0), stream_ptr()), "bs_mlp2_add")
+
+
+def projector_level(z, b_c1, emb_prev, Wc2, b_c2, We, b_e, x_out, emb_out, eh_out, B, Hl, Wl, H, W, PM, E, NE):
+    """one level of the bins head's projector path in one launch (include/bodyslam_hip.h: bs_projector_level)"""
+    check(load_library().bs_projector_level(p(z), p(b_c1), p(emb_prev), p(Wc2), p(b_c2), p(We), p(b_e), p(x_out), p(emb_out), p(eh_out), B, Hl, Wl,
+                                            H, W, PM, E, NE, dt(z), stream_ptr()), "bs_projector_level")
 
 
 def add_resized(x, prev, out, B, Hp, Wp, H, W, Cch, split=False):

@@ -74,7 +74,7 @@ const std::map<std::string, Entry>& entries() {
         BS_ENGINE_ENTRY(bs_attractor_step), BS_ENGINE_ENTRY(bs_add_resized),        BS_ENGINE_ENTRY(bs_instnorm_relu_nhwc),
         BS_ENGINE_ENTRY(bs_cyclepose_im2col), BS_ENGINE_ENTRY(bs_cyclepose_im2col_window), BS_ENGINE_ENTRY(bs_cyclepose_head),
         BS_ENGINE_ENTRY(bs_avgpool_nhwc),   BS_ENGINE_ENTRY(bs_mlp2),            BS_ENGINE_ENTRY(bs_mlp2_add),
-        BS_ENGINE_ENTRY(bs_upconv_fused),   BS_ENGINE_ENTRY(bs_resize_bias_relu_nhwc),
+        BS_ENGINE_ENTRY(bs_upconv_fused),   BS_ENGINE_ENTRY(bs_resize_bias_relu_nhwc), BS_ENGINE_ENTRY(bs_projector_level),
     };
     return m;
 }

@@ -159,7 +159,8 @@ ACCURATE_NECK_MODE = "full"
 
 _CALIBRATION_CACHE: Dict[Tuple, dict] = {}        # process-wide: (weights fingerprint, geometry, tolerances, ...) -> calibration report
 # environment switches that change the arithmetic a calibration measures (A / B runs): part of the cache key (round-5 advisor)
-_ARITHMETIC_SWITCHES = ("BS_PJ_LOWRES", "BS_UPCONV_FUSED", "BS_CLB_COMPOSED", "BS_RELU_OUT", "BS_NECK_PLAIN", "BS_MLP2", "BS_NECK_BIAS_CORR")
+_ARITHMETIC_SWITCHES = ("BS_PJ_LOWRES", "BS_UPCONV_FUSED", "BS_CLB_COMPOSED", "BS_RELU_OUT", "BS_NECK_PLAIN", "BS_MLP2", "BS_NECK_BIAS_CORR",
+                        "BS_PROJECTOR_LEVEL")
 
 ZOED_NK = ZoeConfig()
 ZOED_N = ZoeConfig(head_names=("nyu",))
@@ -311,14 +312,15 @@ class ZoeDepthEngine:
             return self._wn(t)
         if mode == "w" and t.shape[1] % 256 != 0:
             mode = "full"
-        w8, sb = L.f8_weight(t, self.dtype, planes={"full": "both", "wcls": "both", "wmean": "both", "w": "lo", "a": "hi_only"}[mode])
+        w8, sb = L.f8_weight(t, self.dtype, planes={"full": "both", "wcls": "both", "wmean": "both", "w": "lo", "a": "hi_only"}[mode], device=self.dev)
         self.f8s[key] = sb
         self.wmode[key] = mode
         if key[0] == "l" and mode in ("full", "wcls", "wmean"):
             # "full" / "wcls" / "wmean" read the same packed rows; "wmean" also needs dW = W - round16(W) as bf16 (fp32's exponent
             # range), the W operand of the rank-1 correction GEMM: kept for all three, so the mode is a PLAN-time choice
             # (set_class_modes / calibrate) and not a re-ingestion
-            self.w[key + ".lo"] = (t - t.to(self.dtype).float()).to(torch.bfloat16).to(self.dev).contiguous()
+            td = t.to(self.dev)
+            self.w[key + ".lo"] = (td - td.to(self.dtype).float()).to(torch.bfloat16).contiguous()
         return w8.to(self.dev)
 
     def mode_of(self, wkey: str) -> Optional[str]:
@@ -690,7 +692,7 @@ class ZoeDepthEngine:
 
     def _w8conv(self, key: str, t: torch.Tensor) -> torch.Tensor:
         """conv weight [O, I, kh, kw] for the FP8-correction conv path (L.f8_conv_weight); scales to self.f8s[key]."""
-        w8, sb = L.f8_conv_weight(t.permute(0, 2, 3, 1), self.dtype)
+        w8, sb = L.f8_conv_weight(t.permute(0, 2, 3, 1), self.dtype, device=self.dev)
         self.f8s[key] = sb
         return w8.to(self.dev)
 
@@ -720,15 +722,15 @@ class ZoeDepthEngine:
         """plain GEMM weight [N, K]; accurate: [N, 3K] = [W_hi | W_hi | W_lo] against A = [hi | lo], then hi again."""
         if not self.acc:
             return self._h(t)
-        hi, lo = self._split(t)
-        return torch.cat([hi, hi, lo], 1).to(self.dev).contiguous()
+        hi, lo = self._split(t.to(self.dev))                 # (on the device: the reference precision splits all 300 M backbone weights)
+        return torch.cat([hi, hi, lo], 1).contiguous()
 
     def _wn_conv(self, t: torch.Tensor) -> torch.Tensor:
         """neck conv weight [O, I, kh, kw]; accurate: segment 0 = [W_hi | W_hi] against the 2I (hi | lo) channels,
         segment 1 = W_lo against the hi channels again; each segment in conv K order (chunk, tap, channel)."""
         if not self.acc:
             return self._conv_w(t)
-        k = t.permute(0, 2, 3, 1)                                   # [O, kh, kw, I]
+        k = t.to(self.dev).permute(0, 2, 3, 1)                      # [O, kh, kw, I]
         hi, lo = self._split(k)
         seg0 = L.conv_weight(torch.cat([hi, hi], -1))
         return torch.cat([seg0, L.conv_weight(lo)], 1).to(self.dev).contiguous()
@@ -1468,9 +1470,45 @@ class _ZoePlan:
         # ---- Z7 (continued): projector / attractor levels on the fusion outputs
         ph_, pw_ = bh_, bw_
         clb_composed = os.environ.get("BS_CLB_COMPOSED", "1") != "0"       # (A / B switch: 0 = the embedding product on the 128-channel embedding)
+        # Round 6: the level's projector path in ONE launch (csrc/projector.hip, bs_projector_level): e1 = relu(resize(z) + b), emb = W_c2 e1 + b,
+        # x = round16(emb + resize(emb_prev)) and -- at the last level -- the composed log-binomial embedding product, with e1 and emb never
+        # in memory (rounds 2-5: bs_resize_bias_relu_nhwc + a 3-pass bs_gemm + the sum inside bs_mlp2_add + another 3-pass bs_gemm: 2 368 B
+        # through HBM per finest-level pixel where this moves 640).  BS_PROJECTOR_LEVEL=0: the four launches (A / B, and the path of every
+        # geometry / format the kernel is not built for: rows that are no multiple of 32 pixels, single 16-bit operands).
+        proj_level = (os.environ.get("BS_PROJECTOR_LEVEL", "1") != "0" and acc and pj_lowres and clb_composed and PM == 64 and E == 128
+                      and 2 * HID <= 80 and (2 * HID) % 16 == 0 and eng.fuse_mlp
+                      and all(fw_ % 32 == 0 and 2 * zw_ == fw_ and 2 * zh_ == fh_ for (_, fh_, fw_), (_, zh_, zw_) in zip(fused_list, pj_low))
+                      and all(tuple(w[f"at{i_}.c1.w"].shape) == (256, 128) and 2 * eng.na_eff[i_] <= 32 for i_ in range(4)))
+        Eh = None
         for i in range(4):
             feat, fh, fw = fused_list[i]
             Mi = NB * fh * fw
+            if proj_level:
+                z, zh, zw = pj_low[i]
+                assert (zh, zw) == (ph_, pw_), "the projector's low-resolution map and the previous level's embedding share a grid"
+                last_lv = i == 3
+                x16 = e16(Mi, E)
+                emb = None if last_lv else e16(Mi, E * m2)
+                if last_lv:
+                    Eh = e32(Mi, 2 * HID)
+                P.add(f"pj{i}.level", "bs_projector_level", z, w[f"pj{i}.c1.b"], emb_prev, w[f"pj{i}.c2.w"], w[f"pj{i}.c2.b"],
+                      w["clb.e1.w"] if last_lv else None, w["clb.e1.b"] if last_lv else None, x16, emb, Eh, NB, zh, zw, fh, fw, PM, E, 2 * HID,
+                      L.dt(x16))
+                f_alg = 2.0 * Mi * PM * (E + (2 * HID if last_lv else 0))
+                P.tag_stack(f_alg, 3.0 * f_alg)                          # (three 16-bit passes on (hi | lo) pairs, as the bs_gemm launches it replaces)
+                free(z, emb_prev)
+                na = eng.na_eff[i]
+                A = e32(Mi, 2 * na)
+                P.add(f"at{i}.mlp", "bs_mlp2", x16, E, w[f"at{i}.c1.w"], w[f"at{i}.c1.b"], w[f"at{i}.c2.w"], w[f"at{i}.c2.b"], A, Mi, E, 2 * E,
+                      2 * na, L.ACT_SOFTPLUS_FAST, L.dt(x16))
+                P.tag_stack(2.0 * Mi * (E * 2 * E + 2 * E * 2 * na), 2.0 * Mi * (E * 2 * E + 2 * E * 2 * na))      # the attractor's two 1x1 convolutions
+                free(x16)
+                bins = e32(NB, fh, fw, 2 * nb)
+                P.add(f"at{i}.step", "bs_attractor_step", A, bins_prev, bins, self.route, NB, ph_, pw_, fh, fw, 2, nb, na)
+                free(A, bins_prev)
+                P.mark(f"bins{i}", bins, ("nhwc_route", NB, fh, fw, 2 * nb))
+                bins_prev, emb_prev, ph_, pw_ = bins, emb, fh, fw
+                continue
             e1 = e16(Mi, PM * m2)
             if pj_lowres:
                 z, zh, zw = pj_low[i]
@@ -1521,12 +1559,15 @@ class _ZoePlan:
             free(A, bins_prev)
             P.mark(f"bins{i}", bins, ("nhwc_route", NB, fh, fw, 2 * nb))
             bins_prev, emb_prev, ph_, pw_ = bins, emb, fh, fw
-        Eh = e32(NB * ph_ * pw_, 2 * HID)
-        if clb_composed:
+        if proj_level:
+            pass                                                   # (Eh came out of the last level's launch)
+        elif clb_composed:
+            Eh = e32(NB * ph_ * pw_, 2 * HID)
             P.gemm("clb.emb", e1_last, w["clb.e1.w"], Eh, M=NB * ph_ * pw_, N=2 * HID, K=PM * np3, lda=PM * m2, seg1=PM if acc else 0, bias=w["clb.e1.b"],
                    precision_passes=np3)
             free(e1_last)
         else:
+            Eh = e32(NB * ph_ * pw_, 2 * HID)
             P.gemm("clb.emb", emb_prev, w["clb.emb.w"], Eh, M=NB * ph_ * pw_, N=2 * HID, K=E * np3, lda=E * m2, seg1=E if acc else 0, bias=w["clb.emb.b"],
                    precision_passes=np3)
         free(emb_prev)

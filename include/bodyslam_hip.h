@@ -291,6 +291,18 @@ int bs_mlp2(const void* x, int32_t ldx, const void* W1, const float* b1, const v
 int bs_mlp2_add(const void* emb, const void* prev, const void* W1, const float* b1, const void* W2, const float* b2, float* out,
                 int32_t B, int32_t Hp, int32_t Wp, int32_t H, int32_t W, int32_t K1, int32_t N1, int32_t N2, int32_t act2, int32_t dtype,
                 void* stream);
+/* One level of the bins head's projector path in one launch (round 6; replaces, for that level, bs_resize_bias_relu_nhwc + the projector's
+ * second 1x1 convolution as a 3-pass bs_gemm + the sum inside bs_mlp2_add + -- at the last level -- the log-binomial embedding bs_gemm; HF
+ * modeling_zoedepth.py:749-772 (Projector), :726-730 (the attractor level's input), :376-491 (the conditional log-binomial MLP's first layer):
+ *   e1 = relu(bilinear_align_corners(z) + b_c1);  emb = W_c2 e1 + b_c2;  x = round16(emb + bilinear_align_corners(emb_prev));  Eh = W_e e1 + b_e
+ * z [B,Hl,Wl,2 PM] and emb_prev [B,Hl,Wl,2 E]: (hi | lo) 16-bit pairs on the SAME low-resolution grid; W_c2 [E, 3 PM], W_e [NE, 3 PM]: rows
+ * [W_hi | W_hi | W_lo] (the 3-pass pair packing of bs_gemm's seg1 form); biases fp32.  Outputs: x_out [B,H,W,E] 16-bit (the attractor MLP's
+ * input: bs_mlp2 with ldx = E), emb_out [B,H,W,2 E] (hi | lo) pairs or null (the last level hands no embedding on), eh_out fp32 [B,H,W,NE] or
+ * null (then W_e / b_e are null too).  Built for PM = 64, E = 128, NE a multiple of 16 up to 80, W a multiple of 32.  The products run the K
+ * order of the bs_gemm they replace: Eh carries the same bits; x differs from the two-launch path by the pair rounding of emb it no longer makes. */
+int bs_projector_level(const void* z, const float* b_c1, const void* emb_prev, const void* Wc2, const float* b_c2, const void* We,
+                       const float* b_e, void* x_out, void* emb_out, float* eh_out, int32_t B, int32_t Hl, int32_t Wl, int32_t H, int32_t W,
+                       int32_t PM, int32_t E, int32_t NE, int32_t dtype, void* stream);
 /* out[b,y,x,:] = x[b,y,x,:] + bilinear_align_corners(prev)[b,y,x,:] (fp16/bf16 NHWC); HF :726-730.
  * dtype bit 4 (| 16): x, prev and out hold (hi | lo) pairs of C channels each (pixel stride 2C), see bs_cast_split. */
 int bs_add_resized(const void* x, const void* prev, void* out, int32_t B, int32_t Hp, int32_t Wp, int32_t H,

@@ -1316,3 +1316,73 @@ def test_mlp2_add(L, dtype, geom):
     L.mlp2(y, K1 * m2, w1, b1, w2, b2, two, M, K1, N1, N2, L.ACT_SOFTPLUS_FAST)
     torch.cuda.synchronize()
     assert torch.equal(out, two), f"max |fused - two launches| = {(out - two).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("geom", [(2, 6, 16, True), (1, 12, 32, False), (3, 5, 64, True), (2, 96, 128, True), (2, 96, 128, False)])
+def test_projector_level(L, dtype, geom):
+    """bs_projector_level (round 6: one level of the bins head's projector path in one launch) against the launches it replaces --
+    bs_resize_bias_relu_nhwc, the 3-pass pair bs_gemm of the projector's second convolution, bs_add_resized, and (last level) the 3-pass
+    bs_gemm of the log-binomial embedding -- and against torch in fp64.  Eh and emb come out of the same MFMA sequence as bs_gemm's: equal
+    bits are expected and asserted to 1e-6; x skips the pair rounding of emb, so it may differ from the old path by one step of the 16-bit
+    format on a rounding boundary.  The last geometry is the bench's finest level (more slices than the chip has waves: the persistent loop)."""
+    B, Hl, Wl, last = geom
+    H, W, PM, E, NE = 2 * Hl, 2 * Wl, 64, 128, 80
+    M = B * H * W
+    z = rnd(B, Hl, Wl, 2 * PM, seed=31, dtype=dtype)
+    prev = rnd(B, Hl, Wl, 2 * E, seed=32, dtype=dtype)
+    z[..., PM:] *= 2.0 ** -11           # lo halves of a realistic magnitude
+    prev[..., E:] *= 2.0 ** -11
+    b1, bc2, be = rnd(PM, seed=33), rnd(E, seed=34), rnd(NE, seed=35)
+
+    def pack3(wf):                       # fp32 [N, K] -> [W_hi | W_hi | W_lo] (ZoeDepthEngine._wn)
+        hi = wf.to(dtype)
+        lo = (wf - hi.float()).to(dtype)
+        return torch.cat([hi, hi, lo], 1).contiguous()
+
+    wc2_f, we_f = rnd(E, PM, seed=36) / PM ** 0.5, rnd(NE, PM, seed=37) / PM ** 0.5
+    wc2, we = pack3(wc2_f), pack3(we_f)
+    x = torch.full((M, E), 7.0, device=dev(), dtype=dtype)
+    emb = None if last else torch.full((M, 2 * E), 7.0, device=dev(), dtype=dtype)
+    eh = torch.full((M, NE), -7.0, device=dev()) if last else None
+    L.projector_level(z, b1, prev, wc2, bc2, we if last else None, be if last else None, x, emb, eh, B, Hl, Wl, H, W, PM, E, NE)
+    # ---- the launches it replaces
+    e1 = torch.empty(M, 2 * PM, device=dev(), dtype=dtype)
+    L.resize_bias_relu_nhwc(z, b1, e1, B, Hl, Wl, PM, H, W, split=True)
+    emb32 = torch.empty(M, E, device=dev())
+    L.gemm(e1, wc2, emb32, M=M, N=E, K=3 * PM, lda=2 * PM, seg1=PM, bias=bc2)
+    emb_old = torch.empty(M, 2 * E, device=dev(), dtype=dtype)
+    L.gemm(e1, wc2, emb_old, M=M, N=E, K=3 * PM, lda=2 * PM, seg1=PM, bias=bc2, ldo=2 * E, out_split_off=E)
+    y_old = torch.empty_like(emb_old)
+    L.add_resized(emb_old, prev, y_old, B, Hl, Wl, H, W, E, split=True)
+    torch.cuda.synchronize()
+    x_old = y_old[:, :E].float()
+    ulp = x_old.abs() * (2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7) + 1e-7
+    dx = (x.float() - x_old).abs()
+    assert (dx <= ulp).all(), f"x differs from the four-launch path by more than one step: {(dx / ulp).max().item():.2f}"
+    frac = (dx > 0).float().mean().item()
+    assert frac < 5e-3, f"{frac:.2e} of x's elements differ from the four-launch path"
+    if emb is not None:
+        assert torch.equal(emb, emb_old), f"emb pairs: max |diff| {(emb.float() - emb_old.float()).abs().max().item():.3e}"
+    if last:
+        eh_old = torch.empty(M, NE, device=dev())
+        L.gemm(e1, we, eh_old, M=M, N=NE, K=3 * PM, lda=2 * PM, seg1=PM, bias=be)
+        torch.cuda.synchronize()
+        d = (eh - eh_old).abs().max().item()
+        assert d <= 1e-6 * max(1.0, eh_old.abs().max().item()), f"Eh: max |diff| to the 3-pass bs_gemm {d:.3e}"
+    # ---- fp64
+    zf = (z[..., :PM].double() + z[..., PM:].double()).permute(0, 3, 1, 2)
+    pf = (prev[..., :E].double() + prev[..., E:].double()).permute(0, 3, 1, 2)
+    e64 = torch.relu(F.interpolate(zf, size=(H, W), mode="bilinear", align_corners=True) + b1.double().view(1, -1, 1, 1)).permute(0, 2, 3, 1).reshape(M, PM)
+    emb64 = e64 @ wc2_f.double().t() + bc2.double()
+    x64 = emb64 + F.interpolate(pf, size=(H, W), mode="bilinear", align_corners=True).permute(0, 2, 3, 1).reshape(M, E)
+    ex = ((x.double() - x64).abs() / (x64.abs() + 1.0)).max().item()
+    assert ex < (2e-3 if dtype == torch.float16 else 1.6e-2), ex          # one 16-bit rounding of the sum
+    e_emb = (emb32.double() - emb64).abs().max().item()
+    assert e_emb < (2e-5 if dtype == torch.float16 else 2e-3), e_emb     # (the 3-pass pair product itself: ~22 / ~16 significant bits)
+    if last:
+        eh64 = e64 @ we_f.double().t() + be.double()
+        ee = (eh.double() - eh64).abs().max().item()
+        assert ee < (2e-5 if dtype == torch.float16 else 2e-3), ee
+    report(f"projector_level {dtype} B={B} {Hl}x{Wl}->{H}x{W} last={last}: x differs from the four-launch path on {frac:.2e} of its elements (<= one step), "
+           f"max rel err vs fp64 {ex:.2e}")
