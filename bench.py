@@ -71,7 +71,7 @@ def measure_pmc_traffic(args):
             cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", counter, "--",
                    "python3", os.path.join(ROOT, "bench.py"), "--single-mode", "--precision", args.precision, "--steps", "1", "--warmup", "0",
                    "--batch", str(args.batch), "--dtype", args.dtype, "--height", str(args.height), "--width", str(args.width),
-                   "--weights", args.weights, "--no-cpu-baseline", "--no-kernel-timing", "--no-pmc-traffic", "--no-slam-loop", "--no-outlier-leg",
+                   "--weights", args.weights, "--weights-seed", str(args.weights_seed), "--no-cpu-baseline", "--no-kernel-timing", "--no-pmc-traffic", "--no-slam-loop", "--no-outlier-leg",
                    "--no-pcie-leg", "--no-latency-leg"]
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             path = None
@@ -195,6 +195,8 @@ def main():
     ap.add_argument("--weights", default="gaussian", choices=["gaussian", "outlier", "layerscale", "heavytail"],
                     help="statistics of the random-init ZoeDepth weights (bodyslam_amd.synthetic.WEIGHT_VARIANTS): 'outlier' = 6 channels 50x larger "
                          "behind every LayerNorm, what a trained BEiT carries -- the calibration then has to switch corrections back on")
+    ap.add_argument("--weights-seed", type=int, default=0, help="seed of the random-init ZoeDepth weights (the headline is seed 0; tools/probes/seed_throughput.sh "
+                                                                  "runs eight seeds: the calibration's choice, and with it the rate, depends on the weights)")
     ap.add_argument("--no-outlier-leg", action="store_true", help="skip the extra `outlier_weights` figure (the accurate mode on outlier-channel weights)")
     ap.add_argument("--no-pcie-leg", action="store_true", help="skip the extra `pcie_inclusive` figure (frames from pinned host memory, results copied back)")
     ap.add_argument("--no-latency-leg", action="store_true", help="skip the extra `latency_b1_ms` figures (one frame / one pair per call: the reference's call pattern)")
@@ -239,7 +241,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     cfg = ZoeConfig()
     def zoe_weights(variant):
-        w_ = random_zoedepth_weights(cfg, seed=0)
+        w_ = random_zoedepth_weights(cfg, seed=args.weights_seed)
         if WEIGHT_VARIANTS[variant] is not None:
             WEIGHT_VARIANTS[variant](w_)
         return w_
@@ -657,6 +659,7 @@ def main():
         zc = pipe.zoe.calibration or {}
         out["precision"] = args.precision
         out["weights"] = args.weights
+        out["weights_seed"] = args.weights_seed
         ns_ = zc.get("neck_sites") or {}
         nm_ = pipe.zoe.neck_mode if pipe.zoe.acc else ""
         # (the full neck mode string is in `calibration` above; the tail carries its size)

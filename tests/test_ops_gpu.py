@@ -1357,11 +1357,14 @@ def test_projector_level(L, dtype, geom):
     L.add_resized(emb_old, prev, y_old, B, Hl, Wl, H, W, E, split=True)
     torch.cuda.synchronize()
     x_old = y_old[:, :E].float()
-    ulp = x_old.abs() * (2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7) + 1e-7
+    # one step of the 16-bit format, plus what the old path's pair rounding of emb (22 / 16 significant bits) is worth where emb and the
+    # resampled previous embedding cancel
+    f16 = dtype == torch.float16
+    ulp = x_old.abs() * (2.0 ** -10 if f16 else 2.0 ** -7) + emb32.abs() * (2.0 ** -21 if f16 else 2.0 ** -15) + 1e-7
     dx = (x.float() - x_old).abs()
     assert (dx <= ulp).all(), f"x differs from the four-launch path by more than one step: {(dx / ulp).max().item():.2f}"
     frac = (dx > 0).float().mean().item()
-    assert frac < 5e-3, f"{frac:.2e} of x's elements differ from the four-launch path"
+    assert frac < (5e-3 if f16 else 3e-2), f"{frac:.2e} of x's elements differ from the four-launch path"
     if emb is not None:
         assert torch.equal(emb, emb_old), f"emb pairs: max |diff| {(emb.float() - emb_old.float()).abs().max().item():.3e}"
     if last:
