@@ -87,36 +87,13 @@ __global__ __launch_bounds__(512) void projector_level_kernel(PlArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) bz[e] = a.b1[c8 * 8 + e];
 
-    // A gather = the four corners' (hi, lo) halves of one 8-channel group: eight 16-byte loads.  Issue and use are SEPARATE steps: the loads of
-    // a whole phase (or of the next one) are in flight under the arithmetic of the previous -- a wave has one partner on its SIMD (256 registers),
-    // so it must hide its own latency.
-    struct Raw { v8 h[4], l[4]; };
-    struct Col { int x0, x1; float lx; };
-    auto column = [&](int ox) {
-        Col c;
-        const float fx = a.sx * (float)ox;
-        int x0 = (int)fx;
-        x0 = x0 > a.Wl - 1 ? a.Wl - 1 : x0;
-        c.x0 = x0;
-        c.x1 = x0 + (x0 < a.Wl - 1 ? 1 : 0);
-        c.lx = fx - (float)x0;
-        return c;
-    };
-    auto issue = [&](const T* base, int pstride, int lo_off, int r0, int r1, const Col& c, Raw& r) {
-        const T* q[4] = {base + (int64_t)(r0 + c.x0) * pstride, base + (int64_t)(r0 + c.x1) * pstride, base + (int64_t)(r1 + c.x0) * pstride,
-                         base + (int64_t)(r1 + c.x1) * pstride};
+    auto ld8 = [&](const T* ptr, int lo_off, float (&dst)[8]) {          // hi + lo of 8 channels
+        const v8 h = *reinterpret_cast<const v8*>(ptr);
+        const v8 l = *reinterpret_cast<const v8*>(ptr + lo_off);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            r.h[k] = *reinterpret_cast<const v8*>(q[k]);
-            r.l[k] = *reinterpret_cast<const v8*>(q[k] + lo_off);
-        }
-    };
-    // torch's association hy (hx p00 + lx p01) + ly (hx p10 + lx p11) on hi + lo, two channels at a time (bilerp2)
-    auto lerp2 = [&](const Raw& r, int e, f32x2_ hx2, f32x2_ lx2, f32x2_ hy2, f32x2_ ly2) {
-        f32x2_ q[4];
+        for (int e = 0; e < 8; ++e) dst[e] = (float)h[e];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) q[k] = f32x2_{(float)r.h[k][e] + (float)r.l[k][e], (float)r.h[k][e + 1] + (float)r.l[k][e + 1]};
-        return bilerp2(q[0], q[1], q[2], q[3], hx2, lx2, hy2, ly2);
+        for (int e = 0; e < 8; ++e) dst[e] += (float)l[e];
     };
 
     for (int s = blockIdx.x * 8 + wave; s < a.nslices; s += gridDim.x * 8) {
@@ -135,21 +112,25 @@ __global__ __launch_bounds__(512) void projector_level_kernel(PlArgs a) {
 
         // ---- e1 = relu(bilinear(z) + b_c1) as (hi | lo) pairs into the wave's slice: [hi: 32 rows x 128 B][lo: 32 rows x 128 B], chunk c of row p at c ^ (p & 7)
         const T* zb = zp + img * (2 * PL_PM) + c8 * 8;
-        const T* pb = pp + img * (2 * PL_E) + c8 * 8;
-        Raw rz[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) issue(zb, 2 * PL_PM, PL_PM, r0, r1, column(ox0 + it * 8 + pq), rz[it]);
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            __builtin_amdgcn_sched_barrier(0);            // (keeps a group's conversions behind the previous group's stores: registers)
-            const int p = it * 8 + pq;
-            const Col c = column(ox0 + p);
-            const float hx = 1.0f - c.lx;
-            const f32x2_ hx2 = {hx, hx}, lx2 = {c.lx, c.lx};
+            const int p = it * 8 + pq, ox = ox0 + p;
+            const float fx = a.sx * (float)ox;
+            int x0 = (int)fx;
+            x0 = x0 > a.Wl - 1 ? a.Wl - 1 : x0;
+            const int x1 = x0 + (x0 < a.Wl - 1 ? 1 : 0);
+            const float lx = fx - (float)x0, hx = 1.0f - lx;
+            float q00[8], q01[8], q10[8], q11[8];
+            ld8(zb + (int64_t)(r0 + x0) * (2 * PL_PM), PL_PM, q00);
+            ld8(zb + (int64_t)(r0 + x1) * (2 * PL_PM), PL_PM, q01);
+            ld8(zb + (int64_t)(r1 + x0) * (2 * PL_PM), PL_PM, q10);
+            ld8(zb + (int64_t)(r1 + x1) * (2 * PL_PM), PL_PM, q11);
+            const f32x2_ hx2 = {hx, hx}, lx2 = {lx, lx};
             v8 o, ol;
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
-                f32x2_ v = lerp2(rz[it], e, hx2, lx2, hy2, ly2);
+                f32x2_ v = bilerp2(f32x2_{q00[e], q00[e + 1]}, f32x2_{q01[e], q01[e + 1]}, f32x2_{q10[e], q10[e + 1]}, f32x2_{q11[e], q11[e + 1]}, hx2, lx2,
+                                   hy2, ly2);
                 v += f32x2_{bz[e], bz[e + 1]};
                 v = f32x2_{fmaxf(v[0], 0.0f), fmaxf(v[1], 0.0f)};
 #pragma unroll
@@ -206,13 +187,6 @@ __global__ __launch_bounds__(512) void projector_level_kernel(PlArgs a) {
             }
         }
 
-        // the corners of emb_prev for the first 64 output channels: half of them in flight under the product (the accumulators leave registers
-        // for two of the four pixel groups), the other half issued behind it, under the staging of the first half's sums
-        Raw rp[4];
-#pragma unroll
-        for (int it = 0; it < 2; ++it) issue(pb, 2 * PL_E, PL_E, r0, r1, column(ox0 + it * 8 + pq), rp[it]);
-        __builtin_amdgcn_sched_barrier(0);
-
         // ---- emb = W_c2 e1 + b_c2
         f32x4 acc[2][8];
 #pragma unroll
@@ -237,14 +211,12 @@ __global__ __launch_bounds__(512) void projector_level_kernel(PlArgs a) {
             }
         }
         PL_MFMA_FENCE();
-#pragma unroll
-        for (int it = 2; it < 4; ++it) issue(pb, 2 * PL_E, PL_E, r0, r1, column(ox0 + it * 8 + pq), rp[it]);
-        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // every fragment of e1 has been read: the slice becomes the staging tile
         __builtin_amdgcn_wave_barrier();
 
         // ---- x = round16(emb + bilinear(emb_prev)), 64 output channels at a time through the slice as fp32 [32 rows][64], 16-byte chunk c of
         // row m at c ^ (m & 15): the accumulator layout (a lane: 4 channels of one row) is turned into the gather's (a lane: 8 channels of a pixel)
+        const T* pb = pp + img * (2 * PL_E) + c8 * 8;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -260,23 +232,31 @@ __global__ __launch_bounds__(512) void projector_level_kernel(PlArgs a) {
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                __builtin_amdgcn_sched_barrier(0);
-                const int p = it * 8 + pq;
-                const Col c = column(ox0 + p);
-                const float hx = 1.0f - c.lx;
+                const int p = it * 8 + pq, ox = ox0 + p;
+                const float fx = a.sx * (float)ox;
+                int x0 = (int)fx;
+                x0 = x0 > a.Wl - 1 ? a.Wl - 1 : x0;
+                const int x1 = x0 + (x0 < a.Wl - 1 ? 1 : 0);
+                const float lx = fx - (float)x0, hx = 1.0f - lx;
+                float q00[8], q01[8], q10[8], q11[8];
+                const T* pc = pb + h * 64;
+                ld8(pc + (int64_t)(r0 + x0) * (2 * PL_E), PL_E, q00);
+                ld8(pc + (int64_t)(r0 + x1) * (2 * PL_E), PL_E, q01);
+                ld8(pc + (int64_t)(r1 + x0) * (2 * PL_E), PL_E, q10);
+                ld8(pc + (int64_t)(r1 + x1) * (2 * PL_E), PL_E, q11);
                 const f32x4 e0 = *reinterpret_cast<const f32x4*>(my + p * 256 + (((2 * c8) ^ (p & 15)) << 4));
                 const f32x4 e1v = *reinterpret_cast<const f32x4*>(my + p * 256 + (((2 * c8 + 1) ^ (p & 15)) << 4));
                 const float em[8] = {e0[0], e0[1], e0[2], e0[3], e1v[0], e1v[1], e1v[2], e1v[3]};
-                const f32x2_ hx2 = {hx, hx}, lx2 = {c.lx, c.lx};
+                const f32x2_ hx2 = {hx, hx}, lx2 = {lx, lx};
                 v8 o;
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
-                    f32x2_ v = lerp2(rp[it], e, hx2, lx2, hy2, ly2);
+                    f32x2_ v = bilerp2(f32x2_{q00[e], q00[e + 1]}, f32x2_{q01[e], q01[e + 1]}, f32x2_{q10[e], q10[e + 1]}, f32x2_{q11[e], q11[e + 1]}, hx2,
+                                       lx2, hy2, ly2);
                     v += f32x2_{em[e], em[e + 1]};
                     o[e] = T16<T>::from_f32(v[0]);
                     o[e + 1] = T16<T>::from_f32(v[1]);
                 }
-                if (h == 0) issue(pb + 64, 2 * PL_E, PL_E, r0, r1, c, rp[it]);      // the second half's corners take the registers just consumed
                 *reinterpret_cast<v8*>(xo + (int64_t)(m0 + p) * PL_E + h * 64 + c8 * 8) = o;
                 if (eo) {                    // the level hands its embedding on: emb itself as a (hi | lo) pair
                     v8 eh, el;

@@ -148,6 +148,14 @@ AUTO_NECK_SMALL_GROUPS = {"tiny": ("ro", "ra", "nc", "fu", "pj", "rh")}      # b
 # calibration frames' channel means (site_bias_corr; the data-free-quantisation bias correction) -- no run-time cost.
 AUTO_NECK_PLAIN_MIN_SHARE = 0.001
 AUTO_TOL_NECK_PLAIN_ABS_M = 6.0e-5
+# The two neck stages are gated on what they ADD, not only on where they end (round-5 advisor): a weight set whose backbone choice already sits
+# at or above AUTO_TOL_NECK_ABS_M (the outlier-channel weights: 5.1e-5 m with every class "full" -- the floor of e4m3 correction planes on
+# those weights) got no neck relaxation at all in round 5, although one-pass products with the static bias correction cost it a few 1e-6.
+# Stage 1 may spend up to max(AUTO_TOL_NECK_ABS_M, backbone choice + AUTO_NECK_WONLY_INCREMENT_M), stage 2 up to max(AUTO_TOL_NECK_PLAIN_ABS_M,
+# stage 1's result + AUTO_NECK_PLAIN_INCREMENT_M), both capped at AUTO_TOL_NECK_CAP_M; the hold-out check (AUTO_TOL_HOLDOUT_M) stands behind them.
+AUTO_NECK_WONLY_INCREMENT_M = 0.5e-5
+AUTO_NECK_PLAIN_INCREMENT_M = 0.5e-5
+AUTO_TOL_NECK_CAP_M = 6.5e-5
 AUTO_CAL_FRAMES = 4
 AUTO_HOLDOUT_FRAMES = 4
 AUTO_TOL_HOLDOUT_M = 7.0e-5
@@ -433,6 +441,7 @@ class ZoeDepthEngine:
                     self.auto_classes, self.auto_attn, tuple(sorted(self.class_modes.items())), self.attn_mode, self.neck_mode,
                     self.fuse_mlp, self.add_projection, self.neck_f8,
                     AUTO_TOL_NECK_ABS_M, AUTO_TOL_NECK_PLAIN_ABS_M, AUTO_TOL_HOLDOUT_M, AUTO_CAL_FRAMES, AUTO_HOLDOUT_FRAMES,
+                    AUTO_NECK_WONLY_INCREMENT_M, AUTO_NECK_PLAIN_INCREMENT_M, AUTO_TOL_NECK_CAP_M,
                     tuple(os.environ.get(k_, "") for k_ in _ARITHMETIC_SWITCHES))
             hit = _CALIBRATION_CACHE.get(ckey)
             if hit is not None:
@@ -565,7 +574,8 @@ class ZoeDepthEngine:
             return "wonly:" + ",".join(sorted(k_ for n_ in names for k_ in cand_sites[n_])) + \
                 (";plain:" + ",".join(sorted(k_ for n_ in pl for k_ in cand_sites[n_])) if pl else "")
 
-        if per_site and truth is not None and l1_abs is not None and l1_abs <= AUTO_TOL_NECK_ABS_M:
+        tol_neck1 = min(max(AUTO_TOL_NECK_ABS_M, (l1_abs or 0.0) + AUTO_NECK_WONLY_INCREMENT_M), AUTO_TOL_NECK_CAP_M)
+        if per_site and truth is not None and l1_abs is not None and l1_abs <= AUTO_TOL_NECK_CAP_M - AUTO_NECK_WONLY_INCREMENT_M:
             # ---- the neck, candidate by candidate: what each product (or group of small products) costs when it alone drops the
             # activation-rounding correction (against the combination chosen so far), then the longest prefix of the error-per-FLOP order that
             # stays within the neck's budget against the reference AND within tol_total of the best mode.  The error grows along that order
@@ -588,12 +598,12 @@ class ZoeDepthEngine:
                 mid = (lo + hi + 1) // 2
                 d_s = depth(chosen, site_mode(order[:mid]), attn)
                 a_, t_ = worst(d_s, truth), worst(d_s, ref)
-                if a_ <= AUTO_TOL_NECK_ABS_M and t_ <= tol_total:
+                if a_ <= tol_neck1 and t_ <= tol_total:
                     lo, kept = mid, (a_, t_)
                 else:
                     hi = mid - 1
             wsites = list(order[:lo])
-            report["neck_sites"] = {"tol_abs_m": AUTO_TOL_NECK_ABS_M, "groups": {n_: ks for n_, ks in cand_sites.items() if n_.startswith("group:")},
+            report["neck_sites"] = {"tol_abs_m": tol_neck1, "groups": {n_: ks for n_, ks in cand_sites.items() if n_.startswith("group:")},
                                     "l1_alone_vs_chosen_m": {n_: round(err[n_], 8) for n_ in order}, "weight_only": wsites,
                                     "flops_share_weight_only": round(sum(cflops[n_] for n_ in wsites) / tot_f, 4)}
             if lo > 0:
@@ -610,15 +620,16 @@ class ZoeDepthEngine:
                 cands = sorted((n_ for n_ in wsites if cand_sites[n_] != ["rh.conv2.w"] and (n_.startswith("group:") or cflops[n_] >= AUTO_NECK_PLAIN_MIN_SHARE * tot_f)),
                                key=lambda n_: -cflops[n_])
                 a0 = worst(depth(chosen, neck, attn), truth)
+                tol_neck2 = min(max(AUTO_TOL_NECK_PLAIN_ABS_M, a0 + AUTO_NECK_PLAIN_INCREMENT_M), AUTO_TOL_NECK_CAP_M)
                 trail, a_now = {}, a0
                 for n_ in cands:
                     d_p = depth(chosen, site_mode(wsites, plain + [n_]), attn)
                     a_, t_ = worst(d_p, truth), worst(d_p, ref)
                     trail[n_] = round(a_, 8)
-                    if a_ <= AUTO_TOL_NECK_PLAIN_ABS_M and t_ <= tol_total:
+                    if a_ <= tol_neck2 and t_ <= tol_total:
                         plain.append(n_)
                         a_now, l1_abs, total = a_, a_, t_
-                report["neck_sites"].update(plain_tol_abs_m=AUTO_TOL_NECK_PLAIN_ABS_M, l1_weight_only_m=round(a0, 8), l1_with_candidate_plain_m=trail,
+                report["neck_sites"].update(plain_tol_abs_m=tol_neck2, l1_weight_only_m=round(a0, 8), l1_with_candidate_plain_m=trail,
                                             plain=list(plain), l1_plain_m=round(a_now, 8),
                                             flops_share_plain=round(sum(cflops[n_] for n_ in plain) / tot_f, 4),
                                             static_bias_correction=sorted(self.site_bias_corr))

@@ -1382,10 +1382,10 @@ def test_projector_level(L, dtype, geom):
     ex = ((x.double() - x64).abs() / (x64.abs() + 1.0)).max().item()
     assert ex < (2e-3 if dtype == torch.float16 else 1.6e-2), ex          # one 16-bit rounding of the sum
     e_emb = (emb32.double() - emb64).abs().max().item()
-    assert e_emb < (2e-5 if dtype == torch.float16 else 2e-3), e_emb     # (the 3-pass pair product itself: ~22 / ~16 significant bits)
+    assert e_emb < (5e-5 if dtype == torch.float16 else 5e-3), e_emb     # (the 3-pass pair product itself: ~22 / ~16 significant bits, the maximum over 1e7 values)
     if last:
         eh64 = e64 @ we_f.double().t() + be.double()
         ee = (eh.double() - eh64).abs().max().item()
-        assert ee < (2e-5 if dtype == torch.float16 else 2e-3), ee
+        assert ee < (5e-5 if dtype == torch.float16 else 5e-3), ee
     report(f"projector_level {dtype} B={B} {Hl}x{Wl}->{H}x{W} last={last}: x differs from the four-launch path on {frac:.2e} of its elements (<= one step), "
            f"max rel err vs fp64 {ex:.2e}")
