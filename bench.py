@@ -524,6 +524,11 @@ def main():
                 "value": round(r_["fps"], 2), "unit": "frames/s", "ms_per_step": round(1e3 * r_["elapsed"] / min(K, 4), 3),
                 "class_modes": dict(zo.class_modes), "attn_mode": zo.attn_mode, "neck_mode": zo.neck_mode,
                 "l1_abs_vs_reference_m": (zo.calibration or {}).get("l1_abs_vs_reference_m"), "warning": (zo.calibration or {}).get("warning"),
+                "l1_backbone_choice_vs_reference_m": (zo.calibration or {}).get("l1_backbone_choice_vs_reference_m"),
+                "calibration_holdout": (zo.calibration or {}).get("holdout"),
+                "neck_sites": {k_: v_ for k_, v_ in ((zo.calibration or {}).get("neck_sites") or {}).items() if k_ in
+                               ("tol_abs_m", "plain_tol_abs_m", "weight_only", "plain", "flops_share_weight_only", "flops_share_plain", "l1_weight_only_m", "l1_plain_m")},
+                "executed_gflop_per_input": (zo.calibration or {}).get("executed_gflop_per_input"),
                 "roofline_frac": (r_["roof"] or {}).get("frac"), "conv_stack_frac": (r_["roof_conv"] or {}).get("frac")}
         outl_d = r_["d_timed"]
         r_.pop("pipe"), r_.pop("zplan")
