@@ -659,39 +659,18 @@ class ZoeDepthEngine:
         if per_site and truth is not None and l1_abs is not None:
             best = neck_stages(chosen, attn, d_c, l1_abs, total)
             best_cost = executed_gflop(chosen, attn, best["wsites"], best["plain"])
-            tried = {"backbone as chosen": round(best_cost, 1)}
-            # ---- the trade between the backbone and the neck.  The stages above run in sequence: the backbone classes take the cheapest modes
-            # their own tolerances allow, the neck gets what is left of its budget -- on some weight sets next to nothing (round 6, eight seeds:
-            # a backbone choice at 5.4e-5 m left the neck two products and the rate 8 % under the median).  One backbone class a step further
-            # up can buy the neck ten products; so every single step up is tried with the neck stages redone under it, twice over, and the
-            # combination with the least executed work (executed_gflop) is kept.
-            for _round in range(2):
-                if best["rep"] is not None and best["rep"].get("flops_share_plain", 0.0) >= 0.85:
-                    break                                  # (the neck is not short of budget: nothing to trade)
-                improved = False
-                for k_ in list(switchable) + (["attn"] if (self.auto_attn and attn == "single" and attn_best == "corr") else []):
-                    alt, alt_attn = dict(chosen), attn
-                    if k_ == "attn":
-                        alt_attn = "corr"
-                    elif chosen[k_] == "full":
-                        continue
-                    else:
-                        alt[k_] = AUTO_CANDIDATES[AUTO_CANDIDATES.index(chosen[k_]) + 1]
-                    d_a = depth(alt, neck_full, alt_attn)
-                    r_ = neck_stages(alt, alt_attn, d_a, worst(d_a, truth), worst(d_a, ref))
-                    c_ = executed_gflop(alt, alt_attn, r_["wsites"], r_["plain"])
-                    tried[f"{k_} one step up"] = round(c_, 1)
-                    if c_ < best_cost - 1e-6:
-                        best, best_cost, best_alt, improved = r_, c_, (alt, alt_attn), True
-                if not improved:
-                    break
-                chosen, attn = best_alt
+            # (The stages run in sequence: the backbone classes take the cheapest modes their own tolerances allow, the neck gets what is left of
+            # its budget -- on some weight sets little: eight seeds, round 6: a backbone choice at 5.4e-5 m leaves the neck two products and the
+            # rate 8 % under the median.  Trading the other way was tried and does not pay -- a tighter backbone budget (3.5e-5 / 4.2e-5 m) made
+            # those seeds 21 % / 4 % SLOWER, and a search over single class steps with the neck stages redone under each found no combination
+            # with less executed work on four seeds: a backbone class one step up costs more than the neck products it frees.
+            # profiles/r06_calibration_experiments.txt)
             neck, wsites, plain, l1_abs, total = best["neck"], best["wsites"], best["plain"], best["l1_abs"], best["total"]
             self.site_bias_corr = dict(best["corr"])
             self._bias_corr_cache.clear()
             if best["rep"] is not None:
                 report["neck_sites"] = best["rep"]
-            report["executed_gflop_per_input"] = {"chosen": round(best_cost, 1), "tried": tried}
+            report["executed_gflop_per_input"] = round(best_cost, 1)
         # ---- held-out validation: frames no decision above has seen.  Above the line the latest relaxations are withdrawn, newest first
         if hold is not None:
             hv = {"tol_m": AUTO_TOL_HOLDOUT_M, "frames": int(hold.shape[0]), "withdrawn": []}
