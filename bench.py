@@ -644,7 +644,8 @@ def main():
             # figures a reviewer needs are the LAST ~1500 characters of the line (the driver keeps the tail)
             "kernels": kern_table,
             # (the static bias corrections travel in the report for the other ranks: here only how many values each site carries)
-            "calibration": ({k_: (v_ if k_ != "site_bias_corr" else {s_: len(c_) for s_, c_ in v_.items()}) for k_, v_ in (pipe.zoe.calibration or {}).items()}
+            "calibration": ({k_: (v_ if k_ not in ("site_bias_corr", "backbone_bias_corr") else {"products": len(v_), "values": sum(len(c_) for c_ in v_.values())})
+                             for k_, v_ in (pipe.zoe.calibration or {}).items()}
                             if pipe.zoe.acc else None),
             "hbm_allocated_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
             "power": main_run.get("power"),

@@ -103,7 +103,11 @@ class ZoeConfig:
 # bits per operand -- the REFERENCE precision (precision="reference"), against which calibrate() takes its absolute error.
 BACKBONE_CLASSES = ("qkv", "o", "fc1", "fc2")
 ACCURATE_CLASS_MODES = "auto"
-AUTO_CANDIDATES = ("wmean", "wcls", "full")       # cheapest first
+AUTO_CANDIDATES = ("wstat", "wmean", "wcls", "full")       # cheapest first
+#   "wstat" (round 6) "wmean" with the token-independent part of the weight-rounding error taken from the CALIBRATION frames' channel means instead of
+#           each image's own: a static fp32 bias row per product (backbone_bias_corr), no bs_col_mean / bs_rank1_bias launches at run time (192 per
+#           forward batch, 2.2 ms per 128 network inputs).  The image-dependent remainder Sum_c (mean_t a_tc - E[a_c]) dw_c is what it gives up; the
+#           calibration measures what that costs on its frames and the hold-out frames, like every other choice.
 AUTO_TOL_CLASS_M = 4.0e-5                        # depth L1 against the best mode's result that ONE class may cost
 AUTO_TOL_TOTAL_M = 6.0e-5                        # ... and the chosen combination as a whole
 AUTO_TOL_ABS_M = 8.0e-5                          # ... and the chosen combination against the 3-pass REFERENCE engine on the device (the
@@ -259,7 +263,7 @@ class ZoeDepthEngine:
         self.class_modes = {k: "full" for k in BACKBONE_CLASSES}
         if isinstance(cm, dict):
             self.class_modes.update(cm)
-        assert all(v in ("full", "w", "wcls", "wmean", "a", "single", "pairs") for v in self.class_modes.values()), self.class_modes
+        assert all(v in ("full", "w", "wcls", "wmean", "wstat", "a", "single", "pairs") for v in self.class_modes.values()), self.class_modes
         am_ = attn_mode or os.environ.get("BS_ATTN_MODE") or (ACCURATE_ATTN_MODE if self.acc else "single")
         assert am_ in ("auto", "single", "corr"), am_
         assert self.acc or am_ != "corr", "attn_mode='corr' belongs to precision='accurate'"
@@ -274,6 +278,7 @@ class ZoeDepthEngine:
         # the filter taps, fp32 [N, Cin], kept from ingestion; site_bias_corr[key] = dw_sum[key] @ E[a] with the calibration frames' channel
         # means -- added to the product's bias while it runs one pass (the token-independent part of its weight-rounding error)
         self.dw_sum: Dict[str, torch.Tensor] = {}
+        self.backbone_bias_corr: Dict[str, torch.Tensor] = {}     # "wstat": weight key -> fp32 [1, N] = dW E[a] over the calibration frames' patch rows
         self.site_bias_corr: Dict[str, torch.Tensor] = {}
         self._bias_corr_cache: Dict[str, torch.Tensor] = {}
         # DPT neck / heads (no cls rows there): "full" = both correction products, "w" = the weight-rounding correction only
@@ -320,10 +325,10 @@ class ZoeDepthEngine:
             return self._wn(t)
         if mode == "w" and t.shape[1] % 256 != 0:
             mode = "full"
-        w8, sb = L.f8_weight(t, self.dtype, planes={"full": "both", "wcls": "both", "wmean": "both", "w": "lo", "a": "hi_only"}[mode], device=self.dev)
+        w8, sb = L.f8_weight(t, self.dtype, planes={"full": "both", "wcls": "both", "wmean": "both", "wstat": "both", "w": "lo", "a": "hi_only"}[mode], device=self.dev)
         self.f8s[key] = sb
         self.wmode[key] = mode
-        if key[0] == "l" and mode in ("full", "wcls", "wmean"):
+        if key[0] == "l" and mode in ("full", "wcls", "wmean", "wstat"):
             # "full" / "wcls" / "wmean" read the same packed rows; "wmean" also needs dW = W - round16(W) as bf16 (fp32's exponent
             # range), the W operand of the rank-1 correction GEMM: kept for all three, so the mode is a PLAN-time choice
             # (set_class_modes / calibrate) and not a re-ingestion
@@ -334,7 +339,7 @@ class ZoeDepthEngine:
     def mode_of(self, wkey: str) -> Optional[str]:
         """correction mode of a weight at plan time: a backbone class packed for the switchable modes follows class_modes"""
         m = self.wmode.get(wkey)
-        if m in ("full", "wcls", "wmean") and wkey[0] == "l":
+        if m in ("full", "wcls", "wmean", "wstat") and wkey[0] == "l":
             return self.class_modes.get(wkey.split(".")[-2], m)
         return m
 
@@ -366,8 +371,8 @@ class ZoeDepthEngine:
         """switch the backbone classes between "full" / "wcls" / "wmean" (and the neck mode, the attention mode) without re-ingesting
         the weights; plans built so far are dropped"""
         for k, v in modes.items():
-            assert k in BACKBONE_CLASSES and v in ("full", "wcls", "wmean"), (k, v)
-            assert self.class_modes[k] in ("full", "wcls", "wmean"), f"class {k} was ingested as {self.class_modes[k]!r}: not switchable"
+            assert k in BACKBONE_CLASSES and v in ("full", "wcls", "wmean", "wstat"), (k, v)
+            assert self.class_modes[k] in ("full", "wcls", "wmean", "wstat"), f"class {k} was ingested as {self.class_modes[k]!r}: not switchable"
         self.class_modes.update(modes)
         if neck_mode is not None:
             assert (neck_mode == "pairs") == (self.neck_mode == "pairs"), "the neck's operand format is fixed at ingestion"
@@ -380,8 +385,10 @@ class ZoeDepthEngine:
     def apply_calibration(self, report: dict) -> None:
         """take over a calibration made elsewhere (rank 0 of a sharded run broadcasts its report: every rank must run the same
         arithmetic, and ranks calibrating on their own could fall on different sides of a threshold)"""
-        self.set_class_modes({k: v for k, v in report["class_modes"].items() if self.class_modes[k] in ("full", "wcls", "wmean")},
+        self.set_class_modes({k: v for k, v in report["class_modes"].items() if self.class_modes[k] in ("full", "wcls", "wmean", "wstat")},
                              report["neck_mode"], report.get("attn_mode"))
+        self.backbone_bias_corr = {k: torch.tensor(v, dtype=torch.float32, device=self.dev).view(1, -1)
+                                   for k, v in (report.get("backbone_bias_corr") or {}).items()}
         self.site_bias_corr = {k: torch.tensor(v, dtype=torch.float32, device=self.dev) for k, v in (report.get("site_bias_corr") or {}).items()}
         self._bias_corr_cache.clear()
         self.calibration = dict(report)
@@ -456,7 +463,7 @@ class ZoeDepthEngine:
         frames_u8 = frames_u8.to(self.dev).contiguous()
         ncal = int(frames_u8.shape[0])
         H, W = int(frames_u8.shape[1]), int(frames_u8.shape[2])
-        switchable = [k for k in BACKBONE_CLASSES if self.class_modes[k] in ("full", "wcls", "wmean")] if self.auto_classes else []
+        switchable = [k for k in BACKBONE_CLASSES if self.class_modes[k] in ("full", "wcls", "wmean", "wstat")] if self.auto_classes else []
         neck_cands = ["full"] if (not self.neck_f8 or not self.auto_classes or (neck_candidates is None and (not reference or self._sd is None))) \
             else list(neck_candidates or AUTO_NECK_CANDIDATES)
         # default (no explicit candidates, absolute reference available): the neck is calibrated per site AFTER the backbone classes and
@@ -491,7 +498,13 @@ class ZoeDepthEngine:
 
         full = {k: "full" for k in switchable}
         neck_full = "full" if (len(neck_cands) > 1 or per_site) else neck0
-        ref = depth(full, neck_full, attn_best)
+        bmeans: Dict[str, torch.Tensor] = {}
+        ref = depth(full, neck_full, attn_best, means=bmeans if (switchable and "wstat" in AUTO_CANDIDATES) else None)
+        # "wstat": the static correction rows dW E[a] of every backbone product, from the channel means of its patch rows on the calibration frames
+        # (taken with every correction on: the means of the 16-bit values do not depend on the mode to any digit that matters here)
+        self.backbone_bias_corr = {k_[3:]: (self.w[k_[3:] + ".lo"].double() * m_.double()).sum(1).float().view(1, -1).contiguous()
+                                   for k_, m_ in bmeans.items() if k_[3:] + ".lo" in self.w}       # (deterministic form: see site_bias_corr below)
+        del bmeans
         report = {"frame": f"{H}x{W}", "frames": ncal, "statistic": "worst frame (max over the calibration frames of the per-frame mean |d - d_ref|)",
                   "tol_class_m": tol_class, "tol_total_m": tol_total, "tol_abs_m": tol_abs, "l1_vs_full_m": {}}
         truth = hold = truth_h = None
@@ -531,7 +544,7 @@ class ZoeDepthEngine:
                 neck, cost["neck"] = cand, l1
                 break
         saving = self._saving_gflop(1 + (nh_ // self.cfg.patch) * (nw_ // self.cfg.patch))
-        passes_saved = {"wmean": 1.0, "wcls": 0.5, "full": 0.0}
+        passes_saved = {"wstat": 1.02, "wmean": 1.0, "wcls": 0.5, "full": 0.0}
 
         def step_up():
             """the live choice that pays the most depth error per unit of work saved goes one step back up; False when none is left"""
@@ -577,7 +590,7 @@ class ZoeDepthEngine:
         def executed_gflop(chosen_, attn_, wsites_, plain_):
             """executed work per network input in 16-bit-pass GFLOP (backbone classes + attention + neck products): what the outer loop below
             minimises -- a proxy for time that needs no timing run"""
-            g = sum(saving[k_] * {"wmean": 1.0, "wcls": 1.5, "full": 2.0}.get(chosen_.get(k_, self.class_modes[k_]), 2.0) for k_ in BACKBONE_CLASSES)
+            g = sum(saving[k_] * {"wstat": 0.98, "wmean": 1.0, "wcls": 1.5, "full": 2.0}.get(chosen_.get(k_, self.class_modes[k_]), 2.0) for k_ in BACKBONE_CLASSES)
             g += saving["attn"] * (0.5 if attn_ == "single" else 1.5)
             wk = {k_ for n_ in wsites_ for k_ in cand_sites[n_]}
             pk = {k_ for n_ in plain_ for k_ in cand_sites[n_]}
@@ -634,7 +647,9 @@ class ZoeDepthEngine:
                 for k_, m_ in means.items():
                     k_ = k_[3:]                                       # "in:<weight key>"
                     if k_ in self.dw_sum:
-                        self.site_bias_corr[k_] = (self.dw_sum[k_] @ m_).contiguous()
+                        # (multiply + tree sum in fp64, not a library GEMV: split-K atomics would make the low bits -- and with them a borderline
+                        # decision below -- differ between two processes calibrating the same weights)
+                        self.site_bias_corr[k_] = (self.dw_sum[k_].double() * m_.double()).sum(1).float().contiguous()
                 cands = sorted((n_ for n_ in ws if cand_sites[n_] != ["rh.conv2.w"] and (n_.startswith("group:") or cflops[n_] >= AUTO_NECK_PLAIN_MIN_SHARE * tot_f)),
                                key=lambda n_: -cflops[n_])
                 a0 = worst(depth(chosen_, out["neck"], attn_), truth)
@@ -704,9 +719,12 @@ class ZoeDepthEngine:
         keep_corr = {k_ for part in neck.split(";") if part.startswith("plain:") for k_ in part[6:].split(",")}
         self.site_bias_corr = {k_: v for k_, v in self.site_bias_corr.items() if k_ in keep_corr}
         self._bias_corr_cache.clear()
-        report.update(class_modes={**{k: self.class_modes[k] for k in BACKBONE_CLASSES}, **chosen}, neck_mode=neck, attn_mode=attn,
+        final_modes = {**{k: self.class_modes[k] for k in BACKBONE_CLASSES}, **chosen}
+        self.backbone_bias_corr = {k_: v for k_, v in self.backbone_bias_corr.items() if final_modes.get(k_.split(".")[-2]) == "wstat"}
+        report.update(class_modes=final_modes, neck_mode=neck, attn_mode=attn,
                       l1_total_vs_full_m=total, l1_abs_vs_reference_m=l1_abs,
-                      site_bias_corr={k_: v.cpu().tolist() for k_, v in self.site_bias_corr.items()})
+                      site_bias_corr={k_: v.cpu().tolist() for k_, v in self.site_bias_corr.items()},
+                      backbone_bias_corr={k_: v.view(-1).cpu().tolist() for k_, v in self.backbone_bias_corr.items()})
         if l1_abs is not None and l1_abs > TOLERANCE_M:
             fixed = [k for k in BACKBONE_CLASSES if k not in switchable]
             report["warning"] = (f"depth L1 of the calibration frames against the reference-precision engine is {l1_abs:.2e} m with every calibrated "
@@ -1125,7 +1143,7 @@ class _ZoePlan:
         def prow(wkey):
             """dtype-argument bits of a producer whose consumer GEMM runs no FP8 stage on the patch rows ("wmean"): only the rows
             below CP (the cls tile) need their FP8 planes.  bs_layernorm: rows << 8"""
-            return (CP << 8) if (acc and grouped and fmt(wkey) == 32 and eng.mode_of(wkey) == "wmean") else 0
+            return (CP << 8) if (acc and grouped and fmt(wkey) == 32 and eng.mode_of(wkey) in ("wmean", "wstat")) else 0
 
         MEAN_STEP = 8      # the rank-1 correction's token mean uses every 8th patch row (probe: same depth result as the full mean)
 
@@ -1133,6 +1151,9 @@ class _ZoePlan:
             """backbone GEMM.  Accurate mode: A_hi W_hi + A_hi W_lo + A_lo W_hi in one launch -- the two corrections on the
             block-scaled FP8 MFMA where the weight was packed for it (A = [hi16 | hi8 | lo8], 2 pass-equivalents), else as
             K segments of 16-bit (hi | lo) pairs (3 passes)."""
+            if acc and grouped and wkey in f8s and wkey[0] == "l":
+                # (calibrate(): the channel means of the product's patch rows, what "wstat"'s static correction is formed from)
+                P.mark("in:" + wkey, A, ("chanmean", CP * 2 * K, NB * T0, 2 * K, K))
             if acc and wkey in single:
                 P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=K, precision_passes=1, **kw)
             elif acc and wkey in f8s and eng.mode_of(wkey) == "w":
@@ -1140,7 +1161,13 @@ class _ZoePlan:
                 sb0, _ = f8s[wkey]
                 P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=2 * K, f8_seg=K,
                        f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_HI_EXP, sb0), precision_passes=1, **kw)
-            elif acc and wkey in f8s and eng.mode_of(wkey) == "wmean" and grouped:
+            elif acc and wkey in f8s and eng.mode_of(wkey) == "wstat" and grouped and wkey in eng.backbone_bias_corr:
+                # "wmean" with the calibration frames' channel means in place of the image's own: the correction is a constant row, added to the
+                # patch rows through the bias2 path as ONE group (the cls tile runs both FP8 corrections and must not get it)
+                sb0, sb1 = f8s[wkey]
+                P.gemm(name, A, w[wkey], out, M=M, N=N, K=K, lda=2 * K, f8_seg=2 * K, f8_skip_from=CP, bias2=(eng.backbone_bias_corr[wkey], CP, NB * T0),
+                       f8_scales=(127 - L.F8_ACT_HI_EXP, sb0, 127 - L.F8_ACT_LO_EXP, sb1), precision_passes=1, **kw)
+            elif acc and wkey in f8s and eng.mode_of(wkey) in ("wmean", "wstat") and grouped:
                 # cls tile: both FP8 corrections.  Patch tiles: ONE 16-bit pass; the weight-rounding error A dW^T is replaced by its
                 # token-independent part 1 (mean_tokens(A) dW^T), a per-image bias formed by a column-mean kernel over a sample of
                 # the image's patch rows and bs_rank1_bias, a [NB, K] x [K, N] product (Numerics)
@@ -1195,7 +1222,7 @@ class _ZoePlan:
                   ldo=c.intermediate * am(f"l{l}.fc2.w"), out_split_off=c.intermediate if hfmt else 0,
                   out_f8=(L.F8_ACT_HI_EXP, L.F8_ACT_LO_EXP) if hfmt == 32 else None,
                   # fc2 in "wcls" mode reads the lo8 plane of its cls tile only
-                  out_lo8_rows=CP if (hfmt == 32 and grouped and eng.mode_of(f"l{l}.fc2.w") in ("wcls", "wmean")) else 0,
+                  out_lo8_rows=CP if (hfmt == 32 and grouped and eng.mode_of(f"l{l}.fc2.w") in ("wcls", "wmean", "wstat")) else 0,
                   out_planes_rows=CP if prow(f"l{l}.fc2.w") else 0)
             bgemm(f"l{l}.fc2", hid, f"l{l}.fc2.w", x, MT, Hd, c.intermediate, bias=w[f"l{l}.fc2.b"], scale=w[f"l{l}.lam2"], res=x, ldr=Hd)
             P.mark(f"layer{l + 1}", x, TOK)

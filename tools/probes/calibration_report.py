@@ -14,6 +14,6 @@ if WEIGHT_VARIANTS[variant] is not None:
 eng = ZD.ZoeDepthEngine(w, cfg, precision="accurate")
 t0 = time.time()
 cal = eng.calibrate(480, 640)
-cal = {k: (v if k != "site_bias_corr" else sorted(v)) for k, v in cal.items()}
+cal = {k: (v if k not in ("site_bias_corr", "backbone_bias_corr") else sorted(v)) for k, v in cal.items()}
 print(f"[{variant} seed {seed}] calibrate {time.time() - t0:.1f} s")
 print(json.dumps(cal, indent=1))
