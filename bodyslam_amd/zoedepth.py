@@ -103,11 +103,14 @@ class ZoeConfig:
 # bits per operand -- the REFERENCE precision (precision="reference"), against which calibrate() takes its absolute error.
 BACKBONE_CLASSES = ("qkv", "o", "fc1", "fc2")
 ACCURATE_CLASS_MODES = "auto"
-AUTO_CANDIDATES = ("wstat", "wmean", "wcls", "full")       # cheapest first
-#   "wstat" (round 6) "wmean" with the token-independent part of the weight-rounding error taken from the CALIBRATION frames' channel means instead of
-#           each image's own: a static fp32 bias row per product (backbone_bias_corr), no bs_col_mean / bs_rank1_bias launches at run time (192 per
-#           forward batch, 2.2 ms per 128 network inputs).  The image-dependent remainder Sum_c (mean_t a_tc - E[a_c]) dw_c is what it gives up; the
-#           calibration measures what that costs on its frames and the hold-out frames, like every other choice.
+AUTO_CANDIDATES = ("wmean", "wcls", "full")       # cheapest first
+#   "wstat" (round 6; a candidate in front of "wmean" only with BS_AUTO_WSTAT=1) "wmean" with the token-independent part of the weight-rounding error
+#           taken from the CALIBRATION frames' channel means instead of each image's own: a static fp32 bias row per product (backbone_bias_corr), no
+#           bs_col_mean / bs_rank1_bias launches at run time (192 per forward batch, 2.2 ms per 128 network inputs).  Measured: alone a class costs what
+#           "wmean" costs it (1.2-1.3e-5 m), but the four together read 3.46e-5 m where "wmean" reads 2.81e-5 -- the image-dependent remainder
+#           Sum_c (mean_t a_tc - E[a_c]) dw_c is coherent over an image -- and the neck loses products to it: +0.2 ... +1.1 % frames/s on three weight seeds,
+#           -2 % on the fourth (profiles/r06_calibration_experiments.txt (8)).  Not a default: the gain is inside the box-to-box spread and the static means
+#           stand on the calibration frames' statistics.
 AUTO_TOL_CLASS_M = 4.0e-5                        # depth L1 against the best mode's result that ONE class may cost
 AUTO_TOL_TOTAL_M = 6.0e-5                        # ... and the chosen combination as a whole
 AUTO_TOL_ABS_M = 8.0e-5                          # ... and the chosen combination against the 3-pass REFERENCE engine on the device (the
@@ -172,7 +175,7 @@ ACCURATE_NECK_MODE = "full"
 _CALIBRATION_CACHE: Dict[Tuple, dict] = {}        # process-wide: (weights fingerprint, geometry, tolerances, ...) -> calibration report
 # environment switches that change the arithmetic a calibration measures (A / B runs): part of the cache key (round-5 advisor)
 _ARITHMETIC_SWITCHES = ("BS_PJ_LOWRES", "BS_UPCONV_FUSED", "BS_CLB_COMPOSED", "BS_RELU_OUT", "BS_NECK_PLAIN", "BS_MLP2", "BS_NECK_BIAS_CORR",
-                        "BS_PROJECTOR_LEVEL")
+                        "BS_PROJECTOR_LEVEL", "BS_AUTO_WSTAT")
 
 ZOED_NK = ZoeConfig()
 ZOED_N = ZoeConfig(head_names=("nyu",))
@@ -499,7 +502,7 @@ class ZoeDepthEngine:
         full = {k: "full" for k in switchable}
         neck_full = "full" if (len(neck_cands) > 1 or per_site) else neck0
         bmeans: Dict[str, torch.Tensor] = {}
-        ref = depth(full, neck_full, attn_best, means=bmeans if (switchable and "wstat" in AUTO_CANDIDATES) else None)
+        ref = depth(full, neck_full, attn_best, means=bmeans if (switchable and os.environ.get("BS_AUTO_WSTAT") == "1") else None)
         # "wstat": the static correction rows dW E[a] of every backbone product, from the channel means of its patch rows on the calibration frames
         # (taken with every correction on: the means of the 16-bit values do not depend on the mode to any digit that matters here)
         self.backbone_bias_corr = {k_[3:]: (self.w[k_[3:] + ".lo"].double() * m_.double()).sum(1).float().view(1, -1).contiguous()
@@ -518,8 +521,9 @@ class ZoeDepthEngine:
             truth, truth_h = t_all[:ncal], (t_all[ncal:] if hold is not None else None)
             report["l1_best_vs_reference_m"] = worst(ref, truth)          # the floor: nothing the calibration chooses can be closer than this
         chosen, cost = dict(full), {}
+        cands_cls = (("wstat",) if os.environ.get("BS_AUTO_WSTAT") == "1" else ()) + tuple(AUTO_CANDIDATES)
         for k in switchable:
-            for cand in AUTO_CANDIDATES:
+            for cand in cands_cls:
                 if cand == "full":
                     chosen[k], cost[k] = "full", 0.0
                     break
@@ -562,7 +566,7 @@ class ZoeDepthEngine:
             elif worst_k == "attn":
                 attn = attn_best
             else:
-                chosen[worst_k] = AUTO_CANDIDATES[min(AUTO_CANDIDATES.index(chosen[worst_k]) + 1, len(AUTO_CANDIDATES) - 1)]
+                chosen[worst_k] = cands_cls[min(cands_cls.index(chosen[worst_k]) + 1, len(cands_cls) - 1)]
             cost[worst_k] = 0.0 if (worst_k in ("neck", "attn") or chosen[worst_k] == "full") else report["l1_vs_full_m"].get(f"{worst_k}:{chosen[worst_k]}", 0.0)
             return True
 
