@@ -280,6 +280,17 @@ def test_full_size_zoed_nk_accurate_bf16():
     assert l1 <= 5e-4
 
 
+def test_bf16_reference_precision():
+    """BASELINE config 2 names bf16.  With e4m3 correction planes bf16 storage carries 8 + 4 significant bits -- fp16's single pass -- and
+    misses the tolerance (test_full_size_bf16_accurate: ~1.3e-4 m).  As (hi | lo) bf16 pairs, three MFMA passes per product (precision=
+    "reference"), it carries 16: this is the bf16 configuration that meets 1e-4 m."""
+    from oracle import zoedepth_ref as Z
+    r = run_case(Z.ZOED_NK, torch.bfloat16, B=1, H=480, W=640, target_hw=(384, 512), seed=1, precision="reference")      # (seed 1: the oracle case of the tests above)
+    l1 = (r["dm"] - r["ref"]).abs().mean().item()
+    report(f"[ZoeD_NK bf16 reference precision (3-pass pairs)] 640x480 depth L1={l1:.3e} m, max={(r['dm'] - r['ref']).abs().max().item():.3e} m")
+    assert l1 <= 1e-4
+
+
 @pytest.mark.parametrize("H,W", [(480, 600), (1024, 1280)])
 def test_other_frame_geometries(H, W):
     """BASELINE config 1 (the reference's own 600x480 example image) and config 5 (1280x1024): both resolve to a 416x512
@@ -317,17 +328,6 @@ def test_full_size_zoed_n_accurate():
     assert l1 <= 1e-4
 
 
-def test_bf16_reference_precision():
-    """BASELINE config 2 names bf16.  With e4m3 correction planes bf16 storage carries 8 + 4 significant bits -- fp16's single pass -- and
-    misses the tolerance (test_full_size_bf16_accurate: ~1.3e-4 m).  As (hi | lo) bf16 pairs, three MFMA passes per product (precision=
-    "reference"), it carries 16: this is the bf16 configuration that meets 1e-4 m."""
-    from oracle import zoedepth_ref as Z
-    r = run_case(Z.ZOED_NK, torch.bfloat16, B=1, H=480, W=640, target_hw=(384, 512), seed=2, precision="reference")
-    l1 = (r["dm"] - r["ref"]).abs().mean().item()
-    report(f"[ZoeD_NK bf16 reference precision (3-pass pairs)] 640x480 depth L1={l1:.3e} m, max={(r['dm'] - r['ref']).abs().max().item():.3e} m")
-    assert l1 <= 1e-4
-
-
 @pytest.mark.parametrize("hook", [None, "outlier"])
 def test_reference_precision_engine(hook):
     """precision="reference" (three 16-bit passes on (hi | lo) pairs for every product, split-precision attention): the on-device stand-in
@@ -355,7 +355,7 @@ from bodyslam_amd.synthetic import layerscale_wide as _hook_layerscale_wide  # n
 from bodyslam_amd.synthetic import outlier_channels as _hook_outlier_channels  # noqa: E402
 
 
-@pytest.mark.parametrize("hook", [_hook_layerscale_wide, _hook_outlier_channels, _hook_heavy_tailed])
+@pytest.mark.parametrize("hook", [_hook_outlier_channels, _hook_layerscale_wide, _hook_heavy_tailed])      # (outlier first: the oracle case of the test above)
 def test_auto_modes_hold_tolerance_on_adversarial_weights(hook):
     from oracle import zoedepth_ref as Z
     kw = dict(B=1, H=480, W=640, target_hw=(384, 512), seed=9, precision="accurate", weights_hook=hook)
@@ -394,7 +394,7 @@ def test_auto_modes_hold_tolerance_on_adversarial_weights(hook):
 def test_calibration_holds_on_held_out_frames():
     """The bench's weights (random_zoedepth_weights seed 0), calibrated as the bench calibrates them; then 16 consecutive frames of another
     synthetic sequence -- no calibration frame, no hold-out frame -- against the reference-precision engine on the device (itself held to
-    1e-5 m of the fp32 oracle: test_reference_precision_engine), and two of them against the oracle directly.  Every frame must meet the
+    1e-5 m of the fp32 oracle: test_reference_precision_engine), and one of them against the oracle directly.  Every frame must meet the
     north star's 1e-4 m; the calibration's own hold-out figures must be inside its line."""
     from bodyslam_amd.synthetic import make_sequence, random_zoedepth_weights
     from bodyslam_amd.zoedepth import AUTO_CAL_FRAMES, AUTO_HOLDOUT_FRAMES, AUTO_TOL_HOLDOUT_M, TOLERANCE_M, ZoeConfig, ZoeDepthEngine
@@ -414,7 +414,7 @@ def test_calibration_holds_on_held_out_frames():
     assert cal["holdout"]["l1_max_m"] <= AUTO_TOL_HOLDOUT_M and cal["l1_total_vs_full_m"] <= cal["tol_total_m"]
     assert float(per.max()) <= TOLERANCE_M, f"a held-out frame misses the tolerance: {per.tolist()}"
     assert float(per.max()) <= 1.3 * AUTO_TOL_HOLDOUT_M, "frames the calibration has not seen sit far above the ones it validated on"
-    for i in (3, 11):
+    for i in (11,):
         with torch.no_grad():
             ref = Z.infer_depth(w, Z.ZOED_NK, frames[i:i + 1], flip_aug=True)
         l1 = (d[i].cpu() - ref[0]).abs().mean().item()
