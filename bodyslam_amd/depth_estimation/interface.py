@@ -54,3 +54,16 @@ class DepthEstimator:
         if extension:
             saving_path = os.path.splitext(saving_path)[0] + '.' + extension.lstrip('.')
         image.save(saving_path)
+
+    def debug(self, path_to_frame: str, saving_path: str):
+        """interface.py:88-107: run the class's methods once each (load, infer, save) and print how each went; nothing is raised."""
+        checks = [("load image", lambda: self.load_image(path_to_frame)),
+                  ("infer method", lambda: self.infer_depth_map(path_to_frame)),
+                  ("saving method", lambda: self.save_depth_map(Image.new('RGB', (100, 100)), saving_path))]
+        for name, fn in checks:
+            print(f"[DEBUG]: Testing {name}...")
+            try:
+                fn()
+                print(f"[DEBUG]: {name} status -> ok")
+            except Exception as e:
+                print(f"[DEBUG]: OPS :/ -> {e}")

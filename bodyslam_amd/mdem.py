@@ -41,3 +41,19 @@ class MDEMInterface:
             return True
         except ValueError as e:
             print(f"Error while saving: {e}")
+
+    def debug(self, path_to_frame: str, saving_path: str):
+        """mdem_interface.py:85-121: exercise the inference and the saving method and report each.  (The reference's version calls both
+        unbound and cannot run; this one does what its docstring says and returns the list of outcomes.)"""
+        passed = []
+        for name, fn in (("infer method", lambda: self.infer_monocular_depth_map(path_to_frame)),
+                         ("saving method", lambda: self.save_depth_map(self.infer_monocular_depth_map(path_to_frame), saving_path, ".png"))):
+            print(f"[DEBUG]: Testing {name}...")
+            try:
+                fn()
+                passed.append(True)
+                print(f"[DEBUG]: {name} status -> ok")
+            except Exception as e:
+                passed.append(False)
+                print(f"[DEBUG]: OPS :/ -> {e}")
+        return passed

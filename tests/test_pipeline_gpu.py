@@ -97,6 +97,19 @@ def test_interfaces_roundtrip(tmp_path):
     assert os.path.exists(str(tmp_path / "d.png"))
     assert np.array_equal(np.asarray(Image.open(str(tmp_path / "d.png"))), np.asarray(depth))
     assert MDEMInterface.save_depth_map(depth, str(tmp_path / "e"), ".png") is True and os.path.exists(str(tmp_path / "e.png"))
+    # debug() (interface.py:88-107; mdem_interface.py:85-121): every method once, the outcome printed, nothing raised -- also for a missing frame
+    import contextlib
+    import io
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        est.debug(p1, str(tmp_path / "dbg.png"))
+        est.debug(str(tmp_path / "missing.png"), str(tmp_path / "dbg2.png"))
+    txt = buf.getvalue()
+    assert txt.count("status -> ok") == 3 + 1 and txt.count("OPS :/") == 2 and os.path.exists(str(tmp_path / "dbg.png"))
+    legacy = MDEMInterface.__new__(MDEMInterface)
+    legacy.zoe = est.model
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert legacy.debug(p1, str(tmp_path / "dbg3")) == [True, True] and os.path.exists(str(tmp_path / "dbg3.png"))
     wp = CP.synth_weights(seed=7)
     ck = str(tmp_path / "model.pth")
     torch.save({"epoch": 0, "iter_on_ucbm": 0, "ate": 0, "are": 0, "rte": 0, "rre": 0, "model_state_dict": wp,
