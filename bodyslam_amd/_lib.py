@@ -662,10 +662,9 @@ def attractor_step(A, bins_prev, bins_out, route, B, Hp, Wp, H, W, groups, n_bin
                                            stream_ptr()), "bs_attractor_step")
 
 
-def mlp2(x, ldx, W1, b1, W2, b2, out, M, K1, N1, N2, act2=ACT_SOFTPLUS_FAST, one_block=False):
-    """out = act2(round16(relu(x W1^T + b1)) W2^T + b2) in one launch (include/bodyslam_hip.h: bs_mlp2); one_block: the 256-row tile"""
-    check(load_library().bs_mlp2(p(x), ldx, p(W1), p(b1), p(W2), p(b2), p(out), M, K1, N1, N2, act2, dt(x) | (32 if one_block else 0), stream_ptr()),
-          "bs_mlp2")
+def mlp2(x, ldx, W1, b1, W2, b2, out, M, K1, N1, N2, act2=ACT_SOFTPLUS_FAST):
+    """out = act2(round16(relu(x W1^T + b1)) W2^T + b2) in one launch (include/bodyslam_hip.h: bs_mlp2)"""
+    check(load_library().bs_mlp2(p(x), ldx, p(W1), p(b1), p(W2), p(b2), p(out), M, K1, N1, N2, act2, dt(x), stream_ptr()), "bs_mlp2")
 
 
 def mlp2_add(emb, prev, W1, b1, W2, b2, out, B, Hp, Wp, H, W, K1, N1, N2, act2=ACT_SOFTPLUS_FAST, split=False):

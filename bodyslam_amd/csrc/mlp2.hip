@@ -237,23 +237,13 @@ static int mlp2_check(const char* who, const void* x, const void* W1, const floa
 
 }  // namespace bs
 
-namespace bs {
-template <typename T>
-static int launch_mlp2h(const void* x, int ldx, const void* W1, const float* b1, const void* W2, const float* b2, float* out, int M, int N2, int act2,
-                        hipStream_t st);          // (the 128-row, two-blocks-per-CU form: below)
-}
-
 extern "C" int bs_mlp2(const void* x, int32_t ldx, const void* W1, const float* b1, const void* W2, const float* b2, float* out, int32_t M,
                        int32_t K1, int32_t N1, int32_t N2, int32_t act2, int32_t dtype, void* stream) {
     using namespace bs;
-    const bool one_block = (dtype & 32) != 0;         // bit 5: the 256-row tile, one block per CU (rounds 4-5's form; A / B runs and tests)
-    dtype &= 15;
     const int rc = mlp2_check("bs_mlp2", x, W1, b1, W2, b2, out, M, K1, N1, N2, act2, dtype);
     if (rc != BS_OK) return rc;
     BS_REQUIRE(ldx >= K1 && ldx % 8 == 0, "bs_mlp2: ldx = %d (rows of >= K1 16-bit values, 16-byte aligned)", ldx);
     hipStream_t st = (hipStream_t)stream;
-    if (!one_block)
-        return dtype == BS_F16 ? launch_mlp2h<f16>(x, ldx, W1, b1, W2, b2, out, M, N2, act2, st) : launch_mlp2h<bf16>(x, ldx, W1, b1, W2, b2, out, M, N2, act2, st);
     const MlpAddGeom ag{};
     return dtype == BS_F16 ? launch_mlp2<f16, 0, 0>(x, ldx, W1, b1, W2, b2, out, M, N2, act2, ag, st)
                            : launch_mlp2<bf16, 0, 0>(x, ldx, W1, b1, W2, b2, out, M, N2, act2, ag, st);
@@ -283,149 +273,3 @@ extern "C" int bs_mlp2_add(const void* emb, const void* prev, const void* W1, co
     return split ? launch_mlp2<bf16, 1, 1>(emb, ldx, W1, b1, W2, b2, out, M, N2, act2, ag, st)
                  : launch_mlp2<bf16, 1, 0>(emb, ldx, W1, b1, W2, b2, out, M, N2, act2, ag, st);
 }
-
-// ---------------------------------------------------------------------------------------------------------------------------------------------
-// Round 6: bs_mlp2 on 128-row tiles with W1 staged in two halves -- 64 KiB of LDS, TWO blocks per CU.  mlp2_kernel above holds x (64 KiB) and all
-// of W1 (64 KiB) at once and overlays the 128 KiB hidden tile on both: one block per CU, and the block's phases (two LDS-DMA stagings, product 1,
-// the ReLU / rounding pass, product 2, softplus + stores) run one after the other with nothing beside them -- 12.7 us per 256 pixels at the finest
-// level where the MFMAs take 2.5.  Here a block is 128 pixels: x [2 segments][128 rows][128 B] (32 KiB) + ONE HALF of W1 [2][128 hidden][128 B]
-// (32 KiB); product 1 runs half by half (the second half's DMA lands where the first half was), the accumulators of both halves wait in registers
-// (64), and the hidden tile [4 segments][128 rows][128 B] (64 KiB) takes the place of x and the W1 half.  Two blocks share a CU and fill each
-// other's barriers and DMA waits.  Same MFMAs in the same K order, same roundings: the bits of mlp2_kernel and of the two bs_gemm launches
-// (tests/test_ops_gpu.py::test_mlp2).
-namespace bs {
-
-constexpr int MLPH_BM = 128, MLPH_LDS = 65536;
-
-template <typename T>
-__global__ __launch_bounds__(512, 4) void mlp2h_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ W1, const float* __restrict__ b1,
-                                                       const T* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ out, int M, int N2,
-                                                       int act2) {
-    typedef typename T16<T>::v8 v8;
-    typedef typename T16<T>::v4 v4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * MLPH_BM;
-    const int frow = lane & 15, fq = lane >> 4, sw = frow & 7;
-    const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;           // DMA: lane -> row l / 8 of a group of 8, chunk position l % 8 <- source chunk (l % 8) ^ (row & 7)
-    const bool whole = m0 + MLPH_BM <= M;                         // (block-uniform) the last block clamps its rows
-
-    // ---- stage x (16 row groups x 2 segments) and W1's first half (16 row groups x 2 segments): 64 DMA instructions over 8 waves
-    auto stage_w1 = [&](int half) {
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int rg = wave + it * 8;                         // hidden units half * 128 + rg * 8 + r8
-            const char* wl = reinterpret_cast<const char*>(W1 + (int64_t)(half * 128 + rg * 8 + r8) * MLP_K1 + chunk * 8);
-#pragma unroll
-            for (int seg = 0; seg < 2; ++seg) glds16(wl + seg * 128, smem + 32768 + seg * 16384 + rg * 1024);
-        }
-    };
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int rg = wave + it * 8;
-        int m = m0 + rg * 8 + r8;
-        if (!whole) m = m < M ? m : M - 1;
-        const char* xs = reinterpret_cast<const char*>(x + (int64_t)m * ldx + chunk * 8);
-#pragma unroll
-        for (int seg = 0; seg < 2; ++seg) glds16(xs + seg * 128, smem + seg * 16384 + rg * 1024);
-    }
-    stage_w1(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // ---- product 1, half by half: rows 32 wr + 16 i + frow, hidden units half * 128 + 64 wc + 16 j + 4 fq + e
-    const int wr = wave >> 1, wc = wave & 1;
-    f32x4 acc1[2][2][4];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc1[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int seg = ks >> 1, kc = (ks & 1) * 4;
-            const int coff = ((kc + fq) ^ sw) << 4;
-            v8 xf[2], wf[4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const v8*>(smem + seg * 16384 + (wr * 32 + i * 16 + frow) * 128 + coff);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const v8*>(smem + 32768 + seg * 16384 + (wc * 64 + j * 16 + frow) * 128 + coff);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc1[h][i][j] = T16<T>::mfma16(wf[j], xf[i], acc1[h][i][j]);
-        }
-        if (h == 0) {
-            __syncthreads();                // every wave has read the first half of W1: the second half lands in its place
-            stage_w1(1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-    }
-    __syncthreads();                        // every wave is done reading x and W1: the hidden tile takes their place
-    // hidden tile [4 segments of 64 units][128 rows][128 B]: unit n -> segment n >> 6, chunk (n & 63) >> 3 (swizzled by row & 7)
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = h * 128 + wc * 64 + j * 16 + fq * 4;
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + n);
-            const int seg = n >> 6, chunk_n = (n & 63) >> 3, sub = (n & 7) * 2;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int m = wr * 32 + i * 16 + frow;
-                v4 hv;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) hv[e] = T16<T>::from_f32(fmaxf(acc1[h][i][j][e] + bb[e], 0.0f));
-                *reinterpret_cast<v4*>(smem + seg * 16384 + m * 128 + ((chunk_n ^ (m & 7)) << 4) + sub) = hv;
-            }
-        }
-    __syncthreads();
-
-    // ---- product 2: rows 16 wave + frow, outputs 16 j + 4 fq + e; W2 fragments straight from global (<= 16 KiB, L2-resident), two k-steps ahead
-    const int NF2 = (N2 + 15) >> 4;
-    f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    auto w2frag = [&](int j, int ks) {
-        const int n = j * 16 + frow;
-        v8 z;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) z[e] = T16<T>::from_f32(0.f);
-        return (j < NF2 && n < N2) ? *reinterpret_cast<const v8*>(W2 + (int64_t)n * MLP_N1 + ks * 32 + fq * 8) : z;
-    };
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        const int seg = ks >> 1, kc = (ks & 1) * 4;
-        const int coff = ((kc + fq) ^ sw) << 4;
-        const v8 af = *reinterpret_cast<const v8*>(smem + seg * 16384 + (wave * 16 + frow) * 128 + coff);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            if (j < NF2) acc2[j] = T16<T>::mfma16(w2frag(j, ks), af, acc2[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = j * 16 + fq * 4;
-        if (j >= NF2 || n >= N2) continue;
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + n);
-        const int m = m0 + wave * 16 + frow;
-        if (m >= M) continue;
-        f32x4 y;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = apply_act(acc2[j][e] + bb[e], act2);
-        *reinterpret_cast<f32x4*>(out + (int64_t)m * N2 + n) = y;
-    }
-}
-
-template <typename T>
-static int launch_mlp2h(const void* x, int ldx, const void* W1, const float* b1, const void* W2, const float* b2, float* out, int M, int N2, int act2,
-                        hipStream_t st) {
-    BS_MAX_DYNAMIC_LDS(((const void*)mlp2h_kernel<T>), MLPH_LDS);
-    hipLaunchKernelGGL((mlp2h_kernel<T>), dim3(cdiv(M, MLPH_BM)), dim3(512), MLPH_LDS, st, (const T*)x, ldx, (const T*)W1, b1, (const T*)W2, b2, out, M, N2, act2);
-    BS_CHECK_LAUNCH();
-    return BS_OK;
-}
-
-}  // namespace bs

@@ -281,8 +281,7 @@ int bs_attractor_step(const float* A, const float* bins_prev, float* bins_out, c
  * both metric heads' MLPs stacked):  out = act2(round16(relu(x W1^T + b1)) W2^T + b2).
  * x rows of ldx 16-bit values (the first K1 are read), W1 [N1, K1], W2 [N2, N1] 16-bit, b1 / b2 fp32, out fp32 [M, N2].
  * Built for K1 = 128, N1 = 256, N2 a multiple of 4 up to 32; bit-identical to bs_gemm(act = ReLU, 16-bit out) followed by
- * bs_gemm(act = act2, fp32 out) -- the hidden map (M x 256) never reaches memory.  Round 6: 128-row tiles with W1 staged in two halves (64 KiB of
- * LDS, two blocks per CU); dtype bit 5 (| 32) selects the 256-row tile of rounds 4-5 (one block per CU; same bits). */
+ * bs_gemm(act = act2, fp32 out) -- the hidden map (M x 256) never reaches memory. */
 int bs_mlp2(const void* x, int32_t ldx, const void* W1, const float* b1, const void* W2, const float* b2, float* out, int32_t M,
             int32_t K1, int32_t N1, int32_t N2, int32_t act2, int32_t dtype, void* stream);
 /* bs_add_resized + bs_mlp2 in one launch (an attractor level, HF modeling_zoedepth.py:726-730 then :665-700): the MLP's input row is

@@ -1,23 +1,23 @@
-"""Probe: bs_mlp2 at the bench's finest level (NB = 128, 192 x 256 pixels), the 128-row two-blocks-per-CU tile against the 256-row tile."""
+"""Probe: bs_mlp2 on the finest attractor level's shape (M = 128 x 192 x 256 pixels, pair rows), alone.   python tools/probes/mlp2_time.py [reps]"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 from bodyslam_amd import _lib as L
 L.init(0)
-M, K1, N1, N2 = 128 * 192 * 256, 128, 256, 32
-g = torch.Generator().manual_seed(0)
-x = torch.randn(M, K1, generator=g).half().cuda()
-w1 = (torch.randn(N1, K1, generator=g) / K1 ** 0.5).half().cuda()
-w2 = (torch.randn(N2, N1, generator=g) / N1 ** 0.5).half().cuda()
-b1, b2 = torch.randn(N1, generator=g).cuda(), torch.randn(N2, generator=g).cuda()
-out = torch.empty(M, N2, device="cuda")
-for name, ob in (("128-row tile, two blocks per CU", False), ("256-row tile, one block per CU", True), ("128-row tile, two blocks per CU", False)):
-    for _ in range(3):
-        L.mlp2(x, K1, w1, b1, w2, b2, out, M, K1, N1, N2, one_block=ob)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20):
-        L.mlp2(x, K1, w1, b1, w2, b2, out, M, K1, N1, N2, one_block=ob)
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 50.0
-    print(f"bs_mlp2 M = {M} ({name}): {us:.1f} us, {2.0 * M * (K1 * N1 + N1 * N2) / us / 1e6:.0f} TFLOP/s, {M * (K1 * 2 + N2 * 4) / us / 1e3:.0f} GB/s of in + out")
+dev = torch.device("cuda:0")
+M, N2 = 128 * 192 * 256, 8
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+x = torch.randn(M, 256, device=dev).half()
+w1 = (torch.randn(256, 128, device=dev) / 11).half()
+w2 = (torch.randn(N2, 256, device=dev) / 16).half()
+b1, b2 = torch.randn(256, device=dev), torch.randn(N2, device=dev)
+out = torch.empty(M, N2, device=dev)
+for _ in range(2):
+    L.mlp2(x, 256, w1, b1, w2, b2, out, M, 128, 256, N2)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    L.mlp2(x, 256, w1, b1, w2, b2, out, M, 128, 256, N2)
+e1.record()
+torch.cuda.synchronize()
+print(f"bs_mlp2 M={M} N2={N2}: {e0.elapsed_time(e1) / reps * 1e3:.1f} us per launch")
