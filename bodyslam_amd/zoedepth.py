@@ -737,6 +737,13 @@ class ZoeDepthEngine:
             warnings.warn("ZoeDepthEngine.calibrate: " + report["warning"])
         elif truth is None:
             report["note"] = "no absolute reference (the engine holds no source weights): l1_total_vs_full_m is relative to the best mode only"
+        if truth is not None and report.get("l1_best_vs_reference_m", 0.0) > 0.5 * TOLERANCE_M and "warning" not in report:
+            # (round 6, the outlier-channel weights: the best mode reads 5.1e-5 m on the calibration frames and 1.2e-5 ... 2.2e-4 m on eight frames of
+            # the bench's sequence -- on such weights the error of the e4m3 correction planes varies several-fold from frame to frame)
+            report["margin_note"] = (f"even with every correction on, the calibration frames read {report['l1_best_vs_reference_m']:.2e} m against the reference-precision "
+                                     f"engine -- more than half the {TOLERANCE_M:.0e} m tolerance: frames with other statistics may exceed it.  precision='reference' "
+                                     "(three 16-bit passes per product) holds ~1.5e-5 m on such weights at about half the rate")
+            warnings.warn("ZoeDepthEngine.calibrate: " + report["margin_note"])
         self.set_class_modes(chosen, neck, attn)
         self.auto_modes = saved_auto
         torch.cuda.synchronize(self.dev)

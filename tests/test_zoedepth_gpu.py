@@ -414,6 +414,19 @@ def test_calibration_holds_on_held_out_frames():
     assert cal["holdout"]["l1_max_m"] <= AUTO_TOL_HOLDOUT_M and cal["l1_total_vs_full_m"] <= cal["tol_total_m"]
     assert float(per.max()) <= TOLERANCE_M, f"a held-out frame misses the tolerance: {per.tolist()}"
     assert float(per.max()) <= 1.3 * AUTO_TOL_HOLDOUT_M, "frames the calibration has not seen sit far above the ones it validated on"
+    # what the static bias correction of the one-pass products is worth: the same engine, the same frames, the corrections not applied
+    if eng.site_bias_corr:
+        os.environ["BS_NECK_BIAS_CORR"] = "0"
+        try:
+            eng._plans.clear()
+            d_off = eng.infer(frames[:4].cuda())[0].clone()
+        finally:
+            del os.environ["BS_NECK_BIAS_CORR"]
+            eng._plans.clear()
+        per_off = (d_off - truth[:4]).abs().flatten(1).mean(1).cpu()
+        report(f"[held-out frames] one-pass products WITHOUT their static bias correction: {per_off.mean():.3e} m (with it {per[:4].mean():.3e}) on frames 0-3; "
+               f"{len(eng.site_bias_corr)} products carry one")
+        assert float(per[:4].mean()) < float(per_off.mean()), "the static bias correction must not make the one-pass products worse"
     for i in (11,):
         with torch.no_grad():
             ref = Z.infer_depth(w, Z.ZOED_NK, frames[i:i + 1], flip_aug=True)
