@@ -471,7 +471,7 @@ def _f8_pack_device(device):
     """where the weight planes are formed: on `device` when torch's e4m3 cast there reproduces the CPU cast bit for bit (checked once on a
     sample that covers ties, the subnormal range and the saturation bound), else on the host.  One-off weight re-layout, not the compute
     path -- but a ZoeD_NK engine packs 300 M weights, 40 s of an 8-core host against < 1 s on the GPU."""
-    if device is None:
+    if device is None or os.environ.get("BS_PACK_ON_HOST") == "1":       # (the switch: A / B of the two packings)
         return torch.device("cpu")
     device = torch.device(device)
     if device.type != "cuda":

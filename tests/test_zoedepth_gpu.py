@@ -435,6 +435,34 @@ def test_calibration_holds_on_held_out_frames():
         assert l1 <= TOLERANCE_M and abs(l1 - float(per[i])) <= 1.5e-5
 
 
+def test_wstat_opt_in_holds_tolerance():
+    """BS_AUTO_WSTAT=1: the backbone's rank-1 weight-rounding correction as a static bias row from the calibration frames' channel means (no
+    bs_col_mean / bs_rank1_bias launches).  An opt-in (profiles/r06_calibration_experiments.txt (8)): the calibration must pick it where the
+    class tolerance allows, the plan must run without the two helper launches for those classes, and unseen frames must hold the tolerance."""
+    from bodyslam_amd.synthetic import make_sequence, random_zoedepth_weights
+    from bodyslam_amd.zoedepth import TOLERANCE_M, ZoeConfig, ZoeDepthEngine
+    cfg = ZoeConfig()
+    w = random_zoedepth_weights(cfg, seed=0)
+    os.environ["BS_AUTO_WSTAT"] = "1"
+    try:
+        eng = ZoeDepthEngine(w, cfg, precision="accurate")
+        frames = torch.from_numpy(make_sequence(4, 480, 640, seed=78)).cuda()
+        d = eng.infer(frames)[0].clone()
+        cal = eng.calibration
+        names = eng.plan_for(4, 480, 640, True).plan.names
+    finally:
+        del os.environ["BS_AUTO_WSTAT"]
+    stat = [k for k, v in cal["class_modes"].items() if v == "wstat"]
+    assert stat, f"no class took the static form: {cal['class_modes']} ({cal['l1_vs_full_m']})"
+    assert len(cal["backbone_bias_corr"]) == len(stat) * cfg.layers and sorted(eng.backbone_bias_corr) == sorted(cal["backbone_bias_corr"])
+    for k in stat:
+        assert not any(n.endswith(f".{k}.cm") or n.endswith(f".{k}.r1") for n in names), f"class {k} still launches its rank-1 pair"
+    truth = eng.reference_depth(frames)
+    per = (d - truth).abs().flatten(1).mean(1).cpu()
+    report(f"[wstat opt-in] classes {cal['class_modes']}: 4 unseen frames vs the reference-precision engine {per.tolist()}; hold-out {cal['holdout']['l1_max_m']:.3e}")
+    assert float(per.max()) <= TOLERANCE_M
+
+
 def test_calibration_uses_every_frame_it_is_given():
     """calibrate(frames_u8=...) judges on ALL the caller's frames (round 5 silently kept the first) and validates on the caller's hold-out set"""
     from bodyslam_amd.synthetic import make_sequence
@@ -451,3 +479,38 @@ def test_calibration_uses_every_frame_it_is_given():
     eng2.apply_calibration(rep)
     assert eng2.neck_mode == eng.neck_mode and sorted(eng2.site_bias_corr) == sorted(eng.site_bias_corr)
     assert torch.equal(eng.infer(fr[:2])[0], eng2.infer(fr[:2])[0])
+
+
+@pytest.mark.parametrize("neck", ["full", "one_pass"])
+def test_no_launch_reads_memory_the_plan_has_not_written(neck):
+    """A plan's intermediates are torch.empty blocks, and producers skip the planes their consumers do not read (lo8 / hi8 planes in front of
+    weight-only / one-pass products, the unrouted head's half of the bins tensors).  With the caching allocator's free memory filled with 0xFF
+    (NaN in fp16, fp32 and e4m3) before the plan is built, the router logits and the network's depth map must come out bit for bit as from clean
+    memory: nothing that reaches the output is read before it is written (tools/probes/poisoned_pool.py runs the same on the full-size network)."""
+    from bodyslam_amd.synthetic import make_sequence
+    from bodyslam_amd.zoedepth import ZoeDepthEngine, _ZoePlan
+    from oracle import zoedepth_ref as Z
+    cfg_o = small_oracle_cfg()
+    eng = ZoeDepthEngine(Z.synth_weights(cfg_o, seed=4), product_cfg(cfg_o), dtype=torch.float16, target_hw=(96, 128), precision="accurate",
+                         class_modes="full", attn_mode="single", neck_mode="full")
+    if neck == "one_pass":
+        sites = sorted(k for k in eng.f8s if not (k[0] == "l" and k[1].isdigit()) and k != "pe.w" and not k.endswith("w_cls") and not k.startswith("mh."))
+        eng.set_class_modes({}, "wonly:" + ",".join(sites) + ";plain:" + ",".join(k for k in sites if k != "rh.conv2.w"))
+    frames = torch.from_numpy(make_sequence(3, 120, 160, seed=9)).cuda()
+
+    def run():
+        plan = _ZoePlan(eng, 3, 120, 160, True)
+        plan.frames.copy_(frames)
+        plan.run(None)
+        torch.cuda.synchronize()
+        return plan.depth_net.clone(), plan.logits.clone(), plan.depth_m.clone()
+
+    torch.cuda.empty_cache()
+    clean = run()
+    for pat in (0xFF, 0x3C):
+        torch.cuda.empty_cache()
+        junk = torch.full((4 << 30,), pat, dtype=torch.uint8, device="cuda")      # what the next plan's buffers are carved from
+        del junk
+        got = run()
+        for a, b, name in zip(clean, got, ("depth_net", "logits", "depth_m")):
+            assert torch.isfinite(b).all() and torch.equal(a, b), f"{name} depends on memory the plan did not write (pool pattern 0x{pat:02X}, neck {neck})"
