@@ -489,7 +489,8 @@ def main():
             cex = sum(a["flops"] for (kd, _), a in agg.items() if kd == "conv")
             if st["ms"] > 0:
                 g_ = zplan.geom
-                forwards = K * g_["NB"]
+                first_ci = min(zplan.plan.gemm_info)                       # the plan's first GEMM: once per plan run (a strong-scaling step runs the plan once per batch)
+                forwards = sum(1 for (ci, _, _) in events if ci == first_ci) * g_["NB"]
                 ref_gflop = CONV_STACK_GFLOP_PER_FORWARD * (g_["nh"] * g_["nw"]) / (384.0 * 512.0)
                 tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12
                 ach_s = tf(ref_gflop * 1e9 * forwards, st["ms"])
