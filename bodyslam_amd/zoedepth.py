@@ -1669,6 +1669,7 @@ class _ZoePlan:
         free(emb_prev)
         self.depth_net = torch.empty(NB, nh_, nw_, device=dev, dtype=torch.float32)        # plan outputs are not pooled
         assert (nh_, nw_) == (2 * h3, 2 * w3)
+        P.mark("clb_eh", Eh, ("raw",))
         P.add("logbinom", "bs_logbinom_depth_ex", last, Eh, bins_prev, w["clb.w0_last"], w["clb.w2"], w["clb.b2"], w.get("clb.rel"), HID,
               self.route, self.depth_net, NB, nh_, nw_, ph_, pw_, c.min_temp, c.max_temp, L.dt(last) | NSP)
         P.mark("depth_net", self.depth_net, ("raw",))
