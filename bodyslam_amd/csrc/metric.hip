@@ -106,11 +106,27 @@ constexpr int LB_IN = 32, LB_BINS = 64;      // hidden width LB_HID is a templat
 constexpr int LB_T = 16;                 // output tile edge (256 threads = 16 x 16 pixels)
 constexpr int LB_MAXSRC = 12;            // most low-res rows / columns a 16-pixel span may touch (>= 1.7x upsampling); the launch sizes LDS for the actual ratio
 
+// everything the wave has in flight on the LDS / scalar-memory counter has arrived (a workgroup-scope fence on the LDS address space is
+// `s_waitcnt lgkmcnt(0)`, dropped by the compiler where nothing is outstanding), and the scheduler moves nothing across.  A fence and not
+// __builtin_amdgcn_s_waitcnt or inline assembly: behind either of those the compiler no longer treats the MLP weights as unmodified and
+// reads them with vector loads (92 global_load per kernel instead of s_load: measured in the ISA).
+#define LB_LGKM_FENCE()                              \
+    do {                                             \
+        __builtin_amdgcn_sched_barrier(0);           \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local"); \
+        __builtin_amdgcn_sched_barrier(0);           \
+    } while (0)
+
+#ifdef BS_DIAG
+// diagnostics build only: per-pixel intermediates (pt[0..3], sum of the inputs, max logit, den, num) for tools/probes/rerun_determinism.py
+__device__ float* lb_dbg = nullptr;
+#endif
+
 template <typename T, int LSPLIT, int LB_HID>
 __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const float* Eh, const float* bins, const float* w0_last,
                                                         const float* w2, const float* b2, const float* rel_w, const int32_t* route,
                                                         float* depth, int B, int H, int W, int He, int We, float sy, float sx,
-                                                        float min_temp, float max_temp, int ncell_max) {
+                                                        float min_temp, float max_temp, int ncell_max, int interleaved) {
     // LDS: the block's low-res patch of bin centres [rows][cols][64] and of Eh [rows][cols][40] for the routed head only,
     // loaded once (coalesced) instead of 4 x (256 + 160) bytes per output pixel; plus the small MLP weights.
     // dynamic LDS sized by the launcher for the window the upsampling ratio really needs (2x: 10 x 10 cells = 41.6 KB, 3 blocks/CU)
@@ -199,33 +215,84 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
     // two hidden units per pass: the 32-term dot products run on v_pk_fma_f32 (both halves read the same input, the weights of units h and
     // h + 1 sit in scalar registers) -- the build has -ffp-contract=off, so without the explicit fused form every term was a multiply
     // AND an add (2 560 issue slots per pixel for this loop; now 640)
-    static_assert(LB_HID % 2 == 0, "hidden width");
-#pragma unroll 2
-    for (int h = 0; h < LB_HID; h += 2) {
-        // each unit's dot product as an (even inputs, odd inputs) pair: the weight pairs are adjacent in memory -- they arrive as aligned
-        // scalar register pairs, no s_mov to pair up weights of two rows -- and so are the input pairs in the vector registers
-        f32x2_ sv[2];
+    //
+    // Round 6: the interpolated Eh of EIGHT units is read from LDS in one go, between two `s_waitcnt lgkmcnt(0)` fences, so that no scalar
+    // load is in flight while an LDS read is.  Rounds 2-5 read the four corners of two units inside the loop, interleaved with the s_loads
+    // of their weights under one lgkmcnt wait.  Beside a second process that allocates and frees device memory, that form was seen to
+    // consume the LDS data of the LAST SIXTEEN LANES of a wave before they had arrived (the registers still held the read's addresses):
+    // 5 % of the launches, 16 pixels of one output row per affected wave, every other stage of the plan bit-identical
+    // (profiles/r06_reproducibility.txt (6), tools/probes/rerun_determinism.py with DBG=1).  Alone it never happened; the form is kept in
+    // the diagnostics build (BS_LOGBINOM_INTERLEAVED=1) for that comparison.
+    static_assert(LB_HID % 8 == 0, "hidden width");
+#ifdef BS_DIAG
+    float dg_interp = 0.f, dg_pre = 0.f, dg_act = 0.f;       // sums over the hidden units of: interpolated Eh, pre-activation, activation
+#endif
+    for (int h0 = 0; h0 < LB_HID; h0 += 8) {
+        float ehv[8];
+#ifdef BS_DIAG
+        if (!interleaved)
+#endif
+        {
+            LB_LGKM_FENCE();
+            f32x4 e00[2], e01[2], e10[2], e11[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {   // same bilinear operation order as torch: hy*(hx*p00 + lx*p01) + ly*(hx*p10 + lx*p11)
-            sv[u][0] = l.hy * (l.hx * s_eh[c00 * LB_HID + h + u] + l.lx * s_eh[c01 * LB_HID + h + u]) +
-                       l.ly * (l.hx * s_eh[c10 * LB_HID + h + u] + l.lx * s_eh[c11 * LB_HID + h + u]);
-            sv[u][1] = 0.0f;
+            for (int q = 0; q < 2; ++q) {
+                e00[q] = *reinterpret_cast<const f32x4*>(s_eh + c00 * LB_HID + h0 + 4 * q);
+                e01[q] = *reinterpret_cast<const f32x4*>(s_eh + c01 * LB_HID + h0 + 4 * q);
+                e10[q] = *reinterpret_cast<const f32x4*>(s_eh + c10 * LB_HID + h0 + 4 * q);
+                e11[q] = *reinterpret_cast<const f32x4*>(s_eh + c11 * LB_HID + h0 + 4 * q);
+            }
+            LB_LGKM_FENCE();
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)      // same bilinear operation order as torch: hy*(hx*p00 + lx*p01) + ly*(hx*p10 + lx*p11)
+                    ehv[4 * q + e] = l.hy * (l.hx * e00[q][e] + l.lx * e01[q][e]) + l.ly * (l.hx * e10[q][e] + l.lx * e11[q][e]);
         }
 #pragma unroll
-        for (int c = 0; c < LB_IN; c += 2) {
-            const f32x2_ x2 = {xin[c], xin[c + 1]};
+        for (int hh = 0; hh < 8; hh += 2) {
+            const int h = h0 + hh;
+            // each unit's dot product as an (even inputs, odd inputs) pair: the weight pairs are adjacent in memory -- they arrive as aligned
+            // scalar register pairs, no s_mov to pair up weights of two rows -- and so are the input pairs in the vector registers
+            f32x2_ sv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                sv[u][0] = ehv[hh + u];
+#ifdef BS_DIAG
+                if (interleaved)
+                    sv[u][0] = l.hy * (l.hx * s_eh[c00 * LB_HID + h + u] + l.lx * s_eh[c01 * LB_HID + h + u]) +
+                               l.ly * (l.hx * s_eh[c10 * LB_HID + h + u] + l.lx * s_eh[c11 * LB_HID + h + u]);
+                dg_interp += sv[u][0];
+#endif
+                sv[u][1] = 0.0f;
+            }
+#pragma unroll
+            for (int c = 0; c < LB_IN; c += 2) {
+                const f32x2_ x2 = {xin[c], xin[c + 1]};
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    sv[u] = __builtin_elementwise_fma(*reinterpret_cast<const f32x2_*>(gw0 + (h + u) * LB_IN + c), x2, sv[u]);
+            }
+            f32x2_ a2 = {sv[0][0] + sv[0][1], sv[1][0] + sv[1][1]};
+            if (grel) a2 = __builtin_elementwise_fma(f32x2_{grel[h], grel[h + 1]}, f32x2_{rd, rd}, a2);
+            const f32x2_ ga = gelu_erf_as2(a2);
+#ifdef BS_DIAG
+            dg_pre += a2[0] + a2[1];
+            dg_act += ga[0] + ga[1];
+#endif
 #pragma unroll
             for (int u = 0; u < 2; ++u)
-                sv[u] = __builtin_elementwise_fma(*reinterpret_cast<const f32x2_*>(gw0 + (h + u) * LB_IN + c), x2, sv[u]);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) pt[o] = fmaf(gw2[o * LB_HID + h + u], ga[u], pt[o]);
         }
-        f32x2_ a2 = {sv[0][0] + sv[0][1], sv[1][0] + sv[1][1]};
-        if (grel) a2 = __builtin_elementwise_fma(f32x2_{grel[h], grel[h + 1]}, f32x2_{rd, rd}, a2);
-        const f32x2_ ga = gelu_erf_as2(a2);
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int o = 0; o < 4; ++o) pt[o] = fmaf(gw2[o * LB_HID + h + u], ga[u], pt[o]);
     }
+    LB_LGKM_FENCE();       // (the softmax loop below reads the bin centres from LDS: nothing scalar in flight there either)
+#ifdef BS_DIAG
+    const float dg_pt[4] = {pt[0], pt[1], pt[2], pt[3]};
+    float dg_x = 0.f;
+#pragma unroll
+    for (int c = 0; c < LB_IN; ++c) dg_x += xin[c];
+#endif
 #pragma unroll
     for (int o = 0; o < 4; ++o) pt[o] = softplus20(pt[o]);
     const float eps = 1e-4f;
@@ -277,6 +344,13 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
     }
     const float den = den2[0] + den2[1], num = num2[0] + num2[1];
     depth[gid] = num / den;
+#ifdef BS_DIAG
+    if (lb_dbg) {
+        float* d = lb_dbg + gid * 8;
+        d[0] = dg_x; d[1] = dg_interp; d[2] = dg_pre; d[3] = dg_act;
+        d[4] = dg_pt[0]; d[5] = dg_pt[1]; d[6] = dg_pt[2]; d[7] = dg_pt[3];
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -390,13 +464,14 @@ extern "C" int bs_logbinom_depth_ex(const void* last, const float* Eh, const flo
     const int nr_max = (int)(sy * (LB_T - 1)) + 3, nc_max = (int)(sx * (LB_T - 1)) + 3;
     const int ncell_max = nr_max * nc_max;
     const size_t lds = sizeof(float) * (size_t)(LB_BINS + ncell_max * (LB_BINS + hid));
+    static const int interleaved = diag_env("BS_LOGBINOM_INTERLEAVED") != nullptr;      // diagnostics build only (the rounds 2-5 form of the hidden layer)
     const int lsplit = (dtype & 32) ? 2 : ((dtype & 16) ? 1 : 0);   // bit 4: `last` holds (hi | lo) 16-bit pairs; bit 5: (hi16 | hi8 | lo8)
     dtype &= 15;
 #define BS_LB_LAUNCH(TT, LS, HD)                                                                                                 \
     do {                                                                                                                         \
         BS_MAX_DYNAMIC_LDS(reinterpret_cast<const void*>(&logbinom_kernel<TT, LS, HD>), 96 * 1024); \
         hipLaunchKernelGGL((logbinom_kernel<TT, LS, HD>), grid, dim3(256), lds, st, (const TT*)last, Eh, bins, w0_last, w2, b2,   \
-                           rel_w, route, depth, B, H, W, He, We, sy, sx, min_temp, max_temp, ncell_max);                         \
+                           rel_w, route, depth, B, H, W, He, We, sy, sx, min_temp, max_temp, ncell_max, interleaved);            \
     } while (0)
 #define BS_LB_HID(TT, LS)             \
     do {                              \
@@ -417,6 +492,12 @@ extern "C" int bs_logbinom_depth_ex(const void* last, const float* Eh, const flo
     BS_CHECK_LAUNCH();
     return BS_OK;
 }
+
+#ifdef BS_DIAG
+extern "C" int bs_diag_logbinom_buffer(float* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(bs::lb_dbg), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int bs_logbinom_depth(const void* last, const float* Eh, const float* bins, const float* w0_last, const float* w2,
                                  const float* b2, const int32_t* route, float* depth, int32_t B, int32_t H, int32_t W, int32_t He,
