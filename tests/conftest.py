@@ -46,10 +46,13 @@ def pytest_collection_finish(session):
     TWO_PROC["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "two_process_shard.py"), TWO_PROC["dir"]],
                                         stdout=TWO_PROC["log"], stderr=subprocess.STDOUT, cwd=ROOT, start_new_session=True)
     # Round 6: the helper runs to its end BEFORE the first test touches the GPU (~40 s).  Rounds 4-5 let it run beside the suite; with the
-    # calibration now ~90 forwards per process that overlap cost the test its meaning twice in four runs: under ANOTHER process's load on the same
-    # GPU one forward in a few hundred has come out with other bits than its rerun (tools/probes/calibration_repro.py: 1 process of 21 under load,
-    # 0 of 30 alone; not located), and one such forward inside a calibration moves a borderline decision -- the three processes
-    # then run different arithmetic and cannot be bit-equal.  Sharing a GPU between processes is not how the path is deployed (one process per GPU).
+    # calibration now ~90 forwards per process that overlap cost the test its meaning twice in four runs: beside other processes allocating on the
+    # same GPU a forward could come out with other bits than its rerun, and one such forward inside a calibration moves a borderline decision -- the
+    # three processes then run different arithmetic and cannot be bit-equal.  The cause was found later in the round and removed (the log-binomial
+    # kernel's LDS reads sharing a wait with scalar loads); the order is kept: one process per GPU is how the path is deployed, and the suite's own tests are not
+    # what this test is about.  BODYSLAM_TEST_HELPER_CONCURRENT=1: the rounds 4-5 behaviour.
+    if os.environ.get("BODYSLAM_TEST_HELPER_CONCURRENT") == "1":
+        return
     try:
         TWO_PROC["proc"].wait(timeout=600)
     except subprocess.TimeoutExpired:
