@@ -503,9 +503,10 @@ class ZoeDepthEngine:
         neck_full = "full" if (len(neck_cands) > 1 or per_site) else neck0
         bmeans: Dict[str, torch.Tensor] = {}
         ref = depth(full, neck_full, attn_best, means=bmeans if (switchable and os.environ.get("BS_AUTO_WSTAT") == "1") else None)
-        # The yardstick of every decision below is run twice: the same launches must give the same bits (they do, run after run, when the process has
-        # the GPU to itself; beside another process's load one forward in a few hundred has differed -- DESIGN section 7).  A yardstick that does not
-        # reproduce is measured a third time and the report says so.
+        # The yardstick of every decision below is run twice: the same launches must give the same bits.  (Earlier in round 6 one forward in a few
+        # hundred differed beside another process allocating on the same GPU; the cause -- the log-binomial kernel's LDS reads sharing a wait with
+        # scalar loads, DESIGN section 7 -- is removed, the check costs one forward and stays.)  A yardstick that does not reproduce is measured a
+        # third time and the report says so.
         ref2 = depth(full, neck_full, attn_best)
         rerun_equal = bool(torch.equal(ref, ref2))
         if not rerun_equal:
