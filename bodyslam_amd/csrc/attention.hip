@@ -361,6 +361,7 @@ template <typename T, int QW>
 __global__ __launch_bounds__(QW * 64) void attention_tab_kernel(const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ Vt,
                                                                  const float* __restrict__ table, T* __restrict__ out, int split, int B, int nh,
                                                                  int hp, int Sp, int nqb, int ntab, int grouped, int ablate) {
+    BS_ARG_NOW(out);
     const bool cls_planes = (split & 4) != 0;   // FP8 planes for the cls query's row only (bs_attention_table, dtype bit 6)
     split &= 3;
     typedef typename T16<T>::v8 v8;
@@ -724,6 +725,7 @@ __global__ __launch_bounds__(QW * 64, WPE) void attention_tab2_kernel(const T* _
                                                                   const T* __restrict__ Ql, const T* __restrict__ Kl, const T* __restrict__ Vtl,
                                                                   const float* __restrict__ table, T* __restrict__ out, int split, int B, int nh,
                                                                   int hp, int Sp, int nqb, int ntab, int grouped) {
+    BS_ARG_NOW(out);
     const bool cls_planes = (split & 4) != 0;   // FP8 planes for the cls query's row only (bs_attention_table, dtype bit 6)
     const int abl = split >> 3;                 // diagnostics (BS_ATTN_ABL): 1 = no ring barrier, 2 = no DMA wait, 4 = no DMA after tile 1 -- wrong results, timing only
     split &= 3;

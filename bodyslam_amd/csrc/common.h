@@ -46,6 +46,12 @@ int cu_count();                   // compute units of the device bs_init bound (
 
 #define BS_CHECK_LAUNCH() BS_CHECK_HIP(hipGetLastError())
 
+// A kernel argument loaded NOW, with the others at the top of the kernel, and not where the compiler first needs it -- in the middle of LDS
+// traffic, its scalar load sharing an `s_waitcnt lgkmcnt` with LDS reads.  Round 6 found a kernel whose LDS reads were consumed before they had
+// landed when scalar loads shared their wait beside a second process; tools/probes/lgkm_mix_audit.py checks that no
+// kernel has the pattern.
+#define BS_ARG_NOW(p) asm volatile("" ::"s"(p))
+
 // Large dynamic LDS must be enabled per kernel AND per device: one bit per device ordinal, set after the attribute call succeeded (the
 // call is idempotent, so two threads racing on a fresh device both make it).  Rounds 2-5 kept one process-wide flag per kernel: a
 // process driving a second device launched there with LDS that was never enabled (round-5 advisor).

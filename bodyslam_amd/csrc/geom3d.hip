@@ -34,6 +34,7 @@ __device__ __forceinline__ void load8_u16(const uint16_t* img, int64_t base, int
 
 __global__ __launch_bounds__(BP_THREADS) void bp_count_kernel(const uint16_t* depth, int64_t npix, int nchunk, float scale32,
                                                                float trunc32, int32_t* chunk_count) {
+    BS_ARG_NOW(chunk_count);
     const int b = blockIdx.y, c = blockIdx.x;
     const uint16_t* img = depth + (int64_t)b * npix;
     const int64_t base = (int64_t)c * BP_CHUNK + threadIdx.x * BP_PER_THREAD;
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(BP_THREADS) void bp_count_kernel(const uint16_t* de
 
 // one block per image: exclusive scan of the chunk counts (in place), total -> count[b]
 __global__ __launch_bounds__(256) void bp_scan_kernel(int32_t* chunk_count, int nchunk, int32_t* count) {
+    BS_ARG_NOW(count);
     const int b = blockIdx.x;
     int32_t* cc = chunk_count + (int64_t)b * (nchunk + 1);
     __shared__ int carry_s;
