@@ -47,9 +47,8 @@ int cu_count();                   // compute units of the device bs_init bound (
 #define BS_CHECK_LAUNCH() BS_CHECK_HIP(hipGetLastError())
 
 // A kernel argument loaded NOW, with the others at the top of the kernel, and not where the compiler first needs it -- in the middle of LDS
-// traffic, its scalar load sharing an `s_waitcnt lgkmcnt` with LDS reads.  Round 6 found a kernel whose LDS reads were consumed before they had
-// landed when scalar loads shared their wait beside a second process; tools/probes/lgkm_mix_audit.py checks that no
-// kernel has the pattern.
+// traffic, its scalar load sharing an `s_waitcnt lgkmcnt` with LDS reads.  A precaution from round 6's search for a cross-process effect
+// (the hypothesis it was taken under did not hold; neutral in time, kept); tools/probes/lgkm_mix_audit.py checks the pattern.
 #define BS_ARG_NOW(p) asm volatile("" ::"s"(p))
 
 // Large dynamic LDS must be enabled per kernel AND per device: one bit per device ordinal, set after the attribute call succeeded (the

@@ -474,7 +474,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
         };
         int t = 0;
         // (kernel-argument loads still outstanding from the prologue are retired here, before the first LDS fragment read: no scalar load
-        // shares a wait with an LDS read anywhere in the plan's kernels -- tools/probes/lgkm_mix_audit.py)
+        // shares a wait with an LDS read -- tools/probes/lgkm_mix_audit.py; a precaution from round 6, neutral in time)
         __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0) alone: a fence would also wait for the LDS-DMA of the staged tiles (vmcnt)
         for (; t < nt16; ++t) iteration(t, std::integral_constant<int, 0>{});
         if constexpr (F8 && BK == 64 && !RELU_A) {

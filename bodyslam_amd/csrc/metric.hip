@@ -216,13 +216,15 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
     // h + 1 sit in scalar registers) -- the build has -ffp-contract=off, so without the explicit fused form every term was a multiply
     // AND an add (2 560 issue slots per pixel for this loop; now 640)
     //
-    // Round 6: the interpolated Eh of EIGHT units is read from LDS in one go, between two `s_waitcnt lgkmcnt(0)` fences, so that no scalar
-    // load is in flight while an LDS read is.  Rounds 2-5 read the four corners of two units inside the loop, interleaved with the s_loads
-    // of their weights under one lgkmcnt wait.  Beside a second process that allocates and frees device memory, that form was seen to
-    // consume the LDS data of the LAST SIXTEEN LANES of a wave before they had arrived (the registers still held the read's addresses):
-    // 5 % of the launches, 16 pixels of one output row per affected wave, every other stage of the plan bit-identical
-    // (profiles/r06_reproducibility.txt (6), tools/probes/rerun_determinism.py with DBG=1).  Alone it never happened; the form is kept in
-    // the diagnostics build (BS_LOGBINOM_INTERLEAVED=1) for that comparison.
+    // Round 6: the interpolated Eh of EIGHT units is read from LDS in one go (eight ds_read_b128), between two `s_waitcnt lgkmcnt(0)` fences.
+    // Rounds 2-5 read the four corners of two units inside the loop (per-lane 8-byte gathers among the s_loads of the units' weights).  Beside a
+    // second process that allocates and frees device memory, that form was seen to compute with wrong LDS read results in the LAST SIXTEEN LANES
+    // of a wave: 2 % of the launches, 16 pixels of one output row per affected wave, every other stage of the plan bit-identical
+    // (profiles/r06_reproducibility.txt (5)-(7), tools/probes/rerun_determinism.py with DBG=1).  Alone it never happened.  The per-unit reads
+    // fail the same way with a fence on both sides (diagnostics build, BS_LOGBINOM_INTERLEAVED=4), so the scalar loads are not the cause; the
+    // mechanism is not identified.  This form has not failed in 17 600 reruns beside the same neighbour (three builds, the release library among
+    // them) with the old forms failing in the same calls -- and it is 6 % faster.  BS_LOGBINOM_INTERLEAVED=1 / 4 keep the old reads in the
+    // diagnostics build for that comparison.
     static_assert(LB_HID % 8 == 0, "hidden width");
 #ifdef BS_DIAG
     float dg_interp = 0.f, dg_pre = 0.f, dg_act = 0.f;       // sums over the hidden units of: interpolated Eh, pre-activation, activation
@@ -259,9 +261,16 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
             for (int u = 0; u < 2; ++u) {
                 sv[u][0] = ehv[hh + u];
 #ifdef BS_DIAG
-                if (interleaved)
+                if (interleaved == 1)      // the rounds 2-5 form: the compiler places these reads among the scalar loads of the units' weights
                     sv[u][0] = l.hy * (l.hx * s_eh[c00 * LB_HID + h + u] + l.lx * s_eh[c01 * LB_HID + h + u]) +
                                l.ly * (l.hx * s_eh[c10 * LB_HID + h + u] + l.lx * s_eh[c11 * LB_HID + h + u]);
+                else if (interleaved == 4) {      // the same reads, fenced off from the scalar loads on both sides
+                    LB_LGKM_FENCE();
+                    const float g00 = s_eh[c00 * LB_HID + h + u], g01 = s_eh[c01 * LB_HID + h + u];
+                    const float g10 = s_eh[c10 * LB_HID + h + u], g11 = s_eh[c11 * LB_HID + h + u];
+                    LB_LGKM_FENCE();
+                    sv[u][0] = l.hy * (l.hx * g00 + l.lx * g01) + l.ly * (l.hx * g10 + l.lx * g11);
+                }
                 dg_interp += sv[u][0];
 #endif
                 sv[u][1] = 0.0f;
@@ -464,7 +473,7 @@ extern "C" int bs_logbinom_depth_ex(const void* last, const float* Eh, const flo
     const int nr_max = (int)(sy * (LB_T - 1)) + 3, nc_max = (int)(sx * (LB_T - 1)) + 3;
     const int ncell_max = nr_max * nc_max;
     const size_t lds = sizeof(float) * (size_t)(LB_BINS + ncell_max * (LB_BINS + hid));
-    static const int interleaved = diag_env("BS_LOGBINOM_INTERLEAVED") != nullptr;      // diagnostics build only (the rounds 2-5 form of the hidden layer)
+    static const int interleaved = diag_env("BS_LOGBINOM_INTERLEAVED") ? atoi(diag_env("BS_LOGBINOM_INTERLEAVED")) : 0;      // diagnostics build only: 1 = the rounds 2-5 form of the hidden layer, 4 = that form's reads between fences
     const int lsplit = (dtype & 32) ? 2 : ((dtype & 16) ? 1 : 0);   // bit 4: `last` holds (hi | lo) 16-bit pairs; bit 5: (hi16 | hi8 | lo8)
     dtype &= 15;
 #define BS_LB_LAUNCH(TT, LS, HD)                                                                                                 \

@@ -504,8 +504,8 @@ class ZoeDepthEngine:
         bmeans: Dict[str, torch.Tensor] = {}
         ref = depth(full, neck_full, attn_best, means=bmeans if (switchable and os.environ.get("BS_AUTO_WSTAT") == "1") else None)
         # The yardstick of every decision below is run twice: the same launches must give the same bits.  (Earlier in round 6 one forward in a few
-        # hundred differed beside another process allocating on the same GPU; the cause -- the log-binomial kernel's LDS reads sharing a wait with
-        # scalar loads, DESIGN section 7 -- is removed, the check costs one forward and stays.)  A yardstick that does not reproduce is measured a
+        # hundred differed beside another process allocating on the same GPU; it was located in the log-binomial kernel, whose shipped form has not
+        # shown it since -- DESIGN section 7 -- and the check costs one forward and stays.)  A yardstick that does not reproduce is measured a
         # third time and the report says so.
         ref2 = depth(full, neck_full, attn_best)
         rerun_equal = bool(torch.equal(ref, ref2))
