@@ -915,7 +915,14 @@ extern "C" int bs_col_mean(const void* A, int64_t lda, int32_t row0, int32_t row
 // 16-64 dependent fragment loads per wave).  Round 3: a block owns 16 columns x 64 rows x ALL of K, its four waves each take a
 // QUARTER of K (8-32 steps, four in flight), fragments go straight from L2 to registers (both operands are a few MB), 16x16x32 bf16
 // MFMA, and the four partial tiles meet in LDS in wave order: no atomics, the sum has a fixed order.
-__global__ __launch_bounds__(256) void rank1_bias_kernel(const bf16* abar, const bf16* dW, float* out, int G, int N, int K) {
+#ifdef BS_DIAG
+#define R1_ABL(x) (abl & (x))
+#else
+#define R1_ABL(x) 0
+#endif
+__global__ __launch_bounds__(256) void rank1_bias_kernel(const bf16* abar, const bf16* dW, float* out, int G, int N, int K, int abl) {
+    // abl: diagnostics build only (BS_RANK1_ABLATE: 1 = no MFMA, 2 = no LDS exchange, 4 = no read-modify-write of the output) -- wrong results, for
+    // tools/probes/rank1_ablate.sh: which part of this kernel disturbs a kernel of another stream (the MFMA: profiles/r06_reproducibility.txt (8))
     typedef T16<bf16>::v8 v8;
     __shared__ float red[4][64][17];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -942,7 +949,10 @@ __global__ __launch_bounds__(256) void rank1_bias_kernel(const bf16* abar, const
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8*>(ap[i] + k);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = T16<bf16>::mfma16(bf, af[i], acc[i]);
+        for (int i = 0; i < 4; ++i) {
+            if (R1_ABL(1)) acc[i][0] += (float)af[i][0] + (float)bf[0];
+            else acc[i] = T16<bf16>::mfma16(bf, af[i], acc[i]);
+        }
     };
     int st = s0;
     for (; st + 4 <= s1; st += 4) {            // four steps' loads in flight
@@ -953,7 +963,8 @@ __global__ __launch_bounds__(256) void rank1_bias_kernel(const bf16* abar, const
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) red[wave][i * 16 + frow][fq * 4 + e] = acc[i][e];
+        for (int e = 0; e < 4; ++e)
+            if (!R1_ABL(2)) red[wave][i * 16 + frow][fq * 4 + e] = acc[i][e];
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -961,7 +972,9 @@ __global__ __launch_bounds__(256) void rank1_bias_kernel(const bf16* abar, const
         const int g = g0 + gl, nn = n0 + c;
         if (g < G && nn < N) {
             float* o = out + (int64_t)g * N + nn;
-            *o += ((red[0][gl][c] + red[1][gl][c]) + red[2][gl][c]) + red[3][gl][c];
+            if (R1_ABL(2)) *o += acc[0][0];
+            else if (R1_ABL(4)) *o = ((red[0][gl][c] + red[1][gl][c]) + red[2][gl][c]) + red[3][gl][c];
+            else *o += ((red[0][gl][c] + red[1][gl][c]) + red[2][gl][c]) + red[3][gl][c];
         }
     }
 }
@@ -970,8 +983,9 @@ extern "C" int bs_rank1_bias(const void* abar_bf16, const void* dw_bf16, float* 
     BS_ENTRY("bs_rank1_bias");
     BS_REQUIRE(abar_bf16 && dw_bf16 && out, "bs_rank1_bias: null operand");
     BS_REQUIRE(G > 0 && N > 0 && K > 0 && K % 64 == 0, "bs_rank1_bias: K=%d must be a multiple of 64", K);
+    static const int abl = diag_env("BS_RANK1_ABLATE") ? atoi(diag_env("BS_RANK1_ABLATE")) : 0;
     hipLaunchKernelGGL(rank1_bias_kernel, dim3(cdiv(N, 16), cdiv(G, 64)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const bf16*)abar_bf16,
-                       (const bf16*)dw_bf16, out, G, N, K);
+                       (const bf16*)dw_bf16, out, G, N, K, abl);
     BS_CHECK_LAUNCH();
     return BS_OK;
 }

@@ -217,14 +217,12 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
     // AND an add (2 560 issue slots per pixel for this loop; now 640)
     //
     // Round 6: the interpolated Eh of EIGHT units is read from LDS in one go (eight ds_read_b128), between two `s_waitcnt lgkmcnt(0)` fences.
-    // Rounds 2-5 read the four corners of two units inside the loop (per-lane 8-byte gathers among the s_loads of the units' weights).  Beside a
-    // second process that allocates and frees device memory, that form was seen to compute with wrong LDS read results in the LAST SIXTEEN LANES
-    // of a wave: 2 % of the launches, 16 pixels of one output row per affected wave, every other stage of the plan bit-identical
-    // (profiles/r06_reproducibility.txt (5)-(7), tools/probes/rerun_determinism.py with DBG=1).  Alone it never happened.  The per-unit reads
-    // fail the same way with a fence on both sides (diagnostics build, BS_LOGBINOM_INTERLEAVED=4), so the scalar loads are not the cause; the
-    // mechanism is not identified.  This form has not failed in 17 600 reruns beside the same neighbour (three builds, the release library among
-    // them) with the old forms failing in the same calls -- and it is 6 % faster.  BS_LOGBINOM_INTERLEAVED=1 / 4 keep the old reads in the
-    // diagnostics build for that comparison.
+    // Rounds 2-5 read the four corners of two units inside the loop with per-lane 8-byte (in other builds 4-byte) gathers.  Those forms compute with
+    // wrong LDS read results in the LAST SIXTEEN LANES of a wave when a kernel of ANOTHER stream (or process) shares the CU and issues MFMA --
+    // bs_rank1_bias is the plan's one MFMA kernel small enough to do so: 11-14 % of the launches beside it, 0 with its MFMA removed, 0 alone
+    // (profiles/r06_reproducibility.txt (5)-(8); tools/probes/gather_beside_stream.py).  Fencing the small reads off from the scalar loads does not
+    // help; reading 16 bytes per lane does: this form has not differed in 57 600 reruns with the other forms failing in the same calls, and it is
+    // 6 % faster.  Why the hardware does this is not known.  BS_LOGBINOM_INTERLEAVED=1 / 4 / 5 keep the small-read forms in the diagnostics build.
     static_assert(LB_HID % 8 == 0, "hidden width");
 #ifdef BS_DIAG
     float dg_interp = 0.f, dg_pre = 0.f, dg_act = 0.f;       // sums over the hidden units of: interpolated Eh, pre-activation, activation
@@ -232,7 +230,20 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
     for (int h0 = 0; h0 < LB_HID; h0 += 8) {
         float ehv[8];
 #ifdef BS_DIAG
-        if (!interleaved)
+        if (interleaved == 5) {       // the block position of the shipped form, but as 32 four-byte per-lane reads (volatile: not merged) between the fences
+            LB_LGKM_FENCE();
+            float g00[8], g01[8], g10[8], g11[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                g00[k] = *reinterpret_cast<volatile const float*>(s_eh + c00 * LB_HID + h0 + k);
+                g01[k] = *reinterpret_cast<volatile const float*>(s_eh + c01 * LB_HID + h0 + k);
+                g10[k] = *reinterpret_cast<volatile const float*>(s_eh + c10 * LB_HID + h0 + k);
+                g11[k] = *reinterpret_cast<volatile const float*>(s_eh + c11 * LB_HID + h0 + k);
+            }
+            LB_LGKM_FENCE();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ehv[k] = l.hy * (l.hx * g00[k] + l.lx * g01[k]) + l.ly * (l.hx * g10[k] + l.lx * g11[k]);
+        } else if (!interleaved)
 #endif
         {
             LB_LGKM_FENCE();
@@ -473,7 +484,7 @@ extern "C" int bs_logbinom_depth_ex(const void* last, const float* Eh, const flo
     const int nr_max = (int)(sy * (LB_T - 1)) + 3, nc_max = (int)(sx * (LB_T - 1)) + 3;
     const int ncell_max = nr_max * nc_max;
     const size_t lds = sizeof(float) * (size_t)(LB_BINS + ncell_max * (LB_BINS + hid));
-    static const int interleaved = diag_env("BS_LOGBINOM_INTERLEAVED") ? atoi(diag_env("BS_LOGBINOM_INTERLEAVED")) : 0;      // diagnostics build only: 1 = the rounds 2-5 form of the hidden layer, 4 = that form's reads between fences
+    static const int interleaved = diag_env("BS_LOGBINOM_INTERLEAVED") ? atoi(diag_env("BS_LOGBINOM_INTERLEAVED")) : 0;      // diagnostics build only: 1 = the rounds 2-5 form of the hidden layer, 4 = that form's reads between fences, 5 = the shipped position with four-byte reads
     const int lsplit = (dtype & 32) ? 2 : ((dtype & 16) ? 1 : 0);   // bit 4: `last` holds (hi | lo) 16-bit pairs; bit 5: (hi16 | hi8 | lo8)
     dtype &= 15;
 #define BS_LB_LAUNCH(TT, LS, HD)                                                                                                 \

@@ -48,8 +48,8 @@ def pytest_collection_finish(session):
     # Round 6: the helper runs to its end BEFORE the first test touches the GPU (~40 s).  Rounds 4-5 let it run beside the suite; with the
     # calibration now ~90 forwards per process that overlap cost the test its meaning twice in four runs: beside other processes allocating on the
     # same GPU a forward could come out with other bits than its rerun, and one such forward inside a calibration moves a borderline decision -- the
-    # three processes then run different arithmetic and cannot be bit-equal.  It was located later in the round (the log-binomial kernel's per-unit
-    # LDS gathers; the form that ships has not shown it in 17 600 reruns beside such a neighbour); the order is kept: one process per GPU is how the path is deployed, and the suite's own tests are not
+    # three processes then run different arithmetic and cannot be bit-equal.  It was located later in the round (the log-binomial kernel's 4- / 8-byte
+    # LDS gathers beside another stream's MFMA kernel; the form that ships reads 16 bytes and has not shown it); the order is kept: one process per GPU is how the path is deployed, and the suite's own tests are not
     # what this test is about.  BODYSLAM_TEST_HELPER_CONCURRENT=1: the rounds 4-5 behaviour.
     if os.environ.get("BODYSLAM_TEST_HELPER_CONCURRENT") == "1":
         return

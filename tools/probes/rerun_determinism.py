@@ -20,6 +20,23 @@ if os.environ.get("DBG") == "1":             # diagnostics build (BODYSLAM_HIP_L
     lib.bs_diag_logbinom_buffer.argtypes = [ctypes.c_void_p]
     dbg = torch.zeros(plan.depth_net.numel() * 8, device="cuda")
     assert lib.bs_diag_logbinom_buffer(dbg.data_ptr()) == 0
+# NEIGHBOUR_STREAM=1: a full-size ZoeD_NK plan of the SAME process runs on a second stream beside every rerun (kernels of another stream sharing the CUs)
+neighbour = None
+if os.environ.get("NEIGHBOUR_STREAM") == "1":
+    import bodyslam_amd.zoedepth as ZD
+    from bodyslam_amd.synthetic import make_sequence, random_zoedepth_weights
+    cfg_b = ZD.ZoeConfig()
+    big = ZoeDepthEngine(random_zoedepth_weights(cfg_b, seed=0), cfg_b, precision="accurate", class_modes="wmean", attn_mode="single", neck_mode="full")
+    bplan = _ZoePlan(big, int(os.environ.get("NEIGHBOUR_B", "8")), 480, 640, True)
+    bplan.frames.copy_(torch.from_numpy(make_sequence(bplan.frames.shape[0], 480, 640, seed=1)).cuda())
+    sB = torch.cuda.Stream()
+
+    def neighbour():
+        with torch.cuda.stream(sB):
+            bplan.run(None)
+            bplan.run(None)
+    neighbour()
+    torch.cuda.synchronize()
 base = {}
 plan.run(base)
 torch.cuda.synchronize()
@@ -85,6 +102,8 @@ for it in range(n):
         plan = _ZoePlan(eng, 4, T.H, T.W, True)
         plan.frames.copy_(torch.from_numpy(frames[:4]).cuda())
     taps = {}
+    if neighbour is not None:
+        neighbour()
     if fresh and it % 2:
         plan.run(None)                 # the plain path every other time: only the final maps can be compared
         torch.cuda.synchronize()
@@ -105,6 +124,8 @@ print(f"{n} reruns of the tap path: stages that differed first: " + (", ".join(f
 ref = None
 nbad = 0
 for it in range(n):
+    if neighbour is not None:
+        neighbour()
     plan.run(None)
     torch.cuda.synchronize()
     d = plan.depth_m.clone()
