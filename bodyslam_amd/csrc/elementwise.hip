@@ -921,7 +921,7 @@ extern "C" int bs_col_mean(const void* A, int64_t lda, int32_t row0, int32_t row
 #define R1_ABL(x) 0
 #endif
 __global__ __launch_bounds__(256) void rank1_bias_kernel(const bf16* abar, const bf16* dW, float* out, int G, int N, int K, int abl) {
-    // abl: diagnostics build only (BS_RANK1_ABLATE: 1 = no MFMA, 2 = no LDS exchange, 4 = no read-modify-write of the output) -- wrong results, for
+    // abl: diagnostics build only (BS_RANK1_ABLATE: 1 = no MFMA, 2 = no LDS exchange, 4 = no read-modify-write of the output, 8 = the f16 MFMA in place of the bf16 one) -- wrong results, for
     // tools/probes/rank1_ablate.sh: which part of this kernel disturbs a kernel of another stream (the MFMA: profiles/r06_reproducibility.txt (8))
     typedef T16<bf16>::v8 v8;
     __shared__ float red[4][64][17];
@@ -951,6 +951,7 @@ __global__ __launch_bounds__(256) void rank1_bias_kernel(const bf16* abar, const
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (R1_ABL(1)) acc[i][0] += (float)af[i][0] + (float)bf[0];
+            else if (R1_ABL(8)) acc[i] = T16<f16>::mfma16(__builtin_bit_cast(T16<f16>::v8, bf), __builtin_bit_cast(T16<f16>::v8, af[i]), acc[i]);   // the f16 instruction on the same bits
             else acc[i] = T16<bf16>::mfma16(bf, af[i], acc[i]);
         }
     };

@@ -13,8 +13,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-template <int W>      // bytes per lane and read: 4, 8, 16
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int W, int VALU>      // bytes per lane and read: 4, 8, 16; packed FMAs per pass
 __global__ __launch_bounds__(256) void victim(int iters, unsigned long long* bad) {
+    f32x2 p0 = {1.0f + threadIdx.x * 1e-6f, 0.5f}, p1 = {0.25f, 0.125f};
+    const f32x2 pk = {0.999f, 1.001f};
     __shared__ __attribute__((aligned(16))) unsigned lds[10240];          // 40 KiB: three blocks per CU, like the kernel it stands for
     for (int i = threadIdx.x; i < 10240; i += 256) lds[i] = 0x40000000u + i;
     __syncthreads();
@@ -56,7 +59,16 @@ __global__ __launch_bounds__(256) void victim(int iters, unsigned long long* bad
             for (int e = 0; e < W / 4; ++e) wrong += o[j][e] != 0x40000000u + bb[j] / 4 + e;
         nbad += wrong;
         if (lane >= 48) q3 += wrong;
+        if (VALU) {          // the victim's own arithmetic: packed-fp32 FMAs (other waves of the SIMD run these while this one reads LDS) and a transcendental
+#pragma unroll
+            for (int r = 0; r < VALU; ++r) {
+                p0 = __builtin_elementwise_fma(p0, pk, p1);
+                p1 = __builtin_elementwise_fma(p1, pk, p0);
+            }
+            p0[0] += __builtin_amdgcn_rcpf(p1[1] + 2.0f);
+        }
     }
+    if (p0[0] == 123.456f) nbad += 1;                      // (keeps the arithmetic)
     if (nbad) { atomicAdd(&bad[0], nbad); atomicAdd(&bad[1], q3); }
 }
 
@@ -80,15 +92,15 @@ __global__ __launch_bounds__(256) void neighbour(int iters, float* sink) {
     sink[blockIdx.x * 256 + threadIdx.x] = acc[0] + acc16[0] + f;
 }
 
-template <int W, int KIND>
+template <int W, int KIND, int VALU = 0>
 static void combo(double secs, unsigned long long* bad, float* sink, hipStream_t sA, hipStream_t sB, const char* vname, const char* nname) {
     (void)hipMemset(bad, 0, 4 * sizeof(unsigned long long));
     long launches = 0;
     const auto t0 = std::chrono::steady_clock::now();
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {
         if (KIND >= 0)
-            for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(neighbour<(KIND < 0 ? 3 : KIND)>, dim3(192), dim3(256), 0, sB, 2048, sink);
-        for (int r = 0; r < 16; ++r) hipLaunchKernelGGL(victim<W>, dim3(288), dim3(256), 0, sA, 512, bad);
+            for (int r = 0; r < 24; ++r) hipLaunchKernelGGL(neighbour<(KIND < 0 ? 3 : KIND)>, dim3(192), dim3(256), 0, sB, 512, sink);
+        for (int r = 0; r < 16; ++r) hipLaunchKernelGGL((victim<W, VALU>), dim3(288), dim3(256), 0, sA, 512, bad);
         (void)hipDeviceSynchronize();
         launches += 16;
     }
@@ -117,5 +129,11 @@ int main(int argc, char** argv) {
     combo<8, 2>(secs, bad, sink, sA, sB, "ds_read_b64", "mfma_f32_32x32x16_f16");
     combo<16, 0>(secs, bad, sink, sA, sB, "ds_read_b128", "mfma_f32_16x16x32_bf16");
     combo<16, 2>(secs, bad, sink, sA, sB, "ds_read_b128", "mfma_f32_32x32x16_f16");
+    printf("the victim with 32 + 32 packed FMAs and a v_rcp after every pass:\n");
+    combo<4, -1, 32>(secs, bad, sink, sA, sB, "ds_read_b32", "nothing");
+    combo<4, 0, 32>(secs, bad, sink, sA, sB, "ds_read_b32", "mfma_f32_16x16x32_bf16");
+    combo<4, 1, 32>(secs, bad, sink, sA, sB, "ds_read_b32", "mfma_f32_16x16x32_f16");
+    combo<8, 1, 32>(secs, bad, sink, sA, sB, "ds_read_b64", "mfma_f32_16x16x32_f16");
+    combo<16, 1, 32>(secs, bad, sink, sA, sB, "ds_read_b128", "mfma_f32_16x16x32_f16");
     return 0;
 }
