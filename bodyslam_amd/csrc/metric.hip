@@ -170,6 +170,12 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
 
     // the 32 `last` features of this pixel
     float xin[LB_IN];
+#ifdef BS_DIAG
+    if ((interleaved >> 4) & 16) {
+#pragma unroll
+        for (int c = 0; c < LB_IN; ++c) xin[c] = 0.0f;
+    } else
+#endif
     {
         typedef typename T16<T>::v8 v8;
         const T* lp = last + gid * LB_IN * (LSPLIT ? 2 : 1);     // LSPLIT: (hi | lo) pairs, 32 + 32 values per pixel
@@ -225,6 +231,10 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
     // 6 % faster.  Why the hardware does this is not known.  BS_LOGBINOM_INTERLEAVED=1 / 4 / 5 keep the small-read forms in the diagnostics build.
     static_assert(LB_HID % 8 == 0, "hidden width");
 #ifdef BS_DIAG
+    // diagnostics build: BS_LOGBINOM_SKIP (bits 4.. of the switch): 1 = no dot products, 2 = no GELU, 4 = no softmax phase (the sum of the MLP's outputs is
+    // written instead), 8 = no output-layer weights (no scalar load in the loop), 16 = the pixel's inputs not loaded -- wrong results; which part of this kernel has to be there for another stream's MFMA kernel to disturb its small LDS reads
+    const int skip = interleaved >> 4;
+    interleaved &= 15;
     float dg_interp = 0.f, dg_pre = 0.f, dg_act = 0.f;       // sums over the hidden units of: interpolated Eh, pre-activation, activation
 #endif
     for (int h0 = 0; h0 < LB_HID; h0 += 8) {
@@ -286,6 +296,9 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
 #endif
                 sv[u][1] = 0.0f;
             }
+#ifdef BS_DIAG
+            if (!(skip & 1))
+#endif
 #pragma unroll
             for (int c = 0; c < LB_IN; c += 2) {
                 const f32x2_ x2 = {xin[c], xin[c + 1]};
@@ -295,7 +308,11 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
             }
             f32x2_ a2 = {sv[0][0] + sv[0][1], sv[1][0] + sv[1][1]};
             if (grel) a2 = __builtin_elementwise_fma(f32x2_{grel[h], grel[h + 1]}, f32x2_{rd, rd}, a2);
+#ifdef BS_DIAG
+            const f32x2_ ga = (skip & 2) ? a2 : gelu_erf_as2(a2);
+#else
             const f32x2_ ga = gelu_erf_as2(a2);
+#endif
 #ifdef BS_DIAG
             dg_pre += a2[0] + a2[1];
             dg_act += ga[0] + ga[1];
@@ -303,11 +320,21 @@ __global__ __launch_bounds__(256) void logbinom_kernel(const T* last, const floa
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int o = 0; o < 4; ++o) pt[o] = fmaf(gw2[o * LB_HID + h + u], ga[u], pt[o]);
+                for (int o = 0; o < 4; ++o) {
+#ifdef BS_DIAG
+                    if (skip & 8) pt[o] += ga[u];
+                    else
+#endif
+                    pt[o] = fmaf(gw2[o * LB_HID + h + u], ga[u], pt[o]);
+                }
         }
     }
     LB_LGKM_FENCE();       // (the softmax loop below reads the bin centres from LDS: nothing scalar in flight there either)
 #ifdef BS_DIAG
+    if (skip & 4) {
+        depth[gid] = (pt[0] + pt[1]) + (pt[2] + pt[3]);
+        return;
+    }
     const float dg_pt[4] = {pt[0], pt[1], pt[2], pt[3]};
     float dg_x = 0.f;
 #pragma unroll
@@ -484,7 +511,8 @@ extern "C" int bs_logbinom_depth_ex(const void* last, const float* Eh, const flo
     const int nr_max = (int)(sy * (LB_T - 1)) + 3, nc_max = (int)(sx * (LB_T - 1)) + 3;
     const int ncell_max = nr_max * nc_max;
     const size_t lds = sizeof(float) * (size_t)(LB_BINS + ncell_max * (LB_BINS + hid));
-    static const int interleaved = diag_env("BS_LOGBINOM_INTERLEAVED") ? atoi(diag_env("BS_LOGBINOM_INTERLEAVED")) : 0;      // diagnostics build only: 1 = the rounds 2-5 form of the hidden layer, 4 = that form's reads between fences, 5 = the shipped position with four-byte reads
+    static const int interleaved = (diag_env("BS_LOGBINOM_INTERLEAVED") ? atoi(diag_env("BS_LOGBINOM_INTERLEAVED")) : 0) +
+                                   16 * (diag_env("BS_LOGBINOM_SKIP") ? atoi(diag_env("BS_LOGBINOM_SKIP")) : 0);      // diagnostics build only: 1 = the rounds 2-5 form of the hidden layer, 4 = that form's reads between fences, 5 = the shipped position with four-byte reads
     const int lsplit = (dtype & 32) ? 2 : ((dtype & 16) ? 1 : 0);   // bit 4: `last` holds (hi | lo) 16-bit pairs; bit 5: (hi16 | hi8 | lo8)
     dtype &= 15;
 #define BS_LB_LAUNCH(TT, LS, HD)                                                                                                 \

@@ -92,6 +92,50 @@ __global__ __launch_bounds__(256) void neighbour(int iters, float* sink) {
     sink[blockIdx.x * 256 + threadIdx.x] = acc[0] + acc16[0] + f;
 }
 
+// the victim as the real kernel lives: MANY SHORT blocks, each stages its 40 KiB from global memory (16-byte LDS writes: other blocks of the CU are staging
+// while this one gathers), one barrier, 40 passes of four per-lane reads, done
+template <int W>
+__global__ __launch_bounds__(256) void victim_staged(const unsigned* src, unsigned long long* bad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned dl[];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned* g = src + (size_t)(blockIdx.x & 255) * 10240;
+    for (int i = threadIdx.x; i < 2560; i += 256) *reinterpret_cast<u32x4*>(dl + 4 * i) = *reinterpret_cast<const u32x4*>(g + 4 * i);
+    __syncthreads();
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6, tag = (blockIdx.x & 255) << 16;
+    const unsigned cell = (lane & 15) / 2 + (lane >> 4 == 3 ? 9 : 0) + wv * 18;
+    const unsigned a0 = cell * 160, a1 = (cell + 1) * 160, a2 = (cell + 9) * 160, a3 = (cell + 10) * 160;
+    unsigned long long nbad = 0, q3 = 0;
+    for (int it = 0; it < 40; ++it) {
+        const unsigned off = (it % 10) * 16 + (it / 10) * 4;
+        const unsigned b0 = a0 + off, b1 = a1 + off, b2 = a2 + off, b3 = a3 + off;
+        unsigned o0 = ~0u, o1 = ~0u, o2 = ~0u, o3 = ~0u;
+        asm volatile("s_nop 4\n ds_read_b32 %0, %4\n ds_read_b32 %1, %5\n ds_read_b32 %2, %6\n ds_read_b32 %3, %7\n s_waitcnt lgkmcnt(0)\n"
+                     : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3) : "v"(b0), "v"(b1), "v"(b2), "v"(b3) : "memory");
+        const int wrong = (o0 != tag + b0 / 4) + (o1 != tag + b1 / 4) + (o2 != tag + b2 / 4) + (o3 != tag + b3 / 4);
+        nbad += wrong;
+        if (lane >= 48) q3 += wrong;
+    }
+    if (nbad) { atomicAdd(&bad[0], nbad); atomicAdd(&bad[1], q3); }
+}
+
+template <int KIND>
+static void combo_staged(double secs, unsigned long long* bad, float* sink, const unsigned* src, hipStream_t sA, hipStream_t sB, const char* nname) {
+    (void)hipMemset(bad, 0, 4 * sizeof(unsigned long long));
+    long launches = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {
+        if (KIND >= 0)
+            for (int r = 0; r < 24; ++r) hipLaunchKernelGGL(neighbour<(KIND < 0 ? 3 : KIND)>, dim3(192), dim3(256), 0, sB, 512, sink);
+        for (int r = 0; r < 8; ++r) hipLaunchKernelGGL(victim_staged<4>, dim3(4608), dim3(256), 41856, sA, src, bad);
+        (void)hipDeviceSynchronize();
+        launches += 8;
+    }
+    unsigned long long h[2];
+    (void)hipMemcpy(h, bad, sizeof(h), hipMemcpyDeviceToHost);
+    printf("  staged ds_read_b32 beside %-28s %7ld launches of 4 608 short blocks   wrong registers %10llu   (in lanes 48-63: %llu)\n", nname, launches, h[0], h[1]);
+    fflush(stdout);
+}
+
 template <int W, int KIND, int VALU = 0>
 static void combo(double secs, unsigned long long* bad, float* sink, hipStream_t sA, hipStream_t sB, const char* vname, const char* nname) {
     (void)hipMemset(bad, 0, 4 * sizeof(unsigned long long));
@@ -135,5 +179,19 @@ int main(int argc, char** argv) {
     combo<4, 1, 32>(secs, bad, sink, sA, sB, "ds_read_b32", "mfma_f32_16x16x32_f16");
     combo<8, 1, 32>(secs, bad, sink, sA, sB, "ds_read_b64", "mfma_f32_16x16x32_f16");
     combo<16, 1, 32>(secs, bad, sink, sA, sB, "ds_read_b128", "mfma_f32_16x16x32_f16");
+    unsigned* src;
+    (void)hipMalloc(&src, (size_t)256 * 10240 * 4);
+    {
+        unsigned* hsrc = (unsigned*)malloc((size_t)256 * 10240 * 4);
+        for (unsigned b = 0; b < 256; ++b)
+            for (unsigned i = 0; i < 10240; ++i) hsrc[(size_t)b * 10240 + i] = (b << 16) + i;
+        (void)hipMemcpy(src, hsrc, (size_t)256 * 10240 * 4, hipMemcpyHostToDevice);
+        free(hsrc);
+    }
+    printf("the victim as many short blocks that stage their LDS content from global memory first (dynamic LDS, 41 856 bytes):\n");
+    combo_staged<-1>(secs, bad, sink, src, sA, sB, "nothing");
+    combo_staged<3>(secs, bad, sink, src, sA, sB, "plain FMAs");
+    combo_staged<0>(secs, bad, sink, src, sA, sB, "mfma_f32_16x16x32_bf16");
+    combo_staged<1>(secs, bad, sink, src, sA, sB, "mfma_f32_16x16x32_f16");
     return 0;
 }
