@@ -1,3 +1,5 @@
+# same-box A / B of two builds of the library through bench.py (BODYSLAM_HIP_LIB): the build in the tree against bodyslam_amd/libbodyslam_hip_prev.so, which the caller
+# makes first (e.g. `git archive <commit> bodyslam_amd/csrc include | tar -x -C /tmp/prev && make -C /tmp/prev/bodyslam_amd/csrc` and copies the .so here)
 mkdir -p gpurun_out/r06
 for k in 1 2; do
   for v in new prev; do

@@ -2,7 +2,8 @@
 #   form 0: shipped -- eight units' corners in one go between two lgkmcnt(0) fences
 #   form 4: the rounds 2-5 reads (two units' corners per pass, inside the loop) with a fence in front of and behind them
 #   form 1: the rounds 2-5 reads among the scalar loads.  Whether the compiler really places them there depends on the surrounding code: the control
-#           arm uses the library built from the commit whose ISA tools/probes/lgkm_mix_audit.py flags (MIXED_LIB), not the current diagnostics build
+#           arm uses the diagnostics library built from commit fb3c4d5, whose ISA tools/probes/lgkm_mix_audit.py flags (MIXED_LIB: `git archive fb3c4d5
+#           bodyslam_amd/csrc include | tar -x -C /tmp/x && make -C /tmp/x/bodyslam_amd/csrc DIAG=1`), not the current diagnostics build
 mkdir -p gpurun_out/r06
 rm -f /tmp/gpu_load_ready
 python tools/probes/gpu_churn.py ${CHURN_S:-760} > gpurun_out/r06/churn.log 2>&1 &
