@@ -514,3 +514,44 @@ def test_no_launch_reads_memory_the_plan_has_not_written(neck):
         got = run()
         for a, b, name in zip(clean, got, ("depth_net", "logits", "depth_m")):
             assert torch.isfinite(b).all() and torch.equal(a, b), f"{name} depends on memory the plan did not write (pool pattern 0x{pat:02X}, neck {neck})"
+
+
+def test_last_launch_reproducible_beside_another_streams_mfma_kernel():
+    """Round 6 (profiles/r06_reproducibility.txt (5)-(8)): bs_logbinom_depth_ex in the forms that gathered the embedding's corners with 4- / 8-byte
+    LDS reads gave wrong values in the last 16 lanes of a few waves whenever a kernel of ANOTHER stream shared its CUs and issued MFMA -- bs_rank1_bias is the plan's
+    one MFMA kernel small enough to do so (4-40 % of the launches beside it, 0 alone; tools/probes/gather_beside_stream.py).  The shipped form reads 16 bytes per
+    lane: relaunched on its untouched inputs beside bursts of bs_rank1_bias on a second stream it must give the first launch's bits every time."""
+    from bodyslam_amd import _lib as LL
+    from bodyslam_amd.synthetic import make_sequence
+    from bodyslam_amd.zoedepth import ZoeDepthEngine, _ZoePlan
+    from oracle import zoedepth_ref as Z
+    cfg_o = small_oracle_cfg()
+    eng = ZoeDepthEngine(Z.synth_weights(cfg_o, seed=4), product_cfg(cfg_o), dtype=torch.float16, target_hw=(96, 128), precision="accurate",
+                         class_modes="full", attn_mode="single", neck_mode="full")
+    plan = _ZoePlan(eng, 4, 120, 160, True)
+    plan.frames.copy_(torch.from_numpy(make_sequence(4, 120, 160, seed=9)).cuda())
+    plan.run(None)
+    torch.cuda.synchronize()
+    base = plan.depth_net.clone()
+    P = plan.plan
+    fn, args = P.calls[P.names.index("logbinom")]
+    lib = LL.load_library()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    abar = torch.randn(16, 1024, generator=g).to(torch.bfloat16).cuda()
+    dw = (torch.randn(3072, 1024, generator=g) * 0.01).to(torch.bfloat16).cuda()
+    acc = torch.zeros(16, 3072, device="cuda")
+    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    bad = n = 0
+    for _ in range(20):
+        for _ in range(480):
+            LL.check(lib.bs_rank1_bias(abar.data_ptr(), dw.data_ptr(), acc.data_ptr(), 16, 3072, 1024, sB.cuda_stream), "bs_rank1_bias")
+        outs = []
+        with torch.cuda.stream(sA):
+            for _ in range(100):
+                LL.check(fn(*args, sA.cuda_stream), "logbinom")
+                outs.append(plan.depth_net.clone())
+        torch.cuda.synchronize()
+        bad += sum(int(not torch.equal(o, base)) for o in outs)
+        n += len(outs)
+    assert bad == 0, f"{bad} of {n} relaunches beside bs_rank1_bias on a second stream differ from the first"
