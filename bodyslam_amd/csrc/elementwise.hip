@@ -921,7 +921,7 @@ extern "C" int bs_col_mean(const void* A, int64_t lda, int32_t row0, int32_t row
 #define R1_ABL(x) 0
 #endif
 __global__ __launch_bounds__(256) void rank1_bias_kernel(const bf16* abar, const bf16* dW, float* out, int G, int N, int K, int abl) {
-    // abl: diagnostics build only (BS_RANK1_ABLATE: 1 = no MFMA, 2 = no LDS exchange, 4 = no read-modify-write of the output, 8 = the f16 MFMA in place of the bf16 one) -- wrong results, for
+    // abl: diagnostics build only (BS_RANK1_ABLATE: 1 = no MFMA, 2 = no LDS exchange, 4 = no read-modify-write of the output, 8 = the f16 MFMA in place of the bf16 one, 16 = 120 KiB of unused dynamic LDS per block) -- wrong results, for
     // tools/probes/rank1_ablate.sh: which part of this kernel disturbs a kernel of another stream (the MFMA: profiles/r06_reproducibility.txt (8))
     typedef T16<bf16>::v8 v8;
     __shared__ float red[4][64][17];
@@ -985,7 +985,14 @@ extern "C" int bs_rank1_bias(const void* abar_bf16, const void* dw_bf16, float* 
     BS_REQUIRE(abar_bf16 && dw_bf16 && out, "bs_rank1_bias: null operand");
     BS_REQUIRE(G > 0 && N > 0 && K > 0 && K % 64 == 0, "bs_rank1_bias: K=%d must be a multiple of 64", K);
     static const int abl = diag_env("BS_RANK1_ABLATE") ? atoi(diag_env("BS_RANK1_ABLATE")) : 0;
-    hipLaunchKernelGGL(rank1_bias_kernel, dim3(cdiv(N, 16), cdiv(G, 64)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const bf16*)abar_bf16,
+    size_t lds = 0;
+#ifdef BS_DIAG
+    if (abl & 16) {       // diagnostics: 120 KiB of (unused) dynamic LDS per block -- no other kernel's 42-KiB block fits on the CU beside it
+        lds = 120 * 1024;
+        BS_MAX_DYNAMIC_LDS(reinterpret_cast<const void*>(&rank1_bias_kernel), 120 * 1024);
+    }
+#endif
+    hipLaunchKernelGGL(rank1_bias_kernel, dim3(cdiv(N, 16), cdiv(G, 64)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), (const bf16*)abar_bf16,
                        (const bf16*)dw_bf16, out, G, N, K, abl);
     BS_CHECK_LAUNCH();
     return BS_OK;
