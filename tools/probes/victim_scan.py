@@ -48,7 +48,8 @@ for k, ((fn, args), name) in enumerate(zip(P.calls, P.names)):
         gi += 1
     else:
         tens = [by_ptr[a] for a in args if isinstance(a, int) and a in by_ptr]
-    if re.match(r"l[1-9]\d*\.", name) or re.match(r"(rt|ro|ra|pj|at|fu)[1-9]", name):      # one instance of each kind of launch: layer 0, level 0
+    # one instance of each kind of launch: layer 0, and level 0 (LEVEL=3: the last, finest level -- the same kernels at their largest)
+    if re.match(r"l[1-9]\d*\.", name) or re.match(r"(rt|ro|ra|pj|at|fu)[0-2]" if os.environ.get("LEVEL") == "3" else r"(rt|ro|ra|pj|at|fu)[1-9]", name):
         continue
     tens = [t for t in tens if t.numel() * t.element_size() <= (64 << 20)]
     if not tens:
